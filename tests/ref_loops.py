@@ -1,0 +1,91 @@
+"""Independent restatement of the loop references inside the reference's tests/apps.
+
+The reference's tests hold no stored vectors: each test file computes its expected
+result with hand-written raster loops and prints the difference
+(/root/reference/tests/test_*.cpp, apps/summed_table/summed_table.cpp:66-82,
+apps/bspline/bicubic_filter.cpp:124-156).  Those loops are the known-answer
+definition the oracle is pinned against, so they are restated here in plain
+Python/numpy scalar arithmetic (float32 like the tests), written in the *tests'*
+form -- `ref += tap1 + tap2 + ...` walking the image in raster order -- not in
+the oracle's form.  Small images only (pure-Python loops).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+
+
+def _lines(img: np.ndarray, dim: int):
+    """Yield 1-D views along scan dim `dim` (0 = x = last numpy axis)."""
+    axis = img.ndim - 1 - dim
+    moved = np.moveaxis(img, axis, -1)
+    for idx in np.ndindex(*moved.shape[:-1]):
+        yield moved[idx]
+
+
+def zero_border_loops(image: np.ndarray, scans) -> np.ndarray:
+    """The `ref(x,y) += (x>0 ? W0*ref(x-1,y) : 0) + (x>1 ? W1*ref(x-2,y) : 0) ...` loops of
+    tests/test_generic_xy.cpp:62-110 and friends (feedforward is 1 in every such test)."""
+    ref = np.array(image, copy=True)
+    is_int = np.issubdtype(ref.dtype, np.integer)
+    for dim, causal, coeff in scans:
+        assert float(coeff[0]) == 1.0, "the tests' loops hard-code feedforward 1"
+        fb = coeff[1:]
+        for line in _lines(ref, dim):
+            n = line.shape[0]
+            for r in range(n):
+                i = r if causal else n - 1 - r
+                if is_int:
+                    # tests/test_type_invariance.cpp:48-60: int16_t(W)*ref(...)
+                    acc = 0
+                    for j, w in enumerate(fb):
+                        if r > j:
+                            acc += int(w) * int(line[i - (j + 1) if causal else i + (j + 1)])
+                    line[i] = np.array(int(line[i]) + acc).astype(ref.dtype)
+                else:
+                    acc = f32(0.0)
+                    for j, w in enumerate(fb):
+                        if r > j:
+                            acc = f32(acc + f32(f32(w) * line[i - (j + 1) if causal else i + (j + 1)]))
+                    line[i] = f32(line[i] + acc)
+    return ref
+
+
+def summed_table_loops(image: np.ndarray) -> np.ndarray:
+    """apps/summed_table/summed_table.cpp:66-82."""
+    ref = np.array(image, copy=True)
+    h, w = ref.shape
+    for y in range(h):
+        for x in range(1, w):
+            ref[y, x] = ref[y, x] + ref[y, x - 1]
+    for y in range(1, h):
+        for x in range(w):
+            ref[y, x] = ref[y, x] + ref[y - 1, x]
+    return ref
+
+
+def clamped_xy_loops(image: np.ndarray, coeff) -> np.ndarray:
+    """apps/bspline/bicubic_filter.cpp:124-156: b0*ref + a1*ref(max(x-1,0)) + a2*ref(max(x-2,0)),
+    applied +x, +y, -x, -y in place.  (The app reads filter_coeff[2] of a 2-vector, an
+    out-of-bounds read; the restatement uses a2 = 0 for order-1 filters.)"""
+    ref = np.array(image, dtype=np.float32, copy=True)
+    h, w = ref.shape
+    b0 = f32(coeff[0])
+    a1 = f32(coeff[1]) if len(coeff) > 1 else f32(0)
+    a2 = f32(coeff[2]) if len(coeff) > 2 else f32(0)
+    for y in range(h):
+        for x in range(w):
+            ref[y, x] = b0 * ref[y, x] + a1 * ref[y, max(x - 1, 0)] + a2 * ref[y, max(x - 2, 0)]
+    for y in range(h):
+        for x in range(w):
+            ref[y, x] = b0 * ref[y, x] + a1 * ref[max(y - 1, 0), x] + a2 * ref[max(y - 2, 0), x]
+    for y in range(h):
+        for x in range(w):
+            ref[y, w - 1 - x] = (b0 * ref[y, w - 1 - x] + a1 * ref[y, w - 1 - max(x - 1, 0)]
+                                 + a2 * ref[y, w - 1 - max(x - 2, 0)])
+    for y in range(h):
+        for x in range(w):
+            ref[h - 1 - y, x] = (b0 * ref[h - 1 - y, x] + a1 * ref[h - 1 - max(y - 1, 0), x]
+                                 + a2 * ref[h - 1 - max(y - 2, 0), x])
+    return ref

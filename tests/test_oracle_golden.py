@@ -1,0 +1,142 @@
+"""Pin the CPU oracle (oracle/recfilter_oracle.c) before anything trusts it.
+
+Sources of truth, all from the reference itself:
+  * the loop references inside its tests/apps, restated independently in ref_loops.py;
+  * the known answers those loops give on the reference's all-ones input;
+  * coefficient / matrix values of lib/iir_coeff.cpp and lib/coefficients.cpp.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import ref_cases as rc
+import ref_loops
+
+
+def _anchors(arr):
+    centre = tuple(s // 2 for s in arr.shape)
+    return (float(arr.flat[0]), float(arr.flat[-1]), float(arr[centre]), float(arr.sum(dtype=np.float64)))
+
+
+@pytest.mark.parametrize("name", sorted(rc.ANCHORS_ALL_ONES))
+def test_known_answers_all_ones(name):
+    case = rc.REFERENCE_TESTS[name]
+    out = oracle.apply_filter(rc.ones_image(case["shape"], case["dtype"]), case["scans"], case["clamped"])
+    got = _anchors(out)
+    np.testing.assert_allclose(got, rc.ANCHORS_ALL_ONES[name], rtol=2e-6)
+
+
+@pytest.mark.parametrize("name", sorted(rc.REFERENCE_TESTS))
+@pytest.mark.parametrize("gen", ["ones", "random"])
+def test_oracle_matches_reference_test_loops(name, gen):
+    case = rc.REFERENCE_TESTS[name]
+    img = rc.ones_image(case["shape"], case["dtype"]) if gen == "ones" else rc.random_image(case["shape"], case["dtype"])
+    got = oracle.apply_filter(img, case["scans"], case["clamped"])
+    want = ref_loops.zero_border_loops(img, case["scans"])
+    if np.issubdtype(img.dtype, np.integer):
+        np.testing.assert_array_equal(got, want)          # bit-exact for integer pixel types
+    else:
+        assert rc.rel_err(got, want) < 2e-6
+
+
+def test_trivial_closed_form():
+    # tests/test_trivial.cpp: SAT of ones = (x+1)(y+1)
+    case = rc.REFERENCE_TESTS["test_trivial"]
+    out = oracle.apply_filter(rc.ones_image(case["shape"]), case["scans"])
+    yy, xx = np.mgrid[0:20, 0:20]
+    np.testing.assert_array_equal(out, ((xx + 1) * (yy + 1)).astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_summed_table_app_loops(dtype):
+    img = rc.random_image((24, 40), dtype)
+    scans = rc.BASELINE_CONFIGS["cfg2_summed_table"]["scans"]
+    got = oracle.apply_filter(img, scans)
+    want = ref_loops.summed_table_loops(img)
+    if dtype is np.int32:
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got, img.cumsum(axis=1).cumsum(axis=0))
+    else:
+        assert rc.rel_err(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("coeff", [rc.BICUBIC_COEFF, rc.GAUSS2])
+def test_clamped_app_loops(coeff):
+    # apps/bspline/bicubic_filter.cpp:124-156 applies +x,+y,-x,-y; the filter is +x,-x,+y,-y
+    img = rc.random_image((20, 28))
+    got = oracle.apply_filter(img, rc.xy_pm(coeff), clamped=True)
+    want = ref_loops.clamped_xy_loops(img, coeff)
+    assert rc.rel_err(got, want) < 5e-5   # scan order differs (x/y commute up to rounding)
+
+
+def test_clamped_constant_is_fixed_point():
+    # any clamped filter with b + sum(a) = 1 maps constants to themselves
+    img = np.full((16, 32), 3.0, dtype=np.float64)
+    out = oracle.apply_filter(img, rc.xy_pm([float(c) for c in rc.GAUSS2]), clamped=True)
+    assert np.max(np.abs(out - 3.0)) < 1e-5
+
+
+def test_cfg3_random64_anchor():
+    img = np.random.default_rng(1234).random((64, 64), dtype=np.float32)
+    out = oracle.apply_filter(img, rc.xy_pm(rc.GAUSS2), clamped=True)
+    np.testing.assert_allclose(_anchors(out), rc.CFG3_RANDOM64, rtol=3e-6)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_gaussian_weights(order):
+    np.testing.assert_allclose(oracle.gaussian_weights(5.0, order), rc.GAUSS_SIGMA5[order], rtol=3e-7)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_integral_image_coeff(n):
+    np.testing.assert_array_equal(oracle.integral_image_coeff(n), np.array(rc.INTEGRAL_COEFF[n], dtype=np.float32))
+
+
+def test_overlap_feedback_coeff():
+    np.testing.assert_allclose(oracle.overlap_feedback_coeff([2, -1], [1]), [3, -3, 1])
+
+
+def test_gaussian_box_filter():
+    assert oracle.gaussian_box_filter(3, 1.0) == 2
+    assert oracle.gaussian_box_filter(3, 2.0) == 4
+
+
+def test_matrix_R_example():
+    ex = rc.MATRIX_R_EXAMPLE
+    np.testing.assert_allclose(oracle.matrix_R(ex["feedback"], ex["tile"]), ex["rows"])
+
+
+def test_matrix_B_is_the_scan():
+    # B (lib/coefficients.cpp:8-49) applied to a tile == the zero-border scan on that tile
+    fb = [0.5, 0.25, 0.125]
+    B = oracle.matrix_B(0.7, fb, 8)
+    x = rc.random_image((8,))
+    want = oracle.apply_filter(x, [(0, True, [0.7] + fb)])
+    np.testing.assert_allclose(B @ x, want, rtol=1e-5)
+
+
+def test_overlap_filter_order():
+    # tests/test_overlap_filter_order.cpp:21-33: cascade of two filters == one higher-order filter
+    img = rc.random_image((12, 12))
+    f1 = [(0, True, [1.0, 2.0, -1.0]), (1, True, [1.0, 1.0])]
+    f2 = [(0, True, [1.0, 1.0]), (1, True, [1.0, 2.0, -1.0])]
+    cascaded = oracle.apply_filter(oracle.apply_filter(img, f1), f2)
+    cx = oracle.overlap_feedback_coeff([2.0, -1.0], [1.0])
+    cy = oracle.overlap_feedback_coeff([1.0], [2.0, -1.0])
+    overlapped = oracle.apply_filter(img, [(0, True, [1.0] + list(cx)), (1, True, [1.0] + list(cy))])
+    assert rc.rel_err(overlapped, cascaded) < 1e-5
+
+
+def test_threads_do_not_change_results():
+    img = rc.random_image((9, 33, 70))
+    scans = rc.REFERENCE_TESTS["test_generic_xyz"]["scans"]
+    a = oracle.apply_filter(img, scans, threads=1)
+    b = oracle.apply_filter(img, scans, threads=4)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_check_result_metric():
+    ref = np.array([1.0, 2.0, 4.0], dtype=np.float32)
+    out = np.array([1.0, 2.2, 4.0], dtype=np.float32)
+    mx, mean = oracle.check_result(ref, out)
+    assert abs(mx - 10.0) < 1e-3 and abs(mean - 10.0 / 3) < 1e-3
