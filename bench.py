@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the tiled recursive-filter hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--size S]
+
+A "step" is one execute of the whole filter (pass 1, carry stages, pass 2) over one synthetic
+image already resident in HBM.  N=1 runs BASELINE.json configs[2] ("apps/gaussian: 2D order-2
+causal+anticausal x/y, 16384^2 f32") -- the configuration the metric is quoted
+on.  N>1 (launched by torch.distributed.run, one rank per GPU) shards the image by rows: every rank
+owns a 16384-row slab of a (N*16384) x 16384 image (weak scaling) and the ranks exchange the k-row
+boundary carry of the two y scans with one RCCL all-gather per scan.
+
+Prints ONE JSON line (rank 0).  `value` = Mpixels/s over all GPUs; `roofline` prices the dominant
+kernel against the 8 TB/s HBM peak with HIP-event timing of that kernel; `cpu_baseline` is the CPU
+oracle (a port of the reference's scan operator, OpenMP over all host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def workload(name, size):
+    import ref_cases as rc
+    cfg = dict(rc.BASELINE_CONFIGS[{"cfg2": "cfg2_summed_table", "cfg3": "cfg3_gaussian2_xy",
+                                    "cfg4a": "cfg4a_bicubic_rgb", "cfg4b": "cfg4b_gaussian3_rgb",
+                                    "cfg5": "cfg5_generic_xyz"}[name]])
+    if size:
+        cfg["shape"] = tuple(size for _ in cfg["shape"])
+    cfg.setdefault("planes", 1)
+    return cfg
+
+
+def algorithmic_bytes_per_launch(kernel_name, samples, itemsize):
+    """Compulsory HBM bytes of one launch (DESIGN.md "roofline accounting"): the final pass reads
+    every sample once and writes it once; pass 1 only reads; carry kernels touch no image bytes."""
+    if "pass2" in kernel_name:
+        return 2 * itemsize * samples
+    if "pass1" in kernel_name:
+        return itemsize * samples
+    return 0
+
+
+def cpu_baseline(cfg, budget_px=16 * 1024 * 1024):
+    """Times the CPU oracle (oracle/, a port of lib/recfilter.cpp:302-343 with OpenMP over lines --
+    the shape of the reference's cpu_auto_full_schedule) on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    shape = list(cfg["shape"])
+    while int(np.prod(shape)) > budget_px:
+        i = int(np.argmax(shape))
+        shape[i] //= 2
+    img = np.random.default_rng(1).random(tuple(shape), dtype=np.float32)
+    threads = max(1, min(oracle.max_threads(), os.cpu_count() or 1))
+    oracle.apply_filter(img[..., :64], cfg["scans"], cfg["clamped"], threads=threads)   # warm the library
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oracle.apply_filter(img, cfg["scans"], cfg["clamped"], threads=threads)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    px = float(np.prod(shape))
+    return {"value": round(px / best / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": f"{'x'.join(map(str, shape))} f32 crop of the workload, 1 plane, best of 2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
+    ap.add_argument("--path", type=int, default=0, help="rf_path override (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import recfilter_amd as rfa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = workload(args.workload, args.size)
+    shape, planes = cfg["shape"], cfg["planes"]
+    dtype = torch.float32
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    inputs = [torch.rand(shape, generator=gen, device="cuda", dtype=dtype) for _ in range(planes)]
+    outputs = [torch.empty_like(t) for t in inputs]
+    samples_local = int(np.prod(shape)) * planes
+
+    from recfilter_amd.dist import ShardedFilter
+    filt = ShardedFilter(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, rank=rank, world=world,
+                         path=args.path, dtype=np.float32, group=None)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        filt.execute(inputs, outputs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        filt.execute(inputs, outputs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1000.0 / args.steps
+    total_px = samples_local * world
+    value = total_px / (ms_per_step * 1e-3) / 1e6
+
+    # --- per-kernel timing with HIP events on the launch stream (rank 0, single-device plan) --------
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        plan = filt.plan if world == 1 else rfa.Plan(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes,
+                                                     path=args.path)
+        reps = max(5, min(args.steps, 20))
+        acc = {}
+        order = []
+        for _ in range(reps):
+            _, times = plan.execute_timed(inputs, outputs)
+            for name, ms in times:
+                if name not in acc:
+                    acc[name] = []
+                    order.append(name)
+                acc[name].append(ms)
+        kernels = {n: float(np.mean(acc[n])) for n in order}        # ms per step, all planes
+        dom = max(kernels, key=lambda n: kernels[n])
+        launches = planes
+        alg = algorithmic_bytes_per_launch(dom, samples_local // planes, 4)
+        avg_ms = kernels[dom] / launches
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg}
+        if world > 1:
+            plan.close()
+
+    if rank == 0:
+        whole = 8.0 * total_px / (ms_per_step * 1e-3) / 1e9      # 8 B per f32 sample per filter
+        line = {
+            "metric": "Mpixels/s + achieved HBM GB/s, 16384^2 order-2 x/y Gaussian IIR",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
+                                   f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
+                       "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
+                       "sharding": "rows (outermost dim), one all-gather per y scan" if world > 1 else "none"},
+            "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / world, 4),
+            "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
+            "roofline": roofline,
+            "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

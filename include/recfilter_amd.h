@@ -1,0 +1,160 @@
+/*
+ * recfilter_amd.h -- C ABI of the MI355X-native tiled recursive-filter runtime.
+ *
+ * This is the drop-in boundary for the hot path of mit-gfx/recfilter: everything
+ * the reference hands to Halide at
+ *      RecFilter::realize()   lib/recfilter.cpp:984-989  (Func::realize)
+ *      RecFilter::profile()   lib/recfilter.cpp:991-1016
+ *      RecFilter::compile_jit lib/recfilter.cpp:918-930  (Func::compile_jit)
+ * after it has built the scan list with RecFilter::add_filter
+ * (lib/recfilter.cpp:260-392) and tiled it with RecFilter::split
+ * (lib/split.cpp:1850-2080).  A plan replaces the Func graph that split() builds and
+ * the schedule that RecFilterSchedule (lib/schedule.cpp) attaches to it: the tiling
+ * algebra becomes host-side tables, the four stages (intra-tile scans, tail extraction,
+ * cross-tile carry recurrence, final correction) are hand-written gfx950 kernels.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an rf_status code, 0 = ok, and never throws;
+ *     rf_last_error_string() describes the last failure on the calling thread.
+ *   - images are dense, planar, x fastest (Halide's layout, lib/recfilter.cpp:969-981);
+ *     a Halide Tuple is n_planes separate buffers that share the filter.
+ *   - all image pointers are DEVICE pointers (hipMalloc or torch); `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream).  rf_plan_execute is
+ *     asynchronous on that stream.
+ *   - the library has no CPU fallback: without a usable HIP device every entry point that
+ *     needs one fails with RF_ERR_HIP.
+ */
+#ifndef RECFILTER_AMD_H
+#define RECFILTER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_MAX_DIMS    3    /* the reference's auto-schedules stop at 3 (lib/recfilter.cpp:6,734) */
+#define RF_MAX_ORDER   8    /* feedback taps per scan */
+#define RF_MAX_SCANS   32
+#define RF_MAX_PLANES  16
+/* desc.device value that builds the plan's host tables without touching a device; such a plan
+ * answers rf_plan_table / rf_plan_tiles / rf_plan_path but refuses to execute (RF_ERR_HIP). */
+#define RF_DEVICE_HOST_ONLY (-2)
+
+typedef enum {
+    RF_OK = 0,
+    RF_ERR_INVALID_ARG = 1,   /* the misuse cases the reference asserts on (lib/recfilter.cpp:274,296) */
+    RF_ERR_UNSUPPORTED = 2,
+    RF_ERR_HIP = 3,           /* HIP runtime error or no device */
+    RF_ERR_NOMEM = 4,
+    RF_ERR_STATE = 5          /* stepping API called out of order */
+} rf_status;
+
+/* pixel type P = type of the defining expression (lib/recfilter.cpp:197); coefficients are
+ * cast to P (lib/recfilter.cpp:324,335) */
+typedef enum { RF_F32 = 0, RF_F64 = 1, RF_I32 = 2, RF_I16 = 3 } rf_dtype;
+
+/* default border is zero; RecFilter::set_clamped_image_border (lib/recfilter.cpp:252-258) */
+typedef enum { RF_BORDER_ZERO = 0, RF_BORDER_CLAMP = 1 } rf_border;
+
+/* how a plan executes */
+typedef enum {
+    RF_PATH_AUTO = 0,      /* fastest path the shape admits                                        */
+    RF_PATH_UNTILED = 1,   /* one serial recurrence per line (a filter that was never split())      */
+    RF_PATH_TILED_GENERIC = 2, /* tiled, any tile width dividing the extent (split(x,tx,..))        */
+    RF_PATH_TILED_FUSED = 3    /* tiled, LDS-staged fused x/y tiles with fixed MI355X tile shapes   */
+} rf_path;
+
+/* one RecFilter::add_filter(+-dim, {feedfwd, fb1..fbk}) call, lib/recfilter.cpp:264-343 */
+typedef struct {
+    int32_t dim;                    /* 0 = x (fastest), 1 = y, 2 = z                      */
+    int32_t causal;                 /* 1 = +dim, 0 = -dim                                 */
+    int32_t order;                  /* number of feedback coefficients, 1..RF_MAX_ORDER   */
+    float   feedfwd;
+    float   feedback[RF_MAX_ORDER]; /* y[i] = feedfwd*x[i] + sum_j feedback[j]*y[i-j-1]   */
+} rf_scan_desc;
+
+typedef struct {
+    int32_t  ndim;                    /* 1..RF_MAX_DIMS                                          */
+    int64_t  extent[RF_MAX_DIMS];     /* extent[0] = width (x)                                   */
+    int32_t  dtype;                   /* rf_dtype                                                */
+    int32_t  n_planes;                /* Tuple size, >= 1                                        */
+    int32_t  border;                  /* rf_border                                               */
+    int32_t  n_scans;
+    const rf_scan_desc *scans;        /* in add_filter call order                                */
+    int32_t  tile[RF_MAX_DIMS];       /* RecFilter::split widths; 0 = let the plan choose        */
+    int32_t  path;                    /* rf_path                                                 */
+    int32_t  device;                  /* HIP device ordinal, -1 = current, RF_DEVICE_HOST_ONLY   */
+    /* outermost-dimension shard (multi-GPU); world = 1 for a single GPU.  extent[] is the LOCAL
+     * slab; the slab of rank r follows the slab of rank r-1 along dimension ndim-1. */
+    int32_t  shard_rank;
+    int32_t  shard_world;
+} rf_filter_desc;
+
+typedef struct rf_plan rf_plan;
+
+/* ---- plan lifetime (replaces split()+schedule+compile_jit) ------------------------------- */
+int rf_plan_create(const rf_filter_desc *desc, rf_plan **plan_out);
+int rf_plan_destroy(rf_plan *plan);
+
+/* bytes of device workspace the plan allocated for tails/carries (owned by the plan) */
+size_t rf_plan_workspace_bytes(const rf_plan *plan);
+/* which rf_path the plan resolved to, and the tile widths it uses (0 for an untiled dim) */
+int rf_plan_path(const rf_plan *plan);
+int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]);
+/* number of kernels one execute launches, and their names (for profilers) */
+int rf_plan_num_kernels(const rf_plan *plan);
+
+/* ---- execution (replaces Func::realize) --------------------------------------------------- */
+/* in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed. */
+int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes,
+                    void *stream);
+
+/* Same, but brackets every kernel with HIP events on `stream` and returns per-kernel
+ * milliseconds in ms_out[0..n) (n = rf_plan_num_kernels) and their names in names_out
+ * (pointers stay valid for the life of the plan).  Synchronises the stream. */
+int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *const *out_planes,
+                          void *stream, float *ms_out, const char **names_out, int capacity);
+
+/* ---- sharded execution: the same work as rf_plan_execute split at the exchange points ----- */
+/* For a plan with shard_world > 1 the scans along the outermost dimension need the carry of
+ * the neighbouring slab.  Protocol, per execute (all calls asynchronous on the begin() stream):
+ *     rf_plan_begin(...)                         pass 1 + every slab-local carry stage
+ *     for e in 0 .. rf_plan_num_exchanges()-1:   one per scan along the sharded dimension
+ *         rf_plan_exchange_local(e, send)        slab-local recurrence; writes this slab's exit
+ *                                                carry (rf_plan_exchange_bytes(e) bytes) to `send`
+ *         -- caller all-gathers `send` over the ranks into `gathered` (world * bytes, rank-major;
+ *            RCCL all-gather on the same stream) --
+ *         rf_plan_exchange_apply(e, gathered)    forms the incoming carry, fixes the slab's tails
+ *     rf_plan_finish(...)                        final correction pass
+ * `send` and `gathered` are caller-owned device buffers.  With shard_world == 1 the apply step
+ * is a no-op and may be skipped. */
+int rf_plan_num_exchanges(const rf_plan *plan);
+size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange);
+int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream);
+int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send);
+int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered);
+int rf_plan_finish(rf_plan *plan);
+
+/* ---- plan tables (host side of the tiling algebra; also what the CPU tests inspect) ------- */
+/* Copies a named table into out (as doubles) and returns its element count through n_out;
+ * pass out = NULL to query the size.  Names are documented in DESIGN.md ("plan tables"). */
+int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t capacity, size_t *n_out);
+
+/* ---- coefficient design (lib/iir_coeff.cpp:162-177, 222-234, 236-263, 205-220) ------------ */
+int rf_gaussian_weights(float sigma, int order, float *coeff_out /* order+1 */);
+int rf_integral_image_coeff(int n, float *coeff_out /* n+1 */);
+int rf_overlap_feedback_coeff(const float *a, int na, const float *b, int nb, float *c_out /* na+nb */);
+int rf_gaussian_box_filter(int k, float sigma, int *width_out);
+
+/* ---- misc ------------------------------------------------------------------------------- */
+const char *rf_last_error_string(void);
+const char *rf_version(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int rf_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECFILTER_AMD_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI declared in include/recfilter_amd.h.
+
+This is plumbing: every call goes straight into librecfilter_amd.so (hand-written gfx950
+kernels).  There is no Python or CPU implementation of the filter behind it -- if the shared
+library is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librecfilter_amd.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+RF_MAX_DIMS = 3
+RF_MAX_ORDER = 8
+RF_MAX_SCANS = 32
+RF_MAX_PLANES = 16
+RF_DEVICE_HOST_ONLY = -2
+
+RF_OK, RF_ERR_INVALID_ARG, RF_ERR_UNSUPPORTED, RF_ERR_HIP, RF_ERR_NOMEM, RF_ERR_STATE = range(6)
+RF_F32, RF_F64, RF_I32, RF_I16 = range(4)
+RF_BORDER_ZERO, RF_BORDER_CLAMP = 0, 1
+RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED = range(4)
+PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
+              RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused"}
+
+# every symbol include/recfilter_amd.h declares
+EXPORTED_SYMBOLS = [
+    "rf_plan_create", "rf_plan_destroy", "rf_plan_workspace_bytes", "rf_plan_path", "rf_plan_tiles",
+    "rf_plan_num_kernels", "rf_plan_execute", "rf_plan_execute_timed", "rf_plan_num_exchanges",
+    "rf_plan_exchange_bytes",
+    "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_finish",
+    "rf_plan_table", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
+    "rf_gaussian_box_filter", "rf_last_error_string", "rf_version", "rf_device_count",
+]
+
+
+class ScanDesc(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int32), ("causal", ctypes.c_int32), ("order", ctypes.c_int32),
+                ("feedfwd", ctypes.c_float), ("feedback", ctypes.c_float * RF_MAX_ORDER)]
+
+
+class FilterDesc(ctypes.Structure):
+    _fields_ = [("ndim", ctypes.c_int32), ("extent", ctypes.c_int64 * RF_MAX_DIMS),
+                ("dtype", ctypes.c_int32), ("n_planes", ctypes.c_int32), ("border", ctypes.c_int32),
+                ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDesc)),
+                ("tile", ctypes.c_int32 * RF_MAX_DIMS), ("path", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32)]
+
+
+class RecFilterError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"recfilter_amd status {status}: {message}")
+        self.status = status
+
+
+def build_library(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into recfilter_amd/librecfilter_amd.so (in-tree)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load librecfilter_amd.so.  torch is imported first so that both share ONE HIP runtime
+    (torch bundles its own libamdhip64 with the same SONAME as /opt/rocm's)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()); "
+            "recfilter_amd has no fallback implementation")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 before ours resolves the SONAME)
+    except Exception:  # pragma: no cover - torch is plumbing, the library works without it
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, vpp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.rf_plan_create.argtypes = [ctypes.POINTER(FilterDesc), vpp]
+    L.rf_plan_destroy.argtypes = [vp]
+    L.rf_plan_workspace_bytes.argtypes = [vp]
+    L.rf_plan_workspace_bytes.restype = ctypes.c_size_t
+    L.rf_plan_path.argtypes = [vp]
+    L.rf_plan_tiles.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    L.rf_plan_num_kernels.argtypes = [vp]
+    L.rf_plan_execute.argtypes = [vp, vpp, vpp, vp]
+    L.rf_plan_execute_timed.argtypes = [vp, vpp, vpp, vp, fp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+    L.rf_plan_num_exchanges.argtypes = [vp]
+    L.rf_plan_begin.argtypes = [vp, vpp, vpp, vp]
+    L.rf_plan_exchange_bytes.argtypes = [vp, ctypes.c_int]
+    L.rf_plan_exchange_bytes.restype = ctypes.c_size_t
+    L.rf_plan_exchange_local.argtypes = [vp, ctypes.c_int, vp]
+    L.rf_plan_exchange_apply.argtypes = [vp, ctypes.c_int, vp]
+    L.rf_plan_finish.argtypes = [vp]
+    L.rf_plan_table.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,
+                                ctypes.POINTER(ctypes.c_size_t)]
+    L.rf_gaussian_weights.argtypes = [ctypes.c_float, ctypes.c_int, fp]
+    L.rf_integral_image_coeff.argtypes = [ctypes.c_int, fp]
+    L.rf_overlap_feedback_coeff.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, fp]
+    L.rf_gaussian_box_filter.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
+    L.rf_last_error_string.restype = ctypes.c_char_p
+    L.rf_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != RF_OK:
+        raise RecFilterError(status, lib().rf_last_error_string().decode())

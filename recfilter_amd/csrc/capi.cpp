@@ -1,0 +1,268 @@
+// capi.cpp -- extern "C" entry points declared in include/recfilter_amd.h.
+#include <cmath>
+#include <complex>
+#include <cstring>
+
+#include "plan.h"
+
+namespace rf {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+namespace {
+
+int run_steps(rf_plan *plan, const std::vector<Step> &steps) {
+    for (const Step &st : steps)
+        for (int pl = 0; pl < plan->n_planes; pl++) {
+            int rc = st.run(pl);
+            if (rc != RF_OK) return rc;
+        }
+    return RF_OK;
+}
+
+int set_context(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
+    if (!plan || !in_planes || !out_planes) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    if (plan->host_only) { set_error("host-only plan (RF_DEVICE_HOST_ONLY) cannot execute"); return RF_ERR_HIP; }
+    for (int pl = 0; pl < plan->n_planes; pl++) {
+        if (!in_planes[pl] || !out_planes[pl]) { set_error("plane %d: null image pointer", pl); return RF_ERR_INVALID_ARG; }
+        plan->in[pl] = in_planes[pl];
+        plan->out[pl] = out_planes[pl];
+    }
+    plan->stream = (hipStream_t)stream;
+    RF_HIP_CHECK(hipSetDevice(plan->device));
+    return RF_OK;
+}
+
+// every step of a single-device execute, in order
+std::vector<const Step *> flat_steps(const rf_plan *plan) {
+    std::vector<const Step *> v;
+    for (const Step &s : plan->begin_steps) v.push_back(&s);
+    for (const auto &ex : plan->exchange_local_steps)
+        for (const Step &s : ex) v.push_back(&s);
+    for (const Step &s : plan->finish_steps) v.push_back(&s);
+    return v;
+}
+
+}  // namespace
+}  // namespace rf
+
+using namespace rf;
+
+extern "C" {
+
+int rf_plan_create(const rf_filter_desc *desc, rf_plan **plan_out) { return build_plan(desc, plan_out); }
+
+int rf_plan_destroy(rf_plan *plan) {
+    if (plan) {
+        if (!plan->host_only) (void)hipSetDevice(plan->device);
+        delete plan;
+    }
+    return RF_OK;
+}
+
+size_t rf_plan_workspace_bytes(const rf_plan *plan) { return plan ? plan->workspace_bytes : 0; }
+int rf_plan_path(const rf_plan *plan) { return plan ? plan->path : -1; }
+
+int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]) {
+    if (!plan || !tile_out) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    for (int d = 0; d < RF_MAX_DIMS; d++) tile_out[d] = d < plan->ndim ? plan->dims[d].T : 0;
+    return RF_OK;
+}
+
+int rf_plan_num_kernels(const rf_plan *plan) { return plan ? (int)flat_steps(plan).size() : 0; }
+int rf_plan_num_exchanges(const rf_plan *plan) { return plan ? (int)plan->exchanges.size() : 0; }
+
+int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
+    int rc = set_context(plan, in_planes, out_planes, stream);
+    if (rc) return rc;
+    if (plan->shard_world > 1) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
+    for (auto &ex : plan->exchanges) ex.send = ex.scratch;
+    for (const Step *st : flat_steps(plan))
+        for (int pl = 0; pl < plan->n_planes; pl++)
+            if ((rc = st->run(pl)) != RF_OK) return rc;
+    return RF_OK;
+}
+
+int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream,
+                          float *ms_out, const char **names_out, int capacity) {
+    int rc = set_context(plan, in_planes, out_planes, stream);
+    if (rc) return rc;
+    if (plan->shard_world > 1) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
+    for (auto &ex : plan->exchanges) ex.send = ex.scratch;
+    auto steps = flat_steps(plan);
+    if (capacity < (int)steps.size() || !ms_out) { set_error("ms_out too small: need %zu", steps.size()); return RF_ERR_INVALID_ARG; }
+    std::vector<hipEvent_t> ev(steps.size() + 1);
+    for (auto &e : ev) RF_HIP_CHECK(hipEventCreate(&e));
+    RF_HIP_CHECK(hipEventRecord(ev[0], plan->stream));
+    for (size_t i = 0; i < steps.size() && rc == RF_OK; i++) {
+        for (int pl = 0; pl < plan->n_planes && rc == RF_OK; pl++) rc = steps[i]->run(pl);
+        if (rc == RF_OK && hipEventRecord(ev[i + 1], plan->stream) != hipSuccess) rc = RF_ERR_HIP;
+    }
+    if (rc == RF_OK && hipEventSynchronize(ev.back()) != hipSuccess) rc = RF_ERR_HIP;
+    for (size_t i = 0; i < steps.size() && rc == RF_OK; i++) {
+        if (hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]) != hipSuccess) rc = RF_ERR_HIP;
+        if (names_out) names_out[i] = steps[i]->name.c_str();
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (rc == RF_ERR_HIP) set_error("HIP event timing failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
+    int rc = set_context(plan, in_planes, out_planes, stream);
+    if (rc) return rc;
+    rc = run_steps(plan, plan->begin_steps);
+    plan->phase = rc == RF_OK ? 1 : 0;
+    return rc;
+}
+
+size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange) {
+    if (!plan || exchange < 0 || exchange >= (int)plan->exchanges.size()) return 0;
+    return plan->exchanges[exchange].bytes;
+}
+
+int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send) {
+    if (!plan || plan->phase != 1) { set_error("rf_plan_exchange_local before rf_plan_begin"); return RF_ERR_STATE; }
+    if (exchange < 0 || exchange >= (int)plan->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
+    if (!send && plan->shard_world > 1) { set_error("null send buffer"); return RF_ERR_INVALID_ARG; }
+    plan->exchanges[exchange].send = send ? send : plan->exchanges[exchange].scratch;
+    return run_steps(plan, plan->exchange_local_steps[exchange]);
+}
+
+int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
+    if (!plan || plan->phase != 1) { set_error("rf_plan_exchange_apply before rf_plan_begin"); return RF_ERR_STATE; }
+    if (exchange < 0 || exchange >= (int)plan->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
+    if (plan->shard_world <= 1) return RF_OK;   // nothing comes in from a neighbour
+    if (!gathered) { set_error("null gathered buffer"); return RF_ERR_INVALID_ARG; }
+    int rc = plan->exchanges[exchange].form_incoming(gathered);
+    if (rc) return rc;
+    return run_steps(plan, plan->exchange_apply_steps[exchange]);
+}
+
+int rf_plan_finish(rf_plan *plan) {
+    if (!plan || plan->phase != 1) { set_error("rf_plan_finish before rf_plan_begin"); return RF_ERR_STATE; }
+    plan->phase = 0;
+    return run_steps(plan, plan->finish_steps);
+}
+
+int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t capacity, size_t *n_out) {
+    if (!plan || !name) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    auto it = plan->tables.find(name);
+    if (it == plan->tables.end()) { set_error("no table named '%s'", name); return RF_ERR_INVALID_ARG; }
+    if (n_out) *n_out = it->second.size();
+    if (out) {
+        if (capacity < it->second.size()) { set_error("table '%s' needs %zu doubles", name, it->second.size()); return RF_ERR_INVALID_ARG; }
+        std::memcpy(out, it->second.data(), it->second.size() * sizeof(double));
+    }
+    return RF_OK;
+}
+
+// ---- coefficient design ------------------------------------------------------------------
+// Recursive Gaussian of van Vliet, Young and Verbeek: the poles of a fixed prototype are
+// rescaled to the requested sigma, d -> |d|^(1/q) e^(i arg(d)/q) with q = 0.00399341 +
+// 0.4715161 sigma (lib/iir_coeff.cpp:38-63,83-85).  Orders 1 and 2 come from one real / one
+// complex-conjugate pole pair (:103-136); order 3 is their cascade (:150-159).  The mix of
+// float and double below mirrors the reference's declared types because its published
+// coefficient values depend on where it rounds.
+namespace {
+struct Gauss1 { float b0, a1; };
+struct Gauss2 { float b0, a1, a2; };
+
+float pole_scale(float sigma) { return (float)(0.00399341 + 0.4715161 * sigma); }
+
+Gauss1 gauss_order1(float sigma) {
+    double q = pole_scale(sigma);
+    float d = (float)std::pow(1.86543f, 1.0 / q);
+    return {(float)(-(1.0 - d) / d), (float)(-1.0 / d)};
+}
+
+Gauss2 gauss_order2(float sigma) {
+    double q = pole_scale(sigma);
+    std::complex<double> proto(1.41650, 1.00829);
+    std::complex<double> d = std::polar(std::pow(std::abs(proto), 1.0 / q), std::arg(proto) / q);
+    float n2 = (float)std::abs(d);
+    n2 *= n2;
+    float re = (float)d.real();
+    return {(float)((1.0 - 2.0 * re + n2) / n2), (float)(-2.0 * re / n2), (float)(1.0 / n2)};
+}
+}  // namespace
+
+int rf_gaussian_weights(float sigma, int order, float *coeff_out) {
+    if (!coeff_out || order < 1 || order > 3) { set_error("gaussian_weights: order must be 1..3"); return RF_ERR_INVALID_ARG; }
+    if (order == 1) {
+        Gauss1 g = gauss_order1(sigma);
+        coeff_out[0] = g.b0; coeff_out[1] = -g.a1;
+    } else if (order == 2) {
+        Gauss2 g = gauss_order2(sigma);
+        coeff_out[0] = g.b0; coeff_out[1] = -g.a1; coeff_out[2] = -g.a2;
+    } else {
+        Gauss1 g1 = gauss_order1(sigma);
+        Gauss2 g2 = gauss_order2(sigma);
+        coeff_out[0] = g1.b0 * g2.b0;
+        coeff_out[1] = -(g1.a1 + g2.a1);
+        coeff_out[2] = -(g1.a1 * g2.a1 + g2.a2);
+        coeff_out[3] = -(g1.a1 * g2.a2);
+    }
+    return RF_OK;
+}
+
+int rf_integral_image_coeff(int n, float *coeff_out) {
+    // feedback = -(binomial expansion of (1-x)^n without the constant term), lib/iir_coeff.cpp:222-234
+    if (!coeff_out || n < 1 || n > RF_MAX_ORDER) { set_error("integral_image_coeff: n must be 1..%d", RF_MAX_ORDER); return RF_ERR_INVALID_ARG; }
+    coeff_out[0] = 1.0f;
+    double binom = 1.0;
+    for (int i = 1; i <= n; i++) {
+        binom = binom * (double)(n - i + 1) / (double)i;
+        coeff_out[i] = (float)((i % 2 == 1) ? binom : -binom);
+    }
+    return RF_OK;
+}
+
+int rf_overlap_feedback_coeff(const float *a, int na, const float *b, int nb, float *c_out) {
+    // (1 - sum a_i z^-i)(1 - sum b_i z^-i) = 1 - sum c_i z^-i, lib/iir_coeff.cpp:236-263
+    if (!a || !b || !c_out || na < 1 || nb < 1) { set_error("overlap_feedback_coeff: bad arguments"); return RF_ERR_INVALID_ARG; }
+    std::vector<float> pa(na + 1), pb(nb + 1), pc(na + nb + 1, 0.0f);
+    pa[0] = pb[0] = 1.0f;
+    for (int i = 0; i < na; i++) pa[i + 1] = -a[i];
+    for (int i = 0; i < nb; i++) pb[i + 1] = -b[i];
+    for (int i = 0; i <= na; i++)
+        for (int j = 0; j <= nb; j++) pc[i + j] += pa[i] * pb[j];
+    for (int i = 1; i <= na + nb; i++) c_out[i - 1] = -pc[i];
+    return RF_OK;
+}
+
+int rf_gaussian_box_filter(int k, float sigma, int *width_out) {
+    // width of k iterated box filters approximating a Gaussian, lib/iir_coeff.cpp:205-220
+    if (!width_out || k < 1 || k > 12) { set_error("gaussian_box_filter: k must be 1..12"); return RF_ERR_INVALID_ARG; }
+    auto fact = [](int n) { int r = 1; for (int i = 2; i <= n; i++) r *= i; return r; };
+    float sum = 0.0f;
+    int limit = (int)std::floor(((float)k - 1.0f) / 2.0f);
+    for (int i = 0; i <= limit; i++) {
+        float f = (float)(fact(k) / (fact(i) * fact(k - i)));
+        float p = (float)(std::pow(-1.0, i) / (float)fact(k - 1));
+        sum += (float)(p * f * std::pow(((float)k / 2.0 - i), k - 1));
+    }
+    sum = (float)(std::sqrt(2.0 * M_PI) * (sum + 0.005f) * sigma);
+    *width_out = (int)std::ceil(sum);
+    return RF_OK;
+}
+
+const char *rf_last_error_string(void) { return g_last_error.c_str(); }
+const char *rf_version(void) { return "recfilter_amd 0.1 (gfx950)"; }
+
+int rf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

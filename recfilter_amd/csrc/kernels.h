@@ -1,0 +1,69 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (definitions in *.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pixel.h"
+#include "rf_internal.h"
+
+namespace rf {
+
+// Device-side description of one scan, in the pixel's arithmetic type.
+template <typename Acc>
+struct DevScan {
+    int32_t causal;
+    int32_t order;
+    Acc b;
+    Acc a[RF_MAX_ORDER];
+};
+
+// Geometry of "lines along one dimension" of a dense x-fastest array:
+//   element (line, i) lives at  (line / inner) * n * inner + (line % inner) + i * inner
+struct LineGeom {
+    int64_t n;       // extent of the filtered dimension
+    int64_t inner;   // stride of the filtered dimension (product of lower extents)
+    int64_t lines;   // number of lines = total / n
+};
+
+// ---- untiled path: one serial recurrence per line (kernels_generic.hip) -------------------
+template <typename P>
+int launch_untiled_scan(const P *in, P *out, LineGeom g, const DevScan<typename PixelTraits<P>::Acc> &sc,
+                        bool clamped, hipStream_t stream);
+
+// ---- generic tiled path, any tile width T <= kGenericMaxTile dividing n -------------------
+constexpr int kGenericMaxTile = 128;
+
+template <typename Acc>
+struct GenericDimArgs {
+    LineGeom g;
+    int32_t T;          // tile width
+    int32_t M;          // tiles per line
+    int32_t k;          // max order in the dimension
+    int32_t n_scans;
+    int32_t clamped;
+    int32_t first_is_border;   // this slab holds the image's first tile along the dimension
+    int32_t last_is_border;    // ... the last tile
+    const DevScan<Acc> *scans; // n_scans entries (device)
+    Acc *tails;                // [scan][tile][r][line]
+    Acc *incoming;             // [scan][r][line]   carry entering the slab (zeros at the image border)
+    const Acc *W;              // [variant 4][q][s][r][o]   (q < s used)
+    const Acc *A;              // [s][r][j]
+};
+
+template <typename P>
+int launch_generic_pass1(const P *src, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream);
+template <typename Acc>
+int launch_generic_carry_scan(GenericDimArgs<Acc> a, int s, Acc *send /* [r][line] or null */, hipStream_t stream);
+template <typename Acc>
+int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream);
+// incoming[s] = sum over the slabs before this one (in scan direction) of (A^M)^(distance-1) * their exit tails
+template <typename Acc>
+int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, int64_t rank_stride,
+                           int64_t plane_offset, int rank, int world, const Acc *AM /* k*k device */,
+                           hipStream_t stream);
+template <typename P>
+int launch_generic_pass2(const P *src, P *dst, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream);
+
+}  // namespace rf

@@ -1,0 +1,322 @@
+// kernels_generic.hip -- shape-agnostic gfx950 kernels.
+//
+//  * untiled_scan      one serial recurrence per line: the operator of
+//                      RecFilter::add_filter (lib/recfilter.cpp:302-343) executed literally.
+//                      This is what the reference runs for a filter that was never split()
+//                      (gpu_auto_full_schedule, lib/recfilter.cpp:692-760).
+//  * generic_pass1/carry/pass2
+//                      the tiled algorithm of lib/split.cpp for ONE dimension at a time with a
+//                      run-time tile width: intra-tile scans + tail extraction
+//                      (create_intra_tile_term :503-665, extract_tails_from_each_scan :256-499),
+//                      cross-tile carry recurrence with same-dimension chaining
+//                      (create_complete_tail_term :743-867, create_tail_residual_term :912-1004)
+//                      and the final correction pass (create_final_residual_term :1008-1130,
+//                      add_residuals_to_final_result :1647-1780).
+//
+// These are the always-correct paths (any extent, any tile that divides it, any pixel type,
+// order <= RF_MAX_ORDER).  The bandwidth-tuned path is kernels_fused.hip.
+#include "kernels.h"
+
+namespace rf {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int64_t line_base(const LineGeom &g, int64_t line) {
+    return (line / g.inner) * g.n * g.inner + (line % g.inner);
+}
+
+// One in-tile scan step shared by every kernel in this file.  hist[j] is the output at
+// direction position p-1-j (from this tile or from the carry), y0 the first output of a
+// clamped border tile.
+template <typename Acc>
+__device__ __forceinline__ Acc scan_step(Acc x, int p, const DevScan<Acc> &sc, int k, bool clamp_first,
+                                         Acc (&hist)[RF_MAX_ORDER], Acc &y0) {
+    Acc acc = sc.b * x;
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) {
+        if (j < k) {
+            Acc g = hist[j];
+            if (clamp_first && p <= j) g = (p == 0) ? x : y0;
+            acc = acc + sc.a[j] * g;
+        }
+    }
+#pragma unroll
+    for (int j = RF_MAX_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+    hist[0] = acc;
+    if (p == 0) y0 = acc;
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename P>
+__global__ void __launch_bounds__(kBlock)
+untiled_scan_kernel(const P *__restrict__ in, P *__restrict__ out, LineGeom g,
+                    DevScan<typename PixelTraits<P>::Acc> sc, int clamped) {
+    using Tr = PixelTraits<P>;
+    using Acc = typename Tr::Acc;
+    int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= g.lines) return;
+    int64_t base = line_base(g, line);
+    Acc hist[RF_MAX_ORDER];
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) hist[j] = Acc(0);
+    Acc y0 = Acc(0);
+    for (int64_t r = 0; r < g.n; r++) {
+        int64_t i = sc.causal ? r : g.n - 1 - r;
+        int p = r < RF_MAX_ORDER ? (int)r : RF_MAX_ORDER;  // only p <= j matters
+        Acc x = Tr::load(in[base + i * g.inner]);
+        Acc y = scan_step<Acc>(x, p, sc, sc.order, clamped != 0, hist, y0);
+        out[base + i * g.inner] = Tr::store(y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic tiled path.  tails index: ((s*M + t)*k + r)*lines + line
+template <typename Acc>
+__device__ __forceinline__ int64_t tail_idx(const GenericDimArgs<Acc> &a, int s, int t, int r, int64_t line) {
+    return (((int64_t)s * a.M + t) * a.k + r) * a.g.lines + line;
+}
+
+template <typename Acc>
+__device__ __forceinline__ bool tile_is_first(const GenericDimArgs<Acc> &a, bool causal, int t) {
+    return causal ? (t == 0) : (t == a.M - 1);
+}
+// the tile is the image's first tile in the scan direction (clamped prologue applies)
+template <typename Acc>
+__device__ __forceinline__ bool tile_is_border(const GenericDimArgs<Acc> &a, bool causal, int t) {
+    return causal ? (t == 0 && a.first_is_border) : (t == a.M - 1 && a.last_is_border);
+}
+template <typename Acc>
+__device__ __forceinline__ int tile_variant(const GenericDimArgs<Acc> &a, int t) {
+    return ((t == 0 && a.first_is_border) ? 1 : 0) | ((t == a.M - 1 && a.last_is_border) ? 2 : 0);
+}
+
+// carry entering tile t for scan s: complete tail of the previous tile, or the slab's incoming carry
+template <typename Acc>
+__device__ __forceinline__ void load_carry(const GenericDimArgs<Acc> &a, int s, bool causal, int t, int64_t line,
+                                           Acc (&c)[RF_MAX_ORDER]) {
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) c[j] = Acc(0);
+    if (tile_is_first(a, causal, t)) {
+        for (int j = 0; j < a.k; j++) c[j] = a.incoming[((int64_t)s * a.k + j) * a.g.lines + line];
+    } else {
+        int tp = causal ? t - 1 : t + 1;
+        for (int j = 0; j < a.k; j++) c[j] = a.tails[tail_idx(a, s, tp, j, line)];
+    }
+}
+
+template <typename P, bool kFinal>
+__global__ void __launch_bounds__(kBlock)
+generic_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, GenericDimArgs<typename PixelTraits<P>::Acc> a) {
+    using Tr = PixelTraits<P>;
+    using Acc = typename Tr::Acc;
+    int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= a.g.lines * a.M) return;
+    int64_t line = idx % a.g.lines;
+    int t = (int)(idx / a.g.lines);
+    int64_t base = line_base(a.g, line) + (int64_t)t * a.T * a.g.inner;
+
+    Acc v[kGenericMaxTile];
+    for (int m = 0; m < a.T; m++) v[m] = Tr::load(src[base + m * a.g.inner]);
+
+    for (int s = 0; s < a.n_scans; s++) {
+        DevScan<Acc> sc = a.scans[s];
+        bool causal = sc.causal != 0;
+        bool clamp_first = a.clamped && tile_is_border(a, causal, t);
+        Acc hist[RF_MAX_ORDER];
+#pragma unroll
+        for (int j = 0; j < RF_MAX_ORDER; j++) hist[j] = Acc(0);
+        if (kFinal) load_carry(a, s, causal, t, line, hist);
+        Acc y0 = Acc(0);
+        for (int p = 0; p < a.T; p++) {
+            int m = causal ? p : a.T - 1 - p;
+            v[m] = scan_step<Acc>(v[m], p < RF_MAX_ORDER ? p : RF_MAX_ORDER, sc, a.k, clamp_first, hist, y0);
+        }
+        if (!kFinal) {
+            // tail r = value at direction position T-1-r, extracted right after the scan
+            for (int r = 0; r < a.k; r++) {
+                int p = a.T - 1 - r;
+                int m = causal ? p : a.T - 1 - p;
+                a.tails[tail_idx(a, s, t, r, line)] = v[m];
+            }
+        }
+    }
+    if (kFinal) {
+        for (int m = 0; m < a.T; m++) dst[base + m * a.g.inner] = Tr::store(v[m]);
+    }
+}
+
+// one scan of the carry stage: same-dimension chaining, then the recurrence along the tiles
+template <typename Acc>
+__global__ void __launch_bounds__(kBlock)
+generic_carry_scan_kernel(GenericDimArgs<Acc> a, int s, Acc *__restrict__ send) {
+    int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int k = a.k;
+    const bool causal = a.scans[s].causal != 0;
+    Acc prev[RF_MAX_ORDER];
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) prev[j] = Acc(0);
+    for (int i = 0; i < a.M; i++) {
+        int t = causal ? i : a.M - 1 - i;
+        int v = tile_variant(a, t);
+        Acc cur[RF_MAX_ORDER];
+#pragma unroll
+        for (int j = 0; j < RF_MAX_ORDER; j++) cur[j] = Acc(0);
+        for (int r = 0; r < k; r++) cur[r] = a.tails[tail_idx(a, s, t, r, line)];
+        // chaining from the scans applied earlier in this dimension
+        for (int q = 0; q < s; q++) {
+            bool qc = a.scans[q].causal != 0;
+            Acc c[RF_MAX_ORDER];
+            load_carry(a, q, qc, t, line, c);
+            const Acc *W = a.W + ((((int64_t)v * a.n_scans + q) * a.n_scans + s) * k) * k;
+            for (int r = 0; r < k; r++)
+                for (int o = 0; o < k; o++) cur[r] = cur[r] + W[r * k + o] * c[o];
+        }
+        // recurrence: tail(t) += A * tail(prev); the slab's incoming carry is added by carry_apply
+        const Acc *A = a.A + (int64_t)s * k * k;
+        if (i > 0) {
+            for (int r = 0; r < k; r++)
+                for (int j = 0; j < k; j++) cur[r] = cur[r] + A[r * k + j] * prev[j];
+        }
+        for (int r = 0; r < k; r++) {
+            a.tails[tail_idx(a, s, t, r, line)] = cur[r];
+            prev[r] = cur[r];
+        }
+    }
+    if (send) {
+        for (int r = 0; r < k; r++) send[(int64_t)r * a.g.lines + line] = prev[r];
+    }
+}
+
+// add the effect of the slab's incoming carry to every tile's complete tail
+template <typename Acc>
+__global__ void __launch_bounds__(kBlock)
+generic_carry_apply_kernel(GenericDimArgs<Acc> a, int s) {
+    int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int k = a.k;
+    const bool causal = a.scans[s].causal != 0;
+    const Acc *A = a.A + (int64_t)s * k * k;
+    Acc x[RF_MAX_ORDER];
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
+    for (int j = 0; j < k; j++) x[j] = a.incoming[((int64_t)s * k + j) * a.g.lines + line];
+    for (int i = 0; i < a.M; i++) {
+        int t = causal ? i : a.M - 1 - i;
+        Acc nx[RF_MAX_ORDER];
+#pragma unroll
+        for (int j = 0; j < RF_MAX_ORDER; j++) nx[j] = Acc(0);
+        for (int r = 0; r < k; r++)
+            for (int j = 0; j < k; j++) nx[r] = nx[r] + A[r * k + j] * x[j];
+        for (int r = 0; r < k; r++) {
+            a.tails[tail_idx(a, s, t, r, line)] = a.tails[tail_idx(a, s, t, r, line)] + nx[r];
+            x[r] = nx[r];
+        }
+    }
+}
+
+template <typename Acc>
+__global__ void __launch_bounds__(kBlock)
+gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gathered, int64_t rank_stride,
+                       int64_t plane_offset, int rank, int world, const Acc *__restrict__ AM) {
+    int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int k = a.k;
+    const bool causal = a.scans[s].causal != 0;
+    Acc x[RF_MAX_ORDER];
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
+    // walk the slabs that precede this one in scan direction, nearest last
+    int count = causal ? rank : world - 1 - rank;
+    for (int i = 0; i < count; i++) {
+        int h = causal ? i : world - 1 - i;
+        Acc nx[RF_MAX_ORDER];
+#pragma unroll
+        for (int j = 0; j < RF_MAX_ORDER; j++) nx[j] = Acc(0);
+        for (int r = 0; r < k; r++) {
+            Acc acc = gathered[h * rank_stride + plane_offset + (int64_t)r * a.g.lines + line];
+            for (int j = 0; j < k; j++) acc = acc + AM[r * k + j] * x[j];
+            nx[r] = acc;
+        }
+        for (int r = 0; r < k; r++) x[r] = nx[r];
+    }
+    for (int r = 0; r < k; r++) a.incoming[((int64_t)s * k + r) * a.g.lines + line] = x[r];
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+template <typename P>
+int launch_untiled_scan(const P *in, P *out, LineGeom g, const DevScan<typename PixelTraits<P>::Acc> &sc,
+                        bool clamped, hipStream_t stream) {
+    if (g.lines <= 0 || g.n <= 0) return RF_OK;
+    hipLaunchKernelGGL(untiled_scan_kernel<P>, dim3(grid_for(g.lines)), dim3(kBlock), 0, stream, in, out, g, sc,
+                       clamped ? 1 : 0);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename P>
+int launch_generic_pass1(const P *src, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream) {
+    hipLaunchKernelGGL((generic_pass_kernel<P, false>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
+                       (P *)nullptr, a);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename P>
+int launch_generic_pass2(const P *src, P *dst, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream) {
+    hipLaunchKernelGGL((generic_pass_kernel<P, true>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
+                       dst, a);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename Acc>
+int launch_generic_carry_scan(GenericDimArgs<Acc> a, int s, Acc *send, hipStream_t stream) {
+    hipLaunchKernelGGL(generic_carry_scan_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s, send);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename Acc>
+int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream) {
+    hipLaunchKernelGGL(generic_carry_apply_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename Acc>
+int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, int64_t rank_stride,
+                           int64_t plane_offset, int rank, int world, const Acc *AM, hipStream_t stream) {
+    hipLaunchKernelGGL(gather_incoming_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s, gathered,
+                       rank_stride, plane_offset, rank, world, AM);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+// explicit instantiations ----------------------------------------------------------------
+#define RF_INSTANTIATE_PIXEL(P)                                                                                    \
+    template int launch_untiled_scan<P>(const P *, P *, LineGeom, const DevScan<PixelTraits<P>::Acc> &, bool,      \
+                                        hipStream_t);                                                              \
+    template int launch_generic_pass1<P>(const P *, GenericDimArgs<PixelTraits<P>::Acc>, hipStream_t);             \
+    template int launch_generic_pass2<P>(const P *, P *, GenericDimArgs<PixelTraits<P>::Acc>, hipStream_t);
+RF_INSTANTIATE_PIXEL(float)
+RF_INSTANTIATE_PIXEL(double)
+RF_INSTANTIATE_PIXEL(int32_t)
+RF_INSTANTIATE_PIXEL(int16_t)
+
+#define RF_INSTANTIATE_ACC(Acc)                                                                                    \
+    template int launch_generic_carry_scan<Acc>(GenericDimArgs<Acc>, int, Acc *, hipStream_t);                     \
+    template int launch_generic_carry_apply<Acc>(GenericDimArgs<Acc>, int, hipStream_t);                           \
+    template int launch_gather_incoming<Acc>(GenericDimArgs<Acc>, int, const Acc *, int64_t, int64_t, int, int,    \
+                                             const Acc *, hipStream_t);
+RF_INSTANTIATE_ACC(float)
+RF_INSTANTIATE_ACC(double)
+RF_INSTANTIATE_ACC(uint32_t)
+
+}  // namespace rf

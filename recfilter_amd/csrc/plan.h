@@ -1,0 +1,86 @@
+// plan.h -- the execution plan behind the C ABI (host side).
+#pragma once
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "rf_internal.h"
+#include "tables.h"
+
+namespace rf {
+
+struct DimInfo {
+    int64_t N = 1;        // local extent
+    int64_t stride = 1;   // elements between neighbours along the dimension
+    int64_t lines = 1;    // total / N
+    int T = 0;            // tile width (0 = dimension not tiled / no scans)
+    int64_t M = 0;        // tiles
+    int k = 0;            // max feedback order of the scans in this dimension
+    std::vector<int> scan_ids;  // indices into Plan::scans (application order)
+};
+
+// One kernel launch (or a small fixed group of them) of a plan.
+struct Step {
+    std::string name;
+    std::function<int(int plane)> run;   // launches on Plan::stream for one plane
+};
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace rf
+
+struct rf_plan {
+    // description
+    int ndim = 0;
+    int dtype = RF_F32;
+    int n_planes = 1;
+    bool clamped = false;
+    int path = RF_PATH_UNTILED;
+    int device = 0;
+    bool host_only = false;               // tables only, no device memory, cannot execute
+    int shard_rank = 0, shard_world = 1;
+    std::vector<rf::Scan> scans;          // grouped by dimension, otherwise in call order
+    rf::DimInfo dims[RF_MAX_DIMS];
+    int64_t total = 1;                    // elements per plane
+
+    // device memory owned by the plan
+    std::vector<rf::DeviceBuffer> buffers;
+    size_t workspace_bytes = 0;
+
+    // steps
+    std::vector<rf::Step> begin_steps;                       // pass 1 + slab-local carry stages
+    std::vector<std::vector<rf::Step>> exchange_local_steps; // per exchange
+    std::vector<std::vector<rf::Step>> exchange_apply_steps; // per exchange (after gather)
+    std::vector<rf::Step> finish_steps;                      // final correction pass
+    struct Exchange {
+        void *send = nullptr;      // caller's buffer for the current call, [plane][r][line]
+        void *scratch = nullptr;   // plan-owned buffer used when the caller passes none (single device)
+        size_t bytes = 0;          // per rank
+        std::function<int(const void *gathered)> form_incoming;  // launches gather kernels
+    };
+    std::vector<Exchange> exchanges;
+
+    // per-execute context
+    const void *in[RF_MAX_PLANES] = {nullptr};
+    void *out[RF_MAX_PLANES] = {nullptr};
+    hipStream_t stream = nullptr;
+    int phase = 0;   // 0 idle, 1 begun
+
+    // host tables exposed through rf_plan_table
+    std::map<std::string, std::vector<double>> tables;
+
+    ~rf_plan();
+    void *alloc(size_t bytes, bool zero, int *status);
+    void *upload(const void *host, size_t bytes, int *status);
+};
+
+namespace rf {
+int build_plan(const rf_filter_desc *desc, rf_plan **out);
+}

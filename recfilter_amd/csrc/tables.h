@@ -1,0 +1,159 @@
+// tables.h -- the tiling algebra as host-side tables.
+//
+// This replaces the symbolic Func-graph rewriting of the reference's lib/split.cpp and the
+// float matrices of lib/coefficients.cpp with a handful of small dense tables per filtered
+// dimension.  Every table is produced by *running the scan recurrence on short vectors*
+// (unit carries, unit inputs), never by a closed-form matrix expression, so the tables are
+// consistent with what the kernels do by construction -- including the clamped-border
+// prologue, where the reference's matrix_B(clamp) (lib/coefficients.cpp:38-39) differs from
+// its own add_filter semantics (lib/recfilter.cpp:330-336) by ~1e-8.
+//
+// Notation (one filtered dimension, tile width T, scans s = 0..n-1 in application order,
+// k = max feedback order in the dimension, shorter scans zero-padded as lib/split.cpp:575-578):
+//   memory position m in [0,T); "direction position" p = m (causal) or T-1-m (anticausal)
+//   carry c[j], j<k  = value at direction position -1-j (the j-th element before the tile)
+//   tail  t[r], r<k  = value at direction position T-1-r   (what the next tile receives)
+//
+//   prop[v][q][s]  (T x k, s >= q, memory rows)   effect on the tile, after scans q..s, of the
+//                   carry entering scan q:   F_s ... F_{q+1} R_q       (lib/split.cpp:152-203)
+//   A[s]           (k x k)  tail rows of prop[.][s][s]: carry -> next carry (lib/split.cpp:770,832)
+//   W[v][q][s]     (k x k)  tail rows (in scan s's direction) of prop[v][q][s], q < s
+//                                                                      (lib/split.cpp:912-1004)
+//   v = border variant of the tile: bit0 = tile is first along the dimension, bit1 = last;
+//   it selects the clamped prologue for the scans whose first tile it is (lib/split.cpp:634-647).
+//
+// The scalar type S is double for floating pixel types and uint64_t (wrap-around ring
+// arithmetic) for integer pixel types, so integer filters stay bit-exact modulo 2^32/2^16
+// however large the true table entries grow.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "rf_internal.h"
+
+namespace rf {
+
+template <typename S>
+struct ScanS {
+    bool causal;
+    S b;
+    S a[RF_MAX_ORDER];
+};
+
+// In-place scan of one tile in memory order -- the operator of lib/recfilter.cpp:321-343
+// restricted to a tile (lib/split.cpp:628-654).
+//   carry      != nullptr : history before the tile (zero-border form), carry[j] = y[-1-j]
+//   clamp_first            : the tile is the first one in the scan's direction of a clamped image
+template <typename S>
+inline void scan_tile(S *v, int T, int k, const ScanS<S> &sc, bool clamp_first, const S *carry) {
+    S hist[RF_MAX_ORDER];
+    for (int j = 0; j < k; j++) hist[j] = carry ? carry[j] : S(0);
+    S y0 = S(0);
+    for (int p = 0; p < T; p++) {
+        int m = sc.causal ? p : T - 1 - p;
+        S x = v[m];
+        S acc = sc.b * x;
+        for (int j = 0; j < k; j++) {
+            S g;
+            if (p > j) g = hist[j];
+            else if (clamp_first) g = (p == 0) ? x : y0;
+            else g = hist[j];  // carry from the previous tile (zero when there is none)
+            acc = acc + sc.a[j] * g;
+        }
+        for (int j = k - 1; j > 0; j--) hist[j] = hist[j - 1];
+        hist[0] = acc;
+        if (p == 0) y0 = acc;
+        v[m] = acc;
+    }
+}
+
+template <typename S>
+struct DimTables {
+    int T = 0, k = 0, n = 0;
+    std::vector<ScanS<S>> scans;
+    // prop[((v*n + q)*n + s)] is a T*k row-major matrix (valid for s >= q)
+    std::vector<std::vector<S>> prop;
+    std::vector<std::vector<S>> A;   // n matrices k*k, A[s][r*k + j]
+    std::vector<std::vector<S>> W;   // 4*n*n matrices k*k, W[(v*n+q)*n+s][r*k + o] (q < s)
+
+    const std::vector<S> &P(int v, int q, int s) const { return prop[(v * n + q) * n + s]; }
+    const std::vector<S> &Wm(int v, int q, int s) const { return W[(v * n + q) * n + s]; }
+};
+
+inline bool variant_clamps(int v, bool causal) { return causal ? (v & 1) != 0 : (v & 2) != 0; }
+
+template <typename S>
+DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, bool clamped) {
+    DimTables<S> t;
+    t.T = T; t.k = k; t.n = (int)scans.size(); t.scans = scans;
+    const int n = t.n;
+    t.prop.assign(4 * n * n, {});
+    t.W.assign(4 * n * n, {});
+    t.A.assign(n, std::vector<S>(k * k, S(0)));
+    std::vector<S> col(T);
+    for (int v = 0; v < 4; v++) {
+        for (int q = 0; q < n; q++) {
+            // R_q: response of an all-zero tile to a unit carry e_o
+            std::vector<std::vector<S>> cols(k, std::vector<S>(T, S(0)));
+            for (int o = 0; o < k; o++) {
+                S carry[RF_MAX_ORDER];
+                for (int j = 0; j < k; j++) carry[j] = (j == o) ? S(1) : S(0);
+                scan_tile<S>(cols[o].data(), T, k, scans[q], false, carry);
+            }
+            for (int s = q; s < n; s++) {
+                if (s > q) {
+                    bool cl = clamped && variant_clamps(v, scans[s].causal);
+                    for (int o = 0; o < k; o++) scan_tile<S>(cols[o].data(), T, k, scans[s], cl, nullptr);
+                }
+                std::vector<S> &P = t.prop[(v * n + q) * n + s];
+                P.assign((size_t)T * k, S(0));
+                for (int m = 0; m < T; m++)
+                    for (int o = 0; o < k; o++) P[(size_t)m * k + o] = cols[o][m];
+                // tail rows in the direction of scan s
+                std::vector<S> tail(k * k);
+                for (int r = 0; r < k; r++) {
+                    int p = T - 1 - r;
+                    int m = scans[s].causal ? p : T - 1 - p;
+                    for (int o = 0; o < k; o++) tail[r * k + o] = cols[o][m];
+                }
+                if (s == q) { if (v == 0) t.A[q] = tail; }
+                else t.W[(v * n + q) * n + s] = tail;
+            }
+        }
+    }
+    return t;
+}
+
+// k x k helpers ------------------------------------------------------------------------
+template <typename S>
+inline std::vector<S> mat_mul(const std::vector<S> &X, const std::vector<S> &Y, int k) {
+    std::vector<S> Z(k * k, S(0));
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            S acc = S(0);
+            for (int l = 0; l < k; l++) acc = acc + X[i * k + l] * Y[l * k + j];
+            Z[i * k + j] = acc;
+        }
+    return Z;
+}
+
+template <typename S>
+inline std::vector<S> mat_identity(int k) {
+    std::vector<S> I(k * k, S(0));
+    for (int i = 0; i < k; i++) I[i * k + i] = S(1);
+    return I;
+}
+
+template <typename S>
+inline std::vector<S> mat_pow(const std::vector<S> &X, long long e, int k) {
+    std::vector<S> R = mat_identity<S>(k), B = X;
+    while (e > 0) {
+        if (e & 1) R = mat_mul(R, B, k);
+        B = mat_mul(B, B, k);
+        e >>= 1;
+    }
+    return R;
+}
+
+}  // namespace rf

@@ -1,0 +1,225 @@
+"""Plan: thin Python handle over rf_plan_* (include/recfilter_amd.h).
+
+Images are torch CUDA(HIP) tensors used purely as device memory: a tensor of shape
+(..., z, y, x), C-contiguous, is the reference's dense x-fastest buffer
+(/root/reference lib/recfilter.cpp:969-981).  All arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+
+Scan = Tuple[int, bool, Sequence[float]]   # (dim, causal, [feedfwd, fb1..fbk]); dim 0 = x
+
+_NP_DTYPES = {np.dtype(np.float32): capi.RF_F32, np.dtype(np.float64): capi.RF_F64,
+              np.dtype(np.int32): capi.RF_I32, np.dtype(np.int16): capi.RF_I16}
+
+
+def _dtype_code(dtype) -> int:
+    try:
+        import torch
+        if isinstance(dtype, torch.dtype):
+            dtype = {torch.float32: np.float32, torch.float64: np.float64,
+                     torch.int32: np.int32, torch.int16: np.int16}[dtype]
+    except ImportError:  # pragma: no cover
+        pass
+    except KeyError:
+        raise TypeError(f"unsupported pixel type {dtype}")
+    dt = np.dtype(dtype)
+    if dt not in _NP_DTYPES:
+        raise TypeError(f"unsupported pixel type {dt}")
+    return _NP_DTYPES[dt]
+
+
+class Plan:
+    """One tiled (or untiled) recursive filter on one device: rf_plan_create .. rf_plan_destroy."""
+
+    def __init__(self, shape: Sequence[int], scans: Sequence[Scan], dtype=np.float32, clamped: bool = False,
+                 planes: int = 1, tile: Optional[Sequence[int]] = None, path: int = capi.RF_PATH_AUTO,
+                 device: int = -1, shard_rank: int = 0, shard_world: int = 1):
+        L = capi.lib()
+        shape = tuple(int(s) for s in shape)
+        if not 1 <= len(shape) <= capi.RF_MAX_DIMS:
+            raise ValueError(f"1..{capi.RF_MAX_DIMS} dimensions supported, got shape {shape}")
+        scans = list(scans)
+        self._scan_arr = (capi.ScanDesc * max(len(scans), 1))()
+        for i, (dim, causal, coeff) in enumerate(scans):
+            coeff = [float(c) for c in coeff]
+            if len(coeff) < 2:
+                # lib/recfilter.cpp:274-278
+                raise ValueError("cannot add a scan without feed forward and feedback coefficients")
+            if len(coeff) - 1 > capi.RF_MAX_ORDER:
+                raise ValueError(f"filter order {len(coeff) - 1} exceeds RF_MAX_ORDER={capi.RF_MAX_ORDER}")
+            s = self._scan_arr[i]
+            s.dim, s.causal, s.order, s.feedfwd = int(dim), int(bool(causal)), len(coeff) - 1, coeff[0]
+            for j, c in enumerate(coeff[1:]):
+                s.feedback[j] = c
+        d = capi.FilterDesc()
+        d.ndim = len(shape)
+        for i, e in enumerate(reversed(shape)):      # numpy (z,y,x) -> extent[0] = x
+            d.extent[i] = e
+        d.dtype = _dtype_code(dtype)
+        d.n_planes = int(planes)
+        d.border = capi.RF_BORDER_CLAMP if clamped else capi.RF_BORDER_ZERO
+        d.n_scans = len(scans)
+        d.scans = ctypes.cast(self._scan_arr, ctypes.POINTER(capi.ScanDesc))
+        if tile is not None:
+            tile = list(tile)
+            if len(tile) != len(shape):
+                raise ValueError("tile needs one entry per dimension, in (x, y, z) order")
+            for i, t in enumerate(tile):
+                d.tile[i] = int(t)
+        d.path = int(path)
+        d.device = int(device)
+        d.shard_rank, d.shard_world = int(shard_rank), int(shard_world)
+        self._desc = d
+        self.shape = shape
+        self.planes = int(planes)
+        self.np_dtype = np.dtype({capi.RF_F32: np.float32, capi.RF_F64: np.float64,
+                                  capi.RF_I32: np.int32, capi.RF_I16: np.int16}[d.dtype])
+        self.shard_world = int(shard_world)
+        self._h = ctypes.c_void_p()
+        capi.check(L.rf_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            capi.lib().rf_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- queries ----------------------------------------------------------------------------
+    @property
+    def path(self) -> int:
+        return capi.lib().rf_plan_path(self._h)
+
+    @property
+    def path_name(self) -> str:
+        return capi.PATH_NAMES.get(self.path, "?")
+
+    @property
+    def tiles(self) -> Tuple[int, ...]:
+        t = (ctypes.c_int32 * capi.RF_MAX_DIMS)()
+        capi.check(capi.lib().rf_plan_tiles(self._h, t))
+        return tuple(t[: len(self.shape)])
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(capi.lib().rf_plan_workspace_bytes(self._h))
+
+    @property
+    def num_kernels(self) -> int:
+        return int(capi.lib().rf_plan_num_kernels(self._h))
+
+    @property
+    def num_exchanges(self) -> int:
+        return int(capi.lib().rf_plan_num_exchanges(self._h))
+
+    def table(self, name: str) -> np.ndarray:
+        n = ctypes.c_size_t()
+        capi.check(capi.lib().rf_plan_table(self._h, name.encode(), None, 0, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        capi.check(capi.lib().rf_plan_table(self._h, name.encode(),
+                                            out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n.value, None))
+        return out
+
+    # -- execution --------------------------------------------------------------------------
+    def _pointers(self, tensors) -> ctypes.Array:
+        if len(tensors) != self.planes:
+            raise ValueError(f"expected {self.planes} planes, got {len(tensors)}")
+        arr = (ctypes.c_void_p * self.planes)()
+        for i, t in enumerate(tensors):
+            if tuple(t.shape) != self.shape:
+                raise ValueError(f"plane {i}: shape {tuple(t.shape)} != plan shape {self.shape}")
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("planes must be contiguous device tensors")
+            if _dtype_code(t.dtype) != self._desc.dtype:
+                raise TypeError(f"plane {i}: dtype {t.dtype} does not match the plan")
+            arr[i] = t.data_ptr()
+        return arr
+
+    @staticmethod
+    def _stream(stream) -> ctypes.c_void_p:
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def execute(self, inputs, outputs=None, stream=None):
+        """rf_plan_execute: asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        if outputs is None:
+            outputs = [torch.empty_like(t) for t in inputs]
+        pin, pout = self._pointers(inputs), self._pointers(outputs)
+        capi.check(capi.lib().rf_plan_execute(self._h, pin, pout, self._stream(stream)))
+        return outputs
+
+    def execute_timed(self, inputs, outputs=None, stream=None):
+        """rf_plan_execute_timed: returns (outputs, [(kernel name, ms), ...]) measured with HIP events."""
+        import torch
+        if outputs is None:
+            outputs = [torch.empty_like(t) for t in inputs]
+        pin, pout = self._pointers(inputs), self._pointers(outputs)
+        n = self.num_kernels
+        ms = (ctypes.c_float * max(n, 1))()
+        names = (ctypes.c_char_p * max(n, 1))()
+        capi.check(capi.lib().rf_plan_execute_timed(self._h, pin, pout, self._stream(stream), ms, names, n))
+        return outputs, [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    # stepping API (sharded execution) ---------------------------------------------------------
+    def begin(self, inputs, outputs, stream=None):
+        pin, pout = self._pointers(inputs), self._pointers(outputs)
+        capi.check(capi.lib().rf_plan_begin(self._h, pin, pout, self._stream(stream)))
+
+    def exchange_bytes(self, i: int) -> int:
+        return int(capi.lib().rf_plan_exchange_bytes(self._h, i))
+
+    def exchange_local(self, i: int, send_ptr: int = 0) -> None:
+        """Slab-local recurrence of exchange i; writes the slab's exit carry to the device buffer `send_ptr`."""
+        capi.check(capi.lib().rf_plan_exchange_local(self._h, i, ctypes.c_void_p(send_ptr or None)))
+
+    def exchange_apply(self, i: int, gathered_ptr: int) -> None:
+        capi.check(capi.lib().rf_plan_exchange_apply(self._h, i, ctypes.c_void_p(gathered_ptr)))
+
+    def finish(self):
+        capi.check(capi.lib().rf_plan_finish(self._h))
+
+
+# ---- coefficient design (lib/iir_coeff.cpp) ---------------------------------------------------
+def gaussian_weights(sigma: float, order: int) -> List[float]:
+    out = (ctypes.c_float * (order + 1))()
+    capi.check(capi.lib().rf_gaussian_weights(float(sigma), int(order), out))
+    return [float(v) for v in out]
+
+
+def integral_image_coeff(n: int) -> List[float]:
+    out = (ctypes.c_float * (n + 1))()
+    capi.check(capi.lib().rf_integral_image_coeff(int(n), out))
+    return [float(v) for v in out]
+
+
+def overlap_feedback_coeff(a: Sequence[float], b: Sequence[float]) -> List[float]:
+    fa, fb = (ctypes.c_float * len(a))(*a), (ctypes.c_float * len(b))(*b)
+    out = (ctypes.c_float * (len(a) + len(b)))()
+    capi.check(capi.lib().rf_overlap_feedback_coeff(fa, len(a), fb, len(b), out))
+    return [float(v) for v in out]
+
+
+def gaussian_box_filter(k: int, sigma: float) -> int:
+    w = ctypes.c_int()
+    capi.check(capi.lib().rf_gaussian_box_filter(int(k), float(sigma), ctypes.byref(w)))
+    return int(w.value)

@@ -1,0 +1,202 @@
+"""CPU tests of the product's host side: the C-ABI library loads, exports every symbol the header
+declares, its coefficient design matches the reference's values, its argument checks mirror the
+reference's, and its plan tables (the tiling algebra) reproduce the untiled oracle when replayed by
+the numpy emulator.  No kernel is launched here (no GPU in this container)."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import ref_cases as rc
+import tiled_emulator as emu
+import recfilter_amd as rfa
+from recfilter_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "recfilter_amd.h")).read()
+    declared = set(re.findall(r"\b(rf_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+    L = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.rf_version()
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    if capi.lib().rf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(rfa.RecFilterError) as e:
+        rfa.Plan((16, 16), [(0, True, [1.0, 1.0])])
+    assert e.value.status == capi.RF_ERR_HIP
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_gaussian_weights_match_reference_values(order):
+    got = rfa.gaussian_weights(5.0, order)
+    np.testing.assert_allclose(got, rc.GAUSS_SIGMA5[order], rtol=3e-7)
+    np.testing.assert_array_equal(np.float32(got), oracle.gaussian_weights(5.0, order))
+
+
+@pytest.mark.parametrize("sigma", [0.8, 1.0, 2.5, 16.0])
+def test_gaussian_weights_match_oracle_other_sigmas(sigma):
+    for order in (1, 2, 3):
+        np.testing.assert_allclose(rfa.gaussian_weights(sigma, order), oracle.gaussian_weights(sigma, order), rtol=1e-6)
+
+
+def test_other_coefficient_helpers():
+    for n in (1, 2, 3):
+        assert rfa.integral_image_coeff(n) == rc.INTEGRAL_COEFF[n]
+    assert rfa.overlap_feedback_coeff([2, -1], [1]) == [3, -3, 1]
+    assert rfa.gaussian_box_filter(3, 1.0) == 2 and rfa.gaussian_box_filter(3, 2.0) == 4
+    for k in (1, 2, 3, 4, 5):
+        assert rfa.gaussian_box_filter(k, 3.0) == oracle.gaussian_box_filter(k, 3.0)
+
+
+def _host_plan(shape, scans, **kw):
+    return rfa.Plan(shape, scans, device=capi.RF_DEVICE_HOST_ONLY, **kw)
+
+
+def test_argument_checks_mirror_the_reference():
+    with pytest.raises(ValueError):                      # lib/recfilter.cpp:274-278
+        _host_plan((8, 8), [(0, True, [1.0])])
+    with pytest.raises(rfa.RecFilterError) as e:         # lib/recfilter.cpp:296-300
+        _host_plan((8, 8), [(2, True, [1.0, 1.0])])
+    assert e.value.status == capi.RF_ERR_INVALID_ARG
+    with pytest.raises(rfa.RecFilterError):              # lib/recfilter.h:311
+        _host_plan((8, 8), [(0, True, [1.0, 1.0])], tile=[3, 0], path=capi.RF_PATH_TILED_GENERIC)
+    with pytest.raises(rfa.RecFilterError) as e:         # host-only plans never execute
+        p = _host_plan((8, 8), [(0, True, [1.0, 1.0])], path=capi.RF_PATH_TILED_GENERIC)
+        capi.check(capi.lib().rf_plan_execute(p._h, (ctypes.c_void_p * 1)(1), (ctypes.c_void_p * 1)(1), None))
+    assert e.value.status == capi.RF_ERR_HIP
+
+
+def test_matrix_A_is_tail_of_reference_matrix_R():
+    # A[s][r][j] = R[T-1-r][j] with R = lib/coefficients.cpp:51-83 (via the oracle's restatement)
+    fb = [0.5, 0.25]
+    p = _host_plan((1, 32), [(0, True, [1.0] + fb)], dtype=np.float64, tile=[8, 0], path=capi.RF_PATH_TILED_GENERIC)
+    A = p.table("A_x").reshape(2, 2)
+    R = oracle.matrix_R(fb, 8)
+    np.testing.assert_allclose(A, R[[7, 6], :], rtol=1e-6)
+    prop = p.table("prop_x").reshape(4, 1, 1, 8, 2)
+    np.testing.assert_allclose(prop[0, 0, 0], R, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", sorted(rc.REFERENCE_TESTS))
+def test_plan_tables_reproduce_oracle_on_reference_tests(name):
+    case = rc.REFERENCE_TESTS[name]
+    if np.issubdtype(np.dtype(case["dtype"]), np.integer):
+        pytest.skip("integer tables are checked in test_integer_tables_are_exact")
+    shape = case["shape"]
+    tile = [case["tile"] if any(s[0] == d for s in case["scans"]) else 0 for d in range(len(shape))]
+    p = _host_plan(shape, case["scans"], dtype=np.float64, clamped=case["clamped"], tile=tile,
+                   path=capi.RF_PATH_TILED_GENERIC)
+    assert p.path == capi.RF_PATH_TILED_GENERIC
+    img = rc.random_image(shape).astype(np.float64)
+    want = oracle.apply_filter(img, case["scans"], case["clamped"])
+    got = emu.emulate_filter(img, case["scans"], p.tiles, case["clamped"], p)
+    assert rc.rel_err(got, want) < 1e-11
+
+
+@pytest.mark.parametrize("tile", [4, 8, 16])
+@pytest.mark.parametrize("coeff", [rc.GAUSS2, rc.GAUSS3, rc.BICUBIC_COEFF])
+def test_plan_tables_clamped_mixed_causality(tile, coeff):
+    # the case where the reference's matrix_B(clamp) is inconsistent with its own add_filter
+    # (SURVEY 8 a-4); the product's tables follow add_filter, so tiled == untiled to rounding
+    shape = (32, 48)
+    scans = rc.xy_pm([float(np.float32(c)) for c in coeff])
+    p = _host_plan(shape, scans, dtype=np.float64, clamped=True, tile=[tile, tile], path=capi.RF_PATH_TILED_GENERIC)
+    img = rc.random_image(shape).astype(np.float64)
+    want = oracle.apply_filter(img, scans, True)
+    got = emu.emulate_filter(img, scans, p.tiles, True, p)
+    assert rc.rel_err(got, want) < 1e-11
+
+
+def test_single_tile_per_dimension():
+    shape = (8, 8)
+    scans = rc.xy_pm([float(np.float32(c)) for c in rc.GAUSS2])
+    p = _host_plan(shape, scans, dtype=np.float64, clamped=True, tile=[8, 8], path=capi.RF_PATH_TILED_GENERIC)
+    img = rc.random_image(shape).astype(np.float64)
+    got = emu.emulate_filter(img, scans, p.tiles, True, p)
+    assert rc.rel_err(got, oracle.apply_filter(img, scans, True)) < 1e-12
+
+
+def test_integer_tables_are_exact():
+    # integer pixel types: tables are built in wrap-around integer arithmetic
+    case = rc.REFERENCE_TESTS["test_type_invariance"]
+    p = _host_plan(case["shape"], case["scans"], dtype=np.int32, tile=[4, 4], path=capi.RF_PATH_TILED_GENERIC)
+    A = p.table("A_x")
+    assert np.all(A == np.round(A))
+    img = rc.random_image(case["shape"], np.int32)
+    want = oracle.apply_filter(img, case["scans"])
+    got = emu.emulate_filter(img.astype(np.float64), case["scans"], p.tiles, False, p)
+    np.testing.assert_array_equal(got.astype(np.int64), want.astype(np.int64))
+
+
+def test_auto_tiles_divide_extents():
+    p = _host_plan((96, 200), [(0, True, [1.0, 0.5]), (1, False, [1.0, 0.5, 0.25])], dtype=np.float32,
+                   path=capi.RF_PATH_TILED_GENERIC)
+    tx, ty = p.tiles
+    assert 200 % tx == 0 and 96 % ty == 0 and tx >= 1 and ty >= 2
+
+
+def test_front_end_misuse_raises_like_the_reference_asserts():
+    x, y = rfa.RecFilterDim("x", 16), rfa.RecFilterDim("y", 16)
+    f = rfa.RecFilter("F")
+    with pytest.raises(rfa.RecFilterUsageError):     # add_filter before define, recfilter.cpp:268-272
+        f.add_filter(+x, [1.0, 0.5])
+
+    class FakeTensor:
+        shape = (16, 16)
+        dtype = np.float32
+    f.define([x, y], [FakeTensor()])
+    with pytest.raises(rfa.RecFilterUsageError):     # redefinition, recfilter.cpp:205-208
+        f.define([x, y], [FakeTensor()])
+    with pytest.raises(rfa.RecFilterUsageError):     # clamped after define, recfilter.cpp:252-256
+        f.set_clamped_image_border()
+    with pytest.raises(rfa.RecFilterUsageError):     # <2 coefficients, recfilter.cpp:274-278
+        f.add_filter(+x, [1.0])
+    with pytest.raises(rfa.RecFilterUsageError):     # unknown dimension, recfilter.cpp:296-300
+        f.add_filter(+rfa.RecFilterDim("w", 4), [1.0, 0.5])
+    f.add_filter(+x, [1.0, 0.5])
+    f.add_filter(-x, [1.0, 0.5])
+    with pytest.raises(rfa.RecFilterUsageError):     # tiling a dimension without scans, split.cpp:1879-1883
+        f.split(y, 4)
+    with pytest.raises(rfa.RecFilterUsageError):     # opposite causality reordered, reorder.cpp:70-75
+        f.cascade([1], [0])
+    with pytest.raises(rfa.RecFilterUsageError):     # scan missing from the cascade lists
+        f.cascade([0], [])
+    parts = f.cascade([0], [1])
+    assert len(parts) == 2 and parts[1]._contents["source"] is parts[0]
+    f.split(x, 4)
+    with pytest.raises(rfa.RecFilterUsageError):     # tiling twice, split.cpp:1851-1854
+        f.split(x, 4)
+    with pytest.raises(rfa.RecFilterUsageError):     # cascade after tiling, reorder.cpp:29-33
+        f.cascade([0], [1])
+    with pytest.raises(rfa.RecFilterUsageError):     # full_schedule on a tiled filter, recfilter.cpp:397-401
+        f.full_schedule()
+    f.intra_schedule(1).compute_locally().unroll("x").gpu_threads("a", "b")   # accepted, recorded
+    assert len(f._contents["schedule_log"]) == 3
+
+
+def test_overlap_to_higher_order_filter_matches_cascade_in_oracle():
+    # tests/test_overlap_filter_order.cpp through the front-end's coefficient algebra
+    x, y = rfa.RecFilterDim("x", 12), rfa.RecFilterDim("y", 12)
+
+    class FakeTensor:
+        shape = (12, 12)
+        dtype = np.float32
+    f1 = rfa.RecFilter("R1"); f1.define([x, y], [FakeTensor()])
+    f1.add_filter(+x, [1.0, 2.0, -1.0]); f1.add_filter(+y, [1.0, 1.0])
+    f2 = rfa.RecFilter("R2"); f2.define([x, y], f1)
+    f2.add_filter(+x, [1.0, 1.0]); f2.add_filter(+y, [1.0, 2.0, -1.0])
+    f3 = f2.overlap_to_higher_order_filter(f1, "O")
+    img = rc.random_image((12, 12))
+    cascaded = oracle.apply_filter(oracle.apply_filter(img, f1._contents["scans"]), f2._contents["scans"])
+    overlapped = oracle.apply_filter(img, f3._contents["scans"])
+    assert rc.rel_err(overlapped, cascaded) < 1e-5
