@@ -1,0 +1,53 @@
+// kernels_fused.h -- argument blocks and launchers of the fused x/y tile kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pixel.h"
+#include "rf_internal.h"
+
+namespace rf {
+
+constexpr int kFusedTX = 256;       // tile width: 16 lanes x 16 samples = one DPP row per tile row
+constexpr int kFusedSeg = 16;       // samples per lane in the x phase
+constexpr int kFusedThreads = 256;  // 4 waves
+constexpr int kFusedMaxK = 3;       // max feedback order on the fused path
+
+// One scan as the fused kernels read it (device memory, uniform -> scalar loads).
+template <typename Acc>
+struct FusedScan {
+    int32_t causal;
+    Acc b;
+    Acc a[kFusedMaxK];
+    // x phase only; "direction coordinates": position p counts from where the scan enters
+    Acc R[kFusedSeg][kFusedMaxK];           // effect on position p of the state entering the segment
+    Acc P[4][kFusedMaxK][kFusedMaxK];       // segment exit-state transfer over 1, 2, 4, 8 segments
+};
+
+template <typename Acc>
+struct FusedArgs {
+    int64_t NX, NY, NZ;      // extents (NZ = batch of planes along z, 1 for 2-D)
+    int32_t MX, MY;          // tiles along x / y
+    int32_t nx, ny;          // scans along x / y
+    int32_t clamped;
+    int32_t y_first_border;  // the slab holds the image's first / last tile row
+    int32_t y_last_border;
+    const FusedScan<Acc> *xs;
+    const FusedScan<Acc> *ys;
+    Acc *xt;                 // x tails   [s][tx][r][y + NY*z]
+    Acc *yt;                 // y tails   [j][ty][r][x + NX*z]
+    const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]
+};
+
+template <typename P>
+int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,
+                      const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);
+template <typename Acc>
+int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t stream);
+template <typename Acc>
+int launch_fused_carry_y(int K, const FusedArgs<Acc> &a, int j, const Acc *tau, const Acc *G, const Acc *W,
+                         const Acc *A, Acc *send, hipStream_t stream);
+
+}  // namespace rf

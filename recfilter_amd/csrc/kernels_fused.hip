@@ -1,2 +1,453 @@
-// kernels_fused.hip -- placeholder, filled in next.
+// kernels_fused.hip -- the bandwidth-tuned path: LDS-staged fused x/y tiles for gfx950.
+//
+// One workgroup owns a 256 x TY tile of one image plane, stages it in LDS once and runs EVERY
+// x scan and EVERY y scan of the filter on it before anything goes back to HBM -- the
+// "overlapped" evaluation of lib/split.cpp (create_intra_tile_term :503-665 for pass 1,
+// add_residuals_to_final_result :1647-1780 for pass 2) with MI355X-shaped tiles instead of
+// the reference's 32 x 32 CUDA tiles:
+//
+//   load     256 threads, one 1 KiB tile row per wave instruction (16 B / lane, coalesced),
+//            written to LDS with an XOR swizzle of the 16-byte chunk index
+//   x phase  thread = (row, 16-sample segment); a tile row is exactly one 16-lane DPP row.
+//            segment-local recurrence in registers -> Kogge-Stone scan of the k-vector segment
+//            states across the 16 lanes with row_shr/row_shl DPP and precomputed powers of the
+//            segment transfer matrix -> rank-k correction of the 16 samples.
+//            LDS reads/writes are ds_read/write_b128, conflict-free thanks to the swizzle.
+//   y phase  thread = column; the TY samples of the column sit in registers, every y scan is
+//            a serial recurrence up or down the registers (no LDS traffic between scans)
+//   pass 1   writes only the k-sample tails of every scan (lib/split.cpp:256-499)
+//   pass 2   injects the completed carries (lib/split.cpp:1008-1130) and stores the tile,
+//            256 B per wave instruction
+//
+// Between the passes: the x carry recurrence (generic_carry_scan_kernel over the x tails), the
+// cross-dimension residual of lib/split.cpp:1215-1633 split into tau_kernel (run the tile-local
+// y scans on the completed x-carry strips, keep their tails) and fused_carry_y_kernel (y carry
+// recurrence with the residual sum_o G[x][o] * tau[o] folded into the tail it starts from).
 #include "kernels.h"
+#include "kernels_fused.h"
+
+namespace rf {
+
+namespace {
+
+// ---- DPP helpers ------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// shift towards higher lanes (causal) = row_shr, towards lower lanes (anticausal) = row_shl;
+// lanes without a source inside their 16-lane row receive 0
+template <bool CAUSAL, int D, typename Acc>
+__device__ __forceinline__ Acc row_shift(Acc v) {
+    return dpp_move<(CAUSAL ? 0x110 : 0x100) + D>(v);
+}
+
+__device__ __forceinline__ int swz_chunk(int c) { return c ^ ((c >> 4) & 3); }
+
+// ---- x phase: one scan over a 256-sample tile row held as 16 samples per lane --------------
+template <typename Acc, bool CAUSAL, int K>
+__device__ __forceinline__ void scan_row16(Acc (&v)[kFusedSeg], const FusedScan<Acc> &sc, bool first_lane,
+                                           bool clamp_first, const Acc (&carry)[kFusedMaxK]) {
+    Acc h[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) h[j] = first_lane ? carry[j] : Acc(0);
+    Acc y0 = Acc(0);
+    // 1. segment-local recurrence (exact for the first lane, which owns the tile's carry)
+#pragma unroll
+    for (int p = 0; p < kFusedSeg; p++) {
+        const int m = CAUSAL ? p : kFusedSeg - 1 - p;
+        Acc x = v[m];
+        Acc acc = sc.b * x;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            Acc g = h[j];
+            if (p <= j) g = clamp_first ? (p == 0 ? x : y0) : g;
+            acc = acc + sc.a[j] * g;
+        }
+#pragma unroll
+        for (int j = K - 1; j > 0; j--) h[j] = h[j - 1];
+        h[0] = acc;
+        if (p == 0) y0 = acc;
+        v[m] = acc;
+    }
+    // 2. Kogge-Stone over the 16 lanes of the row: S_l <- sum_{j<=l} P^(l-j) S_j
+    Acc S[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) S[r] = h[r];
+#define RF_KS_STEP(D, IDX)                                                          \
+    {                                                                               \
+        Acc Sh[K];                                                                  \
+        _Pragma("unroll") for (int j = 0; j < K; j++) Sh[j] = row_shift<CAUSAL, D>(S[j]); \
+        _Pragma("unroll") for (int r = 0; r < K; r++)                               \
+            _Pragma("unroll") for (int j = 0; j < K; j++) S[r] = S[r] + sc.P[IDX][r][j] * Sh[j]; \
+    }
+    RF_KS_STEP(1, 0)
+    RF_KS_STEP(2, 1)
+    RF_KS_STEP(4, 2)
+    RF_KS_STEP(8, 3)
+#undef RF_KS_STEP
+    // 3. state entering this lane's segment, then the rank-K correction of its 16 samples
+    Acc C[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) C[j] = row_shift<CAUSAL, 1>(S[j]);
+#pragma unroll
+    for (int p = 0; p < kFusedSeg; p++) {
+        const int m = CAUSAL ? p : kFusedSeg - 1 - p;
+#pragma unroll
+        for (int j = 0; j < K; j++) v[m] = v[m] + sc.R[p][j] * C[j];
+    }
+}
+
+// ---- y phase: one scan up or down a register column -----------------------------------------
+template <typename Acc, bool CAUSAL, int K, int TY>
+__device__ __forceinline__ void scan_col(Acc (&col)[TY], const FusedScan<Acc> &sc, bool clamp_first,
+                                         const Acc (&carry)[kFusedMaxK]) {
+    Acc h[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) h[j] = carry[j];
+    Acc y0 = Acc(0);
+#pragma unroll
+    for (int p = 0; p < TY; p++) {
+        const int m = CAUSAL ? p : TY - 1 - p;
+        Acc x = col[m];
+        Acc acc = sc.b * x;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            Acc g = h[j];
+            if (p <= j) g = clamp_first ? (p == 0 ? x : y0) : g;
+            acc = acc + sc.a[j] * g;
+        }
+#pragma unroll
+        for (int j = K - 1; j > 0; j--) h[j] = h[j - 1];
+        h[0] = acc;
+        if (p == 0) y0 = acc;
+        col[m] = acc;
+    }
+}
+
+template <typename Acc>
+struct Vec4 {
+    typedef Acc type __attribute__((ext_vector_type(4)));
+};
+
+// ---- the fused pass kernel -----------------------------------------------------------------
+template <typename P, int K, int TY, bool FINAL>
+__global__ void __launch_bounds__(kFusedThreads)
+fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
+    using Acc = typename PixelTraits<P>::Acc;
+    using A4 = typename Vec4<Acc>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Acc *tile = reinterpret_cast<Acc *>(lds_raw);
+    A4 *tile4 = reinterpret_cast<A4 *>(lds_raw);
+
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int64_t plane_off = z * a.NX * a.NY;
+    const int64_t tile_off = plane_off + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
+
+    // ---- load: wave w streams rows w, w+4, ...; one 1 KiB row per instruction ----
+    {
+        const int cc = t & 63, rg = t >> 6;
+        const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
+        const int64_t row_stride4 = a.NX / 4;
+        A4 tmp[TY / 4];
+#pragma unroll
+        for (int i = 0; i < TY / 4; i++) tmp[i] = sp[(int64_t)(rg + 4 * i) * row_stride4 + cc];
+#pragma unroll
+        for (int i = 0; i < TY / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
+    }
+
+    // ---- x phase ----
+    if (a.nx > 0) {
+        __syncthreads();
+        const int l = t & 15, slot = t >> 4;
+        const int64_t Lx = a.NY * a.NZ;
+        const int sw = (l >> 2) & 3;
+#pragma unroll 1
+        for (int i = 0; i < TY / 16; i++) {
+            const int row = slot + 16 * i;
+            const int64_t line = (int64_t)ty * TY + row + a.NY * z;
+            Acc v[kFusedSeg];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                A4 q = tile4[row * 64 + 4 * l + (j ^ sw)];
+                v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+            }
+#pragma unroll 1
+            for (int s = 0; s < a.nx; s++) {
+                const FusedScan<Acc> &sc = a.xs[s];
+                const bool causal = sc.causal != 0;
+                const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
+                const bool first_lane = causal ? (l == 0) : (l == 15);
+                Acc carry[kFusedMaxK] = {Acc(0), Acc(0), Acc(0)};
+                if (FINAL && first_lane && !tile_first) {
+                    const int tp = causal ? tx - 1 : tx + 1;
+#pragma unroll
+                    for (int j = 0; j < K; j++) carry[j] = a.xt[(((int64_t)s * a.MX + tp) * K + j) * Lx + line];
+                }
+                const bool clamp_first = a.clamped && tile_first && first_lane;
+                if (causal) scan_row16<Acc, true, K>(v, sc, first_lane, clamp_first, carry);
+                else        scan_row16<Acc, false, K>(v, sc, first_lane, clamp_first, carry);
+                if (!FINAL) {
+                    // tail r = sample at direction position 255-r: the last lane's last K samples
+                    const bool last_lane = causal ? (l == 15) : (l == 0);
+                    if (last_lane) {
+#pragma unroll
+                        for (int r = 0; r < K; r++)
+                            a.xt[(((int64_t)s * a.MX + tx) * K + r) * Lx + line] = causal ? v[kFusedSeg - 1 - r] : v[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                A4 q;
+                q.x = v[4 * j + 0]; q.y = v[4 * j + 1]; q.z = v[4 * j + 2]; q.w = v[4 * j + 3];
+                tile4[row * 64 + 4 * l + (j ^ sw)] = q;
+            }
+        }
+    }
+    if (!FINAL && a.ny == 0) return;   // pass 1 of an x-only filter has nothing left to extract
+    __syncthreads();
+
+    // ---- y phase: thread = column ----
+    {
+        const int x = t;
+        const int e = (swz_chunk(x >> 2) << 2) | (x & 3);
+        Acc col[TY];
+#pragma unroll
+        for (int i = 0; i < TY; i++) col[i] = tile[i * kFusedTX + e];
+        const int64_t Ly = a.NX * a.NZ;
+        const int64_t line = (int64_t)tx * kFusedTX + x + a.NX * z;
+#pragma unroll 1
+        for (int j = 0; j < a.ny; j++) {
+            const FusedScan<Acc> &sc = a.ys[j];
+            const bool causal = sc.causal != 0;
+            const bool tile_first = causal ? (ty == 0) : (ty == a.MY - 1);
+            const bool border = causal ? (ty == 0 && a.y_first_border) : (ty == a.MY - 1 && a.y_last_border);
+            Acc carry[kFusedMaxK] = {Acc(0), Acc(0), Acc(0)};
+            if (FINAL) {
+                if (tile_first) {
+#pragma unroll
+                    for (int r = 0; r < K; r++) carry[r] = a.y_incoming[((int64_t)j * K + r) * Ly + line];
+                } else {
+                    const int tp = causal ? ty - 1 : ty + 1;
+#pragma unroll
+                    for (int r = 0; r < K; r++) carry[r] = a.yt[(((int64_t)j * a.MY + tp) * K + r) * Ly + line];
+                }
+            }
+            const bool clamp_first = a.clamped && border;
+            if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, carry);
+            else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, carry);
+            if (!FINAL) {
+#pragma unroll
+                for (int r = 0; r < K; r++)
+                    a.yt[(((int64_t)j * a.MY + ty) * K + r) * Ly + line] = causal ? col[TY - 1 - r] : col[r];
+            }
+        }
+        if (FINAL) {
+            P *dp = dst + tile_off + x;
+#pragma unroll
+            for (int i = 0; i < TY; i++) dp[(int64_t)i * a.NX] = PixelTraits<P>::store(col[i]);
+        }
+    }
+}
+
+// ---- tau: tile-local y scans of the completed x-carry strips, tails kept ----------------------
+// tau[((tile*nx + q)*K + o)*ny*K + j*K + r], tile = (z*MY + ty)*MX + tx
+template <typename Acc, int K, int TY>
+__global__ void __launch_bounds__(256)
+tau_kernel(FusedArgs<Acc> a, Acc *__restrict__ tau) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_tiles = (int64_t)a.MX * a.MY * a.NZ;
+    const int strips = a.nx * K;
+    if (idx >= n_tiles * strips) return;
+    // tx fastest so that neighbouring threads work on neighbouring tiles of one tile row
+    const int tx = (int)(idx % a.MX);
+    int64_t rest = idx / a.MX;
+    const int so = (int)(rest % strips);
+    rest /= strips;
+    const int ty = (int)(rest % a.MY);
+    const int64_t z = rest / a.MY;
+    const int q = so / K, o = so % K;
+    const int64_t tile = (z * a.MY + ty) * a.MX + tx;
+    Acc *out = tau + ((tile * a.nx + q) * K + o) * (int64_t)a.ny * K;
+
+    const bool qc = a.xs[q].causal != 0;
+    const bool q_first = qc ? (tx == 0) : (tx == a.MX - 1);
+    if (q_first) {   // no carry enters this tile for scan q
+        for (int e = 0; e < a.ny * K; e++) out[e] = Acc(0);
+        return;
+    }
+    const int tp = qc ? tx - 1 : tx + 1;
+    const int64_t Lx = a.NY * a.NZ;
+    const Acc *strip = a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + (int64_t)ty * TY + a.NY * z;
+    Acc col[TY];
+#pragma unroll
+    for (int i = 0; i < TY; i++) col[i] = strip[i];
+    const Acc zero[kFusedMaxK] = {Acc(0), Acc(0), Acc(0)};
+#pragma unroll 1
+    for (int j = 0; j < a.ny; j++) {
+        const FusedScan<Acc> &sc = a.ys[j];
+        const bool causal = sc.causal != 0;
+        const bool border = causal ? (ty == 0 && a.y_first_border) : (ty == a.MY - 1 && a.y_last_border);
+        const bool clamp_first = a.clamped && border;
+        if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, zero);
+        else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, zero);
+#pragma unroll
+        for (int r = 0; r < K; r++) out[j * K + r] = causal ? col[TY - 1 - r] : col[r];
+    }
+}
+
+// ---- y carry recurrence of one y scan, cross-dimension residual folded in -----------------------
+template <typename Acc, int K>
+__global__ void __launch_bounds__(256)
+fused_carry_y_kernel(FusedArgs<Acc> a, int j, const Acc *__restrict__ tau, const Acc *__restrict__ G,
+                     const Acc *__restrict__ W, const Acc *__restrict__ Amat, Acc *__restrict__ send) {
+    const int64_t line = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t Ly = a.NX * a.NZ;
+    if (line >= Ly) return;
+    const int64_t x = line % a.NX, z = line / a.NX;
+    const int tx = (int)(x / kFusedTX), xi = (int)(x % kFusedTX);
+    const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
+    const bool causal = a.ys[j].causal != 0;
+    Acc prev[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) prev[r] = Acc(0);
+    for (int i = 0; i < a.MY; i++) {
+        const int ty = causal ? i : a.MY - 1 - i;
+        const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
+        Acc cur[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) cur[r] = a.yt[(((int64_t)j * a.MY + ty) * K + r) * Ly + line];
+        // cross-dimension residual: sum_q sum_o G_q[xi][o] * tau[q][o][j][r]
+        if (a.nx > 0) {
+            const int64_t tile = (z * a.MY + ty) * a.MX + tx;
+            for (int q = 0; q < a.nx; q++) {
+                const Acc *g = G + (((int64_t)vx * a.nx + q) * kFusedTX + xi) * K;
+                const Acc *tq = tau + ((tile * a.nx + q) * K) * (int64_t)a.ny * K + (int64_t)j * K;
+#pragma unroll
+                for (int o = 0; o < K; o++)
+#pragma unroll
+                    for (int r = 0; r < K; r++) cur[r] = cur[r] + g[o] * tq[(int64_t)o * a.ny * K + r];
+            }
+        }
+        // chaining from the y scans applied earlier
+        for (int q = 0; q < j; q++) {
+            const bool qc = a.ys[q].causal != 0;
+            const bool q_first = qc ? (ty == 0) : (ty == a.MY - 1);
+            Acc c[K];
+            if (q_first) {
+#pragma unroll
+                for (int o = 0; o < K; o++) c[o] = a.y_incoming[((int64_t)q * K + o) * Ly + line];
+            } else {
+                const int tp = qc ? ty - 1 : ty + 1;
+#pragma unroll
+                for (int o = 0; o < K; o++) c[o] = a.yt[(((int64_t)q * a.MY + tp) * K + o) * Ly + line];
+            }
+            const Acc *Wm = W + ((((int64_t)vy * a.ny + q) * a.ny + j) * K) * K;
+#pragma unroll
+            for (int r = 0; r < K; r++)
+#pragma unroll
+                for (int o = 0; o < K; o++) cur[r] = cur[r] + Wm[r * K + o] * c[o];
+        }
+        if (i > 0) {
+            const Acc *Am = Amat + (int64_t)j * K * K;
+#pragma unroll
+            for (int r = 0; r < K; r++)
+#pragma unroll
+                for (int o = 0; o < K; o++) cur[r] = cur[r] + Am[r * K + o] * prev[o];
+        }
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            a.yt[(((int64_t)j * a.MY + ty) * K + r) * Ly + line] = cur[r];
+            prev[r] = cur[r];
+        }
+    }
+    if (send) {
+#pragma unroll
+        for (int r = 0; r < K; r++) send[(int64_t)r * Ly + line] = prev[r];
+    }
+}
+
+template <typename P, int K, int TY>
+int launch_fused_pass_impl(bool final_pass, const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                           hipStream_t stream) {
+    using Acc = typename PixelTraits<P>::Acc;
+    const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
+    dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
+    if (final_pass) {
+        static bool attr_set = false;
+        if (!attr_set && lds > 48 * 1024) {
+            RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass_kernel<P, K, TY, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((fused_pass_kernel<P, K, TY, true>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set && lds > 48 * 1024) {
+            RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass_kernel<P, K, TY, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((fused_pass_kernel<P, K, TY, false>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+}  // namespace
+
+template <typename P>
+int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,
+                      const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
+    if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
+    if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
+#define RF_CASE(KK, TT) if (K == KK && TY == TT) return launch_fused_pass_impl<P, KK, TT>(final_pass, src, dst, a, stream);
+    RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
+    RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
+#undef RF_CASE
+    set_error("fused path: unsupported order %d / tile height %d", K, TY);
+    return RF_ERR_UNSUPPORTED;
+}
+
+template <typename Acc>
+int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t stream) {
+    const int64_t n = (int64_t)a.MX * a.MY * a.NZ * a.nx * K;
+    if (n <= 0 || a.ny == 0) return RF_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+#define RF_CASE(KK, TT) if (K == KK && TY == TT) { hipLaunchKernelGGL((tau_kernel<Acc, KK, TT>), dim3(grid), dim3(256), 0, stream, a, tau); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
+    RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
+#undef RF_CASE
+    set_error("tau: unsupported order %d / tile height %d", K, TY);
+    return RF_ERR_UNSUPPORTED;
+}
+
+template <typename Acc>
+int launch_fused_carry_y(int K, const FusedArgs<Acc> &a, int j, const Acc *tau, const Acc *G, const Acc *W,
+                         const Acc *A, Acc *send, hipStream_t stream) {
+    const int64_t Ly = a.NX * a.NZ;
+    const unsigned grid = (unsigned)((Ly + 255) / 256);
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((fused_carry_y_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, j, tau, G, W, A, send); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+#undef RF_CASE
+    set_error("fused carry: unsupported order %d", K);
+    return RF_ERR_UNSUPPORTED;
+}
+
+template int launch_fused_pass<float>(bool, int, int, const float *, float *, const FusedArgs<float> &, hipStream_t);
+template int launch_fused_pass<int32_t>(bool, int, int, const int32_t *, int32_t *, const FusedArgs<uint32_t> &, hipStream_t);
+template int launch_tau<float>(int, int, const FusedArgs<float> &, float *, hipStream_t);
+template int launch_tau<uint32_t>(int, int, const FusedArgs<uint32_t> &, uint32_t *, hipStream_t);
+template int launch_fused_carry_y<float>(int, const FusedArgs<float> &, int, const float *, const float *, const float *,
+                                         const float *, float *, hipStream_t);
+template int launch_fused_carry_y<uint32_t>(int, const FusedArgs<uint32_t> &, int, const uint32_t *, const uint32_t *,
+                                            const uint32_t *, const uint32_t *, uint32_t *, hipStream_t);
+
+}  // namespace rf

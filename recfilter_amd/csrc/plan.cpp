@@ -6,6 +6,7 @@
 //     coefficient permutation the reference forgets)
 //   * split() preconditions (tile divides extent)   lib/recfilter.h:311, lib/split.cpp:1879-1931
 #include "plan.h"
+#include "plan_generic.h"
 
 #include <algorithm>
 #include <cmath>
@@ -26,55 +27,6 @@ double cast_coeff(double c, int dtype) {
         case RF_I16: return (double)(int16_t)c;
     }
     return c;
-}
-
-template <typename Acc>
-DevScan<Acc> make_dev_scan(const Scan &s) {
-    DevScan<Acc> d;
-    d.causal = s.causal ? 1 : 0;
-    d.order = s.order;
-    if constexpr (std::is_same<Acc, uint32_t>::value) {
-        d.b = (uint32_t)(int64_t)s.b;
-        for (int j = 0; j < RF_MAX_ORDER; j++) d.a[j] = (uint32_t)(int64_t)s.a[j];
-    } else {
-        d.b = (Acc)s.b;
-        for (int j = 0; j < RF_MAX_ORDER; j++) d.a[j] = (Acc)s.a[j];
-    }
-    return d;
-}
-
-template <typename S>
-ScanS<S> make_table_scan(const Scan &s) {
-    ScanS<S> t;
-    t.causal = s.causal;
-    if constexpr (std::is_same<S, uint64_t>::value) {
-        t.b = (uint64_t)(int64_t)s.b;
-        for (int j = 0; j < RF_MAX_ORDER; j++) t.a[j] = (uint64_t)(int64_t)s.a[j];
-    } else {
-        t.b = (S)s.b;
-        for (int j = 0; j < RF_MAX_ORDER; j++) t.a[j] = (S)s.a[j];
-    }
-    return t;
-}
-
-template <typename S, typename Acc>
-Acc table_to_acc(S v) {
-    if constexpr (std::is_same<Acc, uint32_t>::value) return (uint32_t)v;
-    else return (Acc)v;
-}
-
-template <typename S>
-double table_to_double(S v) {
-    if constexpr (std::is_same<S, uint64_t>::value) return (double)(int64_t)v;
-    else return (double)v;
-}
-
-int pick_generic_tile(int64_t N, int k, int hint) {
-    if (hint > 0 && hint <= kGenericMaxTile && N % hint == 0 && hint >= k) return hint;
-    int cap = hint > 0 ? kGenericMaxTile : 64;
-    for (int T = (int)std::min<int64_t>(cap, N); T >= std::max(k, 1); T--)
-        if (N % T == 0) return T;
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -133,151 +85,10 @@ int build_generic(rf_plan *plan, const rf_filter_desc *desc) {
     }
 
     for (int d = 0; d < plan->ndim; d++) {
-        DimInfo &di = plan->dims[d];
-        if (di.scan_ids.empty()) continue;
-        int T = pick_generic_tile(di.N, di.k, desc->tile[d]);
-        if (T == 0) {
-            set_error("no tile width <= %d divides extent %lld of dimension %d", kGenericMaxTile, (long long)di.N, d);
-            return RF_ERR_UNSUPPORTED;
-        }
-        di.T = T;
-        di.M = di.N / T;
-        const int n = (int)di.scan_ids.size();
-        const int k = di.k;
-
-        // tables
-        std::vector<ScanS<S>> ts;
-        std::vector<DevScan<Acc>> ds;
-        for (int id : di.scan_ids) {
-            ts.push_back(make_table_scan<S>(plan->scans[id]));
-            DevScan<Acc> dv = make_dev_scan<Acc>(plan->scans[id]);
-            dv.order = k;  // shorter scans are zero padded to the dimension's order (lib/split.cpp:575-578)
-            ds.push_back(dv);
-        }
-        DimTables<S> tab = build_dim_tables<S>(ts, k, T, plan->clamped);
-        std::vector<Acc> hW((size_t)4 * n * n * k * k, Acc(0)), hA((size_t)n * k * k, Acc(0));
-        std::vector<double> dW(hW.size(), 0.0), dA(hA.size(), 0.0);
-        for (int v = 0; v < 4; v++)
-            for (int q = 0; q < n; q++)
-                for (int s = q + 1; s < n; s++)
-                    for (int e = 0; e < k * k; e++) {
-                        size_t idx = (((size_t)v * n + q) * n + s) * k * k + e;
-                        hW[idx] = table_to_acc<S, Acc>(tab.Wm(v, q, s)[e]);
-                        dW[idx] = table_to_double<S>(tab.Wm(v, q, s)[e]);
-                    }
-        for (int s = 0; s < n; s++)
-            for (int e = 0; e < k * k; e++) {
-                hA[(size_t)s * k * k + e] = table_to_acc<S, Acc>(tab.A[s][e]);
-                dA[(size_t)s * k * k + e] = table_to_double<S>(tab.A[s][e]);
-            }
-        std::string dn(1, "xyz"[d]);
-        plan->tables["W_" + dn] = dW;
-        plan->tables["A_" + dn] = dA;
-        {
-            std::vector<double> dP;
-            for (int v = 0; v < 4; v++)
-                for (int q = 0; q < n; q++)
-                    for (int s = 0; s < n; s++) {
-                        if (s >= q) for (S x : tab.P(v, q, s)) dP.push_back(table_to_double<S>(x));
-                        else dP.insert(dP.end(), (size_t)T * k, 0.0);
-                    }
-            plan->tables["prop_" + dn] = dP;
-        }
-
-        // A^M for the exchange (sharded outermost dimension)
-        std::vector<Acc> hAM((size_t)n * k * k, Acc(0));
-        for (int s = 0; s < n; s++) {
-            std::vector<S> am = mat_pow<S>(tab.A[s], di.M, k);
-            for (int e = 0; e < k * k; e++) hAM[(size_t)s * k * k + e] = table_to_acc<S, Acc>(am[e]);
-        }
-
-        const DevScan<Acc> *dScans = (const DevScan<Acc> *)plan->upload(ds.data(), ds.size() * sizeof(DevScan<Acc>), &status);
-        const Acc *dWp = (const Acc *)plan->upload(hW.data(), hW.size() * sizeof(Acc), &status);
-        const Acc *dAp = (const Acc *)plan->upload(hA.data(), hA.size() * sizeof(Acc), &status);
-        const Acc *dAMp = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
-        size_t tails_per_plane = (size_t)n * di.M * k * di.lines;
-        size_t inc_per_plane = (size_t)n * k * di.lines;
-        Acc *tails = (Acc *)plan->alloc(tails_per_plane * plan->n_planes * sizeof(Acc), false, &status);
-        Acc *incoming = (Acc *)plan->alloc(inc_per_plane * plan->n_planes * sizeof(Acc), true, &status);
-        if (status != RF_OK) return status;
-
-        const bool sharded_dim = (d == outer) && plan->shard_world > 1;
-        GenericDimArgs<Acc> base{};
-        base.g = LineGeom{di.N, di.stride, di.lines};
-        base.T = T; base.M = (int32_t)di.M; base.k = k; base.n_scans = n;
-        base.clamped = plan->clamped ? 1 : 0;
-        base.first_is_border = (!sharded_dim || plan->shard_rank == 0) ? 1 : 0;
-        base.last_is_border = (!sharded_dim || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
-        base.scans = dScans; base.W = dWp; base.A = dAp;
-        auto args_for = [base, tails, incoming, tails_per_plane, inc_per_plane](int pl) {
-            GenericDimArgs<Acc> a = base;
-            a.tails = tails + (size_t)pl * tails_per_plane;
-            a.incoming = incoming + (size_t)pl * inc_per_plane;
-            return a;
-        };
-
-        const bool from_input = first_dim;
+        if (plan->dims[d].scan_ids.empty()) continue;
+        int rc = add_generic_dimension<P, S>(plan, desc->tile[d], d, first_dim);
+        if (rc != RF_OK) return rc;
         first_dim = false;
-        const bool is_exchange_dim = (d == outer);   // its carry stage is exposed through the stepping API
-
-        Step p1;
-        p1.name = "generic_pass1_" + dn;
-        p1.run = [plan, args_for, from_input](int pl) {
-            const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
-            return launch_generic_pass1<P>(src, args_for(pl), plan->stream);
-        };
-        plan->begin_steps.push_back(p1);
-
-        for (int s = 0; s < n; s++) {
-            int ex_index = -1;
-            if (is_exchange_dim) {
-                ex_index = (int)plan->exchanges.size();
-                rf_plan::Exchange ex;
-                ex.bytes = (size_t)plan->n_planes * k * di.lines * sizeof(Acc);
-                ex.scratch = plan->alloc(ex.bytes, true, &status);
-                if (status != RF_OK) return status;
-                ex.send = ex.scratch;
-                const Acc *AMs = dAMp + (size_t)s * k * k;
-                int64_t rank_stride = (int64_t)plan->n_planes * k * di.lines;
-                int64_t plane_stride = (int64_t)k * di.lines;
-                ex.form_incoming = [plan, args_for, s, rank_stride, plane_stride, AMs](const void *gathered) {
-                    for (int pl = 0; pl < plan->n_planes; pl++) {
-                        int rc = launch_gather_incoming<Acc>(args_for(pl), s, (const Acc *)gathered, rank_stride,
-                                                             pl * plane_stride, plan->shard_rank, plan->shard_world,
-                                                             AMs, plan->stream);
-                        if (rc) return rc;
-                    }
-                    return (int)RF_OK;
-                };
-                plan->exchanges.push_back(ex);
-            }
-            Step cs;
-            cs.name = "generic_carry_" + dn + std::to_string(s);
-            int64_t plane_stride = (int64_t)k * di.lines;
-            cs.run = [plan, args_for, s, ex_index, plane_stride](int pl) {
-                Acc *send = ex_index >= 0 ? (Acc *)plan->exchanges[ex_index].send : nullptr;
-                return launch_generic_carry_scan<Acc>(args_for(pl), s, send ? send + pl * plane_stride : nullptr,
-                                                      plan->stream);
-            };
-            if (is_exchange_dim) {
-                plan->exchange_local_steps.push_back({cs});
-                Step ap;
-                ap.name = "generic_carry_apply_" + dn + std::to_string(s);
-                ap.run = [plan, args_for, s](int pl) { return launch_generic_carry_apply<Acc>(args_for(pl), s, plan->stream); };
-                plan->exchange_apply_steps.push_back({ap});
-            } else {
-                plan->begin_steps.push_back(cs);
-            }
-        }
-
-        Step p2;
-        p2.name = "generic_pass2_" + dn;
-        p2.run = [plan, args_for, from_input](int pl) {
-            const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
-            return launch_generic_pass2<P>(src, (P *)plan->out[pl], args_for(pl), plan->stream);
-        };
-        if (is_exchange_dim) plan->finish_steps.push_back(p2);
-        else plan->begin_steps.push_back(p2);
     }
     // a filter whose outermost dimension has no scans but whose data still has to reach `out`
     // is covered: the last filtered dimension's pass 2 wrote `out`.

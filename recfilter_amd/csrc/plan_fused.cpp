@@ -1,15 +1,310 @@
 // plan_fused.cpp -- plan for the LDS-staged fused x/y path (kernels_fused.hip).
+//
+// Stages of one execute (2-D; a 3-D filter runs this per z plane as a batch and then filters z
+// with the generic dimension builder):
+//   fused_pass1      intra-tile scans of every x and y scan + tail extraction
+//   carry_x<s>       x carry recurrence per x scan (same-dimension chaining included)
+//   tau              tile-local y scans of the completed x-carry strips (cross-dimension residual,
+//                    lib/split.cpp:1215-1633)
+//   carry_y<j>       y carry recurrence per y scan with the residual folded in
+//   fused_pass2      final correction pass
+#include <cstring>
+
+#include "kernels_fused.h"
 #include "plan.h"
+#include "plan_generic.h"
 
 namespace rf {
 
-bool fused_plan_applicable(const rf_plan *, const rf_filter_desc *, std::string *why) {
-    if (why) *why = "not built yet";
-    return false;
+namespace {
+
+int fused_order(const rf_plan *plan) {
+    return std::max(plan->dims[0].k, plan->ndim > 1 ? plan->dims[1].k : 0);
 }
 
-int build_fused_plan(rf_plan *, const rf_filter_desc *) {
-    set_error("fused path not built yet");
+template <typename P, typename S>
+int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
+    using Acc = typename PixelTraits<P>::Acc;
+    int status = RF_OK;
+    const int K = fused_order(plan);
+    DimInfo &dx = plan->dims[0];
+    DimInfo &dy = plan->dims[1];
+    const int64_t NX = dx.N, NY = dy.N, NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
+    const int TY = (NY % 64 == 0) ? 64 : 32;
+    const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
+    dx.T = kFusedTX; dx.M = NX / kFusedTX;
+    dy.T = TY;       dy.M = NY / TY;
+    const int MX = (int)dx.M, MY = (int)dy.M;
+    const int64_t Lx = NY * NZ, Ly = NX * NZ;
+    const int outer = plan->ndim - 1;
+    const bool y_is_exchange_dim = (outer == 1);
+    const bool y_sharded = y_is_exchange_dim && plan->shard_world > 1;
+
+    // ---- tables -------------------------------------------------------------------------
+    auto table_scans = [&](const std::vector<int> &ids) {
+        std::vector<ScanS<S>> v;
+        for (int id : ids) v.push_back(make_table_scan<S>(plan->scans[id]));
+        return v;
+    };
+    auto fused_scans = [&](const std::vector<int> &ids, bool with_segment_tables) {
+        std::vector<FusedScan<Acc>> v;
+        for (int id : ids) {
+            FusedScan<Acc> f;
+            std::memset(&f, 0, sizeof(f));
+            ScanS<S> ts = make_table_scan<S>(plan->scans[id]);
+            f.causal = ts.causal ? 1 : 0;
+            f.b = table_to_acc<S, Acc>(ts.b);
+            for (int j = 0; j < K; j++) f.a[j] = table_to_acc<S, Acc>(ts.a[j]);
+            if (with_segment_tables) {
+                // segment-level tables in direction coordinates = tables of the causal twin at T = 16
+                ScanS<S> twin = ts;
+                twin.causal = true;
+                DimTables<S> seg = build_dim_tables<S>({twin}, K, kFusedSeg, false);
+                const std::vector<S> &R = seg.P(0, 0, 0);
+                for (int p = 0; p < kFusedSeg; p++)
+                    for (int j = 0; j < K; j++) f.R[p][j] = table_to_acc<S, Acc>(R[(size_t)p * K + j]);
+                std::vector<S> Pw = seg.A[0];
+                for (int step = 0; step < 4; step++) {
+                    for (int r = 0; r < K; r++)
+                        for (int j = 0; j < K; j++) f.P[step][r][j] = table_to_acc<S, Acc>(Pw[r * K + j]);
+                    Pw = mat_mul<S>(Pw, Pw, K);
+                }
+            }
+            v.push_back(f);
+        }
+        return v;
+    };
+    auto dev_scans = [&](const std::vector<int> &ids) {
+        std::vector<DevScan<Acc>> v;
+        for (int id : ids) {
+            DevScan<Acc> d = make_dev_scan<Acc>(plan->scans[id]);
+            d.order = K;
+            v.push_back(d);
+        }
+        return v;
+    };
+    auto flatten_W = [&](const DimTables<S> &tab, int n, std::vector<Acc> &hW, std::vector<Acc> &hA,
+                         const std::string &dn) {
+        hW.assign((size_t)4 * n * n * K * K, Acc(0));
+        hA.assign((size_t)n * K * K, Acc(0));
+        std::vector<double> dW(hW.size(), 0.0), dA(hA.size(), 0.0);
+        for (int v = 0; v < 4; v++)
+            for (int q = 0; q < n; q++)
+                for (int s = q + 1; s < n; s++)
+                    for (int e = 0; e < K * K; e++) {
+                        size_t idx = (((size_t)v * n + q) * n + s) * K * K + e;
+                        hW[idx] = table_to_acc<S, Acc>(tab.Wm(v, q, s)[e]);
+                        dW[idx] = table_to_double<S>(tab.Wm(v, q, s)[e]);
+                    }
+        for (int s = 0; s < n; s++)
+            for (int e = 0; e < K * K; e++) {
+                hA[(size_t)s * K * K + e] = table_to_acc<S, Acc>(tab.A[s][e]);
+                dA[(size_t)s * K * K + e] = table_to_double<S>(tab.A[s][e]);
+            }
+        plan->tables["W_" + dn] = dW;
+        plan->tables["A_" + dn] = dA;
+    };
+
+    std::vector<FusedScan<Acc>> hxs = fused_scans(dx.scan_ids, true), hys = fused_scans(dy.scan_ids, false);
+    if (nx > 0) {
+        // segment tables as the x phase reads them (float pixels: exact values of the kernel constants)
+        std::vector<double> sr, sp;
+        for (const auto &f : hxs) {
+            for (int p = 0; p < kFusedSeg; p++)
+                for (int j = 0; j < K; j++) sr.push_back((double)f.R[p][j]);
+            for (int step = 0; step < 4; step++)
+                for (int r = 0; r < K; r++)
+                    for (int j = 0; j < K; j++) sp.push_back((double)f.P[step][r][j]);
+        }
+        plan->tables["seg_R_x"] = sr;
+        plan->tables["seg_P_x"] = sp;
+    }
+    std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
+    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy;
+    if (nx > 0) {
+        DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
+        flatten_W(tx, nx, hWx, hAx, "x");
+        // G[v][q][xi][o]: what the carry entering x scan q adds to the tile after ALL x scans
+        hG.assign((size_t)4 * nx * kFusedTX * K, Acc(0));
+        std::vector<double> dG(hG.size());
+        for (int v = 0; v < 4; v++)
+            for (int q = 0; q < nx; q++) {
+                const std::vector<S> &Pm = tx.P(v, q, nx - 1);
+                for (int e = 0; e < kFusedTX * K; e++) {
+                    size_t idx = ((size_t)v * nx + q) * kFusedTX * K + e;
+                    hG[idx] = table_to_acc<S, Acc>(Pm[e]);
+                    dG[idx] = table_to_double<S>(Pm[e]);
+                }
+            }
+        plan->tables["G_x"] = dG;
+    }
+    if (ny > 0) {
+        DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped);
+        flatten_W(ty, ny, hWy, hAy, "y");
+        hAMy.assign((size_t)ny * K * K, Acc(0));
+        for (int j = 0; j < ny; j++) {
+            std::vector<S> am = mat_pow<S>(ty.A[j], MY, K);
+            for (int e = 0; e < K * K; e++) hAMy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(am[e]);
+        }
+    }
+
+    // ---- device memory --------------------------------------------------------------------
+    auto up = [&](const auto &vec) {
+        using T = typename std::decay<decltype(vec)>::type::value_type;
+        return (const T *)plan->upload(vec.data(), vec.size() * sizeof(T), &status);
+    };
+    const FusedScan<Acc> *d_xs = up(hxs);
+    const FusedScan<Acc> *d_ys = up(hys);
+    const DevScan<Acc> *d_xd = up(hxd);
+    const DevScan<Acc> *d_yd = up(hyd);
+    const Acc *d_Wx = up(hWx), *d_Ax = up(hAx), *d_Wy = up(hWy), *d_Ay = up(hAy), *d_G = up(hG), *d_AMy = up(hAMy);
+
+    const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
+    const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
+    const size_t tau_pp = (size_t)MX * MY * NZ * nx * K * ny * K;
+    const int np = plan->n_planes;
+    Acc *xt = (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status);
+    Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);
+    Acc *xin = (Acc *)plan->alloc(xin_pp * np * sizeof(Acc), true, &status);
+    Acc *yin = (Acc *)plan->alloc(yin_pp * np * sizeof(Acc), true, &status);
+    Acc *tau = (Acc *)plan->alloc(tau_pp * np * sizeof(Acc), false, &status);
+    if (status != RF_OK) return status;
+
+    FusedArgs<Acc> fbase{};
+    fbase.NX = NX; fbase.NY = NY; fbase.NZ = NZ; fbase.MX = MX; fbase.MY = MY; fbase.nx = nx; fbase.ny = ny;
+    fbase.clamped = plan->clamped ? 1 : 0;
+    fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
+    fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
+    fbase.xs = d_xs; fbase.ys = d_ys;
+    auto fargs = [=](int pl) {
+        FusedArgs<Acc> a = fbase;
+        a.xt = xt + (size_t)pl * xt_pp;
+        a.yt = yt + (size_t)pl * yt_pp;
+        a.y_incoming = yin + (size_t)pl * yin_pp;
+        return a;
+    };
+    GenericDimArgs<Acc> gx{};
+    gx.g = LineGeom{NX, 1, Lx};
+    gx.T = kFusedTX; gx.M = MX; gx.k = K; gx.n_scans = nx; gx.clamped = fbase.clamped;
+    gx.first_is_border = 1; gx.last_is_border = 1;
+    gx.scans = d_xd; gx.W = d_Wx; gx.A = d_Ax;
+    auto gxargs = [=](int pl) {
+        GenericDimArgs<Acc> a = gx;
+        a.tails = xt + (size_t)pl * xt_pp;
+        a.incoming = xin + (size_t)pl * xin_pp;
+        return a;
+    };
+    GenericDimArgs<Acc> gy{};
+    gy.g = LineGeom{NY, NX, Ly};
+    gy.T = TY; gy.M = MY; gy.k = K; gy.n_scans = ny; gy.clamped = fbase.clamped;
+    gy.first_is_border = fbase.y_first_border; gy.last_is_border = fbase.y_last_border;
+    gy.scans = d_yd; gy.W = d_Wy; gy.A = d_Ay;
+    auto gyargs = [=](int pl) {
+        GenericDimArgs<Acc> a = gy;
+        a.tails = yt + (size_t)pl * yt_pp;
+        a.incoming = yin + (size_t)pl * yin_pp;
+        return a;
+    };
+
+    // ---- steps -----------------------------------------------------------------------------
+    Step p1;
+    p1.name = "fused_pass1";
+    p1.run = [plan, fargs, K, TY](int pl) {
+        return launch_fused_pass<P>(false, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+    };
+    plan->begin_steps.push_back(p1);
+    for (int s = 0; s < nx; s++) {
+        Step cx;
+        cx.name = "carry_x" + std::to_string(s);
+        cx.run = [plan, gxargs, s](int pl) { return launch_generic_carry_scan<Acc>(gxargs(pl), s, (Acc *)nullptr, plan->stream); };
+        plan->begin_steps.push_back(cx);
+    }
+    if (nx > 0 && ny > 0) {
+        Step tk;
+        tk.name = "tau";
+        tk.run = [plan, fargs, K, TY, tau, tau_pp](int pl) { return launch_tau<Acc>(K, TY, fargs(pl), tau + (size_t)pl * tau_pp, plan->stream); };
+        plan->begin_steps.push_back(tk);
+    }
+    for (int j = 0; j < ny; j++) {
+        int ex_index = -1;
+        const int64_t plane_stride = (int64_t)K * Ly;
+        if (y_is_exchange_dim) {
+            ex_index = (int)plan->exchanges.size();
+            rf_plan::Exchange ex;
+            ex.bytes = (size_t)np * K * Ly * sizeof(Acc);
+            ex.scratch = plan->alloc(ex.bytes, true, &status);
+            if (status != RF_OK) return status;
+            ex.send = ex.scratch;
+            const Acc *AMj = d_AMy + (size_t)j * K * K;
+            const int64_t rank_stride = (int64_t)np * K * Ly;
+            ex.form_incoming = [plan, gyargs, j, rank_stride, plane_stride, AMj](const void *gathered) {
+                for (int pl = 0; pl < plan->n_planes; pl++) {
+                    int rc = launch_gather_incoming<Acc>(gyargs(pl), j, (const Acc *)gathered, rank_stride,
+                                                         pl * plane_stride, plan->shard_rank, plan->shard_world, AMj,
+                                                         plan->stream);
+                    if (rc) return rc;
+                }
+                return (int)RF_OK;
+            };
+            plan->exchanges.push_back(ex);
+        }
+        Step cy;
+        cy.name = "carry_y" + std::to_string(j);
+        cy.run = [plan, fargs, K, j, tau, tau_pp, d_G, d_Wy, d_Ay, ex_index, plane_stride](int pl) {
+            Acc *send = ex_index >= 0 ? (Acc *)plan->exchanges[ex_index].send : nullptr;
+            return launch_fused_carry_y<Acc>(K, fargs(pl), j, tau + (size_t)pl * tau_pp, d_G, d_Wy, d_Ay,
+                                             send ? send + pl * plane_stride : nullptr, plan->stream);
+        };
+        if (y_is_exchange_dim) {
+            plan->exchange_local_steps.push_back({cy});
+            Step ap;
+            ap.name = "carry_y_apply" + std::to_string(j);
+            ap.run = [plan, gyargs, j](int pl) { return launch_generic_carry_apply<Acc>(gyargs(pl), j, plan->stream); };
+            plan->exchange_apply_steps.push_back({ap});
+        } else {
+            plan->begin_steps.push_back(cy);
+        }
+    }
+    Step p2;
+    p2.name = "fused_pass2";
+    p2.run = [plan, fargs, K, TY](int pl) {
+        return launch_fused_pass<P>(true, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+    };
+    if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
+    else plan->begin_steps.push_back(p2);
+
+    // ---- z (3-D): filtered after the fused x/y stage, reading and writing the output planes ----
+    if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
+        int rc = add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
+        if (rc != RF_OK) return rc;
+    }
+    return status;
+}
+
+}  // namespace
+
+bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::string *why) {
+    auto no = [&](const char *msg) { if (why) *why = msg; return false; };
+    if (plan->dtype != RF_F32 && plan->dtype != RF_I32) return no("pixel type must be f32 or i32");
+    if (plan->ndim < 2) return no("needs at least two dimensions");
+    if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
+    if (plan->dims[0].N % kFusedTX != 0) return no("width must be a multiple of 256");
+    if (plan->dims[1].N % 32 != 0) return no("height must be a multiple of 32");
+    const int K = fused_order(plan);
+    if (K > kFusedMaxK) return no("feedback order above 3");
+    const int64_t NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
+    if (NZ > 65535 || plan->dims[1].N / 32 > 65535) return no("grid too large");
+    if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
+        // the z stage runs on the generic dimension builder
+        if (pick_generic_tile(plan->dims[2].N, plan->dims[2].k, 0) == 0) return no("no tile divides the z extent");
+    }
+    return true;
+}
+
+int build_fused_plan(rf_plan *plan, const rf_filter_desc *desc) {
+    if (plan->dtype == RF_F32) return build_fused<float, double>(plan, desc);
+    if (plan->dtype == RF_I32) return build_fused<int32_t, uint64_t>(plan, desc);
+    set_error("fused path: unsupported pixel type");
     return RF_ERR_UNSUPPORTED;
 }
 

@@ -1,0 +1,180 @@
+"""numpy emulation of the fused x/y path (kernels_fused.hip), driven by the product's plan tables.
+
+Mirrors, stage by stage, what the GPU does for a 2-D image: fused pass 1 (x phase at segment
+level with the Kogge-Stone combine over 16 lanes, then y phase), x carry stage, tau (tile-local y
+scans of the completed x-carry strips), y carry stage with the cross-dimension residual folded in,
+fused pass 2.  All constants come from rf_plan_table() of a host-only plan, so the tiling algebra
+of the product is checked against the oracle on the CPU.  Test infrastructure only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from tiled_emulator import scan_tile
+
+TX, SEG = 256, 16
+
+
+def _f32(c):
+    return float(np.float32(c))
+
+
+class FusedEmu:
+    def __init__(self, plan, scans, clamped):
+        self.plan, self.clamped = plan, clamped
+        self.xs = [(bool(c), [_f32(v) for v in co]) for d, c, co in scans if d == 0]
+        self.ys = [(bool(c), [_f32(v) for v in co]) for d, c, co in scans if d == 1]
+        self.K = max([len(co) - 1 for _, co in self.xs + self.ys])
+        K, nx, ny = self.K, len(self.xs), len(self.ys)
+        self.TY = plan.tiles[1]
+        pad = lambda co: (co[0], list(co[1:]) + [0.0] * (K - len(co) + 1))
+        self.xc = [pad(co) for _, co in self.xs]
+        self.yc = [pad(co) for _, co in self.ys]
+        if nx:
+            self.segR = plan.table("seg_R_x").reshape(nx, SEG, K)
+            self.segP = plan.table("seg_P_x").reshape(nx, 4, K, K)
+            self.Wx = plan.table("W_x").reshape(4, nx, nx, K, K)
+            self.Ax = plan.table("A_x").reshape(nx, K, K)
+            self.G = plan.table("G_x").reshape(4, nx, TX, K)
+        if ny:
+            self.Wy = plan.table("W_y").reshape(4, ny, ny, K, K)
+            self.Ay = plan.table("A_y").reshape(ny, K, K)
+
+    # -- x phase of one scan on rows [R, 256], exactly the kernel's decomposition ------------------
+    def xphase(self, rows, s, carry, clamp_first):
+        causal = self.xs[s][0]
+        b, a = self.xc[s]
+        K = self.K
+        R = rows.shape[0]
+        d = rows if causal else rows[:, ::-1]
+        seg = d.reshape(R, SEG, SEG).copy()          # [row, lane, sample] in direction coordinates
+        S = np.zeros((R, SEG, K))
+        for l in range(SEG):
+            v = seg[:, l, :].copy()
+            c = None
+            if l == 0 and carry is not None:
+                c = [carry[j] for j in range(K)]
+            scan_tile(v, True, b, a, K, clamp_first and l == 0, c)
+            seg[:, l, :] = v
+            for r in range(K):
+                S[:, l, r] = v[:, SEG - 1 - r]
+        for step, dist in enumerate((1, 2, 4, 8)):
+            Sh = np.zeros_like(S)
+            Sh[:, dist:, :] = S[:, :-dist, :]
+            S = S + np.einsum("rj,nlj->nlr", self.segP[s, step], Sh)
+        C = np.zeros_like(S)
+        C[:, 1:, :] = S[:, :-1, :]
+        seg = seg + np.einsum("pj,nlj->nlp", self.segR[s], C)
+        out = seg.reshape(R, TX)
+        return out if causal else out[:, ::-1]
+
+    def run(self, img):
+        img = np.asarray(img, dtype=np.float64)
+        NY, NX = img.shape
+        K, TY = self.K, self.TY
+        MX, MY = NX // TX, NY // TY
+        nx, ny = len(self.xs), len(self.ys)
+        xt = np.zeros((nx, MX, K, NY))
+        yt = np.zeros((ny, MY, K, NX))
+        clamped = self.clamped
+
+        def xfirst(s, tx):
+            return tx == 0 if self.xs[s][0] else tx == MX - 1
+
+        def yfirst(j, ty):
+            return ty == 0 if self.ys[j][0] else ty == MY - 1
+
+        def xcarry(s, tx):        # [K, NY]
+            if xfirst(s, tx):
+                return np.zeros((K, NY))
+            return xt[s, tx - 1 if self.xs[s][0] else tx + 1]
+
+        def ycarry(j, ty):
+            if yfirst(j, ty):
+                return np.zeros((K, NX))
+            return yt[j, ty - 1 if self.ys[j][0] else ty + 1]
+
+        def yscan(tile, j, carry, ty):
+            # tile [TY, W]: scan along axis 0 == scan_tile over transposed rows
+            v = np.ascontiguousarray(tile.T)
+            b, a = self.yc[j]
+            scan_tile(v, self.ys[j][0], b, a, K, clamped and yfirst(j, ty),
+                      None if carry is None else [carry[r] for r in range(K)])
+            return v.T
+
+        def ytail(tile, j):
+            return np.stack([tile[TY - 1 - r] if self.ys[j][0] else tile[r] for r in range(K)])
+
+        # ---- pass 1 ----
+        for ty in range(MY):
+            for tx in range(MX):
+                t = img[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX].copy()
+                for s in range(nx):
+                    t = self.xphase(t, s, None, clamped and xfirst(s, tx))
+                    for r in range(K):
+                        xt[s, tx, r, ty * TY:(ty + 1) * TY] = t[:, TX - 1 - r] if self.xs[s][0] else t[:, r]
+                for j in range(ny):
+                    t = yscan(t, j, None, ty)
+                    yt[j, ty, :, tx * TX:(tx + 1) * TX] = ytail(t, j)
+
+        # ---- x carry stage (generic_carry_scan_kernel on the x tails) ----
+        for s in range(nx):
+            prev = None
+            for i in range(MX):
+                tx = i if self.xs[s][0] else MX - 1 - i
+                v = (1 if tx == 0 else 0) | (2 if tx == MX - 1 else 0)
+                cur = xt[s, tx].copy()
+                for q in range(s):
+                    cur = cur + self.Wx[v, q, s] @ xcarry(q, tx)
+                if i > 0:
+                    cur = cur + self.Ax[s] @ prev
+                xt[s, tx] = cur
+                prev = cur
+
+        # ---- tau ----
+        tau = np.zeros((MY, MX, nx, K, ny, K))
+        for ty in range(MY):
+            for tx in range(MX):
+                for q in range(nx):
+                    if xfirst(q, tx):
+                        continue
+                    strips = xcarry(q, tx)[:, ty * TY:(ty + 1) * TY]       # [K(o), TY]
+                    col = strips.T.copy()                                  # [TY, K] : K "columns"
+                    for j in range(ny):
+                        col = yscan(col, j, None, ty)
+                        tau[ty, tx, q, :, j, :] = ytail(col, j).T          # [o, r]
+
+        # ---- y carry stage with the residual ----
+        xi = np.arange(NX) % TX
+        txs = np.arange(NX) // TX
+        vx = np.where(txs == 0, 1, 0) | np.where(txs == MX - 1, 2, 0)
+        for j in range(ny):
+            prev = None
+            for i in range(MY):
+                ty = i if self.ys[j][0] else MY - 1 - i
+                vy = (1 if ty == 0 else 0) | (2 if ty == MY - 1 else 0)
+                cur = yt[j, ty].copy()
+                for q in range(nx):
+                    g = self.G[vx, q, xi, :]                               # [NX, K(o)]
+                    tq = tau[ty, txs, q, :, j, :]                          # [NX, o, r]
+                    cur = cur + np.einsum("xo,xor->rx", g, tq)
+                for q in range(j):
+                    cur = cur + self.Wy[vy, q, j] @ ycarry(q, ty)
+                if i > 0:
+                    cur = cur + self.Ay[j] @ prev
+                yt[j, ty] = cur
+                prev = cur
+
+        # ---- pass 2 ----
+        out = np.empty_like(img)
+        for ty in range(MY):
+            for tx in range(MX):
+                t = img[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX].copy()
+                for s in range(nx):
+                    c = None if xfirst(s, tx) else xcarry(s, tx)[:, ty * TY:(ty + 1) * TY]
+                    t = self.xphase(t, s, c, clamped and xfirst(s, tx))
+                for j in range(ny):
+                    c = None if yfirst(j, ty) else ycarry(j, ty)[:, tx * TX:(tx + 1) * TX]
+                    t = yscan(t, j, c, ty)
+                out[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX] = t
+        return out

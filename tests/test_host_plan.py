@@ -200,3 +200,30 @@ def test_overlap_to_higher_order_filter_matches_cascade_in_oracle():
     cascaded = oracle.apply_filter(oracle.apply_filter(img, f1._contents["scans"]), f2._contents["scans"])
     overlapped = oracle.apply_filter(img, f3._contents["scans"])
     assert rc.rel_err(overlapped, cascaded) < 1e-5
+
+
+# ---- fused x/y path: the whole tiling algebra (segment tables, chaining, cross-dimension residual) ----
+FUSED_CASES = rc.FUSED_CASES
+
+
+@pytest.mark.parametrize("name", sorted(FUSED_CASES))
+def test_fused_plan_tables_reproduce_oracle(name):
+    import fused_emulator
+    case = FUSED_CASES[name]
+    p = _host_plan(case["shape"], case["scans"], dtype=np.float32, clamped=case["clamped"],
+                   path=capi.RF_PATH_TILED_FUSED)
+    assert p.path == capi.RF_PATH_TILED_FUSED and p.tiles[0] == 256 and p.tiles[1] in (32, 64)
+    img = rc.random_image(case["shape"]).astype(np.float64)
+    want = oracle.apply_filter(img, case["scans"], case["clamped"])
+    got = fused_emulator.FusedEmu(p, case["scans"], case["clamped"]).run(img)
+    assert rc.rel_err(got, want) < 2e-6      # tables are stored in f32, the emulation runs in f64
+
+
+def test_fused_not_applicable_falls_back_in_auto_mode():
+    p = _host_plan((100, 300), rc.xy_pm(rc.GAUSS2), clamped=True)       # width not a multiple of 256
+    assert p.path == capi.RF_PATH_TILED_GENERIC
+    with pytest.raises(rfa.RecFilterError) as e:
+        _host_plan((100, 300), rc.xy_pm(rc.GAUSS2), clamped=True, path=capi.RF_PATH_TILED_FUSED)
+    assert e.value.status == capi.RF_ERR_UNSUPPORTED
+    p = _host_plan((64, 512), rc.xy_pm(rc.GAUSS2), clamped=True)
+    assert p.path == capi.RF_PATH_TILED_FUSED
