@@ -5,6 +5,7 @@
 
 #include <cstdint>
 
+#include "kernels.h"
 #include "pixel.h"
 #include "rf_internal.h"
 
@@ -40,6 +41,22 @@ struct FusedArgs {
     Acc *yt;                 // y tails   [j][ty][r][x + NX*z]
     const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]
 };
+
+// Cross-dimension residual folded into the y carry stage (tau == nullptr: none).
+template <typename Acc>
+struct CarryResidual {
+    const Acc *tau;   // [tile][q][o][j][r], tile = (z*MY + ty)*MX + tx
+    const Acc *G;     // [x-variant][q][xi][o]
+    int32_t nx, MX, ny;
+    int64_t NX;       // the carried dimension's line index is x + NX*z
+};
+
+// Blocked parallel carry scan over the tails of one dimension (kernels_carry.hip); scans
+// [s_begin, s_end) of the dimension in one launch.  AC[s] = A[s]^C, C = carry_chunk_length(M).
+template <typename Acc>
+int launch_carry_block(int K, const GenericDimArgs<Acc> &a, int s_begin, int s_end, const CarryResidual<Acc> &res,
+                       Acc *send, const Acc *AC, int C, hipStream_t stream);
+int carry_chunk_length(int64_t M);
 
 template <typename P>
 int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,

@@ -48,42 +48,49 @@ __device__ __forceinline__ Acc row_shift(Acc v) {
 
 __device__ __forceinline__ int swz_chunk(int c) { return c ^ ((c >> 4) & 3); }
 
-// ---- x phase: one scan over a 256-sample tile row held as 16 samples per lane --------------
-template <typename Acc, bool CAUSAL, int K>
-__device__ __forceinline__ void scan_row16(Acc (&v)[kFusedSeg], const FusedScan<Acc> &sc, bool first_lane,
-                                           bool clamp_first, const Acc (&carry)[kFusedMaxK]) {
-    Acc h[K];
+// ---- x phase: one scan over NR 256-sample tile rows, each held as 16 samples per lane -----------
+// The NR rows are independent recurrences; every step is written row-innermost so the compiler
+// interleaves them (ILP = NR) and the dependent-FMA latency of one row hides behind the others.
+template <typename Acc, bool CAUSAL, int K, int NR>
+__device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const FusedScan<Acc> &sc, bool first_lane,
+                                            bool clamp_first, const Acc (&carry)[NR][kFusedMaxK]) {
+    Acc h[NR][K];
+    Acc y0[NR];
 #pragma unroll
-    for (int j = 0; j < K; j++) h[j] = first_lane ? carry[j] : Acc(0);
-    Acc y0 = Acc(0);
+    for (int n = 0; n < NR; n++) {
+#pragma unroll
+        for (int j = 0; j < K; j++) h[n][j] = first_lane ? carry[n][j] : Acc(0);
+        y0[n] = Acc(0);
+    }
     // 1. segment-local recurrence (exact for the first lane, which owns the tile's carry)
 #pragma unroll
     for (int p = 0; p < kFusedSeg; p++) {
         const int m = CAUSAL ? p : kFusedSeg - 1 - p;
-        Acc x = v[m];
-        Acc acc = sc.b * x;
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-            Acc g = h[j];
-            if (p <= j) g = clamp_first ? (p == 0 ? x : y0) : g;
-            acc = acc + sc.a[j] * g;
+        for (int n = 0; n < NR; n++) {
+            Acc x = v[n][m];
+            Acc acc = sc.b * x;
+            // oldest tap first: the newest output h[0] enters last, one dependent FMA per sample
+#pragma unroll
+            for (int j = K - 1; j >= 0; j--) {
+                Acc g = h[n][j];
+                if (p <= j) g = clamp_first ? (p == 0 ? x : y0[n]) : g;
+                acc = acc + sc.a[j] * g;
+            }
+#pragma unroll
+            for (int j = K - 1; j > 0; j--) h[n][j] = h[n][j - 1];
+            h[n][0] = acc;
+            if (p == 0) y0[n] = acc;
+            v[n][m] = acc;
         }
-#pragma unroll
-        for (int j = K - 1; j > 0; j--) h[j] = h[j - 1];
-        h[0] = acc;
-        if (p == 0) y0 = acc;
-        v[m] = acc;
     }
-    // 2. Kogge-Stone over the 16 lanes of the row: S_l <- sum_{j<=l} P^(l-j) S_j
-    Acc S[K];
-#pragma unroll
-    for (int r = 0; r < K; r++) S[r] = h[r];
-#define RF_KS_STEP(D, IDX)                                                          \
-    {                                                                               \
-        Acc Sh[K];                                                                  \
-        _Pragma("unroll") for (int j = 0; j < K; j++) Sh[j] = row_shift<CAUSAL, D>(S[j]); \
-        _Pragma("unroll") for (int r = 0; r < K; r++)                               \
-            _Pragma("unroll") for (int j = 0; j < K; j++) S[r] = S[r] + sc.P[IDX][r][j] * Sh[j]; \
+    // 2. Kogge-Stone over the 16 lanes of each row: S_l <- sum_{j<=l} P^(l-j) S_j
+#define RF_KS_STEP(D, IDX)                                                                        \
+    _Pragma("unroll") for (int n = 0; n < NR; n++) {                                              \
+        Acc Sh[K];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < K; j++) Sh[j] = row_shift<CAUSAL, D>(h[n][j]);      \
+        _Pragma("unroll") for (int r = 0; r < K; r++)                                             \
+            _Pragma("unroll") for (int j = 0; j < K; j++) h[n][r] = h[n][r] + sc.P[IDX][r][j] * Sh[j]; \
     }
     RF_KS_STEP(1, 0)
     RF_KS_STEP(2, 1)
@@ -91,14 +98,18 @@ __device__ __forceinline__ void scan_row16(Acc (&v)[kFusedSeg], const FusedScan<
     RF_KS_STEP(8, 3)
 #undef RF_KS_STEP
     // 3. state entering this lane's segment, then the rank-K correction of its 16 samples
-    Acc C[K];
+    Acc C[NR][K];
 #pragma unroll
-    for (int j = 0; j < K; j++) C[j] = row_shift<CAUSAL, 1>(S[j]);
+    for (int n = 0; n < NR; n++)
+#pragma unroll
+        for (int j = 0; j < K; j++) C[n][j] = row_shift<CAUSAL, 1>(h[n][j]);
 #pragma unroll
     for (int p = 0; p < kFusedSeg; p++) {
         const int m = CAUSAL ? p : kFusedSeg - 1 - p;
 #pragma unroll
-        for (int j = 0; j < K; j++) v[m] = v[m] + sc.R[p][j] * C[j];
+        for (int n = 0; n < NR; n++)
+#pragma unroll
+            for (int j = 0; j < K; j++) v[n][m] = v[n][m] + sc.R[p][j] * C[n][j];
     }
 }
 
@@ -115,8 +126,9 @@ __device__ __forceinline__ void scan_col(Acc (&col)[TY], const FusedScan<Acc> &s
         const int m = CAUSAL ? p : TY - 1 - p;
         Acc x = col[m];
         Acc acc = sc.b * x;
+        // oldest tap first: the newest output h[0] enters last, one dependent FMA per sample
 #pragma unroll
-        for (int j = 0; j < K; j++) {
+        for (int j = K - 1; j >= 0; j--) {
             Acc g = h[j];
             if (p <= j) g = clamp_first ? (p == 0 ? x : y0) : g;
             acc = acc + sc.a[j] * g;
@@ -162,52 +174,65 @@ fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<type
         for (int i = 0; i < TY / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
     }
 
-    // ---- x phase ----
+    // ---- x phase: thread = (row slot, 16-sample segment); TY/16 rows per thread, interleaved ----
     if (a.nx > 0) {
         __syncthreads();
+        constexpr int NR = TY / 16;
         const int l = t & 15, slot = t >> 4;
         const int64_t Lx = a.NY * a.NZ;
         const int sw = (l >> 2) & 3;
-#pragma unroll 1
-        for (int i = 0; i < TY / 16; i++) {
-            const int row = slot + 16 * i;
-            const int64_t line = (int64_t)ty * TY + row + a.NY * z;
-            Acc v[kFusedSeg];
+        const int64_t line0 = (int64_t)ty * TY + slot + a.NY * z;     // row n of this thread: line0 + 16 n
+        Acc v[NR][kFusedSeg];
+#pragma unroll
+        for (int n = 0; n < NR; n++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                A4 q = tile4[row * 64 + 4 * l + (j ^ sw)];
-                v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+                A4 q = tile4[(slot + 16 * n) * 64 + 4 * l + (j ^ sw)];
+                v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
             }
+        }
 #pragma unroll 1
-            for (int s = 0; s < a.nx; s++) {
-                const FusedScan<Acc> &sc = a.xs[s];
-                const bool causal = sc.causal != 0;
-                const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-                const bool first_lane = causal ? (l == 0) : (l == 15);
-                Acc carry[kFusedMaxK] = {Acc(0), Acc(0), Acc(0)};
-                if (FINAL && first_lane && !tile_first) {
-                    const int tp = causal ? tx - 1 : tx + 1;
+        for (int s = 0; s < a.nx; s++) {
+            const FusedScan<Acc> &sc = a.xs[s];
+            const bool causal = sc.causal != 0;
+            const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
+            const bool first_lane = causal ? (l == 0) : (l == 15);
+            Acc carry[NR][kFusedMaxK];
 #pragma unroll
-                    for (int j = 0; j < K; j++) carry[j] = a.xt[(((int64_t)s * a.MX + tp) * K + j) * Lx + line];
-                }
-                const bool clamp_first = a.clamped && tile_first && first_lane;
-                if (causal) scan_row16<Acc, true, K>(v, sc, first_lane, clamp_first, carry);
-                else        scan_row16<Acc, false, K>(v, sc, first_lane, clamp_first, carry);
-                if (!FINAL) {
-                    // tail r = sample at direction position 255-r: the last lane's last K samples
-                    const bool last_lane = causal ? (l == 15) : (l == 0);
-                    if (last_lane) {
+            for (int n = 0; n < NR; n++)
+#pragma unroll
+                for (int j = 0; j < kFusedMaxK; j++) carry[n][j] = Acc(0);
+            if (FINAL && first_lane && !tile_first) {
+                const int tp = causal ? tx - 1 : tx + 1;
+#pragma unroll
+                for (int n = 0; n < NR; n++)
+#pragma unroll
+                    for (int j = 0; j < K; j++)
+                        carry[n][j] = a.xt[(((int64_t)s * a.MX + tp) * K + j) * Lx + line0 + 16 * n];
+            }
+            const bool clamp_first = a.clamped && tile_first && first_lane;
+            if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, carry);
+            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, carry);
+            if (!FINAL) {
+                // tail r = sample at direction position 255-r: the last lane's last K samples
+                const bool last_lane = causal ? (l == 15) : (l == 0);
+                if (last_lane) {
+#pragma unroll
+                    for (int n = 0; n < NR; n++)
 #pragma unroll
                         for (int r = 0; r < K; r++)
-                            a.xt[(((int64_t)s * a.MX + tx) * K + r) * Lx + line] = causal ? v[kFusedSeg - 1 - r] : v[r];
-                    }
+                            a.xt[(((int64_t)s * a.MX + tx) * K + r) * Lx + line0 + 16 * n] =
+                                causal ? v[n][kFusedSeg - 1 - r] : v[n][r];
                 }
             }
+        }
+#pragma unroll
+        for (int n = 0; n < NR; n++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 A4 q;
-                q.x = v[4 * j + 0]; q.y = v[4 * j + 1]; q.z = v[4 * j + 2]; q.w = v[4 * j + 3];
-                tile4[row * 64 + 4 * l + (j ^ sw)] = q;
+                q.x = v[n][4 * j + 0]; q.y = v[n][4 * j + 1]; q.z = v[n][4 * j + 2]; q.w = v[n][4 * j + 3];
+                tile4[(slot + 16 * n) * 64 + 4 * l + (j ^ sw)] = q;
             }
         }
     }

@@ -30,7 +30,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     DimInfo &dx = plan->dims[0];
     DimInfo &dy = plan->dims[1];
     const int64_t NX = dx.N, NY = dy.N, NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
-    const int TY = (NY % 64 == 0) ? 64 : 32;
+    int TY = (NY % 64 == 0) ? 64 : 32;
+    if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
+        const int want = atoi(env);
+        if ((want == 32 || want == 64) && NY % want == 0) TY = want;
+    }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
     dx.T = kFusedTX; dx.M = NX / kFusedTX;
     dy.T = TY;       dy.M = NY / TY;
@@ -120,10 +124,16 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->tables["seg_P_x"] = sp;
     }
     std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
-    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy;
+    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy;
+    const int Cx = carry_chunk_length(MX), Cy = carry_chunk_length(MY);
     if (nx > 0) {
         DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
         flatten_W(tx, nx, hWx, hAx, "x");
+        hACx.assign((size_t)nx * K * K, Acc(0));
+        for (int s = 0; s < nx; s++) {
+            std::vector<S> ac = mat_pow<S>(tx.A[s], Cx, K);
+            for (int e = 0; e < K * K; e++) hACx[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ac[e]);
+        }
         // G[v][q][xi][o]: what the carry entering x scan q adds to the tile after ALL x scans
         hG.assign((size_t)4 * nx * kFusedTX * K, Acc(0));
         std::vector<double> dG(hG.size());
@@ -142,9 +152,14 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped);
         flatten_W(ty, ny, hWy, hAy, "y");
         hAMy.assign((size_t)ny * K * K, Acc(0));
+        hACy.assign((size_t)ny * K * K, Acc(0));
         for (int j = 0; j < ny; j++) {
             std::vector<S> am = mat_pow<S>(ty.A[j], MY, K);
-            for (int e = 0; e < K * K; e++) hAMy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(am[e]);
+            std::vector<S> ac = mat_pow<S>(ty.A[j], Cy, K);
+            for (int e = 0; e < K * K; e++) {
+                hAMy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(am[e]);
+                hACy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(ac[e]);
+            }
         }
     }
 
@@ -158,6 +173,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const DevScan<Acc> *d_xd = up(hxd);
     const DevScan<Acc> *d_yd = up(hyd);
     const Acc *d_Wx = up(hWx), *d_Ax = up(hAx), *d_Wy = up(hWy), *d_Ay = up(hAy), *d_G = up(hG), *d_AMy = up(hAMy);
+    const Acc *d_ACx = up(hACx), *d_ACy = up(hACy);
 
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
@@ -213,10 +229,13 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         return launch_fused_pass<P>(false, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
     };
     plan->begin_steps.push_back(p1);
-    for (int s = 0; s < nx; s++) {
+    if (nx > 0) {
         Step cx;
-        cx.name = "carry_x" + std::to_string(s);
-        cx.run = [plan, gxargs, s](int pl) { return launch_generic_carry_scan<Acc>(gxargs(pl), s, (Acc *)nullptr, plan->stream); };
+        cx.name = "carry_x";
+        cx.run = [plan, gxargs, K, nx, d_ACx, Cx](int pl) {
+            CarryResidual<Acc> none{};
+            return launch_carry_block<Acc>(K, gxargs(pl), 0, nx, none, (Acc *)nullptr, d_ACx, Cx, plan->stream);
+        };
         plan->begin_steps.push_back(cx);
     }
     if (nx > 0 && ny > 0) {
@@ -225,11 +244,27 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         tk.run = [plan, fargs, K, TY, tau, tau_pp](int pl) { return launch_tau<Acc>(K, TY, fargs(pl), tau + (size_t)pl * tau_pp, plan->stream); };
         plan->begin_steps.push_back(tk);
     }
-    for (int j = 0; j < ny; j++) {
-        int ex_index = -1;
-        const int64_t plane_stride = (int64_t)K * Ly;
-        if (y_is_exchange_dim) {
-            ex_index = (int)plan->exchanges.size();
+    CarryResidual<Acc> resy{};
+    resy.tau = (nx > 0 && ny > 0) ? tau : nullptr;
+    resy.G = d_G; resy.nx = nx; resy.MX = MX; resy.ny = ny; resy.NX = NX;
+    auto res_for = [resy, tau_pp](int pl) {
+        CarryResidual<Acc> r = resy;
+        if (r.tau) r.tau += (size_t)pl * tau_pp;
+        return r;
+    };
+    if (!y_is_exchange_dim) {
+        if (ny > 0) {
+            Step cy;
+            cy.name = "carry_y";
+            cy.run = [plan, gyargs, res_for, K, ny, d_ACy, Cy](int pl) {
+                return launch_carry_block<Acc>(K, gyargs(pl), 0, ny, res_for(pl), (Acc *)nullptr, d_ACy, Cy, plan->stream);
+            };
+            plan->begin_steps.push_back(cy);
+        }
+    } else {
+        for (int j = 0; j < ny; j++) {
+            const int64_t plane_stride = (int64_t)K * Ly;
+            const int ex_index = (int)plan->exchanges.size();
             rf_plan::Exchange ex;
             ex.bytes = (size_t)np * K * Ly * sizeof(Acc);
             ex.scratch = plan->alloc(ex.bytes, true, &status);
@@ -247,22 +282,18 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                 return (int)RF_OK;
             };
             plan->exchanges.push_back(ex);
-        }
-        Step cy;
-        cy.name = "carry_y" + std::to_string(j);
-        cy.run = [plan, fargs, K, j, tau, tau_pp, d_G, d_Wy, d_Ay, ex_index, plane_stride](int pl) {
-            Acc *send = ex_index >= 0 ? (Acc *)plan->exchanges[ex_index].send : nullptr;
-            return launch_fused_carry_y<Acc>(K, fargs(pl), j, tau + (size_t)pl * tau_pp, d_G, d_Wy, d_Ay,
-                                             send ? send + pl * plane_stride : nullptr, plan->stream);
-        };
-        if (y_is_exchange_dim) {
+            Step cy;
+            cy.name = "carry_y" + std::to_string(j);
+            cy.run = [plan, gyargs, res_for, K, j, d_ACy, Cy, ex_index, plane_stride](int pl) {
+                Acc *send = (Acc *)plan->exchanges[ex_index].send;
+                return launch_carry_block<Acc>(K, gyargs(pl), j, j + 1, res_for(pl), send ? send + pl * plane_stride : nullptr,
+                                               d_ACy, Cy, plan->stream);
+            };
             plan->exchange_local_steps.push_back({cy});
             Step ap;
             ap.name = "carry_y_apply" + std::to_string(j);
             ap.run = [plan, gyargs, j](int pl) { return launch_generic_carry_apply<Acc>(gyargs(pl), j, plan->stream); };
             plan->exchange_apply_steps.push_back({ap});
-        } else {
-            plan->begin_steps.push_back(cy);
         }
     }
     Step p2;

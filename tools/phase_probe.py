@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of filter variants on one GPU (tuning aid): which phase of the fused pass costs what."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import recfilter_amd as rfa
+import ref_cases as rc
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+g = rc.GAUSS2
+variants = {
+    "xy(+x-x+y-y)": rc.xy_pm(g),
+    "x-only(+x-x)": [(0, True, g), (0, False, g)],
+    "y-only(+y-y)": [(1, True, g), (1, False, g)],
+    "+x": [(0, True, g)],
+    "+y": [(1, True, g)],
+    "sat(+x+y,k=1)": [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])],
+    "gauss3 xy": rc.xy_pm(rc.GAUSS3),
+}
+img = torch.rand((n, n), device="cuda")
+out = torch.empty_like(img)
+for name, scans in variants.items():
+    with rfa.Plan((n, n), scans, clamped=True) as plan:
+        for _ in range(3):
+            plan.execute([img], [out])
+        acc = {}
+        for _ in range(10):
+            _, times = plan.execute_timed([img], [out])
+            for k, ms in times:
+                acc.setdefault(k, []).append(ms)
+        res = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
+        print(f"{name:16s} TY={plan.tiles[1]} total={sum(res.values()):.4f} {json.dumps(res)}", flush=True)
