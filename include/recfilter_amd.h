@@ -142,6 +142,10 @@ int rf_plan_finish(rf_plan *plan);
  * pass out = NULL to query the size.  Names are documented in DESIGN.md ("plan tables"). */
 int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t capacity, size_t *n_out);
 
+/* Debugging aid: device pointer and size of the i-th buffer the plan owns (tables, tails, carries,
+ * in allocation order); RF_ERR_INVALID_ARG past the last one. */
+int rf_plan_debug_buffer(const rf_plan *plan, int index, void **ptr_out, size_t *bytes_out);
+
 /* ---- coefficient design (lib/iir_coeff.cpp:162-177, 222-234, 236-263, 205-220) ------------ */
 int rf_gaussian_weights(float sigma, int order, float *coeff_out /* order+1 */);
 int rf_integral_image_coeff(int n, float *coeff_out /* n+1 */);

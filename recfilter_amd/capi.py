@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "rf_plan_num_kernels", "rf_plan_execute", "rf_plan_execute_timed", "rf_plan_num_exchanges",
     "rf_plan_exchange_bytes",
     "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_finish",
-    "rf_plan_table", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
+    "rf_plan_table", "rf_plan_debug_buffer", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
     "rf_gaussian_box_filter", "rf_last_error_string", "rf_version", "rf_device_count",
 ]
 
@@ -104,6 +104,7 @@ def lib() -> ctypes.CDLL:
     L.rf_plan_finish.argtypes = [vp]
     L.rf_plan_table.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,
                                 ctypes.POINTER(ctypes.c_size_t)]
+    L.rf_plan_debug_buffer.argtypes = [vp, ctypes.c_int, vpp, ctypes.POINTER(ctypes.c_size_t)]
     L.rf_gaussian_weights.argtypes = [ctypes.c_float, ctypes.c_int, fp]
     L.rf_integral_image_coeff.argtypes = [ctypes.c_int, fp]
     L.rf_overlap_feedback_coeff.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, fp]

@@ -166,6 +166,13 @@ int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t cap
     return RF_OK;
 }
 
+int rf_plan_debug_buffer(const rf_plan *plan, int index, void **ptr_out, size_t *bytes_out) {
+    if (!plan || index < 0 || index >= (int)plan->buffers.size()) { set_error("no such buffer"); return RF_ERR_INVALID_ARG; }
+    if (ptr_out) *ptr_out = plan->buffers[index].ptr;
+    if (bytes_out) *bytes_out = plan->buffers[index].bytes;
+    return RF_OK;
+}
+
 // ---- coefficient design ------------------------------------------------------------------
 // Recursive Gaussian of van Vliet, Young and Verbeek: the poles of a fixed prototype are
 // rescaled to the requested sigma, d -> |d|^(1/q) e^(i arg(d)/q) with q = 0.00399341 +

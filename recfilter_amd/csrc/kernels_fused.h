@@ -15,6 +15,7 @@ constexpr int kFusedTX = 256;       // tile width: 16 lanes x 16 samples = one D
 constexpr int kFusedSeg = 16;       // samples per lane in the x phase
 constexpr int kFusedThreads = 256;  // 4 waves
 constexpr int kFusedMaxK = 3;       // max feedback order on the fused path
+constexpr int kFusedMaxScans = 4;   // max scans per dimension on the fused path
 
 // One scan as the fused kernels read it (device memory, uniform -> scalar loads).
 template <typename Acc>
@@ -27,6 +28,18 @@ struct FusedScan {
     Acc P[4][kFusedMaxK][kFusedMaxK];       // segment exit-state transfer over 1, 2, 4, 8 segments
 };
 
+// y scans only need their coefficients
+template <typename Acc>
+struct FusedScanY {
+    int32_t causal;
+    Acc b;
+    Acc a[kFusedMaxK];
+};
+
+// Passed to the kernels BY VALUE: the scan tables then live in the kernarg segment (constant address
+// space), so a run-time scan index still compiles to scalar loads.  Behind a pointer the persistent
+// kernel's own stores make them "possibly clobbered" and the compiler falls back to per-lane vector
+// loads that cost ~50 VGPRs.
 template <typename Acc>
 struct FusedArgs {
     int64_t NX, NY, NZ;      // extents (NZ = batch of planes along z, 1 for 2-D)
@@ -35,8 +48,8 @@ struct FusedArgs {
     int32_t clamped;
     int32_t y_first_border;  // the slab holds the image's first / last tile row
     int32_t y_last_border;
-    const FusedScan<Acc> *xs;
-    const FusedScan<Acc> *ys;
+    FusedScan<Acc> xs[kFusedMaxScans];
+    FusedScanY<Acc> ys[kFusedMaxScans];
     Acc *xt;                 // x tails   [s][tx][r][y + NY*z]
     Acc *yt;                 // y tails   [j][ty][r][x + NX*z]
     const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]

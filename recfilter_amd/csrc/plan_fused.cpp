@@ -168,8 +168,6 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         using T = typename std::decay<decltype(vec)>::type::value_type;
         return (const T *)plan->upload(vec.data(), vec.size() * sizeof(T), &status);
     };
-    const FusedScan<Acc> *d_xs = up(hxs);
-    const FusedScan<Acc> *d_ys = up(hys);
     const DevScan<Acc> *d_xd = up(hxd);
     const DevScan<Acc> *d_yd = up(hyd);
     const Acc *d_Wx = up(hWx), *d_Ax = up(hAx), *d_Wy = up(hWy), *d_Ay = up(hAy), *d_G = up(hG), *d_AMy = up(hAMy);
@@ -191,7 +189,14 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     fbase.clamped = plan->clamped ? 1 : 0;
     fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
     fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
-    fbase.xs = d_xs; fbase.ys = d_ys;
+    std::memset(fbase.xs, 0, sizeof(fbase.xs));
+    std::memset(fbase.ys, 0, sizeof(fbase.ys));
+    for (int s = 0; s < nx; s++) fbase.xs[s] = hxs[s];
+    for (int j = 0; j < ny; j++) {
+        fbase.ys[j].causal = hys[j].causal;
+        fbase.ys[j].b = hys[j].b;
+        for (int e = 0; e < kFusedMaxK; e++) fbase.ys[j].a[e] = hys[j].a[e];
+    }
     auto fargs = [=](int pl) {
         FusedArgs<Acc> a = fbase;
         a.xt = xt + (size_t)pl * xt_pp;
@@ -252,7 +257,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         if (r.tau) r.tau += (size_t)pl * tau_pp;
         return r;
     };
-    if (!y_is_exchange_dim) {
+    if (!y_sharded) {   // one launch for every y scan; per-scan launches only around the exchanges
         if (ny > 0) {
             Step cy;
             cy.name = "carry_y";
@@ -323,6 +328,8 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
     if (plan->dims[1].N % 32 != 0) return no("height must be a multiple of 32");
     const int K = fused_order(plan);
     if (K > kFusedMaxK) return no("feedback order above 3");
+    if ((int)plan->dims[0].scan_ids.size() > kFusedMaxScans || (int)plan->dims[1].scan_ids.size() > kFusedMaxScans)
+        return no("more than 4 scans along x or y");
     const int64_t NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
     if (NZ > 65535 || plan->dims[1].N / 32 > 65535) return no("grid too large");
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
