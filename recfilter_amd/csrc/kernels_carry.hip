@@ -3,8 +3,9 @@
 // The reference runs this stage (create_complete_tail_term, lib/split.cpp:743-867) as one
 // unrolled per-thread loop over all tiles of a line (gpu_auto_inter_schedule,
 // lib/recfilter.cpp:763-785): a chain of M dependent steps, each waiting on a global load.
-// On MI355X that is pure latency (16k lines = one wave per CU).  Here a workgroup owns 16 lines
-// and cuts each line's M tiles into 16 chunks:
+// On MI355X that is pure latency (16k lines = one wave per CU).  Here a workgroup of 16 waves owns
+// 64 lines (lane = line) and cuts each line's M tiles into 16 chunks (wave = chunk, so everything
+// that depends on the tile index is wave-uniform and lives in scalar registers):
 //
 //   A  every thread (line, chunk) loads its <=16 tile tails at once (independent loads), adds
 //      the same-dimension chaining terms (create_tail_residual_term, lib/split.cpp:912-1004)
@@ -25,9 +26,10 @@ namespace rf {
 
 namespace {
 
-constexpr int kCarryLines = 16;    // lines per workgroup
-constexpr int kCarryChunks = 16;   // chunks per line per block of tiles
+constexpr int kCarryLines = 64;    // lines per workgroup = one wave: 256-byte coalesced tail accesses
+constexpr int kCarryChunks = 16;   // chunks per line per block of tiles = waves per workgroup
 constexpr int kCarryMaxC = 16;     // tiles per chunk
+constexpr int kCarryThreads = kCarryLines * kCarryChunks;
 
 template <typename Acc, int K>
 __device__ __forceinline__ void matvec_acc(const Acc *__restrict__ m, const Acc (&x)[K], Acc (&y)[K]) {
@@ -37,40 +39,64 @@ __device__ __forceinline__ void matvec_acc(const Acc *__restrict__ m, const Acc 
         for (int j = 0; j < K; j++) y[r] = y[r] + m[r * K + j] * x[j];
 }
 
+struct CarryGeom {
+    uint32_t lines;          // number of lines (all tails offsets fit 32 bits, checked on the host)
+    int32_t M;               // tiles per line
+    int32_t n_scans;
+    int32_t first_is_border, last_is_border;
+    uint32_t causal_mask;    // bit s = scan s is causal
+    // cross-dimension residual (y dimension of the fused path); tau == nullptr: none
+    int32_t res_nx, res_MX, res_ny;
+    uint32_t res_NX;
+};
+
 template <typename Acc, int K>
-__global__ void __launch_bounds__(256)
-carry_block_kernel(GenericDimArgs<Acc> a, int s_begin, int s_end, CarryResidual<Acc> res, Acc *__restrict__ send,
-                   const Acc *__restrict__ AC, int C) {
+__global__ void __launch_bounds__(kCarryThreads)
+carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
+                   const Acc *__restrict__ tau, const Acc *__restrict__ G, const Acc *__restrict__ Wtab,
+                   const Acc *__restrict__ Atab, const Acc *__restrict__ AC, Acc *__restrict__ send, int C) {
     __shared__ Acc exits[kCarryChunks][kCarryLines][K];
     __shared__ Acc carry_in[kCarryLines][K];
 
-    const int t = threadIdx.x;
-    const int ln = t & (kCarryLines - 1), ch = t >> 4;
-    const int64_t line = (int64_t)blockIdx.x * kCarryLines + ln;
-    const bool line_ok = line < a.g.lines;
-    const int64_t L = a.g.lines;
-    const int M = a.M;
+    const int ln = threadIdx.x & (kCarryLines - 1);
+    const int ch = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kCarryLines);    // wave-uniform
+    const uint32_t L = g.lines;
+    const uint32_t line_raw = blockIdx.x * kCarryLines + ln;
+    const bool line_ok = line_raw < L;
+    const uint32_t line = line_ok ? line_raw : L - 1;     // out-of-range lanes shadow the last line, stores masked
+    const int M = g.M;
+    const uint32_t tile_stride = (uint32_t)K * L;          // elements between consecutive tiles of one scan
     const int tiles_per_block = kCarryChunks * C;
     const int n_blocks = (M + tiles_per_block - 1) / tiles_per_block;
 
-    // residual geometry (y dimension of the fused path): line = x + NX*z
-    int tx = 0, xi = 0, vx = 0;
-    int64_t z = 0;
-    if (res.tau != nullptr && line_ok) {
-        const int64_t x = line % res.NX;
-        z = line / res.NX;
-        tx = (int)(x / kFusedTX);
+    // residual geometry: line = x + NX*z; a wave's 64 lines share the tile column and the plane
+    int xi = 0, vx = 0, tx_u = 0, z_u = 0;
+    if (tau != nullptr) {
+        const uint32_t x = line % g.res_NX;
+        const int tx = (int)(x / kFusedTX);
         xi = (int)(x % kFusedTX);
-        vx = (tx == 0 ? 1 : 0) | (tx == res.MX - 1 ? 2 : 0);
+        vx = (tx == 0 ? 1 : 0) | (tx == g.res_MX - 1 ? 2 : 0);
+        tx_u = __builtin_amdgcn_readfirstlane(tx);
+        z_u = __builtin_amdgcn_readfirstlane((int)(line / g.res_NX));
     }
 
     for (int s = s_begin; s < s_end; s++) {
-        const bool causal = a.scans[s].causal != 0;
-        const Acc *Am = a.A + (int64_t)s * K * K;
-        const Acc *ACm = AC + (int64_t)s * K * K;
+        const bool causal = ((g.causal_mask >> s) & 1u) != 0;
+        const Acc *Am = Atab + s * K * K;
+        const Acc *ACm = AC + s * K * K;
+        const uint32_t scan_base = (uint32_t)s * (uint32_t)M * tile_stride + line;
         if (ch == 0) {
 #pragma unroll
             for (int r = 0; r < K; r++) carry_in[ln][r] = Acc(0);
+        }
+        Acc g_res[kFusedMaxScans * K];
+        const int nxk = g.res_nx * K;
+        if (tau != nullptr) {
+#pragma unroll
+            for (int qo = 0; qo < kFusedMaxScans * K; qo++) {
+                g_res[qo] = Acc(0);
+                if (qo < nxk) g_res[qo] = G[((vx * g.res_nx + qo / K) * kFusedTX + xi) * K + qo % K];
+            }
         }
         Acc last_tail[K];
 #pragma unroll
@@ -79,60 +105,56 @@ carry_block_kernel(GenericDimArgs<Acc> a, int s_begin, int s_end, CarryResidual<
         for (int blk = 0; blk < n_blocks; blk++) {
             const int base_i = blk * tiles_per_block + ch * C;
             int nvalid = M - base_i;
-            nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
-            if (!line_ok) nvalid = 0;
+            nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);      // wave-uniform
 
-            // ---- A: load, add chaining and residual, chunk-local recurrence ----
+            // ---- A: load, add residual and chaining, chunk-local recurrence ----
             Acc cur[kCarryMaxC][K];
 #pragma unroll
             for (int ii = 0; ii < kCarryMaxC; ii++) {
 #pragma unroll
                 for (int r = 0; r < K; r++) cur[ii][r] = Acc(0);
                 if (ii < nvalid) {
-                    const int i = base_i + ii;
-                    const int tt = causal ? i : M - 1 - i;
+                    const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
 #pragma unroll
-                    for (int r = 0; r < K; r++) cur[ii][r] = a.tails[(((int64_t)s * M + tt) * K + r) * L + line];
+                    for (int r = 0; r < K; r++) cur[ii][r] = tails[scan_base + (uint32_t)tt * tile_stride + (uint32_t)r * L];
                 }
             }
-            if (res.tau != nullptr) {
+            if (tau != nullptr) {
+                // residual[r] = sum_{q,o} G_q[xi][o] * tau[tile][s][r][q][o]: G per column (vector registers),
+                // tau per tile through scalar loads (the tile index is wave-uniform)
 #pragma unroll
                 for (int ii = 0; ii < kCarryMaxC; ii++) {
                     if (ii < nvalid) {
-                        const int i = base_i + ii;
-                        const int tt = causal ? i : M - 1 - i;
-                        const int64_t tile = (z * M + tt) * res.MX + tx;
-                        for (int q = 0; q < res.nx; q++) {
-                            const Acc *g = res.G + (((int64_t)vx * res.nx + q) * kFusedTX + xi) * K;
-                            const Acc *tq = res.tau + ((tile * res.nx + q) * K) * (int64_t)res.ny * K + (int64_t)s * K;
+                        const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
+                        const int tile = (z_u * M + tt) * g.res_MX + tx_u;
+                        const Acc *tq = tau + (size_t)((tile * g.res_ny + s) * K) * nxk;
 #pragma unroll
-                            for (int o = 0; o < K; o++)
+                        for (int r = 0; r < K; r++)
 #pragma unroll
-                                for (int r = 0; r < K; r++)
-                                    cur[ii][r] = cur[ii][r] + g[o] * tq[(int64_t)o * res.ny * K + r];
-                        }
+                            for (int qo = 0; qo < kFusedMaxScans * K; qo++)
+                                if (qo < nxk) cur[ii][r] = cur[ii][r] + g_res[qo] * tq[r * nxk + qo];
                     }
                 }
             }
             for (int q = 0; q < s; q++) {
-                const bool qc = a.scans[q].causal != 0;
+                const bool qc = ((g.causal_mask >> q) & 1u) != 0;
+                const uint32_t q_base = (uint32_t)q * (uint32_t)M * tile_stride + line;
 #pragma unroll
                 for (int ii = 0; ii < kCarryMaxC; ii++) {
                     if (ii < nvalid) {
-                        const int i = base_i + ii;
-                        const int tt = causal ? i : M - 1 - i;
-                        const int v = ((tt == 0 && a.first_is_border) ? 1 : 0) | ((tt == M - 1 && a.last_is_border) ? 2 : 0);
+                        const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
+                        const int v = ((tt == 0 && g.first_is_border) ? 1 : 0) | ((tt == M - 1 && g.last_is_border) ? 2 : 0);
                         const bool q_first = qc ? (tt == 0) : (tt == M - 1);
                         Acc c[K];
                         if (q_first) {
 #pragma unroll
-                            for (int o = 0; o < K; o++) c[o] = a.incoming[((int64_t)q * K + o) * L + line];
+                            for (int o = 0; o < K; o++) c[o] = incoming[(uint32_t)(q * K + o) * L + line];
                         } else {
                             const int tp = qc ? tt - 1 : tt + 1;
 #pragma unroll
-                            for (int o = 0; o < K; o++) c[o] = a.tails[(((int64_t)q * M + tp) * K + o) * L + line];
+                            for (int o = 0; o < K; o++) c[o] = tails[q_base + (uint32_t)tp * tile_stride + (uint32_t)o * L];
                         }
-                        const Acc *Wm = a.W + ((((int64_t)v * a.n_scans + q) * a.n_scans + s) * K) * K;
+                        const Acc *Wm = Wtab + (((v * g.n_scans + q) * g.n_scans + s) * K) * K;
                         matvec_acc<Acc, K>(Wm, c, cur[ii]);
                     }
                 }
@@ -173,31 +195,30 @@ carry_block_kernel(GenericDimArgs<Acc> a, int s_begin, int s_end, CarryResidual<
 #pragma unroll
                     for (int r = 0; r < K; r++) y[r] = Acc(0);
                     matvec_acc<Acc, K>(Am, inc, y);
-                    const int i = base_i + ii;
-                    const int tt = causal ? i : M - 1 - i;
+                    const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
 #pragma unroll
                     for (int r = 0; r < K; r++) {
                         inc[r] = y[r];
                         cur[ii][r] = cur[ii][r] + y[r];
-                        a.tails[(((int64_t)s * M + tt) * K + r) * L + line] = cur[ii][r];
                         last_tail[r] = cur[ii][r];
+                        if (line_ok) tails[scan_base + (uint32_t)tt * tile_stride + (uint32_t)r * L] = cur[ii][r];
                     }
                 }
             }
             __syncthreads();   // everyone has read exits / carry_in of this block
-            // the thread that owns the block's last tile publishes the state entering the next block
+            // the wave that owns the block's last tile publishes the state entering the next block
             const int last_i = (blk + 1) * tiles_per_block < M ? (blk + 1) * tiles_per_block - 1 : M - 1;
-            if (line_ok && nvalid > 0 && base_i + nvalid - 1 == last_i) {
+            if (nvalid > 0 && base_i + nvalid - 1 == last_i) {
 #pragma unroll
                 for (int r = 0; r < K; r++) carry_in[ln][r] = last_tail[r];
-                if (send != nullptr && last_i == M - 1) {
+                if (send != nullptr && last_i == M - 1 && line_ok) {
 #pragma unroll
-                    for (int r = 0; r < K; r++) send[(int64_t)r * L + line] = last_tail[r];
+                    for (int r = 0; r < K; r++) send[(uint32_t)r * L + line] = last_tail[r];
                 }
             }
             __syncthreads();
         }
-        // scan s+1 chains on the tails just stored by other threads of this workgroup
+        // scan s+1 chains on the tails just stored by other waves of this workgroup
         __threadfence_block();
         __syncthreads();
     }
@@ -206,12 +227,23 @@ carry_block_kernel(GenericDimArgs<Acc> a, int s_begin, int s_end, CarryResidual<
 }  // namespace
 
 template <typename Acc>
-int launch_carry_block(int K, const GenericDimArgs<Acc> &a, int s_begin, int s_end, const CarryResidual<Acc> &res,
-                       Acc *send, const Acc *AC, int C, hipStream_t stream) {
+int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end,
+                       const CarryResidual<Acc> &res, Acc *send, const Acc *AC, int C, hipStream_t stream) {
     if (a.g.lines <= 0 || a.M <= 0 || s_end <= s_begin) return RF_OK;
     if (C < 1 || C > kCarryMaxC) { set_error("carry: chunk length %d out of range", C); return RF_ERR_INVALID_ARG; }
+    const uint64_t total = (uint64_t)a.n_scans * a.M * a.k * a.g.lines;
+    if (total >= (1ull << 32) || a.g.lines >= (1ll << 31)) {
+        set_error("carry: tails array too large for 32-bit offsets (%llu elements)", (unsigned long long)total);
+        return RF_ERR_UNSUPPORTED;
+    }
+    CarryGeom g{};
+    g.lines = (uint32_t)a.g.lines;
+    g.M = a.M; g.n_scans = a.n_scans;
+    g.first_is_border = a.first_is_border; g.last_is_border = a.last_is_border;
+    g.causal_mask = causal_mask;
+    g.res_nx = res.nx; g.res_MX = res.MX; g.res_ny = res.ny; g.res_NX = (uint32_t)(res.tau ? res.NX : 1);
     const unsigned grid = (unsigned)((a.g.lines + kCarryLines - 1) / kCarryLines);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, s_begin, s_end, res, send, AC, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(kCarryThreads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, res.tau, res.G, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
     RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
     set_error("carry: unsupported order %d", K);
@@ -223,9 +255,9 @@ int carry_chunk_length(int64_t M) {
     return (int)(c < 1 ? 1 : (c > kCarryMaxC ? kCarryMaxC : c));
 }
 
-template int launch_carry_block<float>(int, const GenericDimArgs<float> &, int, int, const CarryResidual<float> &, float *,
-                                       const float *, int, hipStream_t);
-template int launch_carry_block<uint32_t>(int, const GenericDimArgs<uint32_t> &, int, int, const CarryResidual<uint32_t> &,
-                                          uint32_t *, const uint32_t *, int, hipStream_t);
+template int launch_carry_block<float>(int, const GenericDimArgs<float> &, uint32_t, int, int, const CarryResidual<float> &,
+                                       float *, const float *, int, hipStream_t);
+template int launch_carry_block<uint32_t>(int, const GenericDimArgs<uint32_t> &, uint32_t, int, int,
+                                          const CarryResidual<uint32_t> &, uint32_t *, const uint32_t *, int, hipStream_t);
 
 }  // namespace rf

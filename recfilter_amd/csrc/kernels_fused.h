@@ -58,7 +58,7 @@ struct FusedArgs {
 // Cross-dimension residual folded into the y carry stage (tau == nullptr: none).
 template <typename Acc>
 struct CarryResidual {
-    const Acc *tau;   // [tile][q][o][j][r], tile = (z*MY + ty)*MX + tx
+    const Acc *tau;   // [tile][j][r][q][o], tile = (z*MY + ty)*MX + tx
     const Acc *G;     // [x-variant][q][xi][o]
     int32_t nx, MX, ny;
     int64_t NX;       // the carried dimension's line index is x + NX*z
@@ -67,8 +67,8 @@ struct CarryResidual {
 // Blocked parallel carry scan over the tails of one dimension (kernels_carry.hip); scans
 // [s_begin, s_end) of the dimension in one launch.  AC[s] = A[s]^C, C = carry_chunk_length(M).
 template <typename Acc>
-int launch_carry_block(int K, const GenericDimArgs<Acc> &a, int s_begin, int s_end, const CarryResidual<Acc> &res,
-                       Acc *send, const Acc *AC, int C, hipStream_t stream);
+int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end,
+                       const CarryResidual<Acc> &res, Acc *send, const Acc *AC, int C, hipStream_t stream);
 int carry_chunk_length(int64_t M);
 
 template <typename P>
@@ -76,8 +76,4 @@ int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,
                       const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);
 template <typename Acc>
 int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t stream);
-template <typename Acc>
-int launch_fused_carry_y(int K, const FusedArgs<Acc> &a, int j, const Acc *tau, const Acc *G, const Acc *W,
-                         const Acc *A, Acc *send, hipStream_t stream);
-
 }  // namespace rf

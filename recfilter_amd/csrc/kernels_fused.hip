@@ -21,8 +21,8 @@
 //
 // Between the passes: the x carry recurrence (generic_carry_scan_kernel over the x tails), the
 // cross-dimension residual of lib/split.cpp:1215-1633 split into tau_kernel (run the tile-local
-// y scans on the completed x-carry strips, keep their tails) and fused_carry_y_kernel (y carry
-// recurrence with the residual sum_o G[x][o] * tau[o] folded into the tail it starts from).
+// y scans on the completed x-carry strips, keep their tails) and carry_block_kernel (kernels_carry.hip:
+// y carry recurrence with the residual sum_o G[x][o] * tau[o] folded into the tail it starts from).
 #include "kernels.h"
 #include "kernels_fused.h"
 
@@ -503,7 +503,7 @@ fused_pass_persistent_kernel(const P *__restrict__ src, P *__restrict__ dst,
 }
 
 // ---- tau: tile-local y scans of the completed x-carry strips, tails kept ----------------------
-// tau[((tile*nx + q)*K + o)*ny*K + j*K + r], tile = (z*MY + ty)*MX + tx
+// tau[((tile*ny + j)*K + r)*nx*K + q*K + o], tile = (z*MY + ty)*MX + tx
 template <typename Acc, int K, int TY>
 __global__ void __launch_bounds__(256)
 tau_kernel(FusedArgs<Acc> a, Acc *__restrict__ tau) {
@@ -520,12 +520,13 @@ tau_kernel(FusedArgs<Acc> a, Acc *__restrict__ tau) {
     const int64_t z = rest / a.MY;
     const int q = so / K, o = so % K;
     const int64_t tile = (z * a.MY + ty) * a.MX + tx;
-    Acc *out = tau + ((tile * a.nx + q) * K + o) * (int64_t)a.ny * K;
+    Acc *out = tau + tile * (int64_t)a.ny * K * a.nx * K + q * K + o;      // + (j*K + r) * nx*K
+    const int ostride = a.nx * K;
 
     const bool qc = a.xs[q].causal != 0;
     const bool q_first = qc ? (tx == 0) : (tx == a.MX - 1);
     if (q_first) {   // no carry enters this tile for scan q
-        for (int e = 0; e < a.ny * K; e++) out[e] = Acc(0);
+        for (int e = 0; e < a.ny * K; e++) out[e * ostride] = Acc(0);
         return;
     }
     const int tp = qc ? tx - 1 : tx + 1;
@@ -546,78 +547,7 @@ tau_kernel(FusedArgs<Acc> a, Acc *__restrict__ tau) {
         if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, zero);
         else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, zero);
 #pragma unroll
-        for (int r = 0; r < K; r++) out[j * K + r] = causal ? col[TY - 1 - r] : col[r];
-    }
-}
-
-// ---- y carry recurrence of one y scan, cross-dimension residual folded in -----------------------
-template <typename Acc, int K>
-__global__ void __launch_bounds__(256)
-fused_carry_y_kernel(FusedArgs<Acc> a, int j, const Acc *__restrict__ tau, const Acc *__restrict__ G,
-                     const Acc *__restrict__ W, const Acc *__restrict__ Amat, Acc *__restrict__ send) {
-    const int64_t line = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t Ly = a.NX * a.NZ;
-    if (line >= Ly) return;
-    const int64_t x = line % a.NX, z = line / a.NX;
-    const int tx = (int)(x / kFusedTX), xi = (int)(x % kFusedTX);
-    const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
-    const bool causal = a.ys[j].causal != 0;
-    Acc prev[K];
-#pragma unroll
-    for (int r = 0; r < K; r++) prev[r] = Acc(0);
-    for (int i = 0; i < a.MY; i++) {
-        const int ty = causal ? i : a.MY - 1 - i;
-        const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
-        Acc cur[K];
-#pragma unroll
-        for (int r = 0; r < K; r++) cur[r] = a.yt[(((int64_t)j * a.MY + ty) * K + r) * Ly + line];
-        // cross-dimension residual: sum_q sum_o G_q[xi][o] * tau[q][o][j][r]
-        if (a.nx > 0) {
-            const int64_t tile = (z * a.MY + ty) * a.MX + tx;
-            for (int q = 0; q < a.nx; q++) {
-                const Acc *g = G + (((int64_t)vx * a.nx + q) * kFusedTX + xi) * K;
-                const Acc *tq = tau + ((tile * a.nx + q) * K) * (int64_t)a.ny * K + (int64_t)j * K;
-#pragma unroll
-                for (int o = 0; o < K; o++)
-#pragma unroll
-                    for (int r = 0; r < K; r++) cur[r] = cur[r] + g[o] * tq[(int64_t)o * a.ny * K + r];
-            }
-        }
-        // chaining from the y scans applied earlier
-        for (int q = 0; q < j; q++) {
-            const bool qc = a.ys[q].causal != 0;
-            const bool q_first = qc ? (ty == 0) : (ty == a.MY - 1);
-            Acc c[K];
-            if (q_first) {
-#pragma unroll
-                for (int o = 0; o < K; o++) c[o] = a.y_incoming[((int64_t)q * K + o) * Ly + line];
-            } else {
-                const int tp = qc ? ty - 1 : ty + 1;
-#pragma unroll
-                for (int o = 0; o < K; o++) c[o] = a.yt[(((int64_t)q * a.MY + tp) * K + o) * Ly + line];
-            }
-            const Acc *Wm = W + ((((int64_t)vy * a.ny + q) * a.ny + j) * K) * K;
-#pragma unroll
-            for (int r = 0; r < K; r++)
-#pragma unroll
-                for (int o = 0; o < K; o++) cur[r] = cur[r] + Wm[r * K + o] * c[o];
-        }
-        if (i > 0) {
-            const Acc *Am = Amat + (int64_t)j * K * K;
-#pragma unroll
-            for (int r = 0; r < K; r++)
-#pragma unroll
-                for (int o = 0; o < K; o++) cur[r] = cur[r] + Am[r * K + o] * prev[o];
-        }
-#pragma unroll
-        for (int r = 0; r < K; r++) {
-            a.yt[(((int64_t)j * a.MY + ty) * K + r) * Ly + line] = cur[r];
-            prev[r] = cur[r];
-        }
-    }
-    if (send) {
-#pragma unroll
-        for (int r = 0; r < K; r++) send[(int64_t)r * Ly + line] = prev[r];
+        for (int r = 0; r < K; r++) out[(j * K + r) * ostride] = causal ? col[TY - 1 - r] : col[r];
     }
 }
 
@@ -692,25 +622,9 @@ int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t str
     return RF_ERR_UNSUPPORTED;
 }
 
-template <typename Acc>
-int launch_fused_carry_y(int K, const FusedArgs<Acc> &a, int j, const Acc *tau, const Acc *G, const Acc *W,
-                         const Acc *A, Acc *send, hipStream_t stream) {
-    const int64_t Ly = a.NX * a.NZ;
-    const unsigned grid = (unsigned)((Ly + 255) / 256);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((fused_carry_y_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, j, tau, G, W, A, send); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
-    RF_CASE(1) RF_CASE(2) RF_CASE(3)
-#undef RF_CASE
-    set_error("fused carry: unsupported order %d", K);
-    return RF_ERR_UNSUPPORTED;
-}
-
 template int launch_fused_pass<float>(bool, int, int, const float *, float *, const FusedArgs<float> &, hipStream_t);
 template int launch_fused_pass<int32_t>(bool, int, int, const int32_t *, int32_t *, const FusedArgs<uint32_t> &, hipStream_t);
 template int launch_tau<float>(int, int, const FusedArgs<float> &, float *, hipStream_t);
 template int launch_tau<uint32_t>(int, int, const FusedArgs<uint32_t> &, uint32_t *, hipStream_t);
-template int launch_fused_carry_y<float>(int, const FusedArgs<float> &, int, const float *, const float *, const float *,
-                                         const float *, float *, hipStream_t);
-template int launch_fused_carry_y<uint32_t>(int, const FusedArgs<uint32_t> &, int, const uint32_t *, const uint32_t *,
-                                            const uint32_t *, const uint32_t *, uint32_t *, hipStream_t);
 
 }  // namespace rf

@@ -227,6 +227,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         return a;
     };
 
+    uint32_t xmask = 0, ymask = 0;
+    for (int s = 0; s < nx; s++) if (hxs[s].causal) xmask |= 1u << s;
+    for (int j = 0; j < ny; j++) if (hys[j].causal) ymask |= 1u << j;
+
     // ---- steps -----------------------------------------------------------------------------
     Step p1;
     p1.name = "fused_pass1";
@@ -237,9 +241,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (nx > 0) {
         Step cx;
         cx.name = "carry_x";
-        cx.run = [plan, gxargs, K, nx, d_ACx, Cx](int pl) {
+        cx.run = [plan, gxargs, K, nx, d_ACx, Cx, xmask](int pl) {
             CarryResidual<Acc> none{};
-            return launch_carry_block<Acc>(K, gxargs(pl), 0, nx, none, (Acc *)nullptr, d_ACx, Cx, plan->stream);
+            return launch_carry_block<Acc>(K, gxargs(pl), xmask, 0, nx, none, (Acc *)nullptr, d_ACx, Cx, plan->stream);
         };
         plan->begin_steps.push_back(cx);
     }
@@ -261,8 +265,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         if (ny > 0) {
             Step cy;
             cy.name = "carry_y";
-            cy.run = [plan, gyargs, res_for, K, ny, d_ACy, Cy](int pl) {
-                return launch_carry_block<Acc>(K, gyargs(pl), 0, ny, res_for(pl), (Acc *)nullptr, d_ACy, Cy, plan->stream);
+            cy.run = [plan, gyargs, res_for, K, ny, d_ACy, Cy, ymask](int pl) {
+                return launch_carry_block<Acc>(K, gyargs(pl), ymask, 0, ny, res_for(pl), (Acc *)nullptr, d_ACy, Cy, plan->stream);
             };
             plan->begin_steps.push_back(cy);
         }
@@ -289,9 +293,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             plan->exchanges.push_back(ex);
             Step cy;
             cy.name = "carry_y" + std::to_string(j);
-            cy.run = [plan, gyargs, res_for, K, j, d_ACy, Cy, ex_index, plane_stride](int pl) {
+            cy.run = [plan, gyargs, res_for, K, j, d_ACy, Cy, ex_index, plane_stride, ymask](int pl) {
                 Acc *send = (Acc *)plan->exchanges[ex_index].send;
-                return launch_carry_block<Acc>(K, gyargs(pl), j, j + 1, res_for(pl), send ? send + pl * plane_stride : nullptr,
+                return launch_carry_block<Acc>(K, gyargs(pl), ymask, j, j + 1, res_for(pl), send ? send + pl * plane_stride : nullptr,
                                                d_ACy, Cy, plan->stream);
             };
             plan->exchange_local_steps.push_back({cy});
