@@ -1,0 +1,181 @@
+"""A numpy stand-in for recfilter_amd.Plan's stepping API, for the CPU (gloo) tests of the sharded driver.
+
+It implements the SAME protocol the C ABI exposes (rf_plan_begin / exchange_local / exchange_apply /
+finish, include/recfilter_amd.h) and the SAME algebra kernels_generic.hip runs for the sharded
+(outermost) dimension -- pass 1 with zero incoming carry, per-scan chaining + slab-local recurrence,
+the slab's exit tail as the exchange payload, incoming = sum over preceding slabs of
+(A^M)^(distance-1) * exit, propagation A^(t+1) * incoming, pass 2 -- with the W and A tables taken
+from a host-only product plan.  Test infrastructure only; it lets `ShardedFilter` (recfilter_amd/dist.py)
+run end to end over gloo without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+import recfilter_amd as rfa
+from recfilter_amd import capi
+from tiled_emulator import emulate_dimension, scan_tile
+
+
+def _view(ptr: int, n: int) -> np.ndarray:
+    buf = (ctypes.c_float * n).from_address(ptr)
+    return np.frombuffer(buf, dtype=np.float32)
+
+
+class NumpySlabEngine:
+    def __init__(self, local_shape, scans, clamped, planes, rank, world, tile=None):
+        self.shape, self.scans, self.clamped = tuple(local_shape), list(scans), clamped
+        self.planes, self.rank, self.world = planes, rank, world
+        nd = len(self.shape)
+        if tile is None:
+            tile = [0] * nd
+        self.plan = rfa.Plan(self.shape, scans, dtype=np.float64, clamped=clamped, planes=planes, tile=tile,
+                             path=capi.RF_PATH_TILED_GENERIC, device=capi.RF_DEVICE_HOST_ONLY,
+                             shard_rank=rank, shard_world=world)
+        self.tiles = self.plan.tiles
+        self.outer = nd - 1
+        self.outer_scans = [(bool(c), [float(np.float32(v)) for v in co]) for d, c, co in scans if d == self.outer]
+        self.n = len(self.outer_scans)
+        self.k = max([len(co) - 1 for _, co in self.outer_scans], default=0)
+        if self.n:
+            name = "xyz"[self.outer]
+            self.W = self.plan.table("W_" + name).reshape(4, self.n, self.n, self.k, self.k)
+            self.A = self.plan.table("A_" + name).reshape(self.n, self.k, self.k)
+        self.N = self.shape[0]                      # numpy axis 0 is the outermost dimension
+        self.T = self.tiles[self.outer] if self.n else self.N
+        self.M = self.N // self.T if self.n else 1
+        self.lines = int(np.prod(self.shape[1:])) if nd > 1 else 1
+
+    # ---- protocol ---------------------------------------------------------------------------
+    @property
+    def num_exchanges(self):
+        return self.n
+
+    def exchange_bytes(self, i):
+        return self.planes * self.k * self.lines * 4
+
+    def _first(self, s, t):
+        return t == 0 if self.outer_scans[s][0] else t == self.M - 1
+
+    def _border(self, s, t):
+        c = self.outer_scans[s][0]
+        return (t == 0 and self.rank == 0) if c else (t == self.M - 1 and self.rank == self.world - 1)
+
+    def _variant(self, t):
+        return (1 if (t == 0 and self.rank == 0) else 0) | (2 if (t == self.M - 1 and self.rank == self.world - 1) else 0)
+
+    def _coef(self, s):
+        co = self.outer_scans[s][1]
+        return co[0], list(co[1:]) + [0.0] * (self.k - len(co) + 1)
+
+    def _carry_into(self, pl, s, t):
+        if self._first(s, t):
+            return [self.incoming[pl][s][j] for j in range(self.k)]
+        tp = t - 1 if self.outer_scans[s][0] else t + 1
+        return [self.tails[pl][s, tp, j] for j in range(self.k)]
+
+    def begin(self, inputs, outputs, stream=None):
+        self.outputs = outputs
+        nd = len(self.shape)
+        self.data = []
+        for pl in range(self.planes):
+            img = inputs[pl].numpy().astype(np.float64)
+            # inner dimensions are slab-local: run them completely (same tables as the product plan)
+            for d in range(nd - 1):
+                dim_scans = [(c, co) for (dd, c, co) in self.scans if dd == d]
+                if not dim_scans:
+                    continue
+                axis = nd - 1 - d
+                moved = np.moveaxis(img, axis, -1)
+                flat = np.ascontiguousarray(moved).reshape(-1, moved.shape[-1])
+                name = "xyz"[d]
+                res = emulate_dimension(flat, dim_scans, self.tiles[d], self.clamped,
+                                        self.plan.table("W_" + name), self.plan.table("A_" + name))
+                img = np.moveaxis(res.reshape(moved.shape), -1, axis)
+            self.data.append(np.ascontiguousarray(img).reshape(self.N, self.lines).T.copy())   # [lines, N]
+        if not self.n:
+            return
+        k, M, T = self.k, self.M, self.T
+        self.tails = [np.zeros((self.n, M, k, self.lines)) for _ in range(self.planes)]
+        self.incoming = [[[np.zeros(self.lines) for _ in range(k)] for _ in range(self.n)] for _ in range(self.planes)]
+        for pl in range(self.planes):
+            for t in range(M):
+                v = self.data[pl][:, t * T:(t + 1) * T].copy()
+                for s in range(self.n):
+                    b, a = self._coef(s)
+                    c = self.outer_scans[s][0]
+                    scan_tile(v, c, b, a, k, self.clamped and self._border(s, t))
+                    for r in range(k):
+                        p = T - 1 - r
+                        self.tails[pl][s, t, r] = v[:, p if c else T - 1 - p]
+
+    def exchange_local(self, s, send_ptr):
+        k, M = self.k, self.M
+        send = _view(send_ptr, self.planes * k * self.lines).reshape(self.planes, k, self.lines)
+        causal = self.outer_scans[s][0]
+        for pl in range(self.planes):
+            prev = None
+            for i in range(M):
+                t = i if causal else M - 1 - i
+                cur = [self.tails[pl][s, t, r].copy() for r in range(k)]
+                for q in range(s):
+                    c = self._carry_into(pl, q, t)
+                    for r in range(k):
+                        for o in range(k):
+                            cur[r] = cur[r] + self.W[self._variant(t), q, s, r, o] * c[o]
+                if i > 0:
+                    for r in range(k):
+                        for j in range(k):
+                            cur[r] = cur[r] + self.A[s, r, j] * prev[j]
+                for r in range(k):
+                    self.tails[pl][s, t, r] = cur[r]
+                prev = cur
+            for r in range(k):
+                send[pl, r] = prev[r]
+
+    def exchange_apply(self, s, gathered_ptr):
+        k, M = self.k, self.M
+        gathered = _view(gathered_ptr, self.world * self.planes * k * self.lines).reshape(
+            self.world, self.planes, k, self.lines).astype(np.float64)
+        causal = self.outer_scans[s][0]
+        AM = np.linalg.matrix_power(self.A[s], M)
+        for pl in range(self.planes):
+            x = np.zeros((k, self.lines))
+            count = self.rank if causal else self.world - 1 - self.rank
+            for i in range(count):
+                h = i if causal else self.world - 1 - i
+                x = gathered[h, pl] + AM @ x
+            for j in range(k):
+                self.incoming[pl][s][j] = x[j].copy()
+            for i in range(M):
+                t = i if causal else M - 1 - i
+                x = self.A[s] @ x
+                self.tails[pl][s, t] += x
+
+    def finish(self):
+        k, M, T = self.k, self.M, self.T
+        import torch
+        for pl in range(self.planes):
+            out = self.data[pl]
+            if self.n:
+                res = np.empty_like(out)
+                for t in range(M):
+                    v = out[:, t * T:(t + 1) * T].copy()
+                    for s in range(self.n):
+                        b, a = self._coef(s)
+                        scan_tile(v, self.outer_scans[s][0], b, a, k, self.clamped and self._border(s, t),
+                                  self._carry_into(pl, s, t))
+                    res[:, t * T:(t + 1) * T] = v
+                out = res
+            self.outputs[pl].copy_(torch.from_numpy(out.T.reshape(self.shape).astype(np.float32)))
+
+    def execute(self, inputs, outputs, stream=None):      # world == 1 path of ShardedFilter
+        self.begin(inputs, outputs)
+        import torch
+        for i in range(self.n):
+            send = torch.empty(self.exchange_bytes(i), dtype=torch.uint8)
+            self.exchange_local(i, send.data_ptr())
+        self.finish()
+        return outputs

@@ -1,0 +1,101 @@
+"""world_size-2/3 gloo tests (CPU) of the sharded driver recfilter_amd.dist.ShardedFilter.
+
+The driver, its buffer handling and the exchange protocol are the product's; the per-slab engine is the
+numpy stand-in of tests/dist_engine.py (same algebra as kernels_generic.hip, tables from the product's
+host-side plan).  The result must equal the untiled oracle run on the UN-sharded image."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    import ref_cases as rc
+    from dist_engine import NumpySlabEngine
+    from recfilter_amd.dist import ShardedFilter
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shape, scans, clamped, planes, tile = case["shape"], case["scans"], case["clamped"], case["planes"], case["tile"]
+        full = [rc.random_image(shape, np.float32, 77 + p) for p in range(planes)]
+        n = shape[0] // world
+        local_shape = (n,) + tuple(shape[1:])
+        inputs = [torch.from_numpy(np.ascontiguousarray(f[rank * n:(rank + 1) * n])) for f in full]
+        outputs = [torch.empty_like(t) for t in inputs]
+        engine = NumpySlabEngine(local_shape, scans, clamped, planes, rank, world, tile=tile)
+        filt = ShardedFilter(local_shape, scans, clamped=clamped, planes=planes, rank=rank, world=world, engine=engine)
+        filt.execute(inputs, outputs)
+        filt.execute(inputs, outputs)          # a second execute reuses the exchange buffers
+        for p in range(planes):
+            want = oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[rank * n:(rank + 1) * n]
+            err = rc.rel_err(outputs[p].numpy(), want)
+            assert err < 1e-5, f"rank {rank} plane {p}: rel err {err}"
+        assert engine.num_exchanges == sum(1 for s in scans if s[0] == len(shape) - 1)
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = {
+    "gauss2_xy_clamped": dict(shape=(48, 40), planes=1, clamped=True, tile=[8, 8]),
+    "generic_xy_zero_2planes": dict(shape=(32, 24), planes=2, clamped=False, tile=[4, 4]),
+    "generic_xyz": dict(shape=(24, 8, 12), planes=1, clamped=False, tile=[4, 4, 4]),
+    "y_only_mixed": dict(shape=(36, 16), planes=1, clamped=True, tile=[0, 6]),
+}
+
+
+def _scans(name):
+    import ref_cases as rc
+    if name == "gauss2_xy_clamped":
+        return rc.xy_pm(rc.GAUSS2)
+    if name == "generic_xy_zero_2planes":
+        return rc.REFERENCE_TESTS["test_generic_xy"]["scans"]
+    if name == "generic_xyz":
+        return rc.REFERENCE_TESTS["test_generic_xyz"]["scans"]
+    return [(1, False, [0.6, 0.5, -0.1]), (1, True, [0.6, 0.5, -0.1]), (1, False, [1.0, 0.25])]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_sharded_filter_over_gloo(name, world, tmp_path):
+    import torch.multiprocessing as mp
+    case = dict(CASES[name])
+    case["scans"] = _scans(name)
+    if case["shape"][0] % world or (case["shape"][0] // world) % max(case["tile"][len(case["shape"]) - 1], 1):
+        pytest.skip("slab is not a whole number of tiles")
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_single_rank_driver_is_plain_execute(tmp_path):
+    sys.path.insert(0, HERE)
+    import torch
+    import oracle
+    import ref_cases as rc
+    from dist_engine import NumpySlabEngine
+    from recfilter_amd.dist import ShardedFilter
+    scans = rc.xy_pm(rc.GAUSS2)
+    img = rc.random_image((32, 24))
+    eng = NumpySlabEngine((32, 24), scans, True, 1, 0, 1, tile=[8, 8])
+    out = [torch.empty(32, 24)]
+    ShardedFilter((32, 24), scans, clamped=True, engine=eng).execute([torch.from_numpy(img)], out)
+    assert rc.rel_err(out[0].numpy(), oracle.apply_filter(img.astype(np.float64), scans, True)) < 1e-5

@@ -208,3 +208,64 @@ def test_fused_matches_untiled_gpu_at_full_size_properties():
         got = plan.execute([torch.from_numpy(small).cuda()])[0].cpu().numpy()
     want = oracle.apply_filter(small.astype(np.float64), scans, True, threads=8)
     assert rc.rel_err(got, want) < TOL
+
+
+# ---- sharded execution (stepping API of the C ABI), all "ranks" emulated on the one GPU of the test box ----
+def _run_sharded(shape, scans, clamped, world, path, planes=1):
+    import torch
+    import recfilter_amd as rfa
+    full = [rc.random_image(shape, np.float32, 31 + p) for p in range(planes)]
+    n = shape[0] // world
+    local = (n,) + tuple(shape[1:])
+    plans = [rfa.Plan(local, scans, clamped=clamped, planes=planes, path=path, shard_rank=r, shard_world=world)
+             for r in range(world)]
+    ins = [[torch.from_numpy(np.ascontiguousarray(f[r * n:(r + 1) * n])).cuda() for f in full] for r in range(world)]
+    outs = [[torch.empty_like(t) for t in ins[r]] for r in range(world)]
+    for r in range(world):
+        plans[r].begin(ins[r], outs[r])
+    nex = plans[0].num_exchanges
+    for e in range(nex):
+        nbytes = plans[0].exchange_bytes(e)
+        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda")
+        for r in range(world):                         # "all-gather": every rank's send lands rank-major
+            plans[r].exchange_local(e, gathered.data_ptr() + r * nbytes)
+        for r in range(world):
+            plans[r].exchange_apply(e, gathered.data_ptr())
+    for r in range(world):
+        plans[r].finish()
+    torch.cuda.synchronize()
+    got = [np.concatenate([outs[r][p].cpu().numpy() for r in range(world)], axis=0) for p in range(planes)]
+    info = (plans[0].path, nex)
+    for p in plans:
+        p.close()
+    return full, got, info
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_fused_2d_rows(world):
+    """cfg3's filter, rows sharded over `world` slabs: one exchange per y scan."""
+    scans = rc.xy_pm(rc.GAUSS2)
+    full, got, (path, nex) = _run_sharded((64 * 2 * world, 512), scans, True, world, path=0, planes=2)
+    assert path == 3 and nex == 2
+    _check(full, got, scans, True)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_3d_z_slabs(world):
+    """cfg5's filter (tests/test_generic_xyz.cpp), z sharded: fused x/y per plane, exchanges on the z scans."""
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    full, got, (path, nex) = _run_sharded((16 * world, 64, 256), scans, False, world, path=0)
+    assert path == 3 and nex == 2
+    _check(full, got, scans, False)
+
+
+def test_sharded_generic_path_uneven_scans():
+    scans = rc.REFERENCE_TESTS["test_generic_xy"]["scans"]      # 4 x scans, 3 y scans
+    full, got, (path, nex) = _run_sharded((48, 40), scans, False, 3, path=2)
+    assert path == 2 and nex == 3
+    _check(full, got, scans, False)
+    with pytest.raises(Exception):                                # a sharded plan refuses the one-shot execute
+        import torch
+        import recfilter_amd as rfa
+        p = rfa.Plan((16, 40), scans, shard_rank=0, shard_world=3, path=2)
+        p.execute([torch.zeros((16, 40), device="cuda")])
