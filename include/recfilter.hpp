@@ -1,0 +1,449 @@
+// recfilter.hpp -- Halide-free C++ front-end with the surface of the reference's RecFilter
+// (/root/reference lib/recfilter.h:68-566), implemented on top of the C ABI in recfilter_amd.h.
+//
+// Same class and method names, argument meaning and misuse behaviour as the reference.  The two
+// unavoidable differences of a runtime without Halide:
+//   * the defining right-hand side is a bound device image instead of a Halide::Expr:
+//         R(x, y) = RecFilterImage<float>(device_ptr)            // one per Tuple element via {...}
+//     (the reference: R(x,y) = image(x,y), lib/recfilter.cpp:150-162, 192-248)
+//   * realize() returns RecFilterRealization (device pointers owned by the filter) instead of
+//     Halide::Realization (lib/recfilter.cpp:984-989).
+// Where the reference prints to cerr and assert(false)s this throws RecFilterError, which carries
+// the same message.  Header-only; link against librecfilter_amd.so and the HIP runtime.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "recfilter_amd.h"
+
+class RecFilterError : public std::runtime_error {
+public:
+    explicit RecFilterError(const std::string &m) : std::runtime_error(m) {}
+};
+
+/** Filter dimension: a name and the image extent along it (lib/recfilter.h:68-95). */
+class RecFilterDim {
+    std::string v;
+    int e = 0;
+public:
+    RecFilterDim() {}
+    RecFilterDim(std::string var_name, int var_extent) : v(std::move(var_name)), e(var_extent) {}
+    const std::string &var() const { return v; }
+    int num_pixels() const { return e; }
+};
+
+/** Filter dimension augmented with causality (lib/recfilter.h:98-128). */
+class RecFilterDimAndCausality {
+    RecFilterDim r;
+    bool c = true;
+public:
+    RecFilterDimAndCausality() {}
+    RecFilterDimAndCausality(RecFilterDim rec_var, bool causal) : r(std::move(rec_var)), c(causal) {}
+    const std::string &var() const { return r.var(); }
+    int num_pixels() const { return r.num_pixels(); }
+    bool causal() const { return c; }
+};
+
+/** +x: causal scan, -x: anticausal scan (lib/recfilter.h:135-139). */
+inline RecFilterDimAndCausality operator+(RecFilterDim x) { return RecFilterDimAndCausality(std::move(x), true); }
+inline RecFilterDimAndCausality operator-(RecFilterDim x) { return RecFilterDimAndCausality(std::move(x), false); }
+
+template <typename T> struct RecFilterPixel;
+template <> struct RecFilterPixel<float>   { static constexpr int dtype = RF_F32; };
+template <> struct RecFilterPixel<double>  { static constexpr int dtype = RF_F64; };
+template <> struct RecFilterPixel<int32_t> { static constexpr int dtype = RF_I32; };
+template <> struct RecFilterPixel<int16_t> { static constexpr int dtype = RF_I16; };
+
+/** A dense x-fastest DEVICE image bound as (one Tuple element of) the filter's definition. */
+struct RecFilterImageRef {
+    const void *ptr = nullptr;
+    int dtype = RF_F32;
+};
+template <typename T>
+RecFilterImageRef RecFilterImage(const T *device_ptr) { return RecFilterImageRef{device_ptr, RecFilterPixel<T>::dtype}; }
+
+/** Result of realize(): one device buffer per Tuple element, owned by the filter. */
+struct RecFilterRealization {
+    std::vector<void *> planes;
+    std::vector<int64_t> extent;   // x first
+    int dtype = RF_F32;
+    size_t bytes_per_plane = 0;
+    /** copy plane i to host memory */
+    template <typename T> std::vector<T> to_host(size_t i = 0) const {
+        std::vector<T> h(bytes_per_plane / sizeof(T));
+        if (hipMemcpy(h.data(), planes.at(i), bytes_per_plane, hipMemcpyDeviceToHost) != hipSuccess)
+            throw RecFilterError("hipMemcpy to host failed");
+        return h;
+    }
+};
+
+class RecFilter;
+
+/** Handle returned by intra_/inter_/full_schedule (lib/recfilter.h:516-566).  The reference's
+ *  directives steer Halide's code generator; the kernels here are hand written, so every directive
+ *  is accepted and recorded only. */
+class RecFilterSchedule {
+    std::shared_ptr<std::vector<std::string>> log;
+    std::string what;
+    RecFilterSchedule &note(const std::string &n) { log->push_back(what + "." + n); return *this; }
+public:
+    RecFilterSchedule(std::shared_ptr<std::vector<std::string>> l, std::string w) : log(std::move(l)), what(std::move(w)) {}
+    template <typename... A> RecFilterSchedule &compute_globally(A...) { return note("compute_globally"); }
+    template <typename... A> RecFilterSchedule &compute_locally(A...) { return note("compute_locally"); }
+    template <typename... A> RecFilterSchedule &parallel(A...) { return note("parallel"); }
+    template <typename... A> RecFilterSchedule &unroll(A...) { return note("unroll"); }
+    template <typename... A> RecFilterSchedule &vectorize(A...) { return note("vectorize"); }
+    template <typename... A> RecFilterSchedule &gpu_blocks(A...) { return note("gpu_blocks"); }
+    template <typename... A> RecFilterSchedule &gpu_threads(A...) { return note("gpu_threads"); }
+    template <typename... A> RecFilterSchedule &fuse(A...) { return note("fuse"); }
+    template <typename... A> RecFilterSchedule &split(A...) { return note("split"); }
+    template <typename... A> RecFilterSchedule &reorder(A...) { return note("reorder"); }
+    template <typename... A> RecFilterSchedule &storage_layout(A...) { return note("storage_layout"); }
+    template <typename... A> RecFilterSchedule &reorder_storage(A...) { return note("reorder_storage"); }
+};
+
+class RecFilterRefVar;
+
+/** Recursive filter (lib/recfilter.h:146-510).  Copies alias the same contents
+ *  (lib/recfilter.cpp:141-144). */
+class RecFilter {
+    struct Scan { int dim; bool causal; std::vector<float> coeff; };
+    struct Contents {
+        std::string name;
+        std::vector<RecFilterDim> dims;
+        std::vector<RecFilterImageRef> inputs;
+        std::shared_ptr<Contents> source;       // cascaded stage: reads the previous stage's result
+        std::vector<Scan> scans;
+        std::map<std::string, int> tile;
+        bool clamped = false, tiled = false, compiled = false;
+        rf_plan *plan = nullptr;
+        std::vector<void *> out;                 // device buffers of the last realization
+        std::shared_ptr<std::vector<std::string>> schedule_log = std::make_shared<std::vector<std::string>>();
+        ~Contents() {
+            if (plan) rf_plan_destroy(plan);
+            for (void *p : out) if (p) (void)hipFree(p);
+        }
+    };
+    std::shared_ptr<Contents> c;
+    static int &counter() { static int n = 0; return n; }
+    static int &max_threads() { static int v = 128; return v; }
+    static int &vec_width() { static int v = 8; return v; }
+    [[noreturn]] static void fail(const std::string &m) { throw RecFilterError(m); }
+
+    int dim_index(const std::string &var) const {
+        for (size_t i = 0; i < c->dims.size(); i++) if (c->dims[i].var() == var) return (int)i;
+        return -1;
+    }
+    size_t plane_elems() const { size_t n = 1; for (auto &d : c->dims) n *= (size_t)d.num_pixels(); return n; }
+    int dtype() const { return c->source ? RecFilter(c->source).dtype() : c->inputs.at(0).dtype; }
+    size_t n_planes() const { return c->source ? RecFilter(c->source).n_planes() : c->inputs.size(); }
+    static size_t dtype_size(int dt) { return dt == RF_F64 ? 8 : (dt == RF_I16 ? 2 : 4); }
+    explicit RecFilter(std::shared_ptr<Contents> p) : c(std::move(p)) {}
+
+public:
+    explicit RecFilter(std::string name = "") : c(std::make_shared<Contents>()) {
+        c->name = (name.empty() ? std::string("R") : name) + "_" + std::to_string(counter()++);
+    }
+    std::string name() const { return c->name; }
+
+    /** R(x), R(x,y), R(x,y,z) = image   (lib/recfilter.h:207-210) */
+    RecFilterRefVar operator()(RecFilterDim x);
+    RecFilterRefVar operator()(RecFilterDim x, RecFilterDim y);
+    RecFilterRefVar operator()(RecFilterDim x, RecFilterDim y, RecFilterDim z);
+    RecFilterRefVar operator()(std::vector<RecFilterDim> x);
+
+    /** lib/recfilter.cpp:192-248 */
+    void define(std::vector<RecFilterDim> pure_args, std::vector<RecFilterImageRef> pure_def) {
+        if (pure_args.empty() || pure_def.empty()) fail("empty filter definition");
+        for (auto &i : pure_def)
+            if (i.dtype != pure_def[0].dtype) fail("Type of all Tuple elements in filter definition must be same");
+        if (!c->dims.empty()) fail("Recursive filter " + c->name + " already defined");
+        if (pure_args.size() > RF_MAX_DIMS) fail("at most 3 dimensions are supported");
+        c->dims = std::move(pure_args);
+        c->inputs = std::move(pure_def);
+    }
+    /** definition that reads another filter's result: f2(x,y) = f1.as_func()(x,y) in the reference */
+    void define(std::vector<RecFilterDim> pure_args, const RecFilter &source) {
+        if (!c->dims.empty()) fail("Recursive filter " + c->name + " already defined");
+        c->dims = std::move(pure_args);
+        c->source = source.c;
+    }
+
+    /** lib/recfilter.cpp:252-258 */
+    void set_clamped_image_border() {
+        if (!c->dims.empty()) fail("Recursive filter " + c->name + " already defined");
+        c->clamped = true;
+    }
+
+    /** lib/recfilter.cpp:260-392; coeff = {feedforward, feedback_1 .. feedback_k} */
+    void add_filter(RecFilterDim x, std::vector<float> coeff) { add_filter(RecFilterDimAndCausality(x, true), std::move(coeff)); }
+    void add_filter(RecFilterDimAndCausality x, std::vector<float> coeff) {
+        if (c->dims.empty())
+            fail("Cannot add scans to recursive filter " + c->name + " before specifying an initial definition using RecFilter::define()");
+        if (coeff.size() < 2)
+            fail("Cannot add scan to recursive filter " + c->name + " without feed forward and feedback coefficients");
+        int d = dim_index(x.var());
+        if (d < 0) fail("Variable " + x.var() + " is not one of the dimensions of the recursive filter " + c->name);
+        if (c->compiled) fail("cannot add scans after the filter is compiled");
+        c->scans.push_back({d, x.causal(), std::move(coeff)});
+    }
+
+    /** lib/split.cpp:1850-2080 */
+    void split(std::map<std::string, int> dims) {
+        if (c->tiled) fail("Recursive filter cannot be tiled twice");
+        for (auto &kv : dims) {
+            int d = dim_index(kv.first);
+            if (d < 0) fail("Variable " + kv.first + " is not a dimension of " + c->name);
+            bool has = false;
+            for (auto &s : c->scans) has = has || s.dim == d;
+            if (!has) fail("Cannot tile dimension " + kv.first + " without any scans in it");
+            if (kv.second <= 0 || c->dims[d].num_pixels() % kv.second) fail("tile does not divide the extent of " + kv.first);
+        }
+        c->tile = std::move(dims);
+        c->tiled = true;
+    }
+    void split(RecFilterDim x, int tx) { split({{x.var(), tx}}); }
+    void split(RecFilterDim x, int tx, RecFilterDim y, int ty) { split({{x.var(), tx}, {y.var(), ty}}); }
+    void split(RecFilterDim x, int tx, RecFilterDim y, int ty, RecFilterDim z, int tz) {
+        split({{x.var(), tx}, {y.var(), ty}, {z.var(), tz}});
+    }
+    void split_all_dimensions(int tx) {
+        std::map<std::string, int> m;
+        for (size_t d = 0; d < c->dims.size(); d++)
+            for (auto &s : c->scans) if (s.dim == (int)d) { m[c->dims[d].var()] = tx; break; }
+        split(m);
+    }
+
+    /** lib/reorder.cpp:28-229 */
+    std::vector<RecFilter> cascade(std::vector<std::vector<int>> lists) {
+        if (c->tiled || c->compiled)
+            fail("Cascading directive cascade() cannot be used after the filter is already tiled, compiled or realized");
+        std::vector<int> flat;
+        for (auto &g : lists) for (int s : g) flat.push_back(s);
+        const int n = (int)c->scans.size();
+        for (int s : flat) if (s < 0 || s >= n) fail("Scan " + std::to_string(s) + " not found in recursive filter");
+        for (size_t u = 0; u < flat.size(); u++)
+            for (size_t v = u + 1; v < flat.size(); v++) {
+                const Scan &a = c->scans[flat[u]], &b = c->scans[flat[v]];
+                if (a.dim == b.dim && a.causal != b.causal && flat[v] < flat[u])
+                    fail("Scans " + std::to_string(flat[u]) + " " + std::to_string(flat[v]) +
+                         " cannot be reordered during cascading because they have opposite causality");
+            }
+        for (int s = 0; s < n; s++) {
+            int count = 0;
+            for (int f : flat) count += (f == s);
+            if (count == 0) fail("Scan " + std::to_string(s) + " does not appear in the list of scans for cascading");
+            if (count > 1) fail("Scan " + std::to_string(s) + " appears multiple times in the list of scans for cascading");
+        }
+        std::vector<RecFilter> out;
+        for (size_t i = 0; i < lists.size(); i++) {
+            RecFilter rf(c->name + "_" + std::to_string(i));
+            if (c->clamped) rf.set_clamped_image_border();
+            if (i == 0) { rf.c->dims = c->dims; rf.c->inputs = c->inputs; rf.c->source = c->source; }
+            else rf.define(c->dims, out[i - 1]);
+            for (int s : lists[i]) rf.c->scans.push_back(c->scans[s]);
+            out.push_back(rf);
+        }
+        return out;
+    }
+    std::vector<RecFilter> cascade(std::vector<int> a, std::vector<int> b) { return cascade({std::move(a), std::move(b)}); }
+    std::vector<RecFilter> cascade_by_causality() {
+        std::vector<int> causal, anti;
+        for (size_t d = 0; d < c->dims.size(); d++)
+            for (size_t i = 0; i < c->scans.size(); i++)
+                if (c->scans[i].dim == (int)d) (c->scans[i].causal ? causal : anti).push_back((int)i);
+        return cascade({causal, anti});
+    }
+    std::vector<RecFilter> cascade_by_dimension() {
+        std::vector<std::vector<int>> groups;
+        for (size_t d = 0; d < c->dims.size(); d++) {
+            std::vector<int> g;
+            for (size_t i = 0; i < c->scans.size(); i++) if (c->scans[i].dim == (int)d) g.push_back((int)i);
+            if (!g.empty()) groups.push_back(g);
+        }
+        return cascade(groups);
+    }
+
+    /** lib/reorder.cpp:231-381: `this` reads fA's result; merge both into one higher-order filter */
+    RecFilter overlap_to_higher_order_filter(RecFilter fA, std::string name = "O") {
+        if (c->tiled || fA.c->tiled) fail("overlap_to_higher_order_filter cannot be used on tiled filters");
+        if (c->dims.size() != fA.c->dims.size()) fail("filters must have the same dimensions");
+        RecFilter rf(std::move(name));
+        if (fA.c->clamped) rf.set_clamped_image_border();
+        rf.c->dims = fA.c->dims; rf.c->inputs = fA.c->inputs; rf.c->source = fA.c->source;
+        for (size_t d = 0; d < c->dims.size(); d++) {
+            std::vector<Scan> sa, sb;
+            for (auto &s : fA.c->scans) if (s.dim == (int)d) sa.push_back(s);
+            for (auto &s : c->scans) if (s.dim == (int)d) sb.push_back(s);
+            if (sa.size() != sb.size()) fail("each dimension must have the same number of scans in both filters");
+            for (size_t i = 0; i < sa.size(); i++) {
+                if (sa[i].causal != sb[i].causal) fail("each scan of each dimension must have the same causality in both filters");
+                std::vector<float> a(sa[i].coeff.begin() + 1, sa[i].coeff.end()), b(sb[i].coeff.begin() + 1, sb[i].coeff.end());
+                std::vector<float> fb(a.size() + b.size());
+                if (rf_overlap_feedback_coeff(a.data(), (int)a.size(), b.data(), (int)b.size(), fb.data()) != RF_OK)
+                    fail(rf_last_error_string());
+                fb.insert(fb.begin(), sa[i].coeff[0] * sb[i].coeff[0]);
+                rf.c->scans.push_back({(int)d, sa[i].causal, fb});
+            }
+        }
+        return rf;
+    }
+
+    /** schedule handles and auto-schedules: accepted, not needed (lib/recfilter.cpp:396-870) */
+    RecFilterSchedule intra_schedule(int id = 0) { return RecFilterSchedule(c->schedule_log, "intra" + std::to_string(id)); }
+    RecFilterSchedule inter_schedule() { return RecFilterSchedule(c->schedule_log, "inter"); }
+    RecFilterSchedule full_schedule() {
+        if (c->tiled) fail("Filter is tiled, use RecFilter::intra_schedule() and RecFilter::inter_schedule()");
+        return RecFilterSchedule(c->schedule_log, "full");
+    }
+    void compute_at(RecFilter) {}
+    void gpu_auto_schedule(int = 32) {}
+    void gpu_auto_full_schedule(int = 32) {}
+    void gpu_auto_inter_schedule() {}
+    void gpu_auto_intra_schedule(int = 0) {}
+    void cpu_auto_schedule() {}
+    void cpu_auto_full_schedule() {}
+    void cpu_auto_inter_schedule() {}
+    void cpu_auto_intra_schedule() {}
+    static void set_max_threads_per_cuda_warp(int v) {
+        if (v % 32) fail("max threads per warp must be a multiple of 32");
+        max_threads() = v;
+    }
+    static void set_vectorization_width(int v) {
+        if (v < 2 || v > 64 || (v & (v - 1))) fail("vectorization width must be a power of two <= 64");
+        vec_width() = v;
+    }
+
+    /** lib/recfilter.cpp:918-930: builds the plan (tiling tables + kernels), replaces Func::compile_jit */
+    void compile_jit(std::string = "") {
+        if (c->dims.empty()) fail("filter has no definition");
+        if (c->plan) { rf_plan_destroy(c->plan); c->plan = nullptr; }
+        std::vector<rf_scan_desc> sd(c->scans.size());
+        for (size_t i = 0; i < sd.size(); i++) {
+            const Scan &s = c->scans[i];
+            if ((int)s.coeff.size() - 1 > RF_MAX_ORDER) fail("filter order above RF_MAX_ORDER");
+            sd[i].dim = s.dim; sd[i].causal = s.causal; sd[i].order = (int)s.coeff.size() - 1; sd[i].feedfwd = s.coeff[0];
+            for (size_t j = 1; j < s.coeff.size(); j++) sd[i].feedback[j - 1] = s.coeff[j];
+        }
+        rf_filter_desc d{};
+        d.ndim = (int)c->dims.size();
+        for (int i = 0; i < d.ndim; i++) {
+            d.extent[i] = c->dims[i].num_pixels();
+            auto it = c->tile.find(c->dims[i].var());
+            d.tile[i] = it == c->tile.end() ? 0 : it->second;
+        }
+        d.dtype = dtype(); d.n_planes = (int)n_planes();
+        d.border = c->clamped ? RF_BORDER_CLAMP : RF_BORDER_ZERO;
+        d.n_scans = (int)sd.size(); d.scans = sd.data();
+        d.path = c->tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
+        d.device = -1; d.shard_rank = 0; d.shard_world = 1;
+        if (rf_plan_create(&d, &c->plan) != RF_OK) fail(rf_last_error_string());
+        c->compiled = true;
+    }
+
+    /** lib/recfilter.cpp:984-989 */
+    RecFilterRealization realize() {
+        if (!c->compiled) compile_jit();
+        std::vector<const void *> in;
+        if (c->source) { RecFilterRealization r = RecFilter(c->source).realize(); for (void *p : r.planes) in.push_back(p); }
+        else for (auto &i : c->inputs) in.push_back(i.ptr);
+        const size_t bytes = plane_elems() * dtype_size(dtype());
+        if (c->out.size() != in.size()) {
+            for (void *p : c->out) (void)hipFree(p);
+            c->out.assign(in.size(), nullptr);
+            for (auto &p : c->out) if (hipMalloc(&p, bytes) != hipSuccess) fail("hipMalloc failed");
+        }
+        if (rf_plan_execute(c->plan, in.data(), c->out.data(), nullptr) != RF_OK) fail(rf_last_error_string());
+        if (hipDeviceSynchronize() != hipSuccess) fail("device synchronisation failed");
+        RecFilterRealization r;
+        r.planes = c->out; r.dtype = dtype(); r.bytes_per_plane = bytes;
+        for (auto &dm : c->dims) r.extent.push_back(dm.num_pixels());
+        return r;
+    }
+
+    /** lib/recfilter.cpp:991-1016: one warm-up, then the mean time of `iterations` runs in ms
+     *  (unlike the reference the device is synchronised before the clock is read) */
+    float profile(int iterations) {
+        realize();
+        std::vector<const void *> in;
+        if (c->source) for (void *p : RecFilter(c->source).c->out) in.push_back(p);
+        else for (auto &i : c->inputs) in.push_back(i.ptr);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iterations; i++)
+            if (rf_plan_execute(c->plan, in.data(), c->out.data(), nullptr) != RF_OK) fail(rf_last_error_string());
+        if (hipDeviceSynchronize() != hipSuccess) fail("device synchronisation failed");
+        std::chrono::duration<double, std::milli> dt = std::chrono::steady_clock::now() - t0;
+        return (float)(dt.count() / (iterations > 0 ? iterations : 1));
+    }
+
+    std::string print_synopsis() const {
+        std::ostringstream s;
+        s << "RecFilter " << c->name << ":";
+        for (auto &d : c->dims) s << " " << d.var() << "=" << d.num_pixels();
+        s << "\n";
+        for (size_t i = 0; i < c->scans.size(); i++) {
+            s << "  scan " << i << ": " << (c->scans[i].causal ? "+" : "-") << c->dims[c->scans[i].dim].var() << " {";
+            for (float v : c->scans[i].coeff) s << " " << v;
+            s << " }\n";
+        }
+        if (c->plan) {
+            int32_t t[RF_MAX_DIMS];
+            rf_plan_tiles(c->plan, t);
+            s << "  plan: path " << rf_plan_path(c->plan) << " tiles " << t[0] << " " << t[1] << " " << t[2] << "\n";
+        }
+        return s.str();
+    }
+    const std::vector<std::string> &schedule_log() const { return *c->schedule_log; }
+
+    friend class RecFilterRefVar;
+};
+
+/** R(x,y) = image  (lib/recfilter.h:580-600) */
+class RecFilterRefVar {
+    RecFilter rf;
+    std::vector<RecFilterDim> args;
+public:
+    RecFilterRefVar(RecFilter r, std::vector<RecFilterDim> a) : rf(std::move(r)), args(std::move(a)) {}
+    void operator=(RecFilterImageRef image) { rf.define(args, std::vector<RecFilterImageRef>{image}); }
+    void operator=(std::vector<RecFilterImageRef> tuple) { rf.define(args, std::move(tuple)); }
+    void operator=(const RecFilter &source) { rf.define(args, source); }
+};
+
+inline RecFilterRefVar RecFilter::operator()(RecFilterDim x) { return RecFilterRefVar(*this, {x}); }
+inline RecFilterRefVar RecFilter::operator()(RecFilterDim x, RecFilterDim y) { return RecFilterRefVar(*this, {x, y}); }
+inline RecFilterRefVar RecFilter::operator()(RecFilterDim x, RecFilterDim y, RecFilterDim z) { return RecFilterRefVar(*this, {x, y, z}); }
+inline RecFilterRefVar RecFilter::operator()(std::vector<RecFilterDim> x) { return RecFilterRefVar(*this, std::move(x)); }
+
+inline std::ostream &operator<<(std::ostream &s, const RecFilter &r) { return s << r.print_synopsis(); }
+
+/** coefficient helpers of lib/iir_coeff.h */
+inline std::vector<float> gaussian_weights(float sigma, int order) {
+    std::vector<float> c(order + 1);
+    if (rf_gaussian_weights(sigma, order, c.data()) != RF_OK) throw RecFilterError(rf_last_error_string());
+    return c;
+}
+inline std::vector<float> integral_image_coeff(int n) {
+    std::vector<float> c(n + 1);
+    if (rf_integral_image_coeff(n, c.data()) != RF_OK) throw RecFilterError(rf_last_error_string());
+    return c;
+}
+inline std::vector<float> overlap_feedback_coeff(std::vector<float> a, std::vector<float> b) {
+    std::vector<float> c(a.size() + b.size());
+    if (rf_overlap_feedback_coeff(a.data(), (int)a.size(), b.data(), (int)b.size(), c.data()) != RF_OK)
+        throw RecFilterError(rf_last_error_string());
+    return c;
+}
+inline int gaussian_box_filter(int k, float sigma) {
+    int w = 0;
+    if (rf_gaussian_box_filter(k, sigma, &w) != RF_OK) throw RecFilterError(rf_last_error_string());
+    return w;
+}

@@ -1,0 +1,234 @@
+// test_frontend.cpp -- the reference's own tests, written against include/recfilter.hpp.
+//
+// Each case follows one file of /root/reference/tests: build the filter with the RecFilter
+// front-end, tile it, realize it on the GPU, compute the expected image with plain raster loops in
+// this file (the form the reference's tests use) and compare.  Unlike the reference's tests, which
+// only print the error, this exits non-zero when the maximum error exceeds the 1e-4 parity bar.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "recfilter.hpp"
+
+static int failures = 0;
+
+template <typename T>
+static T *upload(const std::vector<T> &h) {
+    T *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(T)) != hipSuccess) { std::fprintf(stderr, "hipMalloc failed\n"); std::exit(2); }
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) std::exit(2);
+    return d;
+}
+
+static std::vector<float> random_image(size_t n, unsigned seed) {
+    std::vector<float> v(n);
+    unsigned long long s = 0x9E3779B97F4A7C15ull * (seed + 1);
+    for (auto &x : v) {       // SplitMix64 -> [0,1)
+        s += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        x = (float)(z >> 40) / 16777216.0f;
+    }
+    return v;
+}
+
+// max |ref-out| / max(|ref|, 1% of peak): the parity metric of tests/ref_cases.py
+static double rel_err(const std::vector<float> &ref, const std::vector<float> &out) {
+    double peak = 0;
+    for (float r : ref) peak = std::fmax(peak, std::fabs(r));
+    double worst = 0;
+    for (size_t i = 0; i < ref.size(); i++)
+        worst = std::fmax(worst, std::fabs((double)ref[i] - out[i]) / std::fmax(std::fabs(ref[i]), 1e-2 * peak));
+    return worst;
+}
+
+static void report(const char *name, double err, double tol = 1e-4) {
+    std::printf("%-34s max rel err %.3e %s\n", name, err, err < tol ? "ok" : "FAILED");
+    if (!(err < tol)) failures++;
+}
+
+// zero-border scan loops in the style of tests/test_generic_xy.cpp:62-110
+static void loop_scan(std::vector<float> &ref, int w, int h, int c, int dim, bool causal, const std::vector<float> &W) {
+    const int ext[3] = {w, h, c};
+    const int n = ext[dim];
+    const long stride[3] = {1, w, (long)w * h};
+    for (int z = 0; z < c; z++) for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+        int idx[3] = {x, y, z};
+        if (idx[dim] != 0) continue;                     // one pass per line
+        long base = x * stride[0] + y * stride[1] + z * stride[2];
+        for (int r = 0; r < n; r++) {
+            int i = causal ? r : n - 1 - r;
+            float acc = 0.0f;
+            for (size_t j = 1; j < W.size(); j++)
+                if (r > (int)j - 1) acc += W[j] * ref[base + (causal ? i - (long)j : i + (long)j) * stride[dim]];
+            ref[base + i * stride[dim]] = W[0] * ref[base + i * stride[dim]] + acc;
+        }
+    }
+}
+
+int main() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "no GPU\n"); return 2; }
+
+    {   // tests/test_trivial.cpp: 20x20, tile 4, summed-area table of ones = (x+1)(y+1)
+        const int width = 20, height = 20, tile = 4;
+        std::vector<float> image(width * height, 1.0f);
+        float *d = upload(image);
+        RecFilterDim x("x", width), y("y", height);
+        RecFilter filter;
+        filter(x, y) = RecFilterImage(d);
+        filter.add_filter(+x, {1.0f, 1.0f});
+        filter.add_filter(+y, {1.0f, 1.0f});
+        filter.split(x, tile, y, tile);
+        std::vector<float> out = filter.realize().to_host<float>();
+        std::vector<float> ref(width * height);
+        for (int j = 0; j < height; j++) for (int i = 0; i < width; i++) ref[j * width + i] = float((i + 1) * (j + 1));
+        report("test_trivial", rel_err(ref, out), 1e-7);
+        (void)hipFree(d);
+    }
+    {   // tests/test_generic_xy.cpp: 16x16, tile 4, seven order-2 scans
+        const int width = 16, height = 16, tile = 4;
+        std::vector<float> image = random_image(width * height, 1);
+        float *d = upload(image);
+        const float W[7][2] = {{0.5f, 0.25f}, {0.5f, 0.125f}, {0.5f, 0.0625f}, {0.5f, 0.125f}, {0.5f, 0.25f}, {0.5f, 0.0625f}, {0.5f, 0.125f}};
+        RecFilterDim x("x", width), y("y", height);
+        RecFilter filter;
+        filter(x, y) = RecFilterImage(d);
+        filter.add_filter(+x, {1.0f, W[0][0], W[0][1]});
+        filter.add_filter(-x, {1.0f, W[1][0], W[1][1]});
+        filter.add_filter(+x, {1.0f, W[2][0], W[2][1]});
+        filter.add_filter(-x, {1.0f, W[3][0], W[3][1]});
+        filter.add_filter(+y, {1.0f, W[4][0], W[4][1]});
+        filter.add_filter(-y, {1.0f, W[5][0], W[5][1]});
+        filter.add_filter(-y, {1.0f, W[6][0], W[6][1]});
+        filter.split(x, tile, y, tile);
+        std::vector<float> out = filter.realize().to_host<float>();
+        std::vector<float> ref = image;
+        const int dims[7] = {0, 0, 0, 0, 1, 1, 1};
+        const bool causal[7] = {true, false, true, false, true, false, false};
+        for (int s = 0; s < 7; s++) loop_scan(ref, width, height, 1, dims[s], causal[s], {1.0f, W[s][0], W[s][1]});
+        report("test_generic_xy", rel_err(ref, out));
+        (void)hipFree(d);
+    }
+    {   // tests/test_generic_xyz.cpp: 16^3, tile 4, six order-2 scans
+        const int n = 16, tile = 4;
+        std::vector<float> image = random_image((size_t)n * n * n, 2);
+        float *d = upload(image);
+        const float W[6][2] = {{0.5f, 0.25f}, {0.5f, 0.125f}, {0.5f, 0.0625f}, {0.5f, 0.125f}, {0.5f, 0.25f}, {0.5f, 0.0625f}};
+        RecFilterDim x("x", n), y("y", n), z("z", n);
+        RecFilter filter;
+        filter(x, y, z) = RecFilterImage(d);
+        filter.add_filter(+x, {1.0f, W[0][0], W[0][1]});
+        filter.add_filter(-x, {1.0f, W[1][0], W[1][1]});
+        filter.add_filter(+y, {1.0f, W[2][0], W[2][1]});
+        filter.add_filter(-y, {1.0f, W[3][0], W[3][1]});
+        filter.add_filter(+z, {1.0f, W[4][0], W[4][1]});
+        filter.add_filter(-z, {1.0f, W[5][0], W[5][1]});
+        filter.split(x, tile, y, tile, z, tile);
+        std::vector<float> out = filter.realize().to_host<float>();
+        std::vector<float> ref = image;
+        for (int s = 0; s < 6; s++) loop_scan(ref, n, n, n, s / 2, s % 2 == 0, {1.0f, W[s][0], W[s][1]});
+        report("test_generic_xyz", rel_err(ref, out));
+        (void)hipFree(d);
+    }
+    {   // tests/test_type_invariance.cpp: int16, coefficients cast to the pixel type, bit-exact
+        const int width = 20, height = 20, tile = 4;
+        std::vector<int16_t> image(width * height);
+        for (size_t i = 0; i < image.size(); i++) image[i] = (int16_t)((i * 37 + 11) % 19);
+        int16_t *d = upload(image);
+        RecFilterDim x("x", width), y("y", height);
+        RecFilter filter;
+        filter(x, y) = RecFilterImage(d);
+        filter.add_filter(+x, {1.0f, 1.0f, -1.0f});
+        filter.add_filter(+y, {1.0f, 1.0f, -1.0f});
+        filter.split(x, tile, y, tile);
+        std::vector<int16_t> out = filter.realize().to_host<int16_t>();
+        std::vector<int16_t> ref = image;
+        for (int j = 0; j < height; j++) for (int i = 0; i < width; i++)
+            ref[j * width + i] = (int16_t)(ref[j * width + i] + (i > 0 ? ref[j * width + i - 1] : 0) - (i > 1 ? ref[j * width + i - 2] : 0));
+        for (int j = 0; j < height; j++) for (int i = 0; i < width; i++)
+            ref[j * width + i] = (int16_t)(ref[j * width + i] + (j > 0 ? ref[(j - 1) * width + i] : 0) - (j > 1 ? ref[(j - 2) * width + i] : 0));
+        int bad = 0;
+        for (size_t i = 0; i < ref.size(); i++) bad += ref[i] != out[i];
+        std::printf("%-34s %d mismatching pixels %s\n", "test_type_invariance (int16)", bad, bad ? "FAILED" : "ok");
+        failures += bad != 0;
+        (void)hipFree(d);
+    }
+    {   // tests/test_overlap_filter_order.cpp: cascade of two filters == one higher-order filter
+        const int width = 12, height = 12;
+        std::vector<float> image = random_image(width * height, 3);
+        float *d = upload(image);
+        RecFilterDim x("x", width), y("y", height);
+        RecFilter f1("R1");
+        f1(x, y) = RecFilterImage(d);
+        f1.add_filter(+x, {1.0f, 2.0f, -1.0f});
+        f1.add_filter(+y, {1.0f, 1.0f});
+        RecFilter f2("R2");
+        f2(x, y) = f1;
+        f2.add_filter(+x, {1.0f, 1.0f});
+        f2.add_filter(+y, {1.0f, 2.0f, -1.0f});
+        RecFilter f3 = f2.overlap_to_higher_order_filter(f1, "O");
+        std::vector<float> ref = f2.realize().to_host<float>();
+        std::vector<float> out = f3.realize().to_host<float>();
+        report("test_overlap_filter_order", rel_err(ref, out));
+        (void)hipFree(d);
+    }
+    {   // apps/gaussian/gaussian_filter_1xy_2xy.cpp: 8 scans cascaded {0-3},{4-7}, clamped, 1024^2 -> fused path
+        const int width = 1024;
+        std::vector<float> image = random_image((size_t)width * width, 4);
+        float *d = upload(image);
+        RecFilterDim x("x", width), y("y", width);
+        std::vector<float> W1 = gaussian_weights(5.0f, 1), W2 = gaussian_weights(5.0f, 2);
+        RecFilter F("Gaussian_1xy_2xy");
+        F.set_clamped_image_border();
+        F(x, y) = RecFilterImage(d);
+        F.add_filter(+x, W1); F.add_filter(-x, W1); F.add_filter(+y, W1); F.add_filter(-y, W1);
+        F.add_filter(+x, W2); F.add_filter(-x, W2); F.add_filter(+y, W2); F.add_filter(-y, W2);
+        std::vector<RecFilter> fc = F.cascade({0, 1, 2, 3}, {4, 5, 6, 7});
+        for (auto &f : fc) { f.split_all_dimensions(32); RecFilter::set_max_threads_per_cuda_warp(128); f.gpu_auto_schedule(); }
+        std::vector<float> out = fc.back().realize().to_host<float>();
+        // untiled version of the same eight scans is the reference result
+        RecFilter U("untiled");
+        U.set_clamped_image_border();
+        U(x, y) = RecFilterImage(d);
+        for (const auto &W : {W1, W2}) { U.add_filter(+x, W); U.add_filter(-x, W); U.add_filter(+y, W); U.add_filter(-y, W); }
+        std::vector<float> ref = U.realize().to_host<float>();
+        report("gaussian_1xy_2xy (tiled vs untiled)", rel_err(ref, out));
+        float ms = fc.back().profile(5);
+        std::printf("%-34s %.3f ms per realize (stage 2, 1024^2)\n", "profile()", ms);
+        failures += !(ms > 0.0f);
+        (void)hipFree(d);
+    }
+    {   // misuse behaves like the reference's assert(false) sites, as exceptions
+        int caught = 0;
+        RecFilterDim x("x", 16), y("y", 16);
+        std::vector<float> image(256, 1.0f);
+        float *d = upload(image);
+        auto expect_throw = [&](const std::function<void()> &fn) { try { fn(); } catch (const RecFilterError &) { caught++; } };
+        RecFilter f;
+        expect_throw([&] { f.add_filter(+x, {1.0f, 0.5f}); });                 // lib/recfilter.cpp:268-272
+        f(x, y) = RecFilterImage(d);
+        expect_throw([&] { f(x, y) = RecFilterImage(d); });                    // :205-208
+        expect_throw([&] { f.set_clamped_image_border(); });                    // :252-256
+        expect_throw([&] { f.add_filter(+x, {1.0f}); });                        // :274-278
+        expect_throw([&] { f.add_filter(+RecFilterDim("w", 4), {1.0f, 0.5f}); }); // :296-300
+        f.add_filter(+x, {1.0f, 0.5f});
+        f.add_filter(-x, {1.0f, 0.5f});
+        expect_throw([&] { f.split(y, 4); });                                   // lib/split.cpp:1879-1883
+        expect_throw([&] { f.cascade({1}, {0}); });                             // lib/reorder.cpp:70-75
+        f.split(x, 4);
+        expect_throw([&] { f.split(x, 4); });                                   // lib/split.cpp:1851-1854
+        expect_throw([&] { f.cascade({0}, {1}); });                             // lib/reorder.cpp:29-33
+        expect_throw([&] { f.full_schedule(); });                               // lib/recfilter.cpp:397-401
+        f.intra_schedule(1).compute_locally().unroll(0).gpu_threads(0, 1);
+        std::printf("%-34s %d/10 misuse cases rejected %s\n", "front-end misuse", caught, caught == 10 ? "ok" : "FAILED");
+        failures += caught != 10;
+        (void)hipFree(d);
+    }
+    std::printf("%s\n", failures ? "SOME TESTS FAILED" : "all front-end tests passed");
+    return failures ? 1 : 0;
+}

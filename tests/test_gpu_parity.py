@@ -269,3 +269,19 @@ def test_sharded_generic_path_uneven_scans():
         import recfilter_amd as rfa
         p = rfa.Plan((16, 40), scans, shard_rank=0, shard_world=3, path=2)
         p.execute([torch.zeros((16, 40), device="cuda")])
+
+
+def test_cpp_front_end_runs_the_reference_tests():
+    """include/recfilter.hpp (the Halide-free RecFilter front-end) driving the C ABI from C++:
+    tests/cpp/test_frontend.cpp restates test_trivial / test_generic_xy / test_generic_xyz /
+    test_type_invariance / test_overlap_filter_order and the gaussian cascade app."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "test_frontend")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(here, "cpp")])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "all front-end tests passed" in res.stdout
