@@ -66,7 +66,8 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     const uint32_t line = line_ok ? line_raw : L - 1;     // out-of-range lanes shadow the last line, stores masked
     const int M = g.M;
     const uint32_t tile_stride = (uint32_t)K * L;          // elements between consecutive tiles of one scan
-    const int tiles_per_block = kCarryChunks * C;
+    const int n_chunks = (int)blockDim.x / kCarryLines;      // <= kCarryChunks; fewer when a line has few tiles
+    const int tiles_per_block = n_chunks * C;
     const int n_blocks = (M + tiles_per_block - 1) / tiles_per_block;
 
     // residual geometry: line = x + NX*z; a wave's 64 lines share the tile column and the plane
@@ -226,6 +227,15 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
 
 }  // namespace
 
+int carry_chunk_count(int64_t M, int64_t lines, int C) {
+    const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
+    int64_t want = (4096 + line_groups - 1) / line_groups;
+    want = want < 1 ? 1 : (want > kCarryChunks ? kCarryChunks : want);
+    int64_t need = (M + C - 1) / C;          // chunks that cover the line in one block
+    int64_t n = need < want ? need : want;
+    return (int)(n < 1 ? 1 : n);
+}
+
 template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end,
                        const CarryResidual<Acc> &res, Acc *send, const Acc *AC, int C, hipStream_t stream) {
@@ -243,15 +253,24 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     g.causal_mask = causal_mask;
     g.res_nx = res.nx; g.res_MX = res.MX; g.res_ny = res.ny; g.res_NX = (uint32_t)(res.tau ? res.NX : 1);
     const unsigned grid = (unsigned)((a.g.lines + kCarryLines - 1) / kCarryLines);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(kCarryThreads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, res.tau, res.G, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
+    int n_chunks = carry_chunk_count(a.M, a.g.lines, C);
+    const unsigned threads = (unsigned)(kCarryLines * n_chunks);
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(threads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, res.tau, res.G, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
     RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
     set_error("carry: unsupported order %d", K);
     return RF_ERR_UNSUPPORTED;
 }
 
-int carry_chunk_length(int64_t M) {
-    int64_t c = (M + kCarryChunks - 1) / kCarryChunks;
+int carry_chunk_length(int64_t M, int64_t lines) {
+    // Chunks (waves) per line: enough to put ~4096 waves on the chip, no more -- with many lines a single
+    // wave walks all tiles of its 64 lines and the cross-chunk combine through LDS disappears.
+    const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
+    int64_t want = (4096 + line_groups - 1) / line_groups;
+    want = want < 1 ? 1 : (want > kCarryChunks ? kCarryChunks : want);
+    if (want > M) want = M < 1 ? 1 : M;
+    int64_t c = (M + want - 1) / want;
     return (int)(c < 1 ? 1 : (c > kCarryMaxC ? kCarryMaxC : c));
 }
 

@@ -55,6 +55,22 @@ struct FusedArgs {
     const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]
 };
 
+// Register-column scans along a strided dimension (kernels_strided.hip), by value like FusedArgs.
+template <typename Acc>
+struct StridedArgs {
+    int64_t n, inner, lines;     // extent and stride of the filtered dimension, number of lines
+    int32_t M;                   // tiles of TZ samples
+    int32_t n_scans;
+    int32_t clamped, first_is_border, last_is_border;
+    FusedScanY<Acc> scans[kFusedMaxScans];
+    Acc *tails;                  // [s][t][r][line]
+    const Acc *incoming;         // [s][r][line]
+};
+
+template <typename P>
+int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
+                        const StridedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);
+
 // Cross-dimension residual folded into the y carry stage (tau == nullptr: none).
 template <typename Acc>
 struct CarryResidual {
@@ -65,11 +81,12 @@ struct CarryResidual {
 };
 
 // Blocked parallel carry scan over the tails of one dimension (kernels_carry.hip); scans
-// [s_begin, s_end) of the dimension in one launch.  AC[s] = A[s]^C, C = carry_chunk_length(M).
+// [s_begin, s_end) of the dimension in one launch.  AC[s] = A[s]^C, C = carry_chunk_length(M, lines).
 template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end,
                        const CarryResidual<Acc> &res, Acc *send, const Acc *AC, int C, hipStream_t stream);
-int carry_chunk_length(int64_t M);
+int carry_chunk_length(int64_t M, int64_t lines);
+int carry_chunk_count(int64_t M, int64_t lines, int C);
 
 template <typename P>
 int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,

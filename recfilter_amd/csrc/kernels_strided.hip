@@ -1,0 +1,114 @@
+// kernels_strided.hip -- tiled scans along a NON-contiguous dimension (z of a volume, or y when a
+// filter has no x scans) with the column held in registers.
+//
+// Thread = one line position (lane = x, so every access of a wave is 256 contiguous bytes), tile =
+// TZ consecutive samples along the filtered dimension, kept in TZ registers.  Every scan of the
+// dimension is a serial recurrence up or down the registers -- no LDS, no transposition.  Pass 1
+// stores only the k-sample tails of each scan (lib/split.cpp:256-499), pass 2 injects the completed
+// carries (lib/split.cpp:1008-1130) and stores the tile; the carry stage in between is
+// carry_block_kernel (kernels_carry.hip).  This is the y phase of the fused kernel fed straight from
+// HBM; it is what the 3-D configs run for z after the fused x/y stage.
+#include "kernels.h"
+#include "kernels_fused.h"
+
+namespace rf {
+
+namespace {
+
+// same recurrence as the fused kernel's y phase (kernels_fused.hip: scan_col)
+template <typename Acc, bool CAUSAL, int K, int TZ>
+__device__ __forceinline__ void scan_regs(Acc (&col)[TZ], const FusedScanY<Acc> &sc, bool clamp_first, const Acc (&carry)[K]) {
+    Acc h[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) h[j] = carry[j];
+    Acc y0 = Acc(0);
+#pragma unroll
+    for (int p = 0; p < TZ; p++) {
+        const int m = CAUSAL ? p : TZ - 1 - p;
+        Acc x = col[m];
+        Acc acc = sc.b * x;
+#pragma unroll
+        for (int j = K - 1; j >= 0; j--) {
+            Acc g = h[j];
+            if (p <= j) g = clamp_first ? (p == 0 ? x : y0) : g;
+            acc = acc + sc.a[j] * g;
+        }
+#pragma unroll
+        for (int j = K - 1; j > 0; j--) h[j] = h[j - 1];
+        h[0] = acc;
+        if (p == 0) y0 = acc;
+        col[m] = acc;
+    }
+}
+
+template <typename P, int K, int TZ, bool FINAL>
+__global__ void __launch_bounds__(256)
+strided_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, StridedArgs<typename PixelTraits<P>::Acc> a) {
+    using Acc = typename PixelTraits<P>::Acc;
+    const int64_t line = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (line >= a.lines) return;
+    const int t = blockIdx.y;
+    const int64_t base = (line / a.inner) * a.n * a.inner + (line % a.inner) + (int64_t)t * TZ * a.inner;
+    Acc col[TZ];
+#pragma unroll
+    for (int i = 0; i < TZ; i++) col[i] = PixelTraits<P>::load(src[base + (int64_t)i * a.inner]);
+#pragma unroll 1
+    for (int s = 0; s < a.n_scans; s++) {
+        const FusedScanY<Acc> &sc = a.scans[s];
+        const bool causal = sc.causal != 0;
+        const bool tile_first = causal ? (t == 0) : (t == a.M - 1);
+        const bool border = causal ? (t == 0 && a.first_is_border) : (t == a.M - 1 && a.last_is_border);
+        Acc carry[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) carry[r] = Acc(0);
+        if (FINAL) {
+            if (tile_first) {
+#pragma unroll
+                for (int r = 0; r < K; r++) carry[r] = a.incoming[((int64_t)s * K + r) * a.lines + line];
+            } else {
+                const int tp = causal ? t - 1 : t + 1;
+#pragma unroll
+                for (int r = 0; r < K; r++) carry[r] = a.tails[(((int64_t)s * a.M + tp) * K + r) * a.lines + line];
+            }
+        }
+        const bool clamp_first = a.clamped && border;
+        if (causal) scan_regs<Acc, true, K, TZ>(col, sc, clamp_first, carry);
+        else        scan_regs<Acc, false, K, TZ>(col, sc, clamp_first, carry);
+        if (!FINAL) {
+#pragma unroll
+            for (int r = 0; r < K; r++)
+                a.tails[(((int64_t)s * a.M + t) * K + r) * a.lines + line] = causal ? col[TZ - 1 - r] : col[r];
+        }
+    }
+    if (FINAL) {
+#pragma unroll
+        for (int i = 0; i < TZ; i++) dst[base + (int64_t)i * a.inner] = PixelTraits<P>::store(col[i]);
+    }
+}
+
+}  // namespace
+
+template <typename P>
+int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
+                        const StridedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
+    if (a.lines <= 0 || a.M <= 0) return RF_OK;
+    if (a.M > 65535) { set_error("strided path: too many tiles"); return RF_ERR_UNSUPPORTED; }
+    dim3 grid((unsigned)((a.lines + 255) / 256), (unsigned)a.M);
+#define RF_CASE(KK, TT)                                                                                              \
+    if (K == KK && TZ == TT) {                                                                                        \
+        if (final_pass) hipLaunchKernelGGL((strided_pass_kernel<P, KK, TT, true>), grid, dim3(256), 0, stream, src, dst, a); \
+        else hipLaunchKernelGGL((strided_pass_kernel<P, KK, TT, false>), grid, dim3(256), 0, stream, src, dst, a);    \
+        RF_HIP_CHECK(hipGetLastError());                                                                              \
+        return RF_OK;                                                                                                 \
+    }
+    RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
+    RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
+#undef RF_CASE
+    set_error("strided path: unsupported order %d / tile %d", K, TZ);
+    return RF_ERR_UNSUPPORTED;
+}
+
+template int launch_strided_pass<float>(bool, int, int, const float *, float *, const StridedArgs<float> &, hipStream_t);
+template int launch_strided_pass<int32_t>(bool, int, int, const int32_t *, int32_t *, const StridedArgs<uint32_t> &, hipStream_t);
+
+}  // namespace rf

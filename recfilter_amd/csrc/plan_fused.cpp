@@ -13,6 +13,7 @@
 #include "kernels_fused.h"
 #include "plan.h"
 #include "plan_generic.h"
+#include "plan_strided.h"
 
 namespace rf {
 
@@ -125,7 +126,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     }
     std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
     std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy;
-    const int Cx = carry_chunk_length(MX), Cy = carry_chunk_length(MY);
+    const int Cx = carry_chunk_length(MX, Lx), Cy = carry_chunk_length(MY, Ly);
     if (nx > 0) {
         DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
         flatten_W(tx, nx, hWx, hAx, "x");
@@ -315,7 +316,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     // ---- z (3-D): filtered after the fused x/y stage, reading and writing the output planes ----
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
-        int rc = add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
+        int rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false)
+                                           : add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
         if (rc != RF_OK) return rc;
     }
     return status;
@@ -338,7 +340,8 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
     if (NZ > 65535 || plan->dims[1].N / 32 > 65535) return no("grid too large");
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
         // the z stage runs on the generic dimension builder
-        if (pick_generic_tile(plan->dims[2].N, plan->dims[2].k, 0) == 0) return no("no tile divides the z extent");
+        if (strided_tile(plan, 2) == 0 && pick_generic_tile(plan->dims[2].N, plan->dims[2].k, 0) == 0)
+            return no("no tile divides the z extent");
     }
     return true;
 }

@@ -1,0 +1,172 @@
+// plan_strided.h -- step list of ONE strided dimension on the register-column path
+// (kernels_strided.hip): pass 1, blocked carry scan, pass 2.  Used by plan_fused.cpp for the z
+// dimension of 3-D filters.  Same exchange structure as plan_generic.h for the sharded dimension.
+#pragma once
+
+#include <cstring>
+
+#include "kernels_fused.h"
+#include "plan.h"
+#include "plan_generic.h"
+
+namespace rf {
+
+inline int strided_tile(const rf_plan *plan, int d) {
+    const DimInfo &di = plan->dims[d];
+    if (di.scan_ids.empty() || di.k > kFusedMaxK || (int)di.scan_ids.size() > kFusedMaxScans) return 0;
+    if (plan->dtype != RF_F32 && plan->dtype != RF_I32) return 0;
+    if (di.N % 64 == 0) return 64;
+    if (di.N % 32 == 0) return 32;
+    return 0;
+}
+
+template <typename P, typename S>
+int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
+    using Acc = typename PixelTraits<P>::Acc;
+    int status = RF_OK;
+    DimInfo &di = plan->dims[d];
+    const int TZ = strided_tile(plan, d);
+    if (TZ == 0) { set_error("strided path not applicable to dimension %d", d); return RF_ERR_UNSUPPORTED; }
+    di.T = TZ;
+    di.M = di.N / TZ;
+    const int n = (int)di.scan_ids.size(), K = di.k, M = (int)di.M;
+    const int outer = plan->ndim - 1;
+    const bool sharded = (d == outer) && plan->shard_world > 1;
+    const int np = plan->n_planes;
+    std::string dn(1, "xyz"[d]);
+
+    std::vector<ScanS<S>> ts;
+    std::vector<DevScan<Acc>> ds;
+    StridedArgs<Acc> base{};
+    std::memset(base.scans, 0, sizeof(base.scans));
+    uint32_t mask = 0;
+    for (int i = 0; i < n; i++) {
+        const Scan &sc = plan->scans[di.scan_ids[i]];
+        ScanS<S> t = make_table_scan<S>(sc);
+        ts.push_back(t);
+        DevScan<Acc> dv = make_dev_scan<Acc>(sc);
+        dv.order = K;
+        ds.push_back(dv);
+        base.scans[i].causal = t.causal ? 1 : 0;
+        base.scans[i].b = table_to_acc<S, Acc>(t.b);
+        for (int j = 0; j < kFusedMaxK; j++) base.scans[i].a[j] = j < K ? table_to_acc<S, Acc>(t.a[j]) : Acc(0);
+        if (t.causal) mask |= 1u << i;
+    }
+    DimTables<S> tab = build_dim_tables<S>(ts, K, TZ, plan->clamped);
+    const int C = carry_chunk_length(M, di.lines);
+    std::vector<Acc> hW((size_t)4 * n * n * K * K, Acc(0)), hA((size_t)n * K * K), hAC(hA.size()), hAM(hA.size());
+    std::vector<double> dW(hW.size(), 0.0), dA(hA.size(), 0.0);
+    for (int v = 0; v < 4; v++)
+        for (int q = 0; q < n; q++)
+            for (int s = q + 1; s < n; s++)
+                for (int e = 0; e < K * K; e++) {
+                    size_t idx = (((size_t)v * n + q) * n + s) * K * K + e;
+                    hW[idx] = table_to_acc<S, Acc>(tab.Wm(v, q, s)[e]);
+                    dW[idx] = table_to_double<S>(tab.Wm(v, q, s)[e]);
+                }
+    for (int s = 0; s < n; s++) {
+        std::vector<S> ac = mat_pow<S>(tab.A[s], C, K), am = mat_pow<S>(tab.A[s], M, K);
+        for (int e = 0; e < K * K; e++) {
+            hA[(size_t)s * K * K + e] = table_to_acc<S, Acc>(tab.A[s][e]);
+            dA[(size_t)s * K * K + e] = table_to_double<S>(tab.A[s][e]);
+            hAC[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ac[e]);
+            hAM[(size_t)s * K * K + e] = table_to_acc<S, Acc>(am[e]);
+        }
+    }
+    plan->tables["W_" + dn] = dW;
+    plan->tables["A_" + dn] = dA;
+
+    const DevScan<Acc> *d_scans = (const DevScan<Acc> *)plan->upload(ds.data(), ds.size() * sizeof(DevScan<Acc>), &status);
+    const Acc *d_W = (const Acc *)plan->upload(hW.data(), hW.size() * sizeof(Acc), &status);
+    const Acc *d_A = (const Acc *)plan->upload(hA.data(), hA.size() * sizeof(Acc), &status);
+    const Acc *d_AC = (const Acc *)plan->upload(hAC.data(), hAC.size() * sizeof(Acc), &status);
+    const Acc *d_AM = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
+    const size_t tails_pp = (size_t)n * M * K * di.lines, inc_pp = (size_t)n * K * di.lines;
+    Acc *tails = (Acc *)plan->alloc(tails_pp * np * sizeof(Acc), false, &status);
+    Acc *incoming = (Acc *)plan->alloc(inc_pp * np * sizeof(Acc), true, &status);
+    if (status != RF_OK) return status;
+
+    base.n = di.N; base.inner = di.stride; base.lines = di.lines; base.M = M; base.n_scans = n;
+    base.clamped = plan->clamped ? 1 : 0;
+    base.first_is_border = (!sharded || plan->shard_rank == 0) ? 1 : 0;
+    base.last_is_border = (!sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
+    auto sargs = [=](int pl) {
+        StridedArgs<Acc> a = base;
+        a.tails = tails + (size_t)pl * tails_pp;
+        a.incoming = incoming + (size_t)pl * inc_pp;
+        return a;
+    };
+    GenericDimArgs<Acc> gb{};
+    gb.g = LineGeom{di.N, di.stride, di.lines};
+    gb.T = TZ; gb.M = M; gb.k = K; gb.n_scans = n; gb.clamped = base.clamped;
+    gb.first_is_border = base.first_is_border; gb.last_is_border = base.last_is_border;
+    gb.scans = d_scans; gb.W = d_W; gb.A = d_A;
+    auto gargs = [=](int pl) {
+        GenericDimArgs<Acc> a = gb;
+        a.tails = tails + (size_t)pl * tails_pp;
+        a.incoming = incoming + (size_t)pl * inc_pp;
+        return a;
+    };
+
+    Step p1;
+    p1.name = "strided_pass1_" + dn;
+    p1.run = [plan, sargs, K, TZ, from_input](int pl) {
+        const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
+        return launch_strided_pass<P>(false, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
+    };
+    plan->begin_steps.push_back(p1);
+
+    CarryResidual<Acc> none{};
+    if (!sharded) {
+        Step cs;
+        cs.name = "carry_" + dn;
+        cs.run = [plan, gargs, K, n, d_AC, C, mask, none](int pl) {
+            return launch_carry_block<Acc>(K, gargs(pl), mask, 0, n, none, (Acc *)nullptr, d_AC, C, plan->stream);
+        };
+        plan->begin_steps.push_back(cs);
+    } else {
+        for (int s = 0; s < n; s++) {
+            const int64_t plane_stride = (int64_t)K * di.lines, rank_stride = (int64_t)np * K * di.lines;
+            const int ex_index = (int)plan->exchanges.size();
+            rf_plan::Exchange ex;
+            ex.bytes = (size_t)np * K * di.lines * sizeof(Acc);
+            ex.scratch = plan->alloc(ex.bytes, true, &status);
+            if (status != RF_OK) return status;
+            ex.send = ex.scratch;
+            const Acc *AMs = d_AM + (size_t)s * K * K;
+            ex.form_incoming = [plan, gargs, s, rank_stride, plane_stride, AMs](const void *gathered) {
+                for (int pl = 0; pl < plan->n_planes; pl++) {
+                    int rc = launch_gather_incoming<Acc>(gargs(pl), s, (const Acc *)gathered, rank_stride, pl * plane_stride,
+                                                         plan->shard_rank, plan->shard_world, AMs, plan->stream);
+                    if (rc) return rc;
+                }
+                return (int)RF_OK;
+            };
+            plan->exchanges.push_back(ex);
+            Step cs;
+            cs.name = "carry_" + dn + std::to_string(s);
+            cs.run = [plan, gargs, K, s, d_AC, C, mask, none, ex_index, plane_stride](int pl) {
+                Acc *send = (Acc *)plan->exchanges[ex_index].send;
+                return launch_carry_block<Acc>(K, gargs(pl), mask, s, s + 1, none, send ? send + pl * plane_stride : nullptr,
+                                               d_AC, C, plan->stream);
+            };
+            plan->exchange_local_steps.push_back({cs});
+            Step ap;
+            ap.name = "carry_apply_" + dn + std::to_string(s);
+            ap.run = [plan, gargs, s](int pl) { return launch_generic_carry_apply<Acc>(gargs(pl), s, plan->stream); };
+            plan->exchange_apply_steps.push_back({ap});
+        }
+    }
+
+    Step p2;
+    p2.name = "strided_pass2_" + dn;
+    p2.run = [plan, sargs, K, TZ, from_input](int pl) {
+        const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
+        return launch_strided_pass<P>(true, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
+    };
+    if (d == outer) plan->finish_steps.push_back(p2);
+    else plan->begin_steps.push_back(p2);
+    return status;
+}
+
+}  // namespace rf
