@@ -91,6 +91,13 @@ int carry_chunk_count(int64_t M, int64_t lines, int C);
 template <typename P>
 int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,
                       const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);
+// pass 1 as a contraction with precomputed impulse responses (kernels_tails.hip)
+template <typename P>
+int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                       const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy,
+                       hipStream_t stream);
+template <typename Acc>
+int launch_xscan_rows(int K, const FusedArgs<Acc> &a, hipStream_t stream);
 template <typename Acc>
 int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t stream);
 }  // namespace rf

@@ -1,0 +1,254 @@
+// kernels_tails.hip -- pass 1 of the fused path as a contraction: per-tile tail extraction without
+// running the scans over the tile.
+//
+// What pass 1 has to produce (extract_tails_from_each_scan, lib/split.cpp:256-499) is, per tile, the
+// k-sample tail of every scan with all carries entering the tile set to zero.  Those tails are LINEAR
+// in the tile, so they can be read off with precomputed impulse responses instead of running every
+// recurrence over every sample (what the reference's <F>_Intra stage and the first version of this
+// pass did, ~25 VALU instructions per sample with long dependent chains):
+//
+//   x tails   xt[s][r](row)  = sum_x Hx[s][r][x] * tile[row][x]            Hx = E_s F_s ... F_0 (k x 256)
+//   y tails   yt[j][r](col)  = F_x( sum_i Hy[j][r][i] * tile[i][.] )(col)  Hy = E_j Y_j ... Y_0 (k x TY)
+//
+// For the y tails the TY rows of the tile are first contracted with Hy into k "combined rows" per y
+// scan (fused_tails_kernel, no recurrence at all), and only those few rows go through the tile-local
+// x scans F_x (xscan_rows_kernel, 1/16 of the samples).  Hx/Hy come from the same scan_tile routine as
+// every other table (border variants included), so the carry stage and pass 2 see exactly the tails
+// they saw before.
+//
+// fused_tails_kernel stages HALF tiles (256 x 32, 32 KiB of LDS) so that four to five workgroups fit a
+// CU; the second half's pixels are already in flight while the first half is contracted.
+#include "kernels.h"
+#include "kernels_fused.h"
+#include "scan_device.h"
+
+namespace rf {
+
+namespace {
+
+constexpr int kTailRows = 32;     // rows staged per step
+
+template <typename P, int K, int TY>
+__global__ void __launch_bounds__(kFusedThreads)
+fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>::Acc> a,
+                   const typename PixelTraits<P>::Acc *__restrict__ Hx,     // [vx][s][r][256]
+                   const typename PixelTraits<P>::Acc *__restrict__ Hy) {   // [vy][j][r][TY]
+    using Acc = typename PixelTraits<P>::Acc;
+    using A4 = typename Vec4<Acc>::type;
+    __shared__ __attribute__((aligned(16))) Acc tile[kTailRows * kFusedTX];
+    __shared__ __attribute__((aligned(16))) Acc hx_lds[kFusedMaxScans * K * kFusedTX];   // Hx of this tile's variant
+    A4 *tile4 = reinterpret_cast<A4 *>(tile);
+    A4 *hx4 = reinterpret_cast<A4 *>(hx_lds);
+    constexpr int NH = TY / kTailRows;            // steps per tile (2 for TY = 64)
+    constexpr int NL = kTailRows / 4;             // float4 loads per thread per step
+    constexpr int NR = kTailRows / 16;            // rows per thread in the x part
+
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
+    const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
+    const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
+    const int nxk = a.nx * K, nyk = a.ny * K;
+
+    const int cc = t & 63, rg = t >> 6;                        // load: 16-byte chunk, row group
+    const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x part: segment lane, row slot
+    const int e = (swz_chunk(t >> 2) << 2) | (t & 3);          // y part: swizzled column offset
+    const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
+    const uint32_t rs4 = (uint32_t)(a.NX / 4);
+    const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
+    const int64_t Lx = a.NY * a.NZ, Ly = a.NX * a.NZ;
+
+    Acc comb[kFusedMaxScans * K];
+#pragma unroll
+    for (int jr = 0; jr < kFusedMaxScans * K; jr++) comb[jr] = Acc(0);
+
+    A4 pre[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) pre[i] = sp[off0 + (uint32_t)(4 * i) * rs4];
+    // impulse responses of the x tails for this tile's border variant -> LDS (read back per segment below);
+    // 16-byte chunk c of a row is stored at chunk c ^ ((c >> 4) & 3), the same swizzle as the pixels
+    if (nxk > 0) {
+        const A4 *hsrc = reinterpret_cast<const A4 *>(Hx + (size_t)vx * nxk * kFusedTX);
+        for (int c = t; c < nxk * 64; c += kFusedThreads) hx4[(c & ~63) | swz_chunk(c & 63)] = hsrc[c];
+    }
+
+#pragma unroll
+    for (int half = 0; half < NH; half++) {
+        if (half > 0) __syncthreads();                          // previous step's readers are done
+#pragma unroll
+        for (int i = 0; i < NL; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = pre[i];
+        __syncthreads();
+        if (half + 1 < NH) {                                    // next half in flight during this one's math
+#pragma unroll
+            for (int i = 0; i < NL; i++) pre[i] = sp[off0 + (uint32_t)(kTailRows * (half + 1) + 4 * i) * rs4];
+        }
+
+        // ---- x tails of this half's rows: dot products + reduction over the 16 lanes of a row ----
+        if (nxk > 0) {
+            Acc v[NR][kFusedSeg];
+#pragma unroll
+            for (int n = 0; n < NR; n++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    A4 q = tile4[(slot + 16 * n) * 64 + 4 * l + (j ^ sw)];
+                    v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
+                }
+            }
+            const int64_t line0 = (int64_t)ty * TY + kTailRows * half + slot + a.NY * z;
+#pragma unroll 1
+            for (int sr = 0; sr < nxk; sr++) {
+                Acc h[kFusedSeg];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    A4 q = hx4[sr * 64 + 4 * l + (j ^ sw)];
+                    h[4 * j + 0] = q.x; h[4 * j + 1] = q.y; h[4 * j + 2] = q.z; h[4 * j + 3] = q.w;
+                }
+                Acc acc[NR];
+#pragma unroll
+                for (int n = 0; n < NR; n++) {
+                    acc[n] = Acc(0);
+#pragma unroll
+                    for (int m = 0; m < kFusedSeg; m++) acc[n] = acc[n] + h[m] * v[n][m];
+                }
+#pragma unroll
+                for (int n = 0; n < NR; n++) {          // sum over the row's 16 lanes; total lands in lane 15
+                    acc[n] = acc[n] + row_shift<true, 8>(acc[n]);
+                    acc[n] = acc[n] + row_shift<true, 4>(acc[n]);
+                    acc[n] = acc[n] + row_shift<true, 2>(acc[n]);
+                    acc[n] = acc[n] + row_shift<true, 1>(acc[n]);
+                }
+                if (l == 15) {
+                    const int s = sr / K, r = sr % K;
+#pragma unroll
+                    for (int n = 0; n < NR; n++)
+                        a.xt[(((int64_t)s * a.MX + tx) * K + r) * Lx + line0 + 16 * n] = acc[n];
+                }
+            }
+        }
+
+        // ---- y: contract this half's rows with Hy (thread = column) ----
+        if (nyk > 0) {
+            Acc col[kTailRows];
+#pragma unroll
+            for (int i = 0; i < kTailRows; i++) col[i] = tile[i * kFusedTX + e];
+#pragma unroll
+            for (int jr = 0; jr < kFusedMaxScans * K; jr++) {
+                if (jr < nyk) {
+                    const Acc *hy = Hy + (size_t)(vy * nyk + jr) * TY + kTailRows * half;     // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < kTailRows; i++) comb[jr] = comb[jr] + hy[i] * col[i];
+                }
+            }
+        }
+    }
+    // combined rows -> yt; with x scans in the filter xscan_rows_kernel finishes them in place
+    if (nyk > 0) {
+        const int64_t line = (int64_t)tx * kFusedTX + t + a.NX * z;
+#pragma unroll
+        for (int jr = 0; jr < kFusedMaxScans * K; jr++)
+            if (jr < nyk) a.yt[(((int64_t)(jr / K) * a.MY + ty) * K + jr % K) * Ly + line] = comb[jr];
+    }
+}
+
+// tile-local x scans (all of them, zero carries) of the combined rows, in place in yt.
+// A workgroup takes 16 row tiles (runs of 256 consecutive yt samples), moves them through LDS with
+// fully coalesced 16-byte accesses, and scans each in one 16-lane DPP row.
+template <typename Acc, int K>
+__global__ void __launch_bounds__(256)
+xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles) {
+    using A4 = typename Vec4<Acc>::type;
+    __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
+    A4 *rows4 = reinterpret_cast<A4 *>(rows);
+    const int t = threadIdx.x;
+    const int64_t rt0 = (int64_t)blockIdx.x * 16;
+    const int cc = t & 63, rg = t >> 6;
+    A4 *g4 = reinterpret_cast<A4 *>(a.yt + rt0 * kFusedTX);
+    A4 tmp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = rg + 4 * i;
+        tmp[i] = (rt0 + r < n_row_tiles) ? g4[r * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) rows4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
+    __syncthreads();
+    {
+        const int l = t & 15, row = t >> 4, sw = (l >> 2) & 3;
+        const int tx = (int)((rt0 + row) % a.MX);
+        Acc v[1][kFusedSeg];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            A4 q = rows4[row * 64 + 4 * l + (j ^ sw)];
+            v[0][4 * j + 0] = q.x; v[0][4 * j + 1] = q.y; v[0][4 * j + 2] = q.z; v[0][4 * j + 3] = q.w;
+        }
+        Acc zero[1][K];
+#pragma unroll
+        for (int j = 0; j < K; j++) zero[0][j] = Acc(0);
+#pragma unroll 1
+        for (int s = 0; s < a.nx; s++) {
+            const FusedScan<Acc> &sc = a.xs[s];
+            const bool causal = sc.causal != 0;
+            const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
+            const bool first_lane = causal ? (l == 0) : (l == 15);
+            const bool clamp_first = a.clamped && tile_first && first_lane;
+            if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, clamp_first, zero);
+            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            A4 q;
+            q.x = v[0][4 * j + 0]; q.y = v[0][4 * j + 1]; q.z = v[0][4 * j + 2]; q.w = v[0][4 * j + 3];
+            rows4[row * 64 + 4 * l + (j ^ sw)] = q;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = rg + 4 * i;
+        if (rt0 + r < n_row_tiles) g4[r * 64 + cc] = rows4[r * 64 + swz_chunk(cc)];
+    }
+}
+
+}  // namespace
+
+template <typename P>
+int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                       const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy,
+                       hipStream_t stream) {
+    if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
+    if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
+    dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
+#define RF_CASE(KK, TT)                                                                                             \
+    if (K == KK && TY == TT) {                                                                                       \
+        hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT>), grid, dim3(kFusedThreads), 0, stream, src, a, Hx, Hy);   \
+        RF_HIP_CHECK(hipGetLastError());                                                                             \
+        return RF_OK;                                                                                                \
+    }
+    RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
+    RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
+#undef RF_CASE
+    set_error("fused tails: unsupported order %d / tile height %d", K, TY);
+    return RF_ERR_UNSUPPORTED;
+}
+
+template <typename Acc>
+int launch_xscan_rows(int K, const FusedArgs<Acc> &a, hipStream_t stream) {
+    // yt is [j][ty][r][x + NX*z]: every run of 256 consecutive samples is one combined row of one x tile
+    const int64_t n_row_tiles = (int64_t)a.ny * a.MY * K * a.NZ * a.MX;
+    if (n_row_tiles <= 0 || a.nx == 0) return RF_OK;
+    const unsigned grid = (unsigned)((n_row_tiles + 15) / 16);
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+#undef RF_CASE
+    set_error("xscan rows: unsupported order %d", K);
+    return RF_ERR_UNSUPPORTED;
+}
+
+template int launch_fused_tails<float>(int, int, const float *, const FusedArgs<float> &, const float *, const float *, hipStream_t);
+template int launch_fused_tails<int32_t>(int, int, const int32_t *, const FusedArgs<uint32_t> &, const uint32_t *,
+                                         const uint32_t *, hipStream_t);
+template int launch_xscan_rows<float>(int, const FusedArgs<float> &, hipStream_t);
+template int launch_xscan_rows<uint32_t>(int, const FusedArgs<uint32_t> &, hipStream_t);
+
+}  // namespace rf

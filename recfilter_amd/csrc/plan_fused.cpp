@@ -125,11 +125,18 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->tables["seg_P_x"] = sp;
     }
     std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
-    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy;
+    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy, hHx, hHy;
     const int Cx = carry_chunk_length(MX, Lx), Cy = carry_chunk_length(MY, Ly);
     if (nx > 0) {
         DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
         flatten_W(tx, nx, hWx, hAx, "x");
+        {
+            std::vector<S> H = build_tail_responses<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
+            std::vector<double> dH(H.size());
+            hHx.resize(H.size());
+            for (size_t e = 0; e < H.size(); e++) { hHx[e] = table_to_acc<S, Acc>(H[e]); dH[e] = table_to_double<S>(H[e]); }
+            plan->tables["H_x"] = dH;
+        }
         hACx.assign((size_t)nx * K * K, Acc(0));
         for (int s = 0; s < nx; s++) {
             std::vector<S> ac = mat_pow<S>(tx.A[s], Cx, K);
@@ -152,6 +159,13 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (ny > 0) {
         DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped);
         flatten_W(ty, ny, hWy, hAy, "y");
+        {
+            std::vector<S> H = build_tail_responses<S>(table_scans(dy.scan_ids), K, TY, plan->clamped);
+            std::vector<double> dH(H.size());
+            hHy.resize(H.size());
+            for (size_t e = 0; e < H.size(); e++) { hHy[e] = table_to_acc<S, Acc>(H[e]); dH[e] = table_to_double<S>(H[e]); }
+            plan->tables["H_y"] = dH;
+        }
         hAMy.assign((size_t)ny * K * K, Acc(0));
         hACy.assign((size_t)ny * K * K, Acc(0));
         for (int j = 0; j < ny; j++) {
@@ -172,7 +186,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const DevScan<Acc> *d_xd = up(hxd);
     const DevScan<Acc> *d_yd = up(hyd);
     const Acc *d_Wx = up(hWx), *d_Ax = up(hAx), *d_Wy = up(hWy), *d_Ay = up(hAy), *d_G = up(hG), *d_AMy = up(hAMy);
-    const Acc *d_ACx = up(hACx), *d_ACy = up(hACy);
+    const Acc *d_ACx = up(hACx), *d_ACy = up(hACy), *d_Hx = up(hHx), *d_Hy = up(hHy);
 
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
@@ -233,12 +247,24 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     for (int j = 0; j < ny; j++) if (hys[j].causal) ymask |= 1u << j;
 
     // ---- steps -----------------------------------------------------------------------------
+    // pass 1: tail extraction by contraction with the impulse responses (kernels_tails.hip); the scan-everything
+    // version of the first round stays selectable for A/B runs (RF_FUSED_PASS1=scan)
+    const char *p1env = getenv("RF_FUSED_PASS1");
+    const bool p1_scan = p1env && std::string(p1env) == "scan";
     Step p1;
-    p1.name = "fused_pass1";
-    p1.run = [plan, fargs, K, TY](int pl) {
-        return launch_fused_pass<P>(false, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+    p1.name = p1_scan ? "fused_pass1" : "fused_tails";
+    p1.run = [plan, fargs, K, TY, p1_scan, d_Hx, d_Hy](int pl) {
+        if (p1_scan)
+            return launch_fused_pass<P>(false, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+        return launch_fused_tails<P>(K, TY, (const P *)plan->in[pl], fargs(pl), d_Hx, d_Hy, plan->stream);
     };
     plan->begin_steps.push_back(p1);
+    if (!p1_scan && nx > 0 && ny > 0) {
+        Step xs;
+        xs.name = "xscan_rows";
+        xs.run = [plan, fargs, K](int pl) { return launch_xscan_rows<Acc>(K, fargs(pl), plan->stream); };
+        plan->begin_steps.push_back(xs);
+    }
     if (nx > 0) {
         Step cx;
         cx.name = "carry_x";

@@ -1,0 +1,130 @@
+// scan_device.h -- device-side building blocks shared by the fused kernels: DPP row shifts, the LDS
+// chunk swizzle, the 16-lane segment scan of the x phase and the register-column scan of the y phase.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_fused.h"
+
+namespace rf {
+namespace {
+
+// ---- DPP helpers ------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// shift towards higher lanes (causal) = row_shr, towards lower lanes (anticausal) = row_shl;
+// lanes without a source inside their 16-lane row receive 0
+template <bool CAUSAL, int D, typename Acc>
+__device__ __forceinline__ Acc row_shift(Acc v) {
+    return dpp_move<(CAUSAL ? 0x110 : 0x100) + D>(v);
+}
+
+__device__ __forceinline__ int swz_chunk(int c) { return c ^ ((c >> 4) & 3); }
+
+// ---- x phase: one scan over NR 256-sample tile rows, each held as 16 samples per lane -----------
+// The NR rows are independent recurrences; every step is written row-innermost so the compiler
+// interleaves them (ILP = NR) and the dependent-FMA latency of one row hides behind the others.
+template <typename Acc, bool CAUSAL, int K, int NR>
+__device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const FusedScan<Acc> &sc, bool first_lane,
+                                            bool clamp_first, const Acc (&carry)[NR][K]) {
+    Acc h[NR][K];
+    Acc y0[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+#pragma unroll
+        for (int j = 0; j < K; j++) h[n][j] = first_lane ? carry[n][j] : Acc(0);
+        y0[n] = Acc(0);
+    }
+    // 1. segment-local recurrence (exact for the first lane, which owns the tile's carry)
+#pragma unroll
+    for (int p = 0; p < kFusedSeg; p++) {
+        const int m = CAUSAL ? p : kFusedSeg - 1 - p;
+#pragma unroll
+        for (int n = 0; n < NR; n++) {
+            Acc x = v[n][m];
+            Acc acc = sc.b * x;
+            // oldest tap first: the newest output h[0] enters last, one dependent FMA per sample
+#pragma unroll
+            for (int j = K - 1; j >= 0; j--) {
+                Acc g = h[n][j];
+                if (p <= j) g = clamp_first ? (p == 0 ? x : y0[n]) : g;
+                acc = acc + sc.a[j] * g;
+            }
+#pragma unroll
+            for (int j = K - 1; j > 0; j--) h[n][j] = h[n][j - 1];
+            h[n][0] = acc;
+            if (p == 0) y0[n] = acc;
+            v[n][m] = acc;
+        }
+    }
+    // 2. Kogge-Stone over the 16 lanes of each row: S_l <- sum_{j<=l} P^(l-j) S_j
+#define RF_KS_STEP(D, IDX)                                                                        \
+    _Pragma("unroll") for (int n = 0; n < NR; n++) {                                              \
+        Acc Sh[K];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < K; j++) Sh[j] = row_shift<CAUSAL, D>(h[n][j]);      \
+        _Pragma("unroll") for (int r = 0; r < K; r++)                                             \
+            _Pragma("unroll") for (int j = 0; j < K; j++) h[n][r] = h[n][r] + sc.P[IDX][r][j] * Sh[j]; \
+    }
+    RF_KS_STEP(1, 0)
+    RF_KS_STEP(2, 1)
+    RF_KS_STEP(4, 2)
+    RF_KS_STEP(8, 3)
+#undef RF_KS_STEP
+    // 3. state entering this lane's segment, then the rank-K correction of its 16 samples
+    Acc C[NR][K];
+#pragma unroll
+    for (int n = 0; n < NR; n++)
+#pragma unroll
+        for (int j = 0; j < K; j++) C[n][j] = row_shift<CAUSAL, 1>(h[n][j]);
+#pragma unroll
+    for (int p = 0; p < kFusedSeg; p++) {
+        const int m = CAUSAL ? p : kFusedSeg - 1 - p;
+#pragma unroll
+        for (int n = 0; n < NR; n++)
+#pragma unroll
+            for (int j = 0; j < K; j++) v[n][m] = v[n][m] + sc.R[p][j] * C[n][j];
+    }
+}
+
+// ---- y phase: one scan up or down a register column -----------------------------------------
+template <typename Acc, bool CAUSAL, int K, int TY, typename SC>
+__device__ __forceinline__ void scan_col(Acc (&col)[TY], const SC &sc, bool clamp_first,
+                                         const Acc (&carry)[K]) {
+    Acc h[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) h[j] = carry[j];
+    Acc y0 = Acc(0);
+#pragma unroll
+    for (int p = 0; p < TY; p++) {
+        const int m = CAUSAL ? p : TY - 1 - p;
+        Acc x = col[m];
+        Acc acc = sc.b * x;
+        // oldest tap first: the newest output h[0] enters last, one dependent FMA per sample
+#pragma unroll
+        for (int j = K - 1; j >= 0; j--) {
+            Acc g = h[j];
+            if (p <= j) g = clamp_first ? (p == 0 ? x : y0) : g;
+            acc = acc + sc.a[j] * g;
+        }
+#pragma unroll
+        for (int j = K - 1; j > 0; j--) h[j] = h[j - 1];
+        h[0] = acc;
+        if (p == 0) y0 = acc;
+        col[m] = acc;
+    }
+}
+
+template <typename Acc>
+struct Vec4 {
+    typedef Acc type __attribute__((ext_vector_type(4)));
+};
+
+
+}  // namespace
+}  // namespace rf

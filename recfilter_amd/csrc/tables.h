@@ -125,6 +125,28 @@ DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, 
     return t;
 }
 
+// Impulse responses of the tile-local tails: H[((v*n + s)*k + r)*T + m] = tail r of scan s (after the
+// tile-local scans 0..s with zero incoming carries) per unit input at memory position m.
+template <typename S>
+std::vector<S> build_tail_responses(const std::vector<ScanS<S>> &scans, int k, int T, bool clamped) {
+    const int n = (int)scans.size();
+    std::vector<S> H((size_t)4 * n * k * T, S(0));
+    std::vector<S> vec(T);
+    for (int v = 0; v < 4; v++)
+        for (int m = 0; m < T; m++) {
+            for (int i = 0; i < T; i++) vec[i] = (i == m) ? S(1) : S(0);
+            for (int s = 0; s < n; s++) {
+                scan_tile<S>(vec.data(), T, k, scans[s], clamped && variant_clamps(v, scans[s].causal), nullptr);
+                for (int r = 0; r < k; r++) {
+                    const int p = T - 1 - r;
+                    const int mm = scans[s].causal ? p : T - 1 - p;
+                    H[(((size_t)v * n + s) * k + r) * T + m] = vec[mm];
+                }
+            }
+        }
+    return H;
+}
+
 // k x k helpers ------------------------------------------------------------------------
 template <typename S>
 inline std::vector<S> mat_mul(const std::vector<S> &X, const std::vector<S> &Y, int k) {

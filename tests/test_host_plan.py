@@ -227,3 +227,29 @@ def test_fused_not_applicable_falls_back_in_auto_mode():
     assert e.value.status == capi.RF_ERR_UNSUPPORTED
     p = _host_plan((64, 512), rc.xy_pm(rc.GAUSS2), clamped=True)
     assert p.path == capi.RF_PATH_TILED_FUSED
+
+
+@pytest.mark.parametrize("name", ["gauss2_clamped", "generic_xy_zero", "bicubic_clamped_ty32"])
+def test_tail_impulse_responses_match_tile_local_scans(name):
+    """H_x / H_y (pass 1 as a contraction, kernels_tails.hip) reproduce the tails the tile-local scans give."""
+    from tiled_emulator import scan_tile
+    case = rc.FUSED_CASES[name]
+    p = _host_plan(case["shape"], case["scans"], dtype=np.float32, clamped=case["clamped"], path=capi.RF_PATH_TILED_FUSED)
+    rng = np.random.default_rng(3)
+    for d, T, tname in ((0, 256, "H_x"), (1, p.tiles[1], "H_y")):
+        scans = [(bool(c), [float(np.float32(v)) for v in co]) for dd, c, co in case["scans"] if dd == d]
+        n = len(scans)
+        K = max(len(co) - 1 for dd, c, co in case["scans"] if dd in (0, 1))
+        H = p.table(tname).reshape(4, n, K, T)
+        rows = rng.random((5, T))
+        for v in range(4):
+            work = rows.copy()
+            for s, (causal, co) in enumerate(scans):
+                a = list(co[1:]) + [0.0] * (K - len(co) + 1)
+                clamp = case["clamped"] and ((v & 1) != 0 if causal else (v & 2) != 0)
+                scan_tile(work, causal, co[0], a, K, clamp)
+                for r in range(K):
+                    pos = T - 1 - r
+                    want = work[:, pos if causal else T - 1 - pos]
+                    got = rows @ H[v, s, r]
+                    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7 * np.abs(want).max())
