@@ -97,7 +97,7 @@ int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename Pix
                        const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy,
                        hipStream_t stream);
 template <typename Acc>
-int launch_xscan_rows(int K, const FusedArgs<Acc> &a, hipStream_t stream);
+int launch_xscan_rows(int K, const FusedArgs<Acc> &a, const Acc *tau, const Acc *G, hipStream_t stream);
 template <typename Acc>
 int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t stream);
 }  // namespace rf

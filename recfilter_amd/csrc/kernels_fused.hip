@@ -31,7 +31,12 @@ namespace rf {
 
 namespace {
 
-// ---- the fused pass kernel -----------------------------------------------------------------
+// ---- the fused pass kernel: one workgroup per tile ------------------------------------------------
+// FINAL = false: intra-tile scans + tail extraction (the scan-everything pass 1 of the first round, kept as
+//                an option; the default pass 1 is the contraction of kernels_tails.hip)
+// FINAL = true : final correction pass.  The completed carries the tile needs (first lane of each row for
+//                the x scans, every column for the y scans) are requested BEFORE the pixels, so their
+//                latency hides behind the 64 KiB pixel load instead of stalling every scan.
 template <typename P, int K, int TY, bool FINAL>
 __global__ void __launch_bounds__(kFusedThreads)
 fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
@@ -40,21 +45,72 @@ fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<type
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Acc *tile = reinterpret_cast<Acc *>(lds_raw);
     A4 *tile4 = reinterpret_cast<A4 *>(lds_raw);
+    constexpr int NR = TY / 16;
 
     const int t = threadIdx.x;
     const int tx = blockIdx.x, ty = blockIdx.y;
     const int64_t z = blockIdx.z;
-    const int64_t plane_off = z * a.NX * a.NY;
-    const int64_t tile_off = plane_off + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
+    const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
+    const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x phase: segment lane, row slot
+    const int64_t Lx = a.NY * a.NZ, Ly = a.NX * a.NZ;
+    const int64_t line0 = (int64_t)ty * TY + slot + a.NY * z;          // x phase: row n -> line0 + 16 n
+    const int64_t line = (int64_t)tx * kFusedTX + t + a.NX * z;        // y phase: this thread's column
+
+    // ---- carries (pass 2) ----
+    Acc CX[kFusedMaxScans][NR][K];
+    Acc CY[kFusedMaxScans][K];
+#pragma unroll
+    for (int s = 0; s < kFusedMaxScans; s++) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            CY[s][j] = Acc(0);
+#pragma unroll
+            for (int n = 0; n < NR; n++) CX[s][n][j] = Acc(0);
+        }
+    }
+    if (FINAL) {
+#pragma unroll
+        for (int s = 0; s < kFusedMaxScans; s++) {
+            if (s < a.nx) {
+                const bool causal = a.xs[s].causal != 0;
+                const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
+                const bool first_lane = causal ? (l == 0) : (l == 15);
+                if (first_lane && !tile_first) {
+                    const int tp = causal ? tx - 1 : tx + 1;
+#pragma unroll
+                    for (int n = 0; n < NR; n++)
+#pragma unroll
+                        for (int j = 0; j < K; j++)
+                            CX[s][n][j] = a.xt[(((int64_t)s * a.MX + tp) * K + j) * Lx + line0 + 16 * n];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kFusedMaxScans; j++) {
+            if (j < a.ny) {
+                const bool causal = a.ys[j].causal != 0;
+                const bool tile_first = causal ? (ty == 0) : (ty == a.MY - 1);
+                if (tile_first) {
+#pragma unroll
+                    for (int r = 0; r < K; r++) CY[j][r] = a.y_incoming[((int64_t)j * K + r) * Ly + line];
+                } else {
+                    const int tp = causal ? ty - 1 : ty + 1;
+#pragma unroll
+                    for (int r = 0; r < K; r++) CY[j][r] = a.yt[(((int64_t)j * a.MY + tp) * K + r) * Ly + line];
+                }
+            }
+        }
+    }
 
     // ---- load: wave w streams rows w, w+4, ...; one 1 KiB row per instruction ----
     {
         const int cc = t & 63, rg = t >> 6;
         const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
-        const int64_t row_stride4 = a.NX / 4;
+        const uint32_t rs4 = (uint32_t)(a.NX / 4);
+        const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
         A4 tmp[TY / 4];
 #pragma unroll
-        for (int i = 0; i < TY / 4; i++) tmp[i] = sp[(int64_t)(rg + 4 * i) * row_stride4 + cc];
+        for (int i = 0; i < TY / 4; i++) tmp[i] = sp[off0 + (uint32_t)(4 * i) * rs4];
 #pragma unroll
         for (int i = 0; i < TY / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
     }
@@ -62,11 +118,6 @@ fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<type
     // ---- x phase: thread = (row slot, 16-sample segment); TY/16 rows per thread, interleaved ----
     if (a.nx > 0) {
         __syncthreads();
-        constexpr int NR = TY / 16;
-        const int l = t & 15, slot = t >> 4;
-        const int64_t Lx = a.NY * a.NZ;
-        const int sw = (l >> 2) & 3;
-        const int64_t line0 = (int64_t)ty * TY + slot + a.NY * z;     // row n of this thread: line0 + 16 n
         Acc v[NR][kFusedSeg];
 #pragma unroll
         for (int n = 0; n < NR; n++) {
@@ -82,22 +133,18 @@ fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<type
             const bool causal = sc.causal != 0;
             const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
             const bool first_lane = causal ? (l == 0) : (l == 15);
-            Acc carry[NR][K];
+            const bool clamp_first = a.clamped && tile_first && first_lane;
+            Acc cx[NR][K];     // CX[s] with a run-time s: a select chain, not an indexed (scratch) array
 #pragma unroll
             for (int n = 0; n < NR; n++)
 #pragma unroll
-                for (int j = 0; j < K; j++) carry[n][j] = Acc(0);
-            if (FINAL && first_lane && !tile_first) {
-                const int tp = causal ? tx - 1 : tx + 1;
+                for (int j = 0; j < K; j++) {
+                    cx[n][j] = CX[0][n][j];
 #pragma unroll
-                for (int n = 0; n < NR; n++)
-#pragma unroll
-                    for (int j = 0; j < K; j++)
-                        carry[n][j] = a.xt[(((int64_t)s * a.MX + tp) * K + j) * Lx + line0 + 16 * n];
-            }
-            const bool clamp_first = a.clamped && tile_first && first_lane;
-            if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, carry);
-            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, carry);
+                    for (int q = 1; q < kFusedMaxScans; q++) cx[n][j] = (s == q) ? CX[q][n][j] : cx[n][j];
+                }
+            if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
+            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx);
             if (!FINAL) {
                 // tail r = sample at direction position 255-r: the last lane's last K samples
                 const bool last_lane = causal ? (l == 15) : (l == 0);
@@ -126,35 +173,25 @@ fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<type
 
     // ---- y phase: thread = column ----
     {
-        const int x = t;
-        const int e = (swz_chunk(x >> 2) << 2) | (x & 3);
+        const int e = (swz_chunk(t >> 2) << 2) | (t & 3);
         Acc col[TY];
 #pragma unroll
         for (int i = 0; i < TY; i++) col[i] = tile[i * kFusedTX + e];
-        const int64_t Ly = a.NX * a.NZ;
-        const int64_t line = (int64_t)tx * kFusedTX + x + a.NX * z;
 #pragma unroll 1
         for (int j = 0; j < a.ny; j++) {
             const FusedScanY<Acc> &sc = a.ys[j];
             const bool causal = sc.causal != 0;
-            const bool tile_first = causal ? (ty == 0) : (ty == a.MY - 1);
             const bool border = causal ? (ty == 0 && a.y_first_border) : (ty == a.MY - 1 && a.y_last_border);
-            Acc carry[K];
-#pragma unroll
-            for (int r = 0; r < K; r++) carry[r] = Acc(0);
-            if (FINAL) {
-                if (tile_first) {
-#pragma unroll
-                    for (int r = 0; r < K; r++) carry[r] = a.y_incoming[((int64_t)j * K + r) * Ly + line];
-                } else {
-                    const int tp = causal ? ty - 1 : ty + 1;
-#pragma unroll
-                    for (int r = 0; r < K; r++) carry[r] = a.yt[(((int64_t)j * a.MY + tp) * K + r) * Ly + line];
-                }
-            }
             const bool clamp_first = a.clamped && border;
-            if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, carry);
-            else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, carry);
+            Acc c[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                c[r] = CY[0][r];
+#pragma unroll
+                for (int q = 1; q < kFusedMaxScans; q++) c[r] = (j == q) ? CY[q][r] : c[r];
+            }
+            if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
+            else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
             if (!FINAL) {
 #pragma unroll
                 for (int r = 0; r < K; r++)
@@ -162,9 +199,10 @@ fused_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<type
             }
         }
         if (FINAL) {
-            P *dp = dst + tile_off + x;
+            P *dp = dst + tile_off;
+            const uint32_t nxu = (uint32_t)a.NX;
 #pragma unroll
-            for (int i = 0; i < TY; i++) dp[(int64_t)i * a.NX] = PixelTraits<P>::store(col[i]);
+            for (int i = 0; i < TY; i++) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
         }
     }
 }

@@ -151,18 +151,27 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     }
 }
 
-// tile-local x scans (all of them, zero carries) of the combined rows, in place in yt.
-// A workgroup takes 16 row tiles (runs of 256 consecutive yt samples), moves them through LDS with
-// fully coalesced 16-byte accesses, and scans each in one 16-lane DPP row.
+// tile-local x scans (all of them, zero carries) of the combined rows, in place in yt, plus the
+// cross-dimension residual.  A workgroup takes 16 row tiles (runs of 256 consecutive yt samples), moves
+// them through LDS with fully coalesced 16-byte accesses and scans each in one 16-lane DPP row.
+//
+// Residual (lib/split.cpp:1215-1633): what the completed x carries entering a tile add to the row after
+// all x scans, sum_{q,o} G_q[x][o] * tau[tile][j][r][q][o].  It is folded in here because this kernel
+// touches every tail sample anyway; the y carry scan then needs no knowledge of x.  The G table of the
+// interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
+// border tiles read their variant from memory.
 template <typename Acc, int K>
 __global__ void __launch_bounds__(256)
-xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles) {
+xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, const Acc *__restrict__ tau, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
+    __shared__ __attribute__((aligned(16))) Acc g_lds[kFusedMaxScans * kFusedTX * K];      // G[variant 0][q][x][o]
     A4 *rows4 = reinterpret_cast<A4 *>(rows);
     const int t = threadIdx.x;
     const int64_t rt0 = (int64_t)blockIdx.x * 16;
     const int cc = t & 63, rg = t >> 6;
+    const int l = t & 15, row = t >> 4, sw = (l >> 2) & 3;
+    const int nxk = a.nx * K;
     A4 *g4 = reinterpret_cast<A4 *>(a.yt + rt0 * kFusedTX);
     A4 tmp[4];
 #pragma unroll
@@ -170,12 +179,37 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles) {
         const int r = rg + 4 * i;
         tmp[i] = (rt0 + r < n_row_tiles) ? g4[r * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
     }
+    // this thread's row tile: index = ((((j*MY + ty)*K + r)*NZ + z)*MX + tx)
+    const int64_t rt = rt0 + row;
+    const bool row_ok = rt < n_row_tiles;
+    const int tx = (int)(rt % a.MX);
+    const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
+    Acc tv[kFusedMaxScans * K];
+#pragma unroll
+    for (int qo = 0; qo < kFusedMaxScans * K; qo++) tv[qo] = Acc(0);
+    if (tau != nullptr) {
+        if (row_ok) {
+            int64_t rest = rt / a.MX;
+            const int64_t z = rest % a.NZ;
+            rest /= a.NZ;
+            const int r = (int)(rest % K);
+            rest /= K;
+            const int ty = (int)(rest % a.MY);
+            const int j = (int)(rest / a.MY);
+            const int64_t tile = (z * a.MY + ty) * a.MX + tx;
+            const Acc *tq = tau + ((tile * a.ny + j) * K + r) * (int64_t)nxk;
+#pragma unroll
+            for (int qo = 0; qo < kFusedMaxScans * K; qo++)
+                if (qo < nxk) tv[qo] = tq[qo];
+        }
+        const A4 *gs = reinterpret_cast<const A4 *>(G);                      // variant 0 comes first in G
+        A4 *gl4 = reinterpret_cast<A4 *>(g_lds);
+        for (int c = t; c < nxk * kFusedTX / 4; c += 256) gl4[c] = gs[c];
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) rows4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
     __syncthreads();
     {
-        const int l = t & 15, row = t >> 4, sw = (l >> 2) & 3;
-        const int tx = (int)((rt0 + row) % a.MX);
         Acc v[1][kFusedSeg];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -194,6 +228,27 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles) {
             const bool clamp_first = a.clamped && tile_first && first_lane;
             if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, clamp_first, zero);
             else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero);
+        }
+        if (tau != nullptr) {
+#pragma unroll
+            for (int q = 0; q < kFusedMaxScans; q++) {
+                if (q < a.nx) {
+                    // this lane's 16 columns x K weights are contiguous
+                    const A4 *gq = (vx == 0)
+                        ? reinterpret_cast<const A4 *>(g_lds + ((size_t)q * kFusedTX + 16 * l) * K)
+                        : reinterpret_cast<const A4 *>(G + (((size_t)vx * a.nx + q) * kFusedTX + 16 * l) * K);
+                    Acc g[kFusedSeg * K];
+#pragma unroll
+                    for (int c = 0; c < 4 * K; c++) {
+                        A4 w = gq[c];
+                        g[4 * c + 0] = w.x; g[4 * c + 1] = w.y; g[4 * c + 2] = w.z; g[4 * c + 3] = w.w;
+                    }
+#pragma unroll
+                    for (int m = 0; m < kFusedSeg; m++)
+#pragma unroll
+                        for (int o = 0; o < K; o++) v[0][m] = v[0][m] + g[m * K + o] * tv[q * K + o];
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -233,12 +288,12 @@ int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename Pix
 }
 
 template <typename Acc>
-int launch_xscan_rows(int K, const FusedArgs<Acc> &a, hipStream_t stream) {
+int launch_xscan_rows(int K, const FusedArgs<Acc> &a, const Acc *tau, const Acc *G, hipStream_t stream) {
     // yt is [j][ty][r][x + NX*z]: every run of 256 consecutive samples is one combined row of one x tile
     const int64_t n_row_tiles = (int64_t)a.ny * a.MY * K * a.NZ * a.MX;
     if (n_row_tiles <= 0 || a.nx == 0) return RF_OK;
     const unsigned grid = (unsigned)((n_row_tiles + 15) / 16);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, tau, G); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
     RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
     set_error("xscan rows: unsupported order %d", K);
@@ -248,7 +303,7 @@ int launch_xscan_rows(int K, const FusedArgs<Acc> &a, hipStream_t stream) {
 template int launch_fused_tails<float>(int, int, const float *, const FusedArgs<float> &, const float *, const float *, hipStream_t);
 template int launch_fused_tails<int32_t>(int, int, const int32_t *, const FusedArgs<uint32_t> &, const uint32_t *,
                                          const uint32_t *, hipStream_t);
-template int launch_xscan_rows<float>(int, const FusedArgs<float> &, hipStream_t);
-template int launch_xscan_rows<uint32_t>(int, const FusedArgs<uint32_t> &, hipStream_t);
+template int launch_xscan_rows<float>(int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
+template int launch_xscan_rows<uint32_t>(int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);
 
 }  // namespace rf

@@ -259,12 +259,6 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         return launch_fused_tails<P>(K, TY, (const P *)plan->in[pl], fargs(pl), d_Hx, d_Hy, plan->stream);
     };
     plan->begin_steps.push_back(p1);
-    if (!p1_scan && nx > 0 && ny > 0) {
-        Step xs;
-        xs.name = "xscan_rows";
-        xs.run = [plan, fargs, K](int pl) { return launch_xscan_rows<Acc>(K, fargs(pl), plan->stream); };
-        plan->begin_steps.push_back(xs);
-    }
     if (nx > 0) {
         Step cx;
         cx.name = "carry_x";
@@ -279,9 +273,18 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         tk.name = "tau";
         tk.run = [plan, fargs, K, TY, tau, tau_pp](int pl) { return launch_tau<Acc>(K, TY, fargs(pl), tau + (size_t)pl * tau_pp, plan->stream); };
         plan->begin_steps.push_back(tk);
+        if (!p1_scan) {
+            // finishes the y tails: tile-local x scans of the combined rows + the cross-dimension residual
+            Step xs;
+            xs.name = "xscan_rows";
+            xs.run = [plan, fargs, K, tau, tau_pp, d_G](int pl) {
+                return launch_xscan_rows<Acc>(K, fargs(pl), tau + (size_t)pl * tau_pp, d_G, plan->stream);
+            };
+            plan->begin_steps.push_back(xs);
+        }
     }
     CarryResidual<Acc> resy{};
-    resy.tau = (nx > 0 && ny > 0) ? tau : nullptr;
+    resy.tau = (p1_scan && nx > 0 && ny > 0) ? tau : nullptr;     // the contraction path folds the residual into xscan_rows
     resy.G = d_G; resy.nx = nx; resy.MX = MX; resy.ny = ny; resy.NX = NX;
     auto res_for = [resy, tau_pp](int pl) {
         CarryResidual<Acc> r = resy;
