@@ -43,9 +43,26 @@ def algorithmic_bytes_per_launch(kernel_name, samples, itemsize):
     every sample once and writes it once; pass 1 only reads; carry kernels touch no image bytes."""
     if "pass2" in kernel_name:
         return 2 * itemsize * samples
-    if "pass1" in kernel_name:
+    if "pass1" in kernel_name or "tails" in kernel_name:
         return itemsize * samples
     return 0
+
+
+def pmc_traffic(kernel_name, workload, shape):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950).
+    Only valid for the exact workload the counters were collected on (cfg3 at full size); else None."""
+    if workload != "cfg3" or tuple(shape) != (16384, 16384):
+        return None
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v3.json")
+    try:
+        table = json.load(open(path))["kernels"]
+    except Exception:
+        return None
+    key = {"fused_pass2": "fused_pass_kernel", "fused_tails": "fused_tails_kernel"}.get(kernel_name)
+    if key not in table:
+        return None
+    return table[key]["fetch_bytes_corrected"] + table[key]["write_bytes"]
 
 
 def cpu_baseline(cfg, budget_px=16 * 1024 * 1024):
@@ -155,7 +172,8 @@ def main():
         avg_ms = kernels[dom] / launches
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": pmc_traffic(dom, args.workload, shape),
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg}
         if world > 1:
             plan.close()
