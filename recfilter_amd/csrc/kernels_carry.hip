@@ -8,10 +8,8 @@
 // that depends on the tile index is wave-uniform and lives in scalar registers):
 //
 //   A  every thread (line, chunk) loads its <=16 tile tails at once (independent loads), adds
-//      the same-dimension chaining terms (create_tail_residual_term, lib/split.cpp:912-1004)
-//      and, for the y dimension of the fused path, the cross-dimension residual
-//      sum_o G[x][o] * tau[o] (lib/split.cpp:1215-1633), then runs the recurrence inside its
-//      chunk with a zero incoming state
+//      the same-dimension chaining terms (create_tail_residual_term, lib/split.cpp:912-1004),
+//      then runs the recurrence inside its chunk with a zero incoming state
 //   B  chunk exit states go through LDS; every thread forms the state entering its chunk with
 //      the precomputed chunk transfer matrix A^C (<= 15 k x k steps, no memory traffic)
 //   C  the entering state is propagated through the chunk and the completed tails are stored
@@ -45,16 +43,13 @@ struct CarryGeom {
     int32_t n_scans;
     int32_t first_is_border, last_is_border;
     uint32_t causal_mask;    // bit s = scan s is causal
-    // cross-dimension residual (y dimension of the fused path); tau == nullptr: none
-    int32_t res_nx, res_MX, res_ny;
-    uint32_t res_NX;
 };
 
 template <typename Acc, int K>
 __global__ void __launch_bounds__(kCarryThreads)
 carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
-                   const Acc *__restrict__ tau, const Acc *__restrict__ G, const Acc *__restrict__ Wtab,
-                   const Acc *__restrict__ Atab, const Acc *__restrict__ AC, Acc *__restrict__ send, int C) {
+                   const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC,
+                   Acc *__restrict__ send, int C) {
     __shared__ Acc exits[kCarryChunks][kCarryLines][K];
     __shared__ Acc carry_in[kCarryLines][K];
 
@@ -70,17 +65,6 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     const int tiles_per_block = n_chunks * C;
     const int n_blocks = (M + tiles_per_block - 1) / tiles_per_block;
 
-    // residual geometry: line = x + NX*z; a wave's 64 lines share the tile column and the plane
-    int xi = 0, vx = 0, tx_u = 0, z_u = 0;
-    if (tau != nullptr) {
-        const uint32_t x = line % g.res_NX;
-        const int tx = (int)(x / kFusedTX);
-        xi = (int)(x % kFusedTX);
-        vx = (tx == 0 ? 1 : 0) | (tx == g.res_MX - 1 ? 2 : 0);
-        tx_u = __builtin_amdgcn_readfirstlane(tx);
-        z_u = __builtin_amdgcn_readfirstlane((int)(line / g.res_NX));
-    }
-
     for (int s = s_begin; s < s_end; s++) {
         const bool causal = ((g.causal_mask >> s) & 1u) != 0;
         const Acc *Am = Atab + s * K * K;
@@ -89,15 +73,6 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
         if (ch == 0) {
 #pragma unroll
             for (int r = 0; r < K; r++) carry_in[ln][r] = Acc(0);
-        }
-        Acc g_res[kFusedMaxScans * K];
-        const int nxk = g.res_nx * K;
-        if (tau != nullptr) {
-#pragma unroll
-            for (int qo = 0; qo < kFusedMaxScans * K; qo++) {
-                g_res[qo] = Acc(0);
-                if (qo < nxk) g_res[qo] = G[((vx * g.res_nx + qo / K) * kFusedTX + xi) * K + qo % K];
-            }
         }
         Acc last_tail[K];
 #pragma unroll
@@ -108,7 +83,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
             int nvalid = M - base_i;
             nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);      // wave-uniform
 
-            // ---- A: load, add residual and chaining, chunk-local recurrence ----
+            // ---- A: load, add chaining, chunk-local recurrence ----
             Acc cur[kCarryMaxC][K];
 #pragma unroll
             for (int ii = 0; ii < kCarryMaxC; ii++) {
@@ -118,23 +93,6 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                     const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
 #pragma unroll
                     for (int r = 0; r < K; r++) cur[ii][r] = tails[scan_base + (uint32_t)tt * tile_stride + (uint32_t)r * L];
-                }
-            }
-            if (tau != nullptr) {
-                // residual[r] = sum_{q,o} G_q[xi][o] * tau[tile][s][r][q][o]: G per column (vector registers),
-                // tau per tile through scalar loads (the tile index is wave-uniform)
-#pragma unroll
-                for (int ii = 0; ii < kCarryMaxC; ii++) {
-                    if (ii < nvalid) {
-                        const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
-                        const int tile = (z_u * M + tt) * g.res_MX + tx_u;
-                        const Acc *tq = tau + (size_t)((tile * g.res_ny + s) * K) * nxk;
-#pragma unroll
-                        for (int r = 0; r < K; r++)
-#pragma unroll
-                            for (int qo = 0; qo < kFusedMaxScans * K; qo++)
-                                if (qo < nxk) cur[ii][r] = cur[ii][r] + g_res[qo] * tq[r * nxk + qo];
-                    }
                 }
             }
             for (int q = 0; q < s; q++) {
@@ -237,8 +195,8 @@ int carry_chunk_count(int64_t M, int64_t lines, int C) {
 }
 
 template <typename Acc>
-int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end,
-                       const CarryResidual<Acc> &res, Acc *send, const Acc *AC, int C, hipStream_t stream) {
+int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
+                       const Acc *AC, int C, hipStream_t stream) {
     if (a.g.lines <= 0 || a.M <= 0 || s_end <= s_begin) return RF_OK;
     if (C < 1 || C > kCarryMaxC) { set_error("carry: chunk length %d out of range", C); return RF_ERR_INVALID_ARG; }
     const uint64_t total = (uint64_t)a.n_scans * a.M * a.k * a.g.lines;
@@ -251,12 +209,11 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     g.M = a.M; g.n_scans = a.n_scans;
     g.first_is_border = a.first_is_border; g.last_is_border = a.last_is_border;
     g.causal_mask = causal_mask;
-    g.res_nx = res.nx; g.res_MX = res.MX; g.res_ny = res.ny; g.res_NX = (uint32_t)(res.tau ? res.NX : 1);
     const unsigned grid = (unsigned)((a.g.lines + kCarryLines - 1) / kCarryLines);
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
     int n_chunks = carry_chunk_count(a.M, a.g.lines, C);
     const unsigned threads = (unsigned)(kCarryLines * n_chunks);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(threads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, res.tau, res.G, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(threads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
     RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
     set_error("carry: unsupported order %d", K);
@@ -274,9 +231,9 @@ int carry_chunk_length(int64_t M, int64_t lines) {
     return (int)(c < 1 ? 1 : (c > kCarryMaxC ? kCarryMaxC : c));
 }
 
-template int launch_carry_block<float>(int, const GenericDimArgs<float> &, uint32_t, int, int, const CarryResidual<float> &,
-                                       float *, const float *, int, hipStream_t);
-template int launch_carry_block<uint32_t>(int, const GenericDimArgs<uint32_t> &, uint32_t, int, int,
-                                          const CarryResidual<uint32_t> &, uint32_t *, const uint32_t *, int, hipStream_t);
+template int launch_carry_block<float>(int, const GenericDimArgs<float> &, uint32_t, int, int, float *, const float *, int,
+                                       hipStream_t);
+template int launch_carry_block<uint32_t>(int, const GenericDimArgs<uint32_t> &, uint32_t, int, int, uint32_t *,
+                                          const uint32_t *, int, hipStream_t);
 
 }  // namespace rf

@@ -71,33 +71,24 @@ template <typename P>
 int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
                         const StridedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);
 
-// Cross-dimension residual folded into the y carry stage (tau == nullptr: none).
-template <typename Acc>
-struct CarryResidual {
-    const Acc *tau;   // [tile][j][r][q][o], tile = (z*MY + ty)*MX + tx
-    const Acc *G;     // [x-variant][q][xi][o]
-    int32_t nx, MX, ny;
-    int64_t NX;       // the carried dimension's line index is x + NX*z
-};
-
 // Blocked parallel carry scan over the tails of one dimension (kernels_carry.hip); scans
 // [s_begin, s_end) of the dimension in one launch.  AC[s] = A[s]^C, C = carry_chunk_length(M, lines).
 template <typename Acc>
-int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end,
-                       const CarryResidual<Acc> &res, Acc *send, const Acc *AC, int C, hipStream_t stream);
+int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
+                       const Acc *AC, int C, hipStream_t stream);
 int carry_chunk_length(int64_t M, int64_t lines);
 int carry_chunk_count(int64_t M, int64_t lines, int C);
 
+// pass 2: the final correction pass (kernels_fused.hip)
 template <typename P>
-int launch_fused_pass(bool final_pass, int K, int TY, const P *src, P *dst,
-                      const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);
+int launch_fused_pass2(int K, int TY, const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                       hipStream_t stream);
 // pass 1 as a contraction with precomputed impulse responses (kernels_tails.hip)
 template <typename P>
 int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                        const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy,
                        hipStream_t stream);
+// tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)
 template <typename Acc>
-int launch_xscan_rows(int K, const FusedArgs<Acc> &a, const Acc *tau, const Acc *G, hipStream_t stream);
-template <typename Acc>
-int launch_tau(int K, int TY, const FusedArgs<Acc> &a, Acc *tau, hipStream_t stream);
+int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream);
 }  // namespace rf

@@ -156,13 +156,13 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
 // them through LDS with fully coalesced 16-byte accesses and scans each in one 16-lane DPP row.
 //
 // Residual (lib/split.cpp:1215-1633): what the completed x carries entering a tile add to the row after
-// all x scans, sum_{q,o} G_q[x][o] * tau[tile][j][r][q][o].  It is folded in here because this kernel
+// all x scans, sum_{q,o} G_q[x][o] * tau[q][o], tau = the same tail functional applied to the carry strip.  It is folded in here because this kernel
 // touches every tail sample anyway; the y carry scan then needs no knowledge of x.  The G table of the
 // interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
 // border tiles read their variant from memory.
 template <typename Acc, int K>
 __global__ void __launch_bounds__(256)
-xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, const Acc *__restrict__ tau, const Acc *__restrict__ G) {
+xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
     __shared__ __attribute__((aligned(16))) Acc g_lds[kFusedMaxScans * kFusedTX * K];      // G[variant 0][q][x][o]
@@ -187,7 +187,11 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, const Acc *__restrict__
     Acc tv[kFusedMaxScans * K];
 #pragma unroll
     for (int qo = 0; qo < kFusedMaxScans * K; qo++) tv[qo] = Acc(0);
-    if (tau != nullptr) {
+    // tau[q][o] = tail r of the tile-local y scans (through scan j) of the strip c_q[o](y): the completed x
+    // carry entering this tile, as a function of the row.  Like every tail it is a contraction with Hy; the
+    // 16 lanes of the row split the TY-term sum and all-reduce it with DPP.
+    const bool residual = (G != nullptr);
+    if (residual) {
         if (row_ok) {
             int64_t rest = rt / a.MX;
             const int64_t z = rest % a.NZ;
@@ -196,11 +200,37 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, const Acc *__restrict__
             rest /= K;
             const int ty = (int)(rest % a.MY);
             const int j = (int)(rest / a.MY);
-            const int64_t tile = (z * a.MY + ty) * a.MX + tx;
-            const Acc *tq = tau + ((tile * a.ny + j) * K + r) * (int64_t)nxk;
+            const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
+            const bool lane_in = 4 * l < TY;
+            A4 hy = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+            if (lane_in) hy = *reinterpret_cast<const A4 *>(Hy + ((size_t)(vy * a.ny + j) * K + r) * TY + 4 * l);
+            const int64_t Lx = a.NY * a.NZ;
+            const int64_t y0 = (int64_t)ty * TY + a.NY * z + 4 * l;
 #pragma unroll
-            for (int qo = 0; qo < kFusedMaxScans * K; qo++)
-                if (qo < nxk) tv[qo] = tq[qo];
+            for (int q = 0; q < kFusedMaxScans; q++) {
+                if (q < a.nx) {
+                    const bool qc = a.xs[q].causal != 0;
+                    const bool q_first = qc ? (tx == 0) : (tx == a.MX - 1);
+                    const int tp = qc ? tx - 1 : tx + 1;
+#pragma unroll
+                    for (int o = 0; o < K; o++) {
+                        A4 c = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+                        if (!q_first && lane_in)
+                            c = *reinterpret_cast<const A4 *>(a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + y0);
+                        tv[q * K + o] = hy.x * c.x + hy.y * c.y + hy.z * c.z + hy.w * c.w;
+                    }
+                }
+            }
+        }
+        // all-reduce over the 16 lanes of the row: xor 1, xor 2, half mirror, mirror
+#pragma unroll
+        for (int qo = 0; qo < kFusedMaxScans * K; qo++) {
+            if (qo < nxk) {
+                tv[qo] = tv[qo] + dpp_move<0xB1>(tv[qo]);
+                tv[qo] = tv[qo] + dpp_move<0x4E>(tv[qo]);
+                tv[qo] = tv[qo] + dpp_move<0x141>(tv[qo]);
+                tv[qo] = tv[qo] + dpp_move<0x140>(tv[qo]);
+            }
         }
         const A4 *gs = reinterpret_cast<const A4 *>(G);                      // variant 0 comes first in G
         A4 *gl4 = reinterpret_cast<A4 *>(g_lds);
@@ -229,7 +259,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, const Acc *__restrict__
             if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, clamp_first, zero);
             else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero);
         }
-        if (tau != nullptr) {
+        if (residual) {
 #pragma unroll
             for (int q = 0; q < kFusedMaxScans; q++) {
                 if (q < a.nx) {
@@ -288,12 +318,12 @@ int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename Pix
 }
 
 template <typename Acc>
-int launch_xscan_rows(int K, const FusedArgs<Acc> &a, const Acc *tau, const Acc *G, hipStream_t stream) {
+int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream) {
     // yt is [j][ty][r][x + NX*z]: every run of 256 consecutive samples is one combined row of one x tile
     const int64_t n_row_tiles = (int64_t)a.ny * a.MY * K * a.NZ * a.MX;
     if (n_row_tiles <= 0 || a.nx == 0) return RF_OK;
     const unsigned grid = (unsigned)((n_row_tiles + 15) / 16);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, tau, G); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, TY, Hy, G); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
     RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
     set_error("xscan rows: unsupported order %d", K);
@@ -303,7 +333,7 @@ int launch_xscan_rows(int K, const FusedArgs<Acc> &a, const Acc *tau, const Acc 
 template int launch_fused_tails<float>(int, int, const float *, const FusedArgs<float> &, const float *, const float *, hipStream_t);
 template int launch_fused_tails<int32_t>(int, int, const int32_t *, const FusedArgs<uint32_t> &, const uint32_t *,
                                          const uint32_t *, hipStream_t);
-template int launch_xscan_rows<float>(int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
-template int launch_xscan_rows<uint32_t>(int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);
+template int launch_xscan_rows<float>(int, int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
+template int launch_xscan_rows<uint32_t>(int, int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);
 
 }  // namespace rf

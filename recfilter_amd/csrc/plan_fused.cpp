@@ -2,11 +2,12 @@
 //
 // Stages of one execute (2-D; a 3-D filter runs this per z plane as a batch and then filters z
 // with the generic dimension builder):
-//   fused_pass1      intra-tile scans of every x and y scan + tail extraction
-//   carry_x<s>       x carry recurrence per x scan (same-dimension chaining included)
-//   tau              tile-local y scans of the completed x-carry strips (cross-dimension residual,
-//                    lib/split.cpp:1215-1633)
-//   carry_y<j>       y carry recurrence per y scan with the residual folded in
+//   fused_tails      pass 1: tile-local tails of every x scan (per row) and the y tails' combined rows, by
+//                    contraction with precomputed impulse responses
+//   carry_x          x carry recurrence, all x scans (same-dimension chaining included)
+//   xscan_rows       finishes the y tails: tile-local x scans of the combined rows + the cross-dimension
+//                    residual of the completed x carries (lib/split.cpp:1215-1633)
+//   carry_y          y carry recurrence, all y scans (one launch per scan around the exchanges when sharded)
 //   fused_pass2      final correction pass
 #include <cstring>
 
@@ -190,13 +191,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
-    const size_t tau_pp = (size_t)MX * MY * NZ * nx * K * ny * K;
     const int np = plan->n_planes;
     Acc *xt = (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status);
     Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);
     Acc *xin = (Acc *)plan->alloc(xin_pp * np * sizeof(Acc), true, &status);
     Acc *yin = (Acc *)plan->alloc(yin_pp * np * sizeof(Acc), true, &status);
-    Acc *tau = (Acc *)plan->alloc(tau_pp * np * sizeof(Acc), false, &status);
     if (status != RF_OK) return status;
 
     FusedArgs<Acc> fbase{};
@@ -247,15 +246,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     for (int j = 0; j < ny; j++) if (hys[j].causal) ymask |= 1u << j;
 
     // ---- steps -----------------------------------------------------------------------------
-    // pass 1: tail extraction by contraction with the impulse responses (kernels_tails.hip); the scan-everything
-    // version of the first round stays selectable for A/B runs (RF_FUSED_PASS1=scan)
-    const char *p1env = getenv("RF_FUSED_PASS1");
-    const bool p1_scan = p1env && std::string(p1env) == "scan";
+    // pass 1: tail extraction by contraction with the impulse responses (kernels_tails.hip)
     Step p1;
-    p1.name = p1_scan ? "fused_pass1" : "fused_tails";
-    p1.run = [plan, fargs, K, TY, p1_scan, d_Hx, d_Hy](int pl) {
-        if (p1_scan)
-            return launch_fused_pass<P>(false, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+    p1.name = "fused_tails";
+    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy](int pl) {
         return launch_fused_tails<P>(K, TY, (const P *)plan->in[pl], fargs(pl), d_Hx, d_Hy, plan->stream);
     };
     plan->begin_steps.push_back(p1);
@@ -263,40 +257,26 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         Step cx;
         cx.name = "carry_x";
         cx.run = [plan, gxargs, K, nx, d_ACx, Cx, xmask](int pl) {
-            CarryResidual<Acc> none{};
-            return launch_carry_block<Acc>(K, gxargs(pl), xmask, 0, nx, none, (Acc *)nullptr, d_ACx, Cx, plan->stream);
+            return launch_carry_block<Acc>(K, gxargs(pl), xmask, 0, nx, (Acc *)nullptr, d_ACx, Cx, plan->stream);
         };
         plan->begin_steps.push_back(cx);
     }
     if (nx > 0 && ny > 0) {
-        Step tk;
-        tk.name = "tau";
-        tk.run = [plan, fargs, K, TY, tau, tau_pp](int pl) { return launch_tau<Acc>(K, TY, fargs(pl), tau + (size_t)pl * tau_pp, plan->stream); };
-        plan->begin_steps.push_back(tk);
-        if (!p1_scan) {
-            // finishes the y tails: tile-local x scans of the combined rows + the cross-dimension residual
-            Step xs;
-            xs.name = "xscan_rows";
-            xs.run = [plan, fargs, K, tau, tau_pp, d_G](int pl) {
-                return launch_xscan_rows<Acc>(K, fargs(pl), tau + (size_t)pl * tau_pp, d_G, plan->stream);
-            };
-            plan->begin_steps.push_back(xs);
-        }
+        // finishes the y tails: tile-local x scans of the combined rows + the cross-dimension residual of the
+        // completed x carries (lib/split.cpp:1215-1633)
+        Step xs;
+        xs.name = "xscan_rows";
+        xs.run = [plan, fargs, K, TY, d_Hy, d_G](int pl) {
+            return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, d_G, plan->stream);
+        };
+        plan->begin_steps.push_back(xs);
     }
-    CarryResidual<Acc> resy{};
-    resy.tau = (p1_scan && nx > 0 && ny > 0) ? tau : nullptr;     // the contraction path folds the residual into xscan_rows
-    resy.G = d_G; resy.nx = nx; resy.MX = MX; resy.ny = ny; resy.NX = NX;
-    auto res_for = [resy, tau_pp](int pl) {
-        CarryResidual<Acc> r = resy;
-        if (r.tau) r.tau += (size_t)pl * tau_pp;
-        return r;
-    };
     if (!y_sharded) {   // one launch for every y scan; per-scan launches only around the exchanges
         if (ny > 0) {
             Step cy;
             cy.name = "carry_y";
-            cy.run = [plan, gyargs, res_for, K, ny, d_ACy, Cy, ymask](int pl) {
-                return launch_carry_block<Acc>(K, gyargs(pl), ymask, 0, ny, res_for(pl), (Acc *)nullptr, d_ACy, Cy, plan->stream);
+            cy.run = [plan, gyargs, K, ny, d_ACy, Cy, ymask](int pl) {
+                return launch_carry_block<Acc>(K, gyargs(pl), ymask, 0, ny, (Acc *)nullptr, d_ACy, Cy, plan->stream);
             };
             plan->begin_steps.push_back(cy);
         }
@@ -323,9 +303,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             plan->exchanges.push_back(ex);
             Step cy;
             cy.name = "carry_y" + std::to_string(j);
-            cy.run = [plan, gyargs, res_for, K, j, d_ACy, Cy, ex_index, plane_stride, ymask](int pl) {
+            cy.run = [plan, gyargs, K, j, d_ACy, Cy, ex_index, plane_stride, ymask](int pl) {
                 Acc *send = (Acc *)plan->exchanges[ex_index].send;
-                return launch_carry_block<Acc>(K, gyargs(pl), ymask, j, j + 1, res_for(pl), send ? send + pl * plane_stride : nullptr,
+                return launch_carry_block<Acc>(K, gyargs(pl), ymask, j, j + 1, send ? send + pl * plane_stride : nullptr,
                                                d_ACy, Cy, plan->stream);
             };
             plan->exchange_local_steps.push_back({cy});
@@ -338,7 +318,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Step p2;
     p2.name = "fused_pass2";
     p2.run = [plan, fargs, K, TY](int pl) {
-        return launch_fused_pass<P>(true, K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+        return launch_fused_pass2<P>(K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
     else plan->begin_steps.push_back(p2);

@@ -116,12 +116,11 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     };
     plan->begin_steps.push_back(p1);
 
-    CarryResidual<Acc> none{};
     if (!sharded) {
         Step cs;
         cs.name = "carry_" + dn;
-        cs.run = [plan, gargs, K, n, d_AC, C, mask, none](int pl) {
-            return launch_carry_block<Acc>(K, gargs(pl), mask, 0, n, none, (Acc *)nullptr, d_AC, C, plan->stream);
+        cs.run = [plan, gargs, K, n, d_AC, C, mask](int pl) {
+            return launch_carry_block<Acc>(K, gargs(pl), mask, 0, n, (Acc *)nullptr, d_AC, C, plan->stream);
         };
         plan->begin_steps.push_back(cs);
     } else {
@@ -145,9 +144,9 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
             plan->exchanges.push_back(ex);
             Step cs;
             cs.name = "carry_" + dn + std::to_string(s);
-            cs.run = [plan, gargs, K, s, d_AC, C, mask, none, ex_index, plane_stride](int pl) {
+            cs.run = [plan, gargs, K, s, d_AC, C, mask, ex_index, plane_stride](int pl) {
                 Acc *send = (Acc *)plan->exchanges[ex_index].send;
-                return launch_carry_block<Acc>(K, gargs(pl), mask, s, s + 1, none, send ? send + pl * plane_stride : nullptr,
+                return launch_carry_block<Acc>(K, gargs(pl), mask, s, s + 1, send ? send + pl * plane_stride : nullptr,
                                                d_AC, C, plan->stream);
             };
             plan->exchange_local_steps.push_back({cs});

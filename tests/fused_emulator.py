@@ -1,10 +1,14 @@
-"""numpy emulation of the fused x/y path (kernels_fused.hip), driven by the product's plan tables.
+"""numpy emulation of the fused x/y path, driven by the product's plan tables.
 
-Mirrors, stage by stage, what the GPU does for a 2-D image: fused pass 1 (x phase at segment
-level with the Kogge-Stone combine over 16 lanes, then y phase), x carry stage, tau (tile-local y
-scans of the completed x-carry strips), y carry stage with the cross-dimension residual folded in,
-fused pass 2.  All constants come from rf_plan_table() of a host-only plan, so the tiling algebra
-of the product is checked against the oracle on the CPU.  Test infrastructure only.
+Mirrors, stage by stage, what the GPU does for a 2-D image:
+  fused_tails   x tails = H_x contraction of every row; y tails' combined rows = H_y contraction of the tile
+  carry_x       blocked carry scan == serial recurrence with W_x / A_x
+  xscan_rows    tile-local x scans of the combined rows (segment level, Kogge-Stone over 16 lanes) + the
+                cross-dimension residual sum G_x * tau, tau = H_y contraction of the completed x-carry strips
+  carry_y       serial recurrence with W_y / A_y
+  fused_pass2   x phase / y phase with the completed carries
+All constants come from rf_plan_table() of a host-only plan, so the tiling algebra of the product is
+checked against the oracle on the CPU.  Test infrastructure only.
 """
 from __future__ import annotations
 
@@ -36,9 +40,11 @@ class FusedEmu:
             self.Wx = plan.table("W_x").reshape(4, nx, nx, K, K)
             self.Ax = plan.table("A_x").reshape(nx, K, K)
             self.G = plan.table("G_x").reshape(4, nx, TX, K)
+            self.Hx = plan.table("H_x").reshape(4, nx, K, TX)
         if ny:
             self.Wy = plan.table("W_y").reshape(4, ny, ny, K, K)
             self.Ay = plan.table("A_y").reshape(ny, K, K)
+            self.Hy = plan.table("H_y").reshape(4, ny, K, self.TY)
 
     # -- x phase of one scan on rows [R, 256], exactly the kernel's decomposition ------------------
     def xphase(self, rows, s, carry, clamp_first):
@@ -105,17 +111,22 @@ class FusedEmu:
         def ytail(tile, j):
             return np.stack([tile[TY - 1 - r] if self.ys[j][0] else tile[r] for r in range(K)])
 
-        # ---- pass 1 ----
+        def vxof(tx):
+            return (1 if tx == 0 else 0) | (2 if tx == MX - 1 else 0)
+
+        def vyof(ty):
+            return (1 if ty == 0 else 0) | (2 if ty == MY - 1 else 0)
+
+        # ---- pass 1 (fused_tails): contractions, no recurrences ----
         for ty in range(MY):
             for tx in range(MX):
-                t = img[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX].copy()
+                t = img[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX]
                 for s in range(nx):
-                    t = self.xphase(t, s, None, clamped and xfirst(s, tx))
                     for r in range(K):
-                        xt[s, tx, r, ty * TY:(ty + 1) * TY] = t[:, TX - 1 - r] if self.xs[s][0] else t[:, r]
+                        xt[s, tx, r, ty * TY:(ty + 1) * TY] = t @ self.Hx[vxof(tx), s, r]
                 for j in range(ny):
-                    t = yscan(t, j, None, ty)
-                    yt[j, ty, :, tx * TX:(tx + 1) * TX] = ytail(t, j)
+                    for r in range(K):
+                        yt[j, ty, r, tx * TX:(tx + 1) * TX] = self.Hy[vyof(ty), j, r] @ t      # combined rows
 
         # ---- x carry stage (generic_carry_scan_kernel on the x tails) ----
         for s in range(nx):
@@ -131,35 +142,33 @@ class FusedEmu:
                 xt[s, tx] = cur
                 prev = cur
 
-        # ---- tau ----
-        tau = np.zeros((MY, MX, nx, K, ny, K))
-        for ty in range(MY):
-            for tx in range(MX):
-                for q in range(nx):
-                    if xfirst(q, tx):
-                        continue
-                    strips = xcarry(q, tx)[:, ty * TY:(ty + 1) * TY]       # [K(o), TY]
-                    col = strips.T.copy()                                  # [TY, K] : K "columns"
+        # ---- xscan_rows: tile-local x scans of the combined rows + cross-dimension residual ----
+        if nx and ny:
+            xi = np.arange(TX)
+            for ty in range(MY):
+                for tx in range(MX):
+                    rows = np.stack([yt[j, ty, r, tx * TX:(tx + 1) * TX] for j in range(ny) for r in range(K)])
+                    for s in range(nx):
+                        rows = self.xphase(rows, s, None, clamped and xfirst(s, tx))
                     for j in range(ny):
-                        col = yscan(col, j, None, ty)
-                        tau[ty, tx, q, :, j, :] = ytail(col, j).T          # [o, r]
+                        for r in range(K):
+                            acc = rows[j * K + r].copy()
+                            for q in range(nx):
+                                if xfirst(q, tx):
+                                    continue
+                                strips = xcarry(q, tx)[:, ty * TY:(ty + 1) * TY]                  # [o, TY]
+                                tau = strips @ self.Hy[vyof(ty), j, r]                              # [o]
+                                acc = acc + self.G[vxof(tx), q, xi, :] @ tau
+                            yt[j, ty, r, tx * TX:(tx + 1) * TX] = acc
 
-        # ---- y carry stage with the residual ----
-        xi = np.arange(NX) % TX
-        txs = np.arange(NX) // TX
-        vx = np.where(txs == 0, 1, 0) | np.where(txs == MX - 1, 2, 0)
+        # ---- y carry stage ----
         for j in range(ny):
             prev = None
             for i in range(MY):
                 ty = i if self.ys[j][0] else MY - 1 - i
-                vy = (1 if ty == 0 else 0) | (2 if ty == MY - 1 else 0)
                 cur = yt[j, ty].copy()
-                for q in range(nx):
-                    g = self.G[vx, q, xi, :]                               # [NX, K(o)]
-                    tq = tau[ty, txs, q, :, j, :]                          # [NX, o, r]
-                    cur = cur + np.einsum("xo,xor->rx", g, tq)
                 for q in range(j):
-                    cur = cur + self.Wy[vy, q, j] @ ycarry(q, ty)
+                    cur = cur + self.Wy[vyof(ty), q, j] @ ycarry(q, ty)
                 if i > 0:
                     cur = cur + self.Ay[j] @ prev
                 yt[j, ty] = cur
