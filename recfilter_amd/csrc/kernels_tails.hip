@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256)
 xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
-    __shared__ __attribute__((aligned(16))) Acc g_lds[kFusedMaxScans * kFusedTX * K];      // G[variant 0][q][x][o]
+    __shared__ __attribute__((aligned(16))) Acc g_lds[kFusedMaxScans * kFusedTX * K];      // G[variant 0][q][o][x]
     A4 *rows4 = reinterpret_cast<A4 *>(rows);
     const int t = threadIdx.x;
     const int64_t rt0 = (int64_t)blockIdx.x * 16;
@@ -232,9 +232,10 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
                 tv[qo] = tv[qo] + dpp_move<0x140>(tv[qo]);
             }
         }
-        const A4 *gs = reinterpret_cast<const A4 *>(G);                      // variant 0 comes first in G
+        // G[variant 0][q][o][256] -> LDS, each 256-sample row chunk-swizzled like the pixel rows
+        const A4 *gs = reinterpret_cast<const A4 *>(G);
         A4 *gl4 = reinterpret_cast<A4 *>(g_lds);
-        for (int c = t; c < nxk * kFusedTX / 4; c += 256) gl4[c] = gs[c];
+        for (int c = t; c < nxk * 64; c += 256) gl4[(c & ~63) | swz_chunk(c & 63)] = gs[c];
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) rows4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
@@ -263,20 +264,20 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
 #pragma unroll
             for (int q = 0; q < kFusedMaxScans; q++) {
                 if (q < a.nx) {
-                    // this lane's 16 columns x K weights are contiguous
-                    const A4 *gq = (vx == 0)
-                        ? reinterpret_cast<const A4 *>(g_lds + ((size_t)q * kFusedTX + 16 * l) * K)
-                        : reinterpret_cast<const A4 *>(G + (((size_t)vx * a.nx + q) * kFusedTX + 16 * l) * K);
-                    Acc g[kFusedSeg * K];
 #pragma unroll
-                    for (int c = 0; c < 4 * K; c++) {
-                        A4 w = gq[c];
-                        g[4 * c + 0] = w.x; g[4 * c + 1] = w.y; g[4 * c + 2] = w.z; g[4 * c + 3] = w.w;
+                    for (int o = 0; o < K; o++) {
+                        // this lane's 16 columns of G_q[.][o]
+                        Acc g[kFusedSeg];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            A4 w = (vx == 0)
+                                ? reinterpret_cast<const A4 *>(g_lds)[(q * K + o) * 64 + 4 * l + (c ^ sw)]
+                                : reinterpret_cast<const A4 *>(G + (((size_t)vx * a.nx + q) * K + o) * kFusedTX)[4 * l + c];
+                            g[4 * c + 0] = w.x; g[4 * c + 1] = w.y; g[4 * c + 2] = w.z; g[4 * c + 3] = w.w;
+                        }
+#pragma unroll
+                        for (int m = 0; m < kFusedSeg; m++) v[0][m] = v[0][m] + g[m] * tv[q * K + o];
                     }
-#pragma unroll
-                    for (int m = 0; m < kFusedSeg; m++)
-#pragma unroll
-                        for (int o = 0; o < K; o++) v[0][m] = v[0][m] + g[m * K + o] * tv[q * K + o];
                 }
             }
         }

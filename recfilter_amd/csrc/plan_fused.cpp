@@ -143,17 +143,18 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             std::vector<S> ac = mat_pow<S>(tx.A[s], Cx, K);
             for (int e = 0; e < K * K; e++) hACx[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ac[e]);
         }
-        // G[v][q][xi][o]: what the carry entering x scan q adds to the tile after ALL x scans
+        // G[v][q][o][xi]: what the carry entering x scan q adds to the tile after ALL x scans
         hG.assign((size_t)4 * nx * kFusedTX * K, Acc(0));
         std::vector<double> dG(hG.size());
         for (int v = 0; v < 4; v++)
             for (int q = 0; q < nx; q++) {
-                const std::vector<S> &Pm = tx.P(v, q, nx - 1);
-                for (int e = 0; e < kFusedTX * K; e++) {
-                    size_t idx = ((size_t)v * nx + q) * kFusedTX * K + e;
-                    hG[idx] = table_to_acc<S, Acc>(Pm[e]);
-                    dG[idx] = table_to_double<S>(Pm[e]);
-                }
+                const std::vector<S> &Pm = tx.P(v, q, nx - 1);          // [xi][o]
+                for (int xi = 0; xi < kFusedTX; xi++)
+                    for (int o = 0; o < K; o++) {
+                        size_t idx = (((size_t)v * nx + q) * K + o) * kFusedTX + xi;
+                        hG[idx] = table_to_acc<S, Acc>(Pm[(size_t)xi * K + o]);
+                        dG[idx] = table_to_double<S>(Pm[(size_t)xi * K + o]);
+                    }
             }
         plan->tables["G_x"] = dG;
     }
@@ -267,7 +268,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         Step xs;
         xs.name = "xscan_rows";
         xs.run = [plan, fargs, K, TY, d_Hy, d_G](int pl) {
-            return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, d_G, plan->stream);
+            static const bool no_res = getenv("RF_DEBUG_NO_RESIDUAL") != nullptr;      // timing experiments only
+            return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, no_res ? (const Acc *)nullptr : d_G, plan->stream);
         };
         plan->begin_steps.push_back(xs);
     }

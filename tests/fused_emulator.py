@@ -39,7 +39,7 @@ class FusedEmu:
             self.segP = plan.table("seg_P_x").reshape(nx, 4, K, K)
             self.Wx = plan.table("W_x").reshape(4, nx, nx, K, K)
             self.Ax = plan.table("A_x").reshape(nx, K, K)
-            self.G = plan.table("G_x").reshape(4, nx, TX, K)
+            self.G = plan.table("G_x").reshape(4, nx, K, TX)
             self.Hx = plan.table("H_x").reshape(4, nx, K, TX)
         if ny:
             self.Wy = plan.table("W_y").reshape(4, ny, ny, K, K)
@@ -158,7 +158,7 @@ class FusedEmu:
                                     continue
                                 strips = xcarry(q, tx)[:, ty * TY:(ty + 1) * TY]                  # [o, TY]
                                 tau = strips @ self.Hy[vyof(ty), j, r]                              # [o]
-                                acc = acc + self.G[vxof(tx), q, xi, :] @ tau
+                                acc = acc + tau @ self.G[vxof(tx), q]
                             yt[j, ty, r, tx * TX:(tx + 1) * TX] = acc
 
         # ---- y carry stage ----
