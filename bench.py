@@ -54,12 +54,12 @@ def pmc_traffic(kernel_name, workload, shape):
     Only valid for the exact workload the counters were collected on (cfg3 at full size); else None."""
     if workload != "cfg3" or tuple(shape) != (16384, 16384):
         return None
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v3.json")
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
     try:
         table = json.load(open(path))["kernels"]
     except Exception:
         return None
-    key = {"fused_pass2": "fused_pass_kernel", "fused_tails": "fused_tails_kernel"}.get(kernel_name)
+    key = {"fused_pass2": "fused_pass2_kernel", "fused_tails": "fused_tails_kernel"}.get(kernel_name)
     if key not in table:
         return None
     return table[key]["fetch_bytes_corrected"] + table[key]["write_bytes"]
