@@ -285,3 +285,52 @@ def test_cpp_front_end_runs_the_reference_tests():
     print(res.stdout)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "all front-end tests passed" in res.stdout
+
+
+# ---- randomized filters: every path against the oracle ------------------------------------------------------
+def _random_filter(rng, ndim, max_order=3, max_per_dim=4, stable=True):
+    scans = []
+    for d in range(ndim):
+        for _ in range(int(rng.integers(0, max_per_dim + 1))):
+            k = int(rng.integers(1, max_order + 1))
+            # feedback with sum |a| < 0.9 keeps the response decaying so f32 stays well conditioned
+            a = rng.uniform(-1.0, 1.0, size=k)
+            a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+            scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+    if not scans:
+        scans.append((0, True, [1.0, 0.5]))
+    return scans
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_filters_fused_and_generic(seed):
+    rng = np.random.default_rng(1000 + seed)
+    ndim = 2 if seed % 3 else 3
+    if ndim == 2:
+        shape = (32 * int(rng.integers(1, 7)), 256 * int(rng.integers(1, 4)))
+    else:
+        shape = (int(rng.choice([8, 32, 64, 96])), 32 * int(rng.integers(1, 4)), 256 * int(rng.integers(1, 3)))
+    scans = _random_filter(rng, ndim)
+    clamped = bool(rng.integers(0, 2))
+    planes = int(rng.integers(1, 3))
+    imgs, outs, (path, tiles) = _run(shape, scans, clamped=clamped, planes=planes, seed=seed)
+    _check(imgs, outs, scans, clamped)
+    # the same filter through the generic tiled path must agree too
+    imgs2, outs2, (path2, _) = _run(shape, scans, clamped=clamped, planes=planes, seed=seed, path=2)
+    assert path2 == 2
+    _check(imgs2, outs2, scans, clamped)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_integer_filters_bit_exact(seed):
+    rng = np.random.default_rng(2000 + seed)
+    shape = (32 * int(rng.integers(1, 5)), 256 * int(rng.integers(1, 3)))
+    scans = []
+    for d in range(2):
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(1, 4))
+            scans.append((d, bool(rng.integers(0, 2)), [float(rng.integers(1, 4))] + [float(rng.integers(-3, 4)) for _ in range(k)]))
+    clamped = bool(rng.integers(0, 2))
+    imgs, outs, (path, _) = _run(shape, scans, dtype=np.int32, clamped=clamped, seed=seed)
+    assert path == 3
+    _check(imgs, outs, scans, clamped)          # wrap-around arithmetic, bit-exact
