@@ -67,6 +67,18 @@ template <> struct RecFilterPixel<int16_t> { static constexpr int dtype = RF_I16
 struct RecFilterImageRef {
     const void *ptr = nullptr;
     int dtype = RF_F32;
+    /** affine defining expression, e.g. `cast<float>(in)/255` (demo/demo_gaussian_filter.cpp:51-53): the filter
+     *  runs on scale*image + bias, applied when the passes load pixels.  Shared by all Tuple elements. */
+    float scale = 1.0f, bias = 0.0f;
+    RecFilterImageRef operator*(float s) const { RecFilterImageRef r = *this; r.scale *= s; r.bias *= s; return r; }
+    RecFilterImageRef operator/(float s) const { return *this * (1.0f / s); }
+    RecFilterImageRef operator+(float b) const { RecFilterImageRef r = *this; r.bias += b; return r; }
+};
+
+/** A pointwise consumer of a filter for RecFilter::compute_at: `w_filtered * F + w_input * I + bias`, I = the filter's
+ *  own (scaled) input -- the unsharp mask `(1+w)*I - w*Blur` of apps/usm/unsharp_mask_optimized.cpp:57. */
+struct RecFilterPointwise {
+    float w_filtered = 1.0f, w_input = 0.0f, bias = 0.0f;
 };
 template <typename T>
 RecFilterImageRef RecFilterImage(const T *device_ptr) { return RecFilterImageRef{device_ptr, RecFilterPixel<T>::dtype}; }
@@ -124,7 +136,8 @@ class RecFilter {
         std::shared_ptr<Contents> source;       // cascaded stage: reads the previous stage's result
         std::vector<Scan> scans;
         std::map<std::string, int> tile;
-        bool clamped = false, tiled = false, compiled = false;
+        bool clamped = false, tiled = false, compiled = false, has_consumer = false;
+        RecFilterPointwise consumer;
         rf_plan *plan = nullptr;
         std::vector<void *> out;                 // device buffers of the last realization
         std::shared_ptr<std::vector<std::string>> schedule_log = std::make_shared<std::vector<std::string>>();
@@ -305,6 +318,15 @@ public:
         if (c->tiled) fail("Filter is tiled, use RecFilter::intra_schedule() and RecFilter::inter_schedule()");
         return RecFilterSchedule(c->schedule_log, "full");
     }
+    /** lib/recfilter.cpp:473-573: compute the result inside a consumer's tiles.  With a pointwise consumer the final
+     *  pass applies it to every sample before its only store; a RecFilter consumer needs nothing here (cascaded stages
+     *  already read their producer's device buffer). */
+    void compute_at(RecFilterPointwise consumer) {
+        if (c->has_consumer) fail("Cannot compute " + c->name + " at another consumer because it already has a consumer");
+        if (c->compiled) fail("compute_at must be called before the filter is compiled or realized");
+        c->consumer = consumer;
+        c->has_consumer = true;
+    }
     void compute_at(RecFilter) {}
     void gpu_auto_schedule(int = 32) {}
     void gpu_auto_full_schedule(int = 32) {}
@@ -346,6 +368,15 @@ public:
         d.n_scans = (int)sd.size(); d.scans = sd.data();
         d.path = c->tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
         d.device = -1; d.shard_rank = 0; d.shard_world = 1;
+        if (!c->source && !c->inputs.empty() && (c->inputs[0].scale != 1.0f || c->inputs[0].bias != 0.0f)) {
+            d.pointwise.flags |= RF_POINTWISE_PRE;
+            d.pointwise.pre_scale = c->inputs[0].scale; d.pointwise.pre_bias = c->inputs[0].bias;
+        }
+        if (c->has_consumer) {
+            d.pointwise.flags |= RF_POINTWISE_POST;
+            d.pointwise.post_filtered = c->consumer.w_filtered; d.pointwise.post_input = c->consumer.w_input;
+            d.pointwise.post_bias = c->consumer.bias;
+        }
         if (rf_plan_create(&d, &c->plan) != RF_OK) fail(rf_last_error_string());
         c->compiled = true;
     }

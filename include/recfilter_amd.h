@@ -75,6 +75,23 @@ typedef struct {
     float   feedback[RF_MAX_ORDER]; /* y[i] = feedfwd*x[i] + sum_j feedback[j]*y[i-j-1]   */
 } rf_scan_desc;
 
+/* Pointwise stages fused around the filter.  The reference writes them as Halide expressions: the
+ * defining expression of the filter (R(x,y) = cast<float>(in(x,y))/255, demo/demo_gaussian_filter.cpp:51-57)
+ * and a consumer computed at the filter's tiles with RecFilter::compute_at (lib/recfilter.cpp:473-573),
+ * e.g. USM = (1+w)*in - w*Blur in apps/usm/unsharp_mask_optimized.cpp:57-61.  Here they are two affine maps:
+ *     x'  = pre_scale * in + pre_bias                               before the first scan
+ *     out = post_filtered * F(x') + post_input * x' + post_bias      after the last scan (F = the filter)
+ * flags = 0 (a zeroed struct) means both are the identity.  Float pixel types only.  On the fused path both
+ * are applied inside pass 1 / pass 2 (no extra pass over the image); the other paths run them as separate
+ * elementwise kernels.  RF_POINTWISE_POST with post_input != 0 needs out != in. */
+#define RF_POINTWISE_PRE   1
+#define RF_POINTWISE_POST  2
+typedef struct {
+    int32_t flags;                    /* RF_POINTWISE_PRE | RF_POINTWISE_POST */
+    float   pre_scale, pre_bias;
+    float   post_filtered, post_input, post_bias;
+} rf_pointwise_desc;
+
 typedef struct {
     int32_t  ndim;                    /* 1..RF_MAX_DIMS                                          */
     int64_t  extent[RF_MAX_DIMS];     /* extent[0] = width (x)                                   */
@@ -90,6 +107,7 @@ typedef struct {
      * slab; the slab of rank r follows the slab of rank r-1 along dimension ndim-1. */
     int32_t  shard_rank;
     int32_t  shard_world;
+    rf_pointwise_desc pointwise;      /* zeroed = none                                           */
 } rf_filter_desc;
 
 typedef struct rf_plan rf_plan;

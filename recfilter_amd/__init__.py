@@ -7,13 +7,13 @@ implementation of the filter.
 """
 from . import capi
 from .capi import RecFilterError, build_library
-from .filter import (RecFilter, RecFilterDim, RecFilterDimAndCausality, RecFilterSchedule,
+from .filter import (Pointwise, RecFilter, RecFilterDim, RecFilterDimAndCausality, RecFilterSchedule,
                      RecFilterUsageError)
 from .plan import (Plan, gaussian_box_filter, gaussian_weights, integral_image_coeff,
                    overlap_feedback_coeff)
 
 __all__ = [
-    "capi", "RecFilterError", "build_library", "RecFilter", "RecFilterDim", "RecFilterDimAndCausality",
+    "capi", "RecFilterError", "build_library", "Pointwise", "RecFilter", "RecFilterDim", "RecFilterDimAndCausality",
     "RecFilterSchedule", "RecFilterUsageError", "Plan", "gaussian_box_filter", "gaussian_weights",
     "integral_image_coeff", "overlap_feedback_coeff",
 ]

@@ -23,6 +23,7 @@ RF_DEVICE_HOST_ONLY = -2
 RF_OK, RF_ERR_INVALID_ARG, RF_ERR_UNSUPPORTED, RF_ERR_HIP, RF_ERR_NOMEM, RF_ERR_STATE = range(6)
 RF_F32, RF_F64, RF_I32, RF_I16 = range(4)
 RF_BORDER_ZERO, RF_BORDER_CLAMP = 0, 1
+RF_POINTWISE_PRE, RF_POINTWISE_POST = 1, 2
 RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED = range(4)
 PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
               RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused"}
@@ -43,12 +44,18 @@ class ScanDesc(ctypes.Structure):
                 ("feedfwd", ctypes.c_float), ("feedback", ctypes.c_float * RF_MAX_ORDER)]
 
 
+class PointwiseDesc(ctypes.Structure):
+    _fields_ = [("flags", ctypes.c_int32), ("pre_scale", ctypes.c_float), ("pre_bias", ctypes.c_float),
+                ("post_filtered", ctypes.c_float), ("post_input", ctypes.c_float), ("post_bias", ctypes.c_float)]
+
+
 class FilterDesc(ctypes.Structure):
     _fields_ = [("ndim", ctypes.c_int32), ("extent", ctypes.c_int64 * RF_MAX_DIMS),
                 ("dtype", ctypes.c_int32), ("n_planes", ctypes.c_int32), ("border", ctypes.c_int32),
                 ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDesc)),
                 ("tile", ctypes.c_int32 * RF_MAX_DIMS), ("path", ctypes.c_int32),
-                ("device", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32)]
+                ("device", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
+                ("pointwise", PointwiseDesc)]
 
 
 class RecFilterError(RuntimeError):

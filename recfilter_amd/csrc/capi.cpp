@@ -34,7 +34,11 @@ int set_context(rf_plan *plan, const void *const *in_planes, void *const *out_pl
     if (plan->host_only) { set_error("host-only plan (RF_DEVICE_HOST_ONLY) cannot execute"); return RF_ERR_HIP; }
     for (int pl = 0; pl < plan->n_planes; pl++) {
         if (!in_planes[pl] || !out_planes[pl]) { set_error("plane %d: null image pointer", pl); return RF_ERR_INVALID_ARG; }
-        plan->in[pl] = in_planes[pl];
+        if (plan->pw.post && plan->pw.post_i != 0.0 && in_planes[pl] == out_planes[pl]) {
+            set_error("plane %d: a pointwise epilogue that reads the input needs out != in", pl);
+            return RF_ERR_INVALID_ARG;
+        }
+        plan->in[pl] = plan->orig_in[pl] = in_planes[pl];
         plan->out[pl] = out_planes[pl];
     }
     plan->stream = (hipStream_t)stream;

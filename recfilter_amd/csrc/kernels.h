@@ -32,6 +32,10 @@ template <typename P>
 int launch_untiled_scan(const P *in, P *out, LineGeom g, const DevScan<typename PixelTraits<P>::Acc> &sc,
                         bool clamped, hipStream_t stream);
 
+// ---- stand-alone pointwise stage: dst = c0*f + c1*x + c2 (float pixel types; x ignored when c1 == 0) ----
+template <typename P>
+int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream);
+
 // ---- generic tiled path, any tile width T <= kGenericMaxTile dividing n -------------------
 constexpr int kGenericMaxTile = 128;
 

@@ -53,6 +53,10 @@ struct FusedArgs {
     Acc *xt;                 // x tails   [s][tx][r][y + NY*z]
     Acc *yt;                 // y tails   [j][ty][r][x + NX*z]
     const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]
+    // pointwise stages fused into the passes (rf_pointwise_desc; float pixels only): bit 0 = x' = pre_s*in + pre_b
+    // on every pixel load, bit 1 = out = post_f*F + post_i*x' + post_b on the final store of pass 2
+    int32_t pw_flags;
+    Acc pre_s, pre_b, post_f, post_i, post_b;
 };
 
 // Register-column scans along a strided dimension (kernels_strided.hip), by value like FusedArgs.

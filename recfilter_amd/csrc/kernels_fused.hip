@@ -109,6 +109,15 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
         A4 tmp[TY / 4];
 #pragma unroll
         for (int i = 0; i < TY / 4; i++) tmp[i] = sp[off0 + (uint32_t)(4 * i) * rs4];
+        if constexpr (!PixelTraits<P>::is_integer) {
+            if (a.pw_flags & 1) {
+#pragma unroll
+                for (int i = 0; i < TY / 4; i++) {
+                    tmp[i].x = a.pre_s * tmp[i].x + a.pre_b; tmp[i].y = a.pre_s * tmp[i].y + a.pre_b;
+                    tmp[i].z = a.pre_s * tmp[i].z + a.pre_b; tmp[i].w = a.pre_s * tmp[i].w + a.pre_b;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TY / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
     }
@@ -177,6 +186,23 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
             }
             if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
             else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
+        }
+        if constexpr (!PixelTraits<P>::is_integer) {
+            // fused epilogue (compute_at of a pointwise consumer, lib/recfilter.cpp:473-573): the tile's own input
+            // samples come back through L2 / the Infinity Cache, the thread's column is 64 coalesced dword loads
+            if (a.pw_flags & 2) {
+                const P *xp = src + tile_off;
+                const uint32_t nxu = (uint32_t)a.NX;
+                const Acc c1 = a.post_i * ((a.pw_flags & 1) ? a.pre_s : Acc(1));
+                const Acc c2 = a.post_b + a.post_i * ((a.pw_flags & 1) ? a.pre_b : Acc(0));
+                if (a.post_i != Acc(0)) {
+#pragma unroll
+                    for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + (c1 * xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + c2;
+                }
+            }
         }
         {
             P *dp = dst + tile_off;

@@ -73,6 +73,20 @@ untiled_scan_kernel(const P *__restrict__ in, P *__restrict__ out, LineGeom g,
 }
 
 // ---------------------------------------------------------------------------------------
+// Stand-alone pointwise stage (rf_pointwise_desc) for the paths that do not fuse it:
+//   dst = c0 * f + c1 * x + c2          (x may be null when c1 == 0)
+template <typename P>
+__global__ void __launch_bounds__(kBlock)
+pointwise_kernel(const P *f, const P *x, P *dst, int64_t n, P c0, P c1, P c2) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        P v = c0 * f[i] + c2;
+        if (x) v = v + c1 * x[i];
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Generic tiled path.  tails index: ((s*M + t)*k + r)*lines + line
 template <typename Acc>
 __device__ __forceinline__ int64_t tail_idx(const GenericDimArgs<Acc> &a, int s, int t, int r, int64_t line) {
@@ -298,6 +312,19 @@ int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, in
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
+
+template <typename P>
+int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream) {
+    if (n <= 0) return RF_OK;
+    const int64_t want = (n + kBlock - 1) / kBlock;
+    const unsigned blocks = (unsigned)(want < 256 * 64 ? want : 256 * 64);
+    hipLaunchKernelGGL((pointwise_kernel<P>), dim3(blocks), dim3(kBlock), 0, stream, f, c1 != 0.0 ? x : (const P *)nullptr, dst, n,
+                       (P)c0, (P)c1, (P)c2);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+template int launch_pointwise<float>(const float *, const float *, float *, int64_t, double, double, double, hipStream_t);
+template int launch_pointwise<double>(const double *, const double *, double *, int64_t, double, double, double, hipStream_t);
 
 // explicit instantiations ----------------------------------------------------------------
 #define RF_INSTANTIATE_PIXEL(P)                                                                                    \

@@ -76,6 +76,15 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
 #pragma unroll
     for (int half = 0; half < NH; half++) {
         if (half > 0) __syncthreads();                          // previous step's readers are done
+        if constexpr (!PixelTraits<P>::is_integer) {
+            if (a.pw_flags & 1) {                                   // fused prologue x' = pre_s * in + pre_b
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    pre[i].x = a.pre_s * pre[i].x + a.pre_b; pre[i].y = a.pre_s * pre[i].y + a.pre_b;
+                    pre[i].z = a.pre_s * pre[i].z + a.pre_b; pre[i].w = a.pre_s * pre[i].w + a.pre_b;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NL; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = pre[i];
         __syncthreads();

@@ -71,9 +71,7 @@ int build_untiled(rf_plan *plan) {
 // ---------------------------------------------------------------------------------------
 template <typename P, typename S>
 int build_generic(rf_plan *plan, const rf_filter_desc *desc) {
-    using Acc = typename PixelTraits<P>::Acc;
     int status = RF_OK;
-    const int outer = plan->ndim - 1;
     bool first_dim = true;
     int last_scan_dim = -1;
     for (int d = 0; d < plan->ndim; d++)
@@ -93,6 +91,42 @@ int build_generic(rf_plan *plan, const rf_filter_desc *desc) {
     // a filter whose outermost dimension has no scans but whose data still has to reach `out`
     // is covered: the last filtered dimension's pass 2 wrote `out`.
     return status;
+}
+
+// The pointwise stages the chosen path does not fuse run as stand-alone elementwise kernels around it:
+// pointwise_pre writes x' into the output planes (every later stage then filters the output planes in
+// place), pointwise_post combines the filtered output with the caller's input.
+template <typename P>
+void add_pointwise_steps_typed(rf_plan *plan) {
+    const Pointwise pw = plan->pw;
+    if (pw.pre && !pw.pre_fused) {
+        Step st;
+        st.name = "pointwise_pre";
+        st.run = [plan, pw](int pl) {
+            int rc = launch_pointwise<P>((const P *)plan->orig_in[pl], (const P *)nullptr, (P *)plan->out[pl], plan->total,
+                                         pw.pre_s, 0.0, pw.pre_b, plan->stream);
+            plan->in[pl] = plan->out[pl];
+            return rc;
+        };
+        plan->begin_steps.insert(plan->begin_steps.begin(), st);
+    }
+    if (pw.post && !pw.post_fused) {
+        Step st;
+        st.name = "pointwise_post";
+        // out = post_f * F + post_i * (pre_s * in + pre_b) + post_b
+        const double c1 = pw.post_i * (pw.pre ? pw.pre_s : 1.0);
+        const double c2 = pw.post_b + pw.post_i * (pw.pre ? pw.pre_b : 0.0);
+        st.run = [plan, pw, c1, c2](int pl) {
+            return launch_pointwise<P>((const P *)plan->out[pl], (const P *)plan->orig_in[pl], (P *)plan->out[pl], plan->total,
+                                       pw.post_f, c1, c2, plan->stream);
+        };
+        plan->finish_steps.push_back(st);
+    }
+}
+
+void add_pointwise_steps(rf_plan *plan) {
+    if (plan->dtype == RF_F32) add_pointwise_steps_typed<float>(plan);
+    else if (plan->dtype == RF_F64) add_pointwise_steps_typed<double>(plan);
 }
 
 template <typename P>
@@ -135,6 +169,12 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
             return RF_ERR_INVALID_ARG;
         }
     }
+    const rf_pointwise_desc &pwd = desc->pointwise;
+    if (pwd.flags & ~(RF_POINTWISE_PRE | RF_POINTWISE_POST)) { set_error("unknown pointwise flags 0x%x", pwd.flags); return RF_ERR_INVALID_ARG; }
+    if (pwd.flags != 0 && desc->dtype != RF_F32 && desc->dtype != RF_F64) {
+        set_error("pointwise stages need a floating-point pixel type");
+        return RF_ERR_UNSUPPORTED;
+    }
     int world = desc->shard_world < 1 ? 1 : desc->shard_world;
     if (desc->shard_rank < 0 || desc->shard_rank >= world) { set_error("shard_rank out of range"); return RF_ERR_INVALID_ARG; }
 
@@ -160,6 +200,10 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     plan->device = device;
     plan->shard_rank = desc->shard_rank;
     plan->shard_world = world;
+    plan->pw.pre = (pwd.flags & RF_POINTWISE_PRE) != 0;
+    plan->pw.post = (pwd.flags & RF_POINTWISE_POST) != 0;
+    if (plan->pw.pre) { plan->pw.pre_s = pwd.pre_scale; plan->pw.pre_b = pwd.pre_bias; }
+    if (plan->pw.post) { plan->pw.post_f = pwd.post_filtered; plan->pw.post_i = pwd.post_input; plan->pw.post_b = pwd.post_bias; }
     plan->total = 1;
     for (int d = 0; d < desc->ndim; d++) {
         plan->dims[d].N = desc->extent[d];
@@ -215,12 +259,14 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         fresh->ndim = plan->ndim; fresh->dtype = plan->dtype; fresh->n_planes = plan->n_planes;
         fresh->clamped = plan->clamped; fresh->device = plan->device; fresh->host_only = plan->host_only;
         fresh->shard_rank = plan->shard_rank; fresh->shard_world = plan->shard_world;
-        fresh->scans = plan->scans; fresh->total = plan->total;
+        fresh->scans = plan->scans; fresh->total = plan->total; fresh->pw = plan->pw;
+        fresh->pw.pre_fused = fresh->pw.post_fused = false;
         for (int d = 0; d < RF_MAX_DIMS; d++) { fresh->dims[d] = plan->dims[d]; fresh->dims[d].T = 0; fresh->dims[d].M = 0; }
         plan.swap(fresh);
         rc = build(RF_PATH_UNTILED);
     }
     if (rc != RF_OK) return rc;
+    add_pointwise_steps(plan.get());
     if (!host_only) RF_HIP_CHECK(hipDeviceSynchronize());   // uploads done before the first execute
     *out = plan.release();
     return RF_OK;

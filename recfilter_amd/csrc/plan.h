@@ -29,6 +29,14 @@ struct Step {
     std::function<int(int plane)> run;   // launches on Plan::stream for one plane
 };
 
+// rf_pointwise_desc as the plan keeps it; *_fused = applied inside the fused kernels, otherwise a
+// stand-alone elementwise step runs it (pointwise_pre first, pointwise_post last).
+struct Pointwise {
+    bool pre = false, post = false;
+    bool pre_fused = false, post_fused = false;
+    double pre_s = 1.0, pre_b = 0.0, post_f = 1.0, post_i = 0.0, post_b = 0.0;
+};
+
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -46,6 +54,7 @@ struct rf_plan {
     int device = 0;
     bool host_only = false;               // tables only, no device memory, cannot execute
     int shard_rank = 0, shard_world = 1;
+    rf::Pointwise pw;
     std::vector<rf::Scan> scans;          // grouped by dimension, otherwise in call order
     rf::DimInfo dims[RF_MAX_DIMS];
     int64_t total = 1;                    // elements per plane
@@ -68,7 +77,8 @@ struct rf_plan {
     std::vector<Exchange> exchanges;
 
     // per-execute context
-    const void *in[RF_MAX_PLANES] = {nullptr};
+    const void *in[RF_MAX_PLANES] = {nullptr};       // what the first filter stage reads (== out after pointwise_pre)
+    const void *orig_in[RF_MAX_PLANES] = {nullptr};  // the caller's input planes
     void *out[RF_MAX_PLANES] = {nullptr};
     hipStream_t stream = nullptr;
     int phase = 0;   // 0 idle, 1 begun

@@ -204,6 +204,14 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     fbase.clamped = plan->clamped ? 1 : 0;
     fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
     fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
+    if constexpr (!PixelTraits<P>::is_integer) {
+        const bool z_follows = plan->ndim > 2 && !plan->dims[2].scan_ids.empty();
+        plan->pw.pre_fused = plan->pw.pre;
+        plan->pw.post_fused = plan->pw.post && !z_follows;     // with a z stage the epilogue runs after it
+        fbase.pw_flags = (plan->pw.pre_fused ? 1 : 0) | (plan->pw.post_fused ? 2 : 0);
+        fbase.pre_s = (Acc)plan->pw.pre_s; fbase.pre_b = (Acc)plan->pw.pre_b;
+        fbase.post_f = (Acc)plan->pw.post_f; fbase.post_i = (Acc)plan->pw.post_i; fbase.post_b = (Acc)plan->pw.post_b;
+    }
     std::memset(fbase.xs, 0, sizeof(fbase.xs));
     std::memset(fbase.ys, 0, sizeof(fbase.ys));
     for (int s = 0; s < nx; s++) fbase.xs[s] = hxs[s];

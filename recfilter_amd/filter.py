@@ -79,6 +79,15 @@ class RecFilterSchedule:
         return lambda *args: self._note(name, *args)
 
 
+class Pointwise:
+    """A pointwise consumer of a filter, `w_filtered * F + w_input * I + bias` with I the filter's own
+    (prologue-transformed) input -- e.g. the unsharp mask `(1+w)*I - w*Blur` of
+    apps/usm/unsharp_mask_optimized.cpp:57.  Passed to RecFilter.compute_at()."""
+
+    def __init__(self, w_filtered: float = 1.0, w_input: float = 0.0, bias: float = 0.0):
+        self.w_filtered, self.w_input, self.bias = float(w_filtered), float(w_input), float(bias)
+
+
 class RecFilter:
     """lib/recfilter.h:146-510.  Copying a RecFilter aliases the same contents
     (lib/recfilter.cpp:141-144); use `RecFilter(other)` for that."""
@@ -93,7 +102,7 @@ class RecFilter:
         self._contents: Dict = dict(
             name=(name or "R") + f"_{next(_counter)}", dims=[], inputs=None, scans=[],
             clamped=False, tiled=False, tile={}, compiled=False, plan=None, schedule_log=[],
-            source=None)
+            source=None, prologue=None, epilogue=None)
 
     # -- definition -----------------------------------------------------------------------------
     def name(self) -> str:
@@ -105,10 +114,14 @@ class RecFilter:
             raise RecFilterUsageError(f"Recursive filter {self.name()} already defined")
         self._contents["clamped"] = True
 
-    def define(self, pure_args: Sequence[RecFilterDim], pure_def) -> None:
+    def define(self, pure_args: Sequence[RecFilterDim], pure_def, scale: float = 1.0, bias: float = 0.0) -> None:
         """lib/recfilter.cpp:192-248.  pure_def: one device tensor per Tuple element, or a RecFilter
-        whose result feeds this one (the `f2(x,y) = f1.as_func()(x,y)` idiom)."""
+        whose result feeds this one (the `f2(x,y) = f1.as_func()(x,y)` idiom).  `scale`/`bias` stand for an
+        affine defining expression such as `in(x,y)/255` (demo/demo_gaussian_filter.cpp:51-53); they are
+        applied on the fly when the passes load pixels."""
         c = self._contents
+        if float(scale) != 1.0 or float(bias) != 0.0:
+            c["prologue"] = (float(scale), float(bias))
         if c["dims"]:
             raise RecFilterUsageError(f"Recursive filter {self.name()} already defined")
         if not pure_args:
@@ -255,6 +268,19 @@ class RecFilter:
                 rf._contents["scans"].append((d, x[1], [x[2][0] * y[2][0]] + fb))
         return rf
 
+    def compute_at(self, consumer: Pointwise) -> None:
+        """lib/recfilter.cpp:473-573: compute this filter's result inside a consumer's tiles instead of writing it to
+        memory first.  The consumer is a Pointwise combination of the result and the filter's input; the final pass
+        applies it to every sample before the only store (no extra pass over the image)."""
+        c = self._contents
+        if not isinstance(consumer, Pointwise):
+            raise RecFilterUsageError("compute_at takes a Pointwise consumer")
+        if c["epilogue"] is not None:
+            raise RecFilterUsageError(f"Cannot compute {self.name()} at another consumer because it already has a consumer")
+        if c["compiled"]:
+            raise RecFilterUsageError("compute_at must be called before the filter is compiled or realized")
+        c["epilogue"] = (consumer.w_filtered, consumer.w_input, consumer.bias)
+
     # -- schedules: accepted, recorded, not needed (lib/recfilter.cpp:396-870) -------------------
     def intra_schedule(self, id: int = 0) -> RecFilterSchedule:
         return RecFilterSchedule(self, f"intra{id}")
@@ -305,7 +331,8 @@ class RecFilter:
         if path is None:
             path = capi.RF_PATH_AUTO if c["tiled"] else capi.RF_PATH_UNTILED
         c["plan"] = Plan(shape, c["scans"], dtype=inputs[0].dtype, clamped=c["clamped"], planes=len(inputs),
-                         tile=tile, path=path, device=inputs[0].device.index or 0)
+                         tile=tile, path=path, device=inputs[0].device.index or 0,
+                         prologue=c["prologue"], epilogue=c["epilogue"])
         c["compiled"] = True
 
     def realize(self):

@@ -40,7 +40,12 @@ class Plan:
 
     def __init__(self, shape: Sequence[int], scans: Sequence[Scan], dtype=np.float32, clamped: bool = False,
                  planes: int = 1, tile: Optional[Sequence[int]] = None, path: int = capi.RF_PATH_AUTO,
-                 device: int = -1, shard_rank: int = 0, shard_world: int = 1):
+                 device: int = -1, shard_rank: int = 0, shard_world: int = 1,
+                 prologue: Optional[Tuple[float, float]] = None,
+                 epilogue: Optional[Tuple[float, float, float]] = None):
+        """prologue = (scale, bias): x' = scale*in + bias before the first scan;
+        epilogue = (w_filtered, w_input, bias): out = w_filtered*F(x') + w_input*x' + bias
+        (rf_pointwise_desc; fused into pass 1 / pass 2 on the fused path)."""
         L = capi.lib()
         shape = tuple(int(s) for s in shape)
         if not 1 <= len(shape) <= capi.RF_MAX_DIMS:
@@ -76,6 +81,12 @@ class Plan:
         d.path = int(path)
         d.device = int(device)
         d.shard_rank, d.shard_world = int(shard_rank), int(shard_world)
+        if prologue is not None:
+            d.pointwise.flags |= capi.RF_POINTWISE_PRE
+            d.pointwise.pre_scale, d.pointwise.pre_bias = float(prologue[0]), float(prologue[1])
+        if epilogue is not None:
+            d.pointwise.flags |= capi.RF_POINTWISE_POST
+            d.pointwise.post_filtered, d.pointwise.post_input, d.pointwise.post_bias = (float(v) for v in epilogue)
         self._desc = d
         self.shape = shape
         self.planes = int(planes)

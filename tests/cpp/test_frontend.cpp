@@ -203,6 +203,38 @@ int main() {
         failures += !(ms > 0.0f);
         (void)hipFree(d);
     }
+    {   // apps/usm/unsharp_mask_optimized.cpp: USM = (1+w)*I - w*Blur(I), Blur computed at USM's tiles; the input is
+        // defined as image/255 like demo/demo_gaussian_filter.cpp:51-53.  Reference result: untiled blur + host loop.
+        const int width = 512, height = 256;
+        const float weight = 1.0f;
+        std::vector<float> image = random_image((size_t)width * height, 5);
+        for (auto &v : image) v *= 255.0f;
+        float *d = upload(image);
+        RecFilterDim x("x", width), y("y", height);
+        std::vector<float> W3 = gaussian_weights(5.0f, 3);
+        RecFilter B("Blur"), U("Blur_untiled");
+        for (RecFilter *f : {&B, &U}) {
+            f->set_clamped_image_border();
+            (*f)(x, y) = RecFilterImage(d) / 255.0f;
+            f->add_filter(+x, W3); f->add_filter(-x, W3); f->add_filter(+y, W3); f->add_filter(-y, W3);
+        }
+        B.split_all_dimensions(32);
+        B.compute_at(RecFilterPointwise{-weight, 1.0f + weight, 0.0f});
+        std::vector<float> out = B.realize().to_host<float>();
+        std::vector<float> ref = U.realize().to_host<float>();
+        // the mask is a difference of two O(1) terms: the 1e-4 bar is relative to the terms it combines
+        double worst = 0, peak = 0;
+        std::vector<double> scale(ref.size());
+        for (size_t i = 0; i < ref.size(); i++) {
+            scale[i] = (1.0 + weight) * std::fabs(image[i] / 255.0f) + weight * std::fabs(ref[i]);
+            peak = std::fmax(peak, scale[i]);
+            ref[i] = (1.0f + weight) * (image[i] / 255.0f) - weight * ref[i];
+        }
+        for (size_t i = 0; i < ref.size(); i++)
+            worst = std::fmax(worst, std::fabs((double)ref[i] - out[i]) / std::fmax(scale[i], 1e-2 * peak));
+        report("unsharp_mask (compute_at, in/255)", worst);
+        (void)hipFree(d);
+    }
     {   // misuse behaves like the reference's assert(false) sites, as exceptions
         int caught = 0;
         RecFilterDim x("x", 16), y("y", 16);

@@ -334,3 +334,97 @@ def test_random_integer_filters_bit_exact(seed):
     imgs, outs, (path, _) = _run(shape, scans, dtype=np.int32, clamped=clamped, seed=seed)
     assert path == 3
     _check(imgs, outs, scans, clamped)          # wrap-around arithmetic, bit-exact
+
+
+# ---- pointwise prologue / epilogue (rf_pointwise_desc; compute_at of a pointwise consumer) ----------------
+def _pointwise_want(img, scans, clamped, prologue, epilogue):
+    x = img.astype(np.float64)
+    if prologue is not None:
+        # the kernels evaluate x' in the pixel type
+        x = (np.float32(prologue[0]) * img + np.float32(prologue[1])).astype(np.float64) if img.dtype == np.float32 \
+            else prologue[0] * x + prologue[1]
+    f = oracle.apply_filter(x, scans, clamped)
+    if epilogue is not None:
+        f = epilogue[0] * f + epilogue[1] * x + epilogue[2]
+    return f
+
+
+@pytest.mark.parametrize("path", [0, 1, 2], ids=["auto_fused", "untiled", "tiled_generic"])
+@pytest.mark.parametrize("which", ["pre", "post", "both", "post_no_input"])
+def test_pointwise_stages_all_paths(path, which):
+    import torch
+    import recfilter_amd as rfa
+    shape = (128, 512)
+    scans = rc.BASELINE_CONFIGS["cfg3_gaussian2_xy"]["scans"]
+    prologue = (1.0 / 255.0, 0.125) if which in ("pre", "both") else None
+    epilogue = {"pre": None, "post": (-1.0, 2.0, 0.0), "both": (-0.75, 1.75, 0.5), "post_no_input": (3.0, 0.0, -1.0)}[which]
+    img = (rc.random_image(shape, np.float32, 7) * (255.0 if prologue else 1.0)).astype(np.float32)
+    dev = torch.from_numpy(img).cuda()
+    with rfa.Plan(shape, scans, clamped=True, path=path, prologue=prologue, epilogue=epilogue) as plan:
+        out = plan.execute([dev])[0].cpu().numpy()
+        names = [n for n, _ in plan.execute_timed([dev])[1]]
+        if path == 0:
+            assert plan.path_name == "tiled_fused"
+            assert not any(n.startswith("pointwise") for n in names)       # fused into pass 1 / pass 2
+        else:
+            assert ("pointwise_pre" in names) == (prologue is not None)
+            assert ("pointwise_post" in names) == (epilogue is not None)
+    want = _pointwise_want(img, scans, True, prologue, epilogue)
+    assert rc.rel_err(out, want) < TOL
+
+
+def test_pointwise_f64_3d_and_planes():
+    import torch
+    import recfilter_amd as rfa
+    cfg = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]
+    shape = (32, 32, 256)
+    for dtype in (np.float32, np.float64):        # f32: fused x/y + strided z (epilogue after z); f64: generic
+        imgs = [rc.random_image(shape, dtype, 3 + i) for i in range(2)]
+        dev = [torch.from_numpy(im).cuda() for im in imgs]
+        with rfa.Plan(shape, cfg["scans"], dtype=dtype, planes=2, prologue=(0.5, -0.25), epilogue=(1.0, -1.0, 0.0)) as plan:
+            outs = [o.cpu().numpy() for o in plan.execute(dev)]
+        for im, out in zip(imgs, outs):
+            assert rc.rel_err(out, _pointwise_want(im, cfg["scans"], False, (0.5, -0.25), (1.0, -1.0, 0.0))) < TOL
+
+
+def test_pointwise_misuse_is_rejected():
+    import torch
+    import recfilter_amd as rfa
+    scans = [(0, True, [1.0, 1.0])]
+    with pytest.raises(rfa.RecFilterError):                       # integer pixels
+        rfa.Plan((64, 256), scans, dtype=np.int32, prologue=(2.0, 0.0))
+    dev = torch.zeros((64, 256), device="cuda")
+    with rfa.Plan((64, 256), scans, epilogue=(1.0, 1.0, 0.0)) as plan:
+        with pytest.raises(rfa.RecFilterError):                   # epilogue reads the input: out must differ from in
+            plan.execute([dev], [dev])
+    with rfa.Plan((64, 256), scans, epilogue=(2.0, 0.0, 1.0)) as plan:
+        out = plan.execute([dev], [dev])[0]                       # no input operand: in place is fine
+        assert float(out.min()) == 1.0 and float(out.max()) == 1.0
+
+
+def test_unsharp_mask_front_end():
+    """apps/usm/unsharp_mask_optimized.cpp: USM = (1+w)*I - w*Blur(I), Blur computed at USM's tiles."""
+    import torch
+    import recfilter_amd as rfa
+    w, h, weight = 512, 128, 1.0
+    img = rc.random_image((h, w), np.float32, 11)
+    x, y = rfa.RecFilterDim("x", w), rfa.RecFilterDim("y", h)
+    W3 = rfa.gaussian_weights(5.0, 3)
+    B = rfa.RecFilter("Blur")
+    B.set_clamped_image_border()
+    B[x, y] = torch.from_numpy(img).cuda()
+    B.add_filter(+x, W3); B.add_filter(-x, W3); B.add_filter(+y, W3); B.add_filter(-y, W3)
+    B.split_all_dimensions(32)
+    B.compute_at(rfa.Pointwise(w_filtered=-weight, w_input=1.0 + weight))
+    with pytest.raises(rfa.RecFilterUsageError):
+        B.compute_at(rfa.Pointwise())                              # already has a consumer
+    out = B.realize()[0].cpu().numpy()
+    assert B.plan().path_name == "tiled_fused" and B.plan().num_kernels == 5
+    blur = oracle.apply_filter(img.astype(np.float64), B._contents["scans"], True)
+    want = (1.0 + weight) * img - weight * blur
+    # The mask is a difference of two O(1) terms, so the 1e-4 bar is taken relative to the terms it combines
+    # (|(1+w) I| + |w Blur|), not to the possibly cancelled result.
+    scale = (1.0 + weight) * np.abs(img) + weight * np.abs(blur)
+    err = np.max(np.abs(out - want) / np.maximum(scale, 1e-2 * scale.max()))
+    assert err < TOL, f"rel err {err}"
+    assert rc.rel_err(out, want) < 10 * TOL

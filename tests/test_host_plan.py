@@ -253,3 +253,21 @@ def test_tail_impulse_responses_match_tile_local_scans(name):
                     want = work[:, pos if causal else T - 1 - pos]
                     got = rows @ H[v, s, r]
                     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7 * np.abs(want).max())
+
+
+def test_pointwise_desc_validation_and_kernel_count():
+    """rf_pointwise_desc: float pixel types only; fused into the passes on the fused path (no extra kernels),
+    stand-alone elementwise steps on the others."""
+    scans = rc.BASELINE_CONFIGS["cfg3_gaussian2_xy"]["scans"]
+    with pytest.raises(rfa.RecFilterError) as e:
+        _host_plan((64, 256), [(0, True, [1.0, 1.0])], dtype=np.int32, epilogue=(1.0, 1.0, 0.0))
+    assert e.value.status == capi.RF_ERR_UNSUPPORTED
+    plain = _host_plan((64, 256), scans, clamped=True)
+    fused = _host_plan((64, 256), scans, clamped=True, prologue=(2.0, 1.0), epilogue=(1.0, -1.0, 0.0))
+    assert fused.path_name == "tiled_fused" and fused.num_kernels == plain.num_kernels
+    gen = _host_plan((64, 256), scans, clamped=True, path=capi.RF_PATH_TILED_GENERIC)
+    gen_pw = _host_plan((64, 256), scans, clamped=True, path=capi.RF_PATH_TILED_GENERIC,
+                        prologue=(2.0, 1.0), epilogue=(1.0, -1.0, 0.0))
+    assert gen_pw.num_kernels == gen.num_kernels + 2
+    # layout of the descriptor the binding fills must match the header's struct
+    assert ctypes.sizeof(capi.PointwiseDesc) == 24

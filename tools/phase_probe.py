@@ -20,8 +20,25 @@ variants = {
 }
 img = torch.rand((n, n), device="cuda")
 out = torch.empty_like(img)
-for name, scans in variants.items():
-    with rfa.Plan((n, n), scans, clamped=True) as plan:
+# ceilings of this box for the same buffers: read-only reduction, device-to-device copy
+def _time(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+gb = img.numel() * 4 / 1e9
+t_copy, t_sum = _time(lambda: out.copy_(img)), _time(lambda: img.sum())
+print(f"ceilings: copy {t_copy:.4f} ms = {2 * gb / t_copy:.1f} TB/s r+w, sum {t_sum:.4f} ms = {gb / t_sum:.1f} TB/s read", flush=True)
+pointwise = {"xy + unsharp epilogue": dict(epilogue=(-1.0, 2.0, 0.0)), "xy + prologue": dict(prologue=(1 / 255.0, 0.0)),
+             "xy + both": dict(prologue=(1 / 255.0, 0.0), epilogue=(-1.0, 2.0, 0.0))}
+runs = [(k, v, {}) for k, v in variants.items()] + [(k, rc.xy_pm(g), kw) for k, kw in pointwise.items()]
+for name, scans, kw in runs:
+    with rfa.Plan((n, n), scans, clamped=True, **kw) as plan:
         for _ in range(3):
             plan.execute([img], [out])
         acc = {}
