@@ -35,8 +35,8 @@ namespace {
 // scans) are requested BEFORE the pixels, so their latency hides behind the 64 KiB pixel load instead of
 // stalling every scan.  (Pass 1 is the contraction of kernels_tails.hip; the scan-everything pass 1 and a
 // persistent, register-prefetching variant of this kernel were measured slower in round 1 and removed.)
-template <typename P, int K, int TY>
-__global__ void __launch_bounds__(kFusedThreads)
+template <typename P, int K, int TY, bool EPI>
+__global__ void __launch_bounds__(kFusedThreads, EPI ? 2 : 1)
 fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
     using A4 = typename Vec4<Acc>::type;
@@ -122,6 +122,16 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
         for (int i = 0; i < TY / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
     }
 
+    // fused epilogue with an input operand: the thread's input column is taken out of LDS before the x phase
+    // overwrites it and rides in registers to the final store (no second read of the image)
+    Acc orig[EPI ? TY : 1];
+    if constexpr (EPI) {
+        __syncthreads();
+        const int e = (swz_chunk(t >> 2) << 2) | (t & 3);
+#pragma unroll
+        for (int i = 0; i < TY; i++) orig[i] = tile[i * kFusedTX + e];
+    }
+
     // ---- x phase: thread = (row slot, 16-sample segment); TY/16 rows per thread, interleaved ----
     if (a.nx > 0) {
         __syncthreads();
@@ -188,19 +198,23 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
             else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
         }
         if constexpr (!PixelTraits<P>::is_integer) {
-            // fused epilogue (compute_at of a pointwise consumer, lib/recfilter.cpp:473-573): the tile's own input
-            // samples come back through L2 / the Infinity Cache, the thread's column is 64 coalesced dword loads
-            if (a.pw_flags & 2) {
-                const P *xp = src + tile_off;
-                const uint32_t nxu = (uint32_t)a.NX;
-                const Acc c1 = a.post_i * ((a.pw_flags & 1) ? a.pre_s : Acc(1));
-                const Acc c2 = a.post_b + a.post_i * ((a.pw_flags & 1) ? a.pre_b : Acc(0));
+            // fused epilogue (compute_at of a pointwise consumer, lib/recfilter.cpp:473-573); x' was applied at the load
+            if constexpr (EPI) {
+#pragma unroll
+                for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + (a.post_i * orig[i] + a.post_b);
+            } else if (a.pw_flags & 2) {
                 if (a.post_i != Acc(0)) {
+                    // order 3 has no registers to spare at two workgroups per CU: its input column comes back through
+                    // L2 / the Infinity Cache instead, 64 coalesced dword loads per thread
+                    const P *xp = src + tile_off;
+                    const uint32_t nxu = (uint32_t)a.NX;
+                    const Acc c1 = a.post_i * ((a.pw_flags & 1) ? a.pre_s : Acc(1));
+                    const Acc c2 = a.post_b + a.post_i * ((a.pw_flags & 1) ? a.pre_b : Acc(0));
 #pragma unroll
                     for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + (c1 * xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + c2;
+                    for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + a.post_b;
                 }
             }
         }
@@ -213,18 +227,18 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
     }
 }
 
-template <typename P, int K, int TY>
+template <typename P, int K, int TY, bool EPI>
 int launch_fused_pass2_impl(const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
     static bool attr_set = false;
     if (!attr_set) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -236,7 +250,15 @@ int launch_fused_pass2(int K, int TY, const P *src, P *dst, const FusedArgs<type
                        hipStream_t stream) {
     if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
     if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
-#define RF_CASE(KK, TT) if (K == KK && TY == TT) return launch_fused_pass2_impl<P, KK, TT>(src, dst, a, stream);
+    // the epilogue variant that keeps the input column in registers exists for float pixels only
+    bool epi = false;
+    if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
+#define RF_CASE(KK, TT)                                                                                     \
+    if (K == KK && TY == TT) {                                                                              \
+        if constexpr (!PixelTraits<P>::is_integer)                                                          \
+            if (epi) return launch_fused_pass2_impl<P, KK, TT, true>(src, dst, a, stream);                  \
+        return launch_fused_pass2_impl<P, KK, TT, false>(src, dst, a, stream);                              \
+    }
     RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
     RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
 #undef RF_CASE
