@@ -183,7 +183,75 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     }
 }
 
+// Row chaining for a long 1-D signal folded into NY rows of MX tiles (plan_fused.cpp, "chained rows"): the
+// blocked scan above completes every row with a zero entering state; this kernel walks the rows' exit states
+// (NY k-vectors -- tiny) and produces the state entering every row.  One wave; lane l owns rows
+// [l*S, (l+1)*S) in scan order: local recurrence, lane states combined through LDS with AM^S, then propagated.
+template <typename Acc, int K>
+__global__ void __launch_bounds__(64)
+row_chain_kernel(const Acc *__restrict__ exit_states, Acc *__restrict__ incoming, int NY, int causal,
+                 const Acc *__restrict__ AM, const Acc *__restrict__ AMS, int S) {
+    __shared__ Acc lane_exit[64][K];
+    const int l = threadIdx.x;
+    const int i0 = l * S;
+    int i1 = i0 + S;
+    i1 = i1 > NY ? NY : i1;
+    Acc x[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) x[r] = Acc(0);
+    for (int i = i0; i < i1; i++) {
+        const int row = causal ? i : NY - 1 - i;
+        Acc nx[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) nx[r] = exit_states[(size_t)r * NY + row];
+        matvec_acc<Acc, K>(AM, x, nx);
+#pragma unroll
+        for (int r = 0; r < K; r++) x[r] = nx[r];
+    }
+#pragma unroll
+    for (int r = 0; r < K; r++) lane_exit[l][r] = x[r];
+    __syncthreads();
+    Acc inc[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) inc[r] = Acc(0);
+    for (int c = 0; c < l; c++) {               // lanes before l own full segments of S rows
+        Acc nx[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) nx[r] = lane_exit[c][r];
+        matvec_acc<Acc, K>(AMS, inc, nx);
+#pragma unroll
+        for (int r = 0; r < K; r++) inc[r] = nx[r];
+    }
+    for (int i = i0; i < i1; i++) {
+        const int row = causal ? i : NY - 1 - i;
+        Acc nx[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            incoming[(size_t)r * NY + row] = inc[r];
+            nx[r] = exit_states[(size_t)r * NY + row];
+        }
+        matvec_acc<Acc, K>(AM, inc, nx);
+#pragma unroll
+        for (int r = 0; r < K; r++) inc[r] = nx[r];
+    }
+}
+
 }  // namespace
+
+template <typename Acc>
+int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool causal, const Acc *AM, const Acc *AMS,
+                     int S, hipStream_t stream) {
+    if (NY <= 0) return RF_OK;
+    if (S < 1 || (int64_t)S * 64 < NY) { set_error("row chain: segment length %d does not cover %d rows", S, NY); return RF_ERR_INVALID_ARG; }
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((row_chain_kernel<Acc, KK>), dim3(1), dim3(64), 0, stream, exit_states, incoming, NY, causal ? 1 : 0, AM, AMS, S); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+#undef RF_CASE
+    set_error("row chain: unsupported order %d", K);
+    return RF_ERR_UNSUPPORTED;
+}
+template int launch_row_chain<float>(int, const float *, float *, int, bool, const float *, const float *, int, hipStream_t);
+template int launch_row_chain<uint32_t>(int, const uint32_t *, uint32_t *, int, bool, const uint32_t *, const uint32_t *, int,
+                                        hipStream_t);
 
 int carry_chunk_count(int64_t M, int64_t lines, int C) {
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;

@@ -53,6 +53,8 @@ struct FusedArgs {
     Acc *xt;                 // x tails   [s][tx][r][y + NY*z]
     Acc *yt;                 // y tails   [j][ty][r][x + NX*z]
     const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]
+    const Acc *x_incoming;   // carry entering each row along x, [s][r][y + NY*z]: zeros for an image; for a long
+                             // 1-D signal folded into rows it is the state the previous row hands over
     // pointwise stages fused into the passes (rf_pointwise_desc; float pixels only): bit 0 = x' = pre_s*in + pre_b
     // on every pixel load, bit 1 = out = post_f*F + post_i*x' + post_b on the final store of pass 2
     int32_t pw_flags;
@@ -81,6 +83,12 @@ template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
                        const Acc *AC, int C, hipStream_t stream);
 int carry_chunk_length(int64_t M, int64_t lines);
+// Chains the rows of a 1-D signal folded into NY rows (kernels_carry.hip): from the rows' local exit states
+// exit[r][y] it forms the state entering every row, incoming[r][y] (entry of the next row = AM * entry + exit,
+// AM = A^MX), with 64 lanes each owning S consecutive rows; AMS = AM^S.
+template <typename Acc>
+int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool causal, const Acc *AM, const Acc *AMS,
+                     int S, hipStream_t stream);
 int carry_chunk_count(int64_t M, int64_t lines, int C);
 
 // pass 2: the final correction pass (kernels_fused.hip)

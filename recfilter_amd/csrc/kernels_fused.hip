@@ -73,13 +73,15 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
                 const bool causal = a.xs[s].causal != 0;
                 const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
                 const bool first_lane = causal ? (l == 0) : (l == 15);
-                if (first_lane && !tile_first) {
+                if (first_lane) {
+                    // previous tile's completed tail, or (first tile of the row) the state entering the row
                     const int tp = causal ? tx - 1 : tx + 1;
+                    const Acc *cp = tile_first ? a.x_incoming + (int64_t)s * K * Lx
+                                               : a.xt + ((int64_t)s * a.MX + tp) * K * Lx;
 #pragma unroll
                     for (int n = 0; n < NR; n++)
 #pragma unroll
-                        for (int j = 0; j < K; j++)
-                            CX[s][n][j] = a.xt[(((int64_t)s * a.MX + tp) * K + j) * Lx + line0 + 16 * n];
+                        for (int j = 0; j < K; j++) CX[s][n][j] = cp[j * Lx + line0 + 16 * n];
                 }
             }
         }

@@ -24,23 +24,37 @@ int fused_order(const rf_plan *plan) {
     return std::max(plan->dims[0].k, plan->ndim > 1 ? plan->dims[1].k : 0);
 }
 
+// A long 1-D signal runs on the fused path folded into rows: N = NY rows of NX samples, every row tiled like an
+// image row and the rows chained through their entering states ("chained rows").  Longest row first: fewer rows
+// to chain, and the blocked carry scan still finds NY * MX/16 waves of work.
+int64_t chained_row_length(int64_t N) {
+    for (int64_t nx = 16384; nx >= kFusedTX; nx /= 2)
+        if (N % nx == 0 && (N / nx) % 64 == 0) return nx;
+    for (int64_t nx = 16384; nx >= kFusedTX; nx /= 2)
+        if (N % nx == 0 && (N / nx) % 32 == 0) return nx;
+    return 0;
+}
+
 template <typename P, typename S>
 int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     using Acc = typename PixelTraits<P>::Acc;
     int status = RF_OK;
     const int K = fused_order(plan);
+    const bool chained = plan->ndim == 1;        // 1-D signal folded into chained rows
     DimInfo &dx = plan->dims[0];
-    DimInfo &dy = plan->dims[1];
-    const int64_t NX = dx.N, NY = dy.N, NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
+    DimInfo no_y;
+    DimInfo &dy = chained ? no_y : plan->dims[1];
+    const int64_t NX = chained ? chained_row_length(dx.N) : dx.N;
+    const int64_t NY = chained ? dx.N / NX : dy.N, NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
     int TY = (NY % 64 == 0) ? 64 : 32;
     if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
         const int want = atoi(env);
         if ((want == 32 || want == 64) && NY % want == 0) TY = want;
     }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
-    dx.T = kFusedTX; dx.M = NX / kFusedTX;
-    dy.T = TY;       dy.M = NY / TY;
-    const int MX = (int)dx.M, MY = (int)dy.M;
+    const int MX = (int)(NX / kFusedTX), MY = (int)(NY / TY);
+    dx.T = kFusedTX; dx.M = dx.N / kFusedTX;
+    dy.T = TY;       dy.M = MY;
     const int64_t Lx = NY * NZ, Ly = NX * NZ;
     const int outer = plan->ndim - 1;
     const bool y_is_exchange_dim = (outer == 1);
@@ -126,7 +140,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->tables["seg_P_x"] = sp;
     }
     std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
-    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy, hHx, hHy;
+    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy, hHx, hHy, hAMx, hAMSx;
+    const int chain_S = (int)((NY + 63) / 64);     // rows per lane of the row-chain kernel
     const int Cx = carry_chunk_length(MX, Lx), Cy = carry_chunk_length(MY, Ly);
     if (nx > 0) {
         DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
@@ -139,9 +154,16 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             plan->tables["H_x"] = dH;
         }
         hACx.assign((size_t)nx * K * K, Acc(0));
+        hAMx.assign((size_t)nx * K * K, Acc(0));
+        hAMSx.assign((size_t)nx * K * K, Acc(0));
         for (int s = 0; s < nx; s++) {
-            std::vector<S> ac = mat_pow<S>(tx.A[s], Cx, K);
-            for (int e = 0; e < K * K; e++) hACx[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ac[e]);
+            std::vector<S> ac = mat_pow<S>(tx.A[s], Cx, K), am = mat_pow<S>(tx.A[s], MX, K);
+            std::vector<S> ams = mat_pow<S>(am, chain_S, K);
+            for (int e = 0; e < K * K; e++) {
+                hACx[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ac[e]);
+                hAMx[(size_t)s * K * K + e] = table_to_acc<S, Acc>(am[e]);
+                hAMSx[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ams[e]);
+            }
         }
         // G[v][q][o][xi]: what the carry entering x scan q adds to the tile after ALL x scans
         hG.assign((size_t)4 * nx * kFusedTX * K, Acc(0));
@@ -189,6 +211,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const DevScan<Acc> *d_yd = up(hyd);
     const Acc *d_Wx = up(hWx), *d_Ax = up(hAx), *d_Wy = up(hWy), *d_Ay = up(hAy), *d_G = up(hG), *d_AMy = up(hAMy);
     const Acc *d_ACx = up(hACx), *d_ACy = up(hACy), *d_Hx = up(hHx), *d_Hy = up(hHy);
+    const Acc *d_AMx = up(hAMx), *d_AMSx = up(hAMSx);
 
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
@@ -197,6 +220,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);
     Acc *xin = (Acc *)plan->alloc(xin_pp * np * sizeof(Acc), true, &status);
     Acc *yin = (Acc *)plan->alloc(yin_pp * np * sizeof(Acc), true, &status);
+    Acc *row_exit = chained ? (Acc *)plan->alloc((size_t)K * Lx * np * sizeof(Acc), true, &status) : nullptr;
     if (status != RF_OK) return status;
 
     FusedArgs<Acc> fbase{};
@@ -225,6 +249,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         a.xt = xt + (size_t)pl * xt_pp;
         a.yt = yt + (size_t)pl * yt_pp;
         a.y_incoming = yin + (size_t)pl * yin_pp;
+        a.x_incoming = xin + (size_t)pl * xin_pp;
         return a;
     };
     GenericDimArgs<Acc> gx{};
@@ -262,13 +287,42 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         return launch_fused_tails<P>(K, TY, (const P *)plan->in[pl], fargs(pl), d_Hx, d_Hy, plan->stream);
     };
     plan->begin_steps.push_back(p1);
-    if (nx > 0) {
+    if (nx > 0 && !chained) {
         Step cx;
         cx.name = "carry_x";
         cx.run = [plan, gxargs, K, nx, d_ACx, Cx, xmask](int pl) {
             return launch_carry_block<Acc>(K, gxargs(pl), xmask, 0, nx, (Acc *)nullptr, d_ACx, Cx, plan->stream);
         };
         plan->begin_steps.push_back(cx);
+    }
+    if (chained) {
+        // Chained rows: per scan, (1) the blocked carry scan of every row with a zero entering state, publishing the
+        // rows' exit states, (2) the chain over the rows -> state entering every row, (3) that state propagated through
+        // the row's tails.  The same three steps as a sharded dimension (exchange_local / gather / exchange_apply),
+        // with rows in the role of slabs.  Scan s+1 chains on scan s's completed carries, hence scan by scan.
+        for (int s = 0; s < nx; s++) {
+            const bool causal = hxs[s].causal != 0;
+            Step cs;
+            cs.name = "carry_x" + std::to_string(s);
+            cs.run = [plan, gxargs, K, s, d_ACx, Cx, xmask, row_exit, Lx](int pl) {
+                return launch_carry_block<Acc>(K, gxargs(pl), xmask, s, s + 1, row_exit + (size_t)pl * K * Lx, d_ACx, Cx,
+                                               plan->stream);
+            };
+            plan->begin_steps.push_back(cs);
+            Step rc;
+            rc.name = "row_chain" + std::to_string(s);
+            const Acc *AMs = d_AMx + (size_t)s * K * K, *AMSs = d_AMSx + (size_t)s * K * K;
+            rc.run = [plan, K, s, causal, row_exit, xin, xin_pp, Lx, AMs, AMSs, chain_S](int pl) {
+                Acc *inc = xin + (size_t)pl * xin_pp + (size_t)s * K * Lx;
+                return launch_row_chain<Acc>(K, row_exit + (size_t)pl * K * Lx, inc, (int)Lx, causal, AMs, AMSs, chain_S,
+                                             plan->stream);
+            };
+            plan->begin_steps.push_back(rc);
+            Step ap;
+            ap.name = "carry_x_apply" + std::to_string(s);
+            ap.run = [plan, gxargs, s](int pl) { return launch_generic_carry_apply<Acc>(gxargs(pl), s, plan->stream); };
+            plan->begin_steps.push_back(ap);
+        }
     }
     if (nx > 0 && ny > 0) {
         // finishes the y tails: tile-local x scans of the combined rows + the cross-dimension residual of the
@@ -347,7 +401,16 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::string *why) {
     auto no = [&](const char *msg) { if (why) *why = msg; return false; };
     if (plan->dtype != RF_F32 && plan->dtype != RF_I32) return no("pixel type must be f32 or i32");
-    if (plan->ndim < 2) return no("needs at least two dimensions");
+    if (plan->ndim == 1) {
+        // a long 1-D signal folded into chained rows (zero border only: the clamped prologue would differ per row)
+        if (plan->clamped) return no("1-D: clamped border not supported on the fused path");
+        if (plan->shard_world > 1) return no("1-D: cannot be sharded");
+        if (plan->dims[0].scan_ids.empty()) return no("no scans");
+        if (chained_row_length(plan->dims[0].N) == 0) return no("1-D: length must be a multiple of 8192");
+        if (plan->dims[0].k > kFusedMaxK) return no("feedback order above 3");
+        if ((int)plan->dims[0].scan_ids.size() > kFusedMaxScans) return no("more than 4 scans");
+        return true;
+    }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
     if (plan->dims[0].N % kFusedTX != 0) return no("width must be a multiple of 256");
     if (plan->dims[1].N % 32 != 0) return no("height must be a multiple of 32");

@@ -428,3 +428,32 @@ def test_unsharp_mask_front_end():
     err = np.max(np.abs(out - want) / np.maximum(scale, 1e-2 * scale.max()))
     assert err < TOL, f"rel err {err}"
     assert rc.rel_err(out, want) < 10 * TOL
+
+
+# ---- long 1-D signals on the fused path (rows chained through their entering states) ------------------------
+@pytest.mark.parametrize("n,scans", [
+    (8192, [(0, True, [1.0, 0.5])]),
+    (8192 * 3, [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)]),
+    (1 << 20, [(0, True, rc.GAUSS3), (0, False, rc.GAUSS3)]),
+    (1 << 20, [(0, False, [0.3, 0.4, 0.2]), (0, True, [0.5, 0.5]), (0, True, [1.0, 0.25, -0.125]), (0, False, [0.9, 0.1])]),
+    (10 << 20, [(0, True, [1.0, 0.1, 0.1])] * 4),        # apps/audio/audio_filter_biquads.cpp: cascaded biquads
+], ids=["8k_o1", "24k_gauss2_pm", "1M_gauss3_pm", "1M_mixed4", "10M_biquads4"])
+def test_long_1d_signal_chained_rows(n, scans):
+    imgs, outs, (path, tiles) = _run((n,), scans, planes=2 if n <= (1 << 20) else 1)
+    assert path == 3 and tiles == (256,)
+    _check(imgs, outs, scans, False)
+
+
+def test_long_1d_signal_int32_prefix_sum_bit_exact_and_fallbacks():
+    import recfilter_amd as rfa
+    scans = [(0, True, [1.0, 1.0])]
+    imgs, outs, (path, _) = _run((1 << 18,), scans, dtype=np.int32)
+    assert path == 3
+    np.testing.assert_array_equal(outs[0], np.cumsum(imgs[0].astype(np.int64)).astype(np.int32))
+    # lengths that do not fold into rows, and clamped borders, take the generic path
+    imgs, outs, (path, _) = _run((8192 + 64,), scans)
+    assert path == 2
+    _check(imgs, outs, scans, False)
+    imgs, outs, (path, _) = _run((8192,), [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], clamped=True)
+    assert path == 2
+    _check(imgs, outs, [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], True)
