@@ -381,11 +381,12 @@ public:
         c->compiled = true;
     }
 
-    /** lib/recfilter.cpp:984-989 */
-    RecFilterRealization realize() {
+    /** launches every upstream cascade stage, then this one, without synchronising: Func::realize on the last stage of
+     *  a cascade recomputes all of its producers (they are compute_root Funcs) */
+    void execute_chain() {
         if (!c->compiled) compile_jit();
         std::vector<const void *> in;
-        if (c->source) { RecFilterRealization r = RecFilter(c->source).realize(); for (void *p : r.planes) in.push_back(p); }
+        if (c->source) { RecFilter up(c->source); up.execute_chain(); for (void *p : up.c->out) in.push_back(p); }
         else for (auto &i : c->inputs) in.push_back(i.ptr);
         const size_t bytes = plane_elems() * dtype_size(dtype());
         if (c->out.size() != in.size()) {
@@ -394,23 +395,24 @@ public:
             for (auto &p : c->out) if (hipMalloc(&p, bytes) != hipSuccess) fail("hipMalloc failed");
         }
         if (rf_plan_execute(c->plan, in.data(), c->out.data(), nullptr) != RF_OK) fail(rf_last_error_string());
+    }
+
+    /** lib/recfilter.cpp:984-989 */
+    RecFilterRealization realize() {
+        execute_chain();
         if (hipDeviceSynchronize() != hipSuccess) fail("device synchronisation failed");
         RecFilterRealization r;
-        r.planes = c->out; r.dtype = dtype(); r.bytes_per_plane = bytes;
+        r.planes = c->out; r.dtype = dtype(); r.bytes_per_plane = plane_elems() * dtype_size(dtype());
         for (auto &dm : c->dims) r.extent.push_back(dm.num_pixels());
         return r;
     }
 
-    /** lib/recfilter.cpp:991-1016: one warm-up, then the mean time of `iterations` runs in ms
-     *  (unlike the reference the device is synchronised before the clock is read) */
+    /** lib/recfilter.cpp:991-1016: one warm-up, then the mean time of `iterations` runs in ms, every run including the
+     *  upstream stages of a cascade (unlike the reference the device is synchronised before the clock is read) */
     float profile(int iterations) {
         realize();
-        std::vector<const void *> in;
-        if (c->source) for (void *p : RecFilter(c->source).c->out) in.push_back(p);
-        else for (auto &i : c->inputs) in.push_back(i.ptr);
         auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < iterations; i++)
-            if (rf_plan_execute(c->plan, in.data(), c->out.data(), nullptr) != RF_OK) fail(rf_last_error_string());
+        for (int i = 0; i < iterations; i++) execute_chain();
         if (hipDeviceSynchronize() != hipSuccess) fail("device synchronisation failed");
         std::chrono::duration<double, std::milli> dt = std::chrono::steady_clock::now() - t0;
         return (float)(dt.count() / (iterations > 0 ? iterations : 1));

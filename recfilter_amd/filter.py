@@ -335,28 +335,32 @@ class RecFilter:
                          prologue=c["prologue"], epilogue=c["epilogue"])
         c["compiled"] = True
 
+    def _execute_chain(self, fresh_outputs: bool):
+        """Launches every upstream cascade stage, then this one (asynchronous).  Like Func::realize on the last stage of
+        a cascade, which recomputes all of its producers (they are compute_root Funcs)."""
+        c = self._contents
+        if not c["compiled"]:
+            self.compile_jit()
+        inputs = c["source"]._execute_chain(False) if c["source"] is not None else c["inputs"]
+        reuse = None if fresh_outputs else c.get("outputs")
+        c["outputs"] = c["plan"].execute(inputs, reuse)
+        return c["outputs"]
+
     def realize(self):
         """Compute the filter; returns the list of output device tensors (one per Tuple element)."""
-        c = self._contents
-        if not c["compiled"]:
-            self.compile_jit()
-        inputs = self._resolve_inputs()
-        return c["plan"].execute(inputs)
+        return self._execute_chain(True)
 
     def profile(self, iterations: int) -> float:
-        """lib/recfilter.cpp:991-1016: one warm-up, then the mean wall time of `iterations` runs (ms).
-        Unlike the reference this synchronises the device before reading the clock."""
+        """lib/recfilter.cpp:991-1016: one warm-up, then the mean wall time of `iterations` runs (ms), every run
+        including the upstream stages of a cascade.  Unlike the reference this synchronises the device before
+        reading the clock."""
         import time
         import torch
-        c = self._contents
-        if not c["compiled"]:
-            self.compile_jit()
-        inputs = self._resolve_inputs()
-        outputs = c["plan"].execute(inputs)
+        self._execute_chain(False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(int(iterations)):
-            c["plan"].execute(inputs, outputs)
+            self._execute_chain(False)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1000.0 / max(int(iterations), 1)
 

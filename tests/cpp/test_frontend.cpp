@@ -199,7 +199,7 @@ int main() {
         std::vector<float> ref = U.realize().to_host<float>();
         report("gaussian_1xy_2xy (tiled vs untiled)", rel_err(ref, out));
         float ms = fc.back().profile(5);
-        std::printf("%-34s %.3f ms per realize (stage 2, 1024^2)\n", "profile()", ms);
+        std::printf("%-34s %.3f ms per realize (both stages, 1024^2)\n", "profile()", ms);
         failures += !(ms > 0.0f);
         (void)hipFree(d);
     }

@@ -1,0 +1,44 @@
+"""tools/profile_app.py: option parsing mirrors the reference's Arguments (lib/recfilter_utils.cpp:31-112) and the
+sweep of scripts/profile_app.sh; on a GPU every app runs and checks against the oracle."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import profile_app as pa
+
+
+def test_arguments_defaults_and_rules():
+    a = pa.Arguments(["gaussian_3xy"])
+    assert (a.width, a.block, a.iterations, a.nocheck) == (4096, 32, 1, False) and a.widths == [4096]
+    a = pa.Arguments(["gaussian_3xy", "-w", "0"])
+    assert a.widths[0] == 64 and a.widths[-1] == 4096 and len(a.widths) == 64 and a.nocheck     # profile_app.sh sweep
+    a = pa.Arguments(["gaussian_3xy", "-width", "1024", "-tile", "64", "-iter", "5"])
+    assert a.widths == [1024] and a.block == 64 and a.nocheck                                   # iter > 1 forces nocheck
+    with pytest.raises(SystemExit):
+        pa.Arguments(["gaussian_3xy", "-w", "1000", "-t", "32"])      # "Width should be a multiple of block size"
+    assert abs(pa.throughput(1.0, 1 << 20) - 1000.0) < 1e-9            # lib/timing.cpp:3-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("app", sorted(pa.APPS))
+def test_every_app_runs_and_checks(app, tmp_path, capsys):
+    assert pa.main([app, "-w", "512", "--outdir", str(tmp_path)]) == 0
+    row = capsys.readouterr().out.strip().splitlines()[-1].split("\t")
+    assert int(row[0]) == 512 and float(row[1]) > 0
+    err = float(row[3].split()[-1])
+    assert err < (1e-3 if app.startswith("usm") else 1e-4)     # the mask cancels O(1) terms, see test_unsharp_mask_front_end
+
+
+@pytest.mark.gpu
+def test_audio_sweeps_and_width_sweep(tmp_path, capsys):
+    assert pa.main(["audio_biquads", "-w", str(1 << 20), "--outdir", str(tmp_path)]) == 0
+    rows = (tmp_path / "audio_biquads.tiled.perflog").read_text().strip().splitlines()
+    assert len(rows) == 15 and all(len(r.split("\t")) == 3 for r in rows)
+    assert pa.main(["audio_high_order", "-w", str(1 << 16), "--outdir", str(tmp_path)]) == 0
+    out = capsys.readouterr().out
+    assert "max rel err" in out
+    for line in out.strip().splitlines():
+        assert float(line.split()[-1]) < 1e-4
