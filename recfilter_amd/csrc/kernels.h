@@ -58,8 +58,7 @@ struct GenericDimArgs {
 
 template <typename P>
 int launch_generic_pass1(const P *src, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream);
-template <typename Acc>
-int launch_generic_carry_scan(GenericDimArgs<Acc> a, int s, Acc *send /* [r][line] or null */, hipStream_t stream);
+// (the carry recurrence itself is the blocked scan of kernels_carry.hip, declared in kernels_fused.h)
 template <typename Acc>
 int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream);
 // incoming[s] = sum over the slabs before this one (in scan direction) of (A^M)^(distance-1) * their exit tails

@@ -26,8 +26,9 @@ namespace {
 
 constexpr int kCarryLines = 64;    // lines per workgroup = one wave: 256-byte coalesced tail accesses
 constexpr int kCarryChunks = 16;   // chunks per line per block of tiles = waves per workgroup
-constexpr int kCarryMaxC = 16;     // tiles per chunk
-constexpr int kCarryThreads = kCarryLines * kCarryChunks;
+constexpr int kCarryMaxC = 16;     // tiles per chunk (orders <= 3; higher orders keep 4 tiles of k-vectors in registers)
+constexpr int kCarryMaxCHigh = 4;
+constexpr int kCarryChunksHigh = 8; // and at most 8 chunk-waves, which bounds the LDS combine buffer (k = 8 in f64: 32 KiB)
 
 template <typename Acc, int K>
 __device__ __forceinline__ void matvec_acc(const Acc *__restrict__ m, const Acc (&x)[K], Acc (&y)[K]) {
@@ -45,12 +46,12 @@ struct CarryGeom {
     uint32_t causal_mask;    // bit s = scan s is causal
 };
 
-template <typename Acc, int K>
-__global__ void __launch_bounds__(kCarryThreads)
+template <typename Acc, int K, int MAXC, int NCH>
+__global__ void __launch_bounds__(kCarryLines * NCH)
 carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
                    const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC,
                    Acc *__restrict__ send, int C) {
-    __shared__ Acc exits[kCarryChunks][kCarryLines][K];
+    __shared__ Acc exits[NCH][kCarryLines][K];
     __shared__ Acc carry_in[kCarryLines][K];
 
     const int ln = threadIdx.x & (kCarryLines - 1);
@@ -61,7 +62,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     const uint32_t line = line_ok ? line_raw : L - 1;     // out-of-range lanes shadow the last line, stores masked
     const int M = g.M;
     const uint32_t tile_stride = (uint32_t)K * L;          // elements between consecutive tiles of one scan
-    const int n_chunks = (int)blockDim.x / kCarryLines;      // <= kCarryChunks; fewer when a line has few tiles
+    const int n_chunks = (int)blockDim.x / kCarryLines;      // <= NCH; fewer when a line has few tiles
     const int tiles_per_block = n_chunks * C;
     const int n_blocks = (M + tiles_per_block - 1) / tiles_per_block;
 
@@ -84,9 +85,9 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
             nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);      // wave-uniform
 
             // ---- A: load, add chaining, chunk-local recurrence ----
-            Acc cur[kCarryMaxC][K];
+            Acc cur[MAXC][K];
 #pragma unroll
-            for (int ii = 0; ii < kCarryMaxC; ii++) {
+            for (int ii = 0; ii < MAXC; ii++) {
 #pragma unroll
                 for (int r = 0; r < K; r++) cur[ii][r] = Acc(0);
                 if (ii < nvalid) {
@@ -99,7 +100,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                 const bool qc = ((g.causal_mask >> q) & 1u) != 0;
                 const uint32_t q_base = (uint32_t)q * (uint32_t)M * tile_stride + line;
 #pragma unroll
-                for (int ii = 0; ii < kCarryMaxC; ii++) {
+                for (int ii = 0; ii < MAXC; ii++) {
                     if (ii < nvalid) {
                         const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
                         const int v = ((tt == 0 && g.first_is_border) ? 1 : 0) | ((tt == M - 1 && g.last_is_border) ? 2 : 0);
@@ -122,7 +123,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
 #pragma unroll
             for (int r = 0; r < K; r++) xstate[r] = Acc(0);
 #pragma unroll
-            for (int ii = 0; ii < kCarryMaxC; ii++) {
+            for (int ii = 0; ii < MAXC; ii++) {
                 if (ii < nvalid) {
                     matvec_acc<Acc, K>(Am, xstate, cur[ii]);   // cur += A * state of the previous tile
 #pragma unroll
@@ -148,7 +149,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
 
             // ---- C: propagate it through the chunk, store the completed tails ----
 #pragma unroll
-            for (int ii = 0; ii < kCarryMaxC; ii++) {
+            for (int ii = 0; ii < MAXC; ii++) {
                 if (ii < nvalid) {
                     Acc y[K];
 #pragma unroll
@@ -253,10 +254,11 @@ template int launch_row_chain<float>(int, const float *, float *, int, bool, con
 template int launch_row_chain<uint32_t>(int, const uint32_t *, uint32_t *, int, bool, const uint32_t *, const uint32_t *, int,
                                         hipStream_t);
 
-int carry_chunk_count(int64_t M, int64_t lines, int C) {
+int carry_chunk_count(int64_t M, int64_t lines, int C, int K) {
+    const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
     int64_t want = (4096 + line_groups - 1) / line_groups;
-    want = want < 1 ? 1 : (want > kCarryChunks ? kCarryChunks : want);
+    want = want < 1 ? 1 : (want > max_chunks ? max_chunks : want);
     int64_t need = (M + C - 1) / C;          // chunks that cover the line in one block
     int64_t n = need < want ? need : want;
     return (int)(n < 1 ? 1 : n);
@@ -266,7 +268,7 @@ template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
                        const Acc *AC, int C, hipStream_t stream) {
     if (a.g.lines <= 0 || a.M <= 0 || s_end <= s_begin) return RF_OK;
-    if (C < 1 || C > kCarryMaxC) { set_error("carry: chunk length %d out of range", C); return RF_ERR_INVALID_ARG; }
+    if (C < 1 || C > (K <= 3 ? kCarryMaxC : kCarryMaxCHigh)) { set_error("carry: chunk length %d out of range", C); return RF_ERR_INVALID_ARG; }
     const uint64_t total = (uint64_t)a.n_scans * a.M * a.k * a.g.lines;
     if (total >= (1ull << 32) || a.g.lines >= (1ll << 31)) {
         set_error("carry: tails array too large for 32-bit offsets (%llu elements)", (unsigned long long)total);
@@ -279,29 +281,35 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     g.causal_mask = causal_mask;
     const unsigned grid = (unsigned)((a.g.lines + kCarryLines - 1) / kCarryLines);
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
-    int n_chunks = carry_chunk_count(a.M, a.g.lines, C);
+    int n_chunks = carry_chunk_count(a.M, a.g.lines, C, K);
     const unsigned threads = (unsigned)(kCarryLines * n_chunks);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK>), dim3(grid), dim3(threads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
-    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+#define RF_CASE(KK, MC) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK, MC, (KK <= 3 ? kCarryChunks : kCarryChunksHigh)>), dim3(grid), dim3(threads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    RF_CASE(1, kCarryMaxC) RF_CASE(2, kCarryMaxC) RF_CASE(3, kCarryMaxC)
+    RF_CASE(4, kCarryMaxCHigh) RF_CASE(5, kCarryMaxCHigh) RF_CASE(6, kCarryMaxCHigh) RF_CASE(7, kCarryMaxCHigh)
+    RF_CASE(8, kCarryMaxCHigh)
 #undef RF_CASE
     set_error("carry: unsupported order %d", K);
     return RF_ERR_UNSUPPORTED;
 }
 
-int carry_chunk_length(int64_t M, int64_t lines) {
+int carry_chunk_length(int64_t M, int64_t lines, int K) {
+    const int max_c = K <= 3 ? kCarryMaxC : kCarryMaxCHigh;
+    const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     // Chunks (waves) per line: enough to put ~4096 waves on the chip, no more -- with many lines a single
     // wave walks all tiles of its 64 lines and the cross-chunk combine through LDS disappears.
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
     int64_t want = (4096 + line_groups - 1) / line_groups;
-    want = want < 1 ? 1 : (want > kCarryChunks ? kCarryChunks : want);
+    want = want < 1 ? 1 : (want > max_chunks ? max_chunks : want);
     if (want > M) want = M < 1 ? 1 : M;
     int64_t c = (M + want - 1) / want;
-    return (int)(c < 1 ? 1 : (c > kCarryMaxC ? kCarryMaxC : c));
+    return (int)(c < 1 ? 1 : (c > max_c ? max_c : c));
 }
 
 template int launch_carry_block<float>(int, const GenericDimArgs<float> &, uint32_t, int, int, float *, const float *, int,
                                        hipStream_t);
 template int launch_carry_block<uint32_t>(int, const GenericDimArgs<uint32_t> &, uint32_t, int, int, uint32_t *,
                                           const uint32_t *, int, hipStream_t);
+template int launch_carry_block<double>(int, const GenericDimArgs<double> &, uint32_t, int, int, double *, const double *, int,
+                                        hipStream_t);
 
 }  // namespace rf

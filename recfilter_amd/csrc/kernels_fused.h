@@ -82,14 +82,14 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
 template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
                        const Acc *AC, int C, hipStream_t stream);
-int carry_chunk_length(int64_t M, int64_t lines);
+int carry_chunk_length(int64_t M, int64_t lines, int K = 1);   // chunk length depends on the order only above 3
 // Chains the rows of a 1-D signal folded into NY rows (kernels_carry.hip): from the rows' local exit states
 // exit[r][y] it forms the state entering every row, incoming[r][y] (entry of the next row = AM * entry + exit,
 // AM = A^MX), with 64 lanes each owning S consecutive rows; AMS = AM^S.
 template <typename Acc>
 int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool causal, const Acc *AM, const Acc *AMS,
                      int S, hipStream_t stream);
-int carry_chunk_count(int64_t M, int64_t lines, int C);
+int carry_chunk_count(int64_t M, int64_t lines, int C, int K = 1);
 
 // pass 2: the final correction pass (kernels_fused.hip)
 template <typename P>

@@ -4,7 +4,7 @@
 //                      RecFilter::add_filter (lib/recfilter.cpp:302-343) executed literally.
 //                      This is what the reference runs for a filter that was never split()
 //                      (gpu_auto_full_schedule, lib/recfilter.cpp:692-760).
-//  * generic_pass1/carry/pass2
+//  * generic_pass1/pass2, carry_apply, gather_incoming
 //                      the tiled algorithm of lib/split.cpp for ONE dimension at a time with a
 //                      run-time tile width: intra-tile scans + tail extraction
 //                      (create_intra_tile_term :503-665, extract_tails_from_each_scan :256-499),
@@ -162,49 +162,6 @@ generic_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, GenericDimAr
     }
 }
 
-// one scan of the carry stage: same-dimension chaining, then the recurrence along the tiles
-template <typename Acc>
-__global__ void __launch_bounds__(kBlock)
-generic_carry_scan_kernel(GenericDimArgs<Acc> a, int s, Acc *__restrict__ send) {
-    int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (line >= a.g.lines) return;
-    const int k = a.k;
-    const bool causal = a.scans[s].causal != 0;
-    Acc prev[RF_MAX_ORDER];
-#pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) prev[j] = Acc(0);
-    for (int i = 0; i < a.M; i++) {
-        int t = causal ? i : a.M - 1 - i;
-        int v = tile_variant(a, t);
-        Acc cur[RF_MAX_ORDER];
-#pragma unroll
-        for (int j = 0; j < RF_MAX_ORDER; j++) cur[j] = Acc(0);
-        for (int r = 0; r < k; r++) cur[r] = a.tails[tail_idx(a, s, t, r, line)];
-        // chaining from the scans applied earlier in this dimension
-        for (int q = 0; q < s; q++) {
-            bool qc = a.scans[q].causal != 0;
-            Acc c[RF_MAX_ORDER];
-            load_carry(a, q, qc, t, line, c);
-            const Acc *W = a.W + ((((int64_t)v * a.n_scans + q) * a.n_scans + s) * k) * k;
-            for (int r = 0; r < k; r++)
-                for (int o = 0; o < k; o++) cur[r] = cur[r] + W[r * k + o] * c[o];
-        }
-        // recurrence: tail(t) += A * tail(prev); the slab's incoming carry is added by carry_apply
-        const Acc *A = a.A + (int64_t)s * k * k;
-        if (i > 0) {
-            for (int r = 0; r < k; r++)
-                for (int j = 0; j < k; j++) cur[r] = cur[r] + A[r * k + j] * prev[j];
-        }
-        for (int r = 0; r < k; r++) {
-            a.tails[tail_idx(a, s, t, r, line)] = cur[r];
-            prev[r] = cur[r];
-        }
-    }
-    if (send) {
-        for (int r = 0; r < k; r++) send[(int64_t)r * a.g.lines + line] = prev[r];
-    }
-}
-
 // add the effect of the slab's incoming carry to every tile's complete tail
 template <typename Acc>
 __global__ void __launch_bounds__(kBlock)
@@ -291,13 +248,6 @@ int launch_generic_pass2(const P *src, P *dst, GenericDimArgs<typename PixelTrai
 }
 
 template <typename Acc>
-int launch_generic_carry_scan(GenericDimArgs<Acc> a, int s, Acc *send, hipStream_t stream) {
-    hipLaunchKernelGGL(generic_carry_scan_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s, send);
-    RF_HIP_CHECK(hipGetLastError());
-    return RF_OK;
-}
-
-template <typename Acc>
 int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream) {
     hipLaunchKernelGGL(generic_carry_apply_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
     RF_HIP_CHECK(hipGetLastError());
@@ -338,7 +288,6 @@ RF_INSTANTIATE_PIXEL(int32_t)
 RF_INSTANTIATE_PIXEL(int16_t)
 
 #define RF_INSTANTIATE_ACC(Acc)                                                                                    \
-    template int launch_generic_carry_scan<Acc>(GenericDimArgs<Acc>, int, Acc *, hipStream_t);                     \
     template int launch_generic_carry_apply<Acc>(GenericDimArgs<Acc>, int, hipStream_t);                           \
     template int launch_gather_incoming<Acc>(GenericDimArgs<Acc>, int, const Acc *, int64_t, int64_t, int, int,    \
                                              const Acc *, hipStream_t);

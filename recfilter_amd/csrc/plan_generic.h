@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "kernels_fused.h"
 #include "plan.h"
 
 namespace rf {
@@ -119,17 +120,24 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
             plan->tables["prop_" + dn] = dP;
         }
 
-        // A^M for the exchange (sharded outermost dimension)
-        std::vector<Acc> hAM((size_t)n * k * k, Acc(0));
+        // A^M for the exchange (sharded outermost dimension), A^C for the blocked carry scan
+        const int C = carry_chunk_length(di.M, di.lines, k);
+        std::vector<Acc> hAM((size_t)n * k * k, Acc(0)), hAC((size_t)n * k * k, Acc(0));
+        uint32_t causal_mask = 0;
         for (int s = 0; s < n; s++) {
-            std::vector<S> am = mat_pow<S>(tab.A[s], di.M, k);
-            for (int e = 0; e < k * k; e++) hAM[(size_t)s * k * k + e] = table_to_acc<S, Acc>(am[e]);
+            std::vector<S> am = mat_pow<S>(tab.A[s], di.M, k), ac = mat_pow<S>(tab.A[s], C, k);
+            for (int e = 0; e < k * k; e++) {
+                hAM[(size_t)s * k * k + e] = table_to_acc<S, Acc>(am[e]);
+                hAC[(size_t)s * k * k + e] = table_to_acc<S, Acc>(ac[e]);
+            }
+            if (ts[s].causal) causal_mask |= 1u << s;
         }
 
         const DevScan<Acc> *dScans = (const DevScan<Acc> *)plan->upload(ds.data(), ds.size() * sizeof(DevScan<Acc>), &status);
         const Acc *dWp = (const Acc *)plan->upload(hW.data(), hW.size() * sizeof(Acc), &status);
         const Acc *dAp = (const Acc *)plan->upload(hA.data(), hA.size() * sizeof(Acc), &status);
         const Acc *dAMp = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
+        const Acc *dACp = (const Acc *)plan->upload(hAC.data(), hAC.size() * sizeof(Acc), &status);
         size_t tails_per_plane = (size_t)n * di.M * k * di.lines;
         size_t inc_per_plane = (size_t)n * k * di.lines;
         Acc *tails = (Acc *)plan->alloc(tails_per_plane * plan->n_planes * sizeof(Acc), false, &status);
@@ -188,10 +196,12 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
             Step cs;
             cs.name = "generic_carry_" + dn + std::to_string(s);
             int64_t plane_stride = (int64_t)k * di.lines;
-            cs.run = [plan, args_for, s, ex_index, plane_stride](int pl) {
+            // the blocked parallel scan of kernels_carry.hip: parallel over lines AND over chunks of tiles, so a 1-D
+            // signal (one line) does not degenerate into one thread walking every tile
+            cs.run = [plan, args_for, s, ex_index, plane_stride, k, causal_mask, dACp, C](int pl) {
                 Acc *send = ex_index >= 0 ? (Acc *)plan->exchanges[ex_index].send : nullptr;
-                return launch_generic_carry_scan<Acc>(args_for(pl), s, send ? send + pl * plane_stride : nullptr,
-                                                      plan->stream);
+                return launch_carry_block<Acc>(k, args_for(pl), causal_mask, s, s + 1, send ? send + pl * plane_stride : nullptr,
+                                               dACp, C, plan->stream);
             };
             if (is_exchange_dim) {
                 plan->exchange_local_steps.push_back({cs});
