@@ -18,6 +18,8 @@
 //
 // fused_tails_kernel stages HALF tiles (256 x 32, 32 KiB of LDS) so that four to five workgroups fit a
 // CU; the second half's pixels are already in flight while the first half is contracted.
+#include <type_traits>
+
 #include "kernels.h"
 #include "kernels_fused.h"
 #include "scan_device.h"
@@ -27,6 +29,8 @@ namespace rf {
 namespace {
 
 constexpr int kTailRows = 32;     // rows staged per step
+
+typedef float F2 __attribute__((ext_vector_type(2)));     // operands of the packed f32 instructions
 
 template <typename P, int K, int TY>
 __global__ void __launch_bounds__(kFusedThreads)
@@ -114,11 +118,31 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
                     h[4 * j + 0] = q.x; h[4 * j + 1] = q.y; h[4 * j + 2] = q.z; h[4 * j + 3] = q.w;
                 }
                 Acc acc[NR];
+                if constexpr (std::is_same<Acc, float>::value) {
+                    // two samples per instruction (v_pk_fma_f32): neighbours along the row sit in adjacent registers
+                    // (two accumulators per row: consecutive packed FMAs are independent, a dependent pair costs a wait state)
+                    F2 acc2[NR][2];
 #pragma unroll
-                for (int n = 0; n < NR; n++) {
-                    acc[n] = Acc(0);
+                    for (int n = 0; n < NR; n++) acc2[n][0] = acc2[n][1] = F2{0.0f, 0.0f};
 #pragma unroll
-                    for (int m = 0; m < kFusedSeg; m++) acc[n] = acc[n] + h[m] * v[n][m];
+                    for (int m = 0; m < kFusedSeg; m += 2) {
+                        const F2 hh = F2{h[m], h[m + 1]};
+#pragma unroll
+                        for (int n = 0; n < NR; n++)
+                            acc2[n][(m >> 1) & 1] = hh * F2{v[n][m], v[n][m + 1]} + acc2[n][(m >> 1) & 1];
+                    }
+#pragma unroll
+                    for (int n = 0; n < NR; n++) {
+                        const F2 s2 = acc2[n][0] + acc2[n][1];
+                        acc[n] = s2.x + s2.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NR; n++) {
+                        acc[n] = Acc(0);
+#pragma unroll
+                        for (int m = 0; m < kFusedSeg; m++) acc[n] = acc[n] + h[m] * v[n][m];
+                    }
                 }
 #pragma unroll
                 for (int n = 0; n < NR; n++) {          // sum over the row's 16 lanes; total lands in lane 15
@@ -141,12 +165,34 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
             Acc col[kTailRows];
 #pragma unroll
             for (int i = 0; i < kTailRows; i++) col[i] = tile[i * kFusedTX + e];
+            if constexpr (std::is_same<Acc, float>::value) {
+                // two rows per instruction (v_pk_fma_f32), two tails at a time so that consecutive packed FMAs are
+                // independent (a dependent pair costs a wait state); an odd last tail is paired with itself
 #pragma unroll
-            for (int jr = 0; jr < kFusedMaxScans * K; jr++) {
-                if (jr < nyk) {
-                    const Acc *hy = Hy + (size_t)(vy * nyk + jr) * TY + kTailRows * half;     // wave-uniform
+                for (int g = 0; g < (kFusedMaxScans * K + 1) / 2; g++) {
+                    if (2 * g < nyk) {
+                        const int j0 = 2 * g, j1 = (2 * g + 1 < nyk) ? 2 * g + 1 : 2 * g;
+                        const Acc *h0 = Hy + (size_t)(vy * nyk + j0) * TY + kTailRows * half;     // wave-uniform
+                        const Acc *h1 = Hy + (size_t)(vy * nyk + j1) * TY + kTailRows * half;
+                        F2 c0 = F2{0.0f, 0.0f}, c1 = F2{0.0f, 0.0f};
 #pragma unroll
-                    for (int i = 0; i < kTailRows; i++) comb[jr] = comb[jr] + hy[i] * col[i];
+                        for (int i = 0; i < kTailRows; i += 2) {
+                            const F2 cc = F2{col[i], col[i + 1]};
+                            c0 = F2{h0[i], h0[i + 1]} * cc + c0;
+                            c1 = F2{h1[i], h1[i + 1]} * cc + c1;
+                        }
+                        comb[2 * g] = comb[2 * g] + (c0.x + c0.y);
+                        if (2 * g + 1 < kFusedMaxScans * K) comb[2 * g + 1] = comb[2 * g + 1] + (c1.x + c1.y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int jr = 0; jr < kFusedMaxScans * K; jr++) {
+                    if (jr < nyk) {
+                        const Acc *hy = Hy + (size_t)(vy * nyk + jr) * TY + kTailRows * half;     // wave-uniform
+#pragma unroll
+                        for (int i = 0; i < kTailRows; i++) comb[jr] = comb[jr] + hy[i] * col[i];
+                    }
                 }
             }
         }
