@@ -43,7 +43,9 @@ struct FusedScanY {
 template <typename Acc>
 struct FusedArgs {
     int64_t NX, NY, NZ;      // extents (NZ = batch of planes along z, 1 for 2-D)
+    int64_t NXP;             // MX * 256: pitch of the y tails / y carries (the last tile of a row may be partial)
     int32_t MX, MY;          // tiles along x / y
+    int32_t last_lane;       // x phase: lane holding the last existing segment of a row's last tile (15 when full)
     int32_t nx, ny;          // scans along x / y
     int32_t clamped;
     int32_t y_first_border;  // the slab holds the image's first / last tile row

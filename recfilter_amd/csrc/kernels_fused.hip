@@ -50,9 +50,12 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
     const int64_t z = blockIdx.z;
     const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
     const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x phase: segment lane, row slot
-    const int64_t Lx = a.NY * a.NZ, Ly = a.NX * a.NZ;
+    const int64_t Lx = a.NY * a.NZ, Ly = a.NXP * a.NZ;
     const int64_t line0 = (int64_t)ty * TY + slot + a.NY * z;          // x phase: row n -> line0 + 16 n
-    const int64_t line = (int64_t)tx * kFusedTX + t + a.NX * z;        // y phase: this thread's column
+    const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;       // y phase: this thread's column
+    // a row's last tile may be partial: its missing samples are zeros on load, skipped on store, and an anticausal
+    // x scan enters at the last existing segment
+    const int last_lane = (tx == a.MX - 1) ? a.last_lane : 15;
 
     // ---- carries (pass 2) ----
     Acc CX[kFusedMaxScans][NR][K];
@@ -72,7 +75,7 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
             if (s < a.nx) {
                 const bool causal = a.xs[s].causal != 0;
                 const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-                const bool first_lane = causal ? (l == 0) : (l == 15);
+                const bool first_lane = causal ? (l == 0) : (l == last_lane);
                 if (first_lane) {
                     // previous tile's completed tail, or (first tile of the row) the state entering the row
                     const int tp = causal ? tx - 1 : tx + 1;
@@ -109,8 +112,9 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
         const uint32_t rs4 = (uint32_t)(a.NX / 4);
         const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
         A4 tmp[TY / 4];
+        const bool chunk_in = cc <= 4 * last_lane + 3;        // this thread's 16-byte chunk exists in the image
 #pragma unroll
-        for (int i = 0; i < TY / 4; i++) tmp[i] = sp[off0 + (uint32_t)(4 * i) * rs4];
+        for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? sp[off0 + (uint32_t)(4 * i) * rs4] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
         if constexpr (!PixelTraits<P>::is_integer) {
             if (a.pw_flags & 1) {
 #pragma unroll
@@ -151,7 +155,7 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
             const FusedScan<Acc> &sc = a.xs[s];
             const bool causal = sc.causal != 0;
             const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-            const bool first_lane = causal ? (l == 0) : (l == 15);
+            const bool first_lane = causal ? (l == 0) : (l == last_lane);
             const bool clamp_first = a.clamped && tile_first && first_lane;
             Acc cx[NR][K];     // CX[s] with a run-time s: a select chain, not an indexed (scratch) array
 #pragma unroll
@@ -163,7 +167,7 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
                     for (int q = 1; q < kFusedMaxScans; q++) cx[n][j] = (s == q) ? CX[q][n][j] : cx[n][j];
                 }
             if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
-            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx);
+            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane);
         }
 #pragma unroll
         for (int n = 0; n < NR; n++) {
@@ -223,8 +227,10 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
         {
             P *dp = dst + tile_off;
             const uint32_t nxu = (uint32_t)a.NX;
+            if (t < 16 * (last_lane + 1)) {
 #pragma unroll
-            for (int i = 0; i < TY; i++) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+                for (int i = 0; i < TY; i++) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+            }
         }
     }
 }

@@ -61,7 +61,10 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
     const uint32_t rs4 = (uint32_t)(a.NX / 4);
     const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
-    const int64_t Lx = a.NY * a.NZ, Ly = a.NX * a.NZ;
+    const int64_t Lx = a.NY * a.NZ, Ly = a.NXP * a.NZ;
+    // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
+    const bool chunk_in = (tx != a.MX - 1) || (cc <= 4 * a.last_lane + 3);
+    const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
 
     Acc comb[kFusedMaxScans * K];
 #pragma unroll
@@ -69,7 +72,7 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
 
     A4 pre[NL];
 #pragma unroll
-    for (int i = 0; i < NL; i++) pre[i] = sp[off0 + (uint32_t)(4 * i) * rs4];
+    for (int i = 0; i < NL; i++) pre[i] = chunk_in ? sp[off0 + (uint32_t)(4 * i) * rs4] : zero4;
     // impulse responses of the x tails for this tile's border variant -> LDS (read back per segment below);
     // 16-byte chunk c of a row is stored at chunk c ^ ((c >> 4) & 3), the same swizzle as the pixels
     if (nxk > 0) {
@@ -94,7 +97,7 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
         __syncthreads();
         if (half + 1 < NH) {                                    // next half in flight during this one's math
 #pragma unroll
-            for (int i = 0; i < NL; i++) pre[i] = sp[off0 + (uint32_t)(kTailRows * (half + 1) + 4 * i) * rs4];
+            for (int i = 0; i < NL; i++) pre[i] = chunk_in ? sp[off0 + (uint32_t)(kTailRows * (half + 1) + 4 * i) * rs4] : zero4;
         }
 
         // ---- x tails of this half's rows: dot products + reduction over the 16 lanes of a row ----
@@ -199,7 +202,7 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     }
     // combined rows -> yt; with x scans in the filter xscan_rows_kernel finishes them in place
     if (nyk > 0) {
-        const int64_t line = (int64_t)tx * kFusedTX + t + a.NX * z;
+        const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;
 #pragma unroll
         for (int jr = 0; jr < kFusedMaxScans * K; jr++)
             if (jr < nyk) a.yt[(((int64_t)(jr / K) * a.MY + ty) * K + jr % K) * Ly + line] = comb[jr];
@@ -310,10 +313,11 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
             const FusedScan<Acc> &sc = a.xs[s];
             const bool causal = sc.causal != 0;
             const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-            const bool first_lane = causal ? (l == 0) : (l == 15);
+            const int last_lane = (tx == a.MX - 1) ? a.last_lane : 15;       // a row's last tile may be partial
+            const bool first_lane = causal ? (l == 0) : (l == last_lane);
             const bool clamp_first = a.clamped && tile_first && first_lane;
             if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, clamp_first, zero);
-            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero);
+            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero, l > last_lane);
         }
         if (residual) {
 #pragma unroll

@@ -52,10 +52,15 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         if ((want == 32 || want == 64) && NY % want == 0) TY = want;
     }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
-    const int MX = (int)(NX / kFusedTX), MY = (int)(NY / TY);
-    dx.T = kFusedTX; dx.M = dx.N / kFusedTX;
+    // The width only has to be a multiple of 16 (one x-phase segment): the last tile of a row may be partial.  Its
+    // missing samples are loaded as zeros and never stored; the tables of the "last tile" variants are built for the
+    // samples that exist (tables.h, T_last), so a clamped anticausal scan enters at the true image border.
+    const int MX = (int)((NX + kFusedTX - 1) / kFusedTX), MY = (int)(NY / TY);
+    const int TVx = (int)(NX - (int64_t)(MX - 1) * kFusedTX);      // samples of the last tile, (0, 256]
+    const int64_t NXP = (int64_t)MX * kFusedTX;                     // padded width: pitch of everything indexed by column
+    dx.T = kFusedTX; dx.M = chained ? dx.N / kFusedTX : MX;
     dy.T = TY;       dy.M = MY;
-    const int64_t Lx = NY * NZ, Ly = NX * NZ;
+    const int64_t Lx = NY * NZ, Ly = NXP * NZ;
     const int outer = plan->ndim - 1;
     const bool y_is_exchange_dim = (outer == 1);
     const bool y_sharded = y_is_exchange_dim && plan->shard_world > 1;
@@ -144,10 +149,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const int chain_S = (int)((NY + 63) / 64);     // rows per lane of the row-chain kernel
     const int Cx = carry_chunk_length(MX, Lx), Cy = carry_chunk_length(MY, Ly);
     if (nx > 0) {
-        DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
+        DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped, TVx);
         flatten_W(tx, nx, hWx, hAx, "x");
         {
-            std::vector<S> H = build_tail_responses<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped);
+            std::vector<S> H = build_tail_responses<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped, TVx);
             std::vector<double> dH(H.size());
             hHx.resize(H.size());
             for (size_t e = 0; e < H.size(); e++) { hHx[e] = table_to_acc<S, Acc>(H[e]); dH[e] = table_to_double<S>(H[e]); }
@@ -225,6 +230,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     FusedArgs<Acc> fbase{};
     fbase.NX = NX; fbase.NY = NY; fbase.NZ = NZ; fbase.MX = MX; fbase.MY = MY; fbase.nx = nx; fbase.ny = ny;
+    fbase.NXP = NXP; fbase.last_lane = TVx / kFusedSeg - 1;
     fbase.clamped = plan->clamped ? 1 : 0;
     fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
     fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
@@ -264,7 +270,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         return a;
     };
     GenericDimArgs<Acc> gy{};
-    gy.g = LineGeom{NY, NX, Ly};
+    gy.g = LineGeom{NY, NXP, Ly};
     gy.T = TY; gy.M = MY; gy.k = K; gy.n_scans = ny; gy.clamped = fbase.clamped;
     gy.first_is_border = fbase.y_first_border; gy.last_is_border = fbase.y_last_border;
     gy.scans = d_yd; gy.W = d_Wy; gy.A = d_Ay;
@@ -412,7 +418,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
         return true;
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
-    if (plan->dims[0].N % kFusedTX != 0) return no("width must be a multiple of 256");
+    if (plan->dims[0].N % kFusedSeg != 0) return no("width must be a multiple of 16");
     if (plan->dims[1].N % 32 != 0) return no("height must be a multiple of 32");
     const int K = fused_order(plan);
     if (K > kFusedMaxK) return no("feedback order above 3");

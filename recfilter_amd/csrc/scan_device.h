@@ -32,7 +32,7 @@ __device__ __forceinline__ int swz_chunk(int c) { return c ^ ((c >> 4) & 3); }
 // interleaves them (ILP = NR) and the dependent-FMA latency of one row hides behind the others.
 template <typename Acc, bool CAUSAL, int K, int NR>
 __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const FusedScan<Acc> &sc, bool first_lane,
-                                            bool clamp_first, const Acc (&carry)[NR][K]) {
+                                            bool clamp_first, const Acc (&carry)[NR][K], bool dead_lane = false) {
     Acc h[NR][K];
     Acc y0[NR];
 #pragma unroll
@@ -62,6 +62,14 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
             if (p == 0) y0[n] = acc;
             v[n][m] = acc;
         }
+    }
+    // A lane beyond the last existing segment of a partial tile (dead_lane) holds no image samples.  Whatever an
+    // earlier causal scan left there must not flow back into the row: its exit state is dropped.
+    if (!CAUSAL) {
+#pragma unroll
+        for (int n = 0; n < NR; n++)
+#pragma unroll
+            for (int j = 0; j < K; j++) h[n][j] = dead_lane ? Acc(0) : h[n][j];
     }
     // 2. Kogge-Stone over the 16 lanes of each row: S_l <- sum_{j<=l} P^(l-j) S_j
 #define RF_KS_STEP(D, IDX)                                                                        \

@@ -45,13 +45,16 @@ struct ScanS {
 // restricted to a tile (lib/split.cpp:628-654).
 //   carry      != nullptr : history before the tile (zero-border form), carry[j] = y[-1-j]
 //   clamp_first            : the tile is the first one in the scan's direction of a clamped image
+//   T_valid < T             : only the first T_valid samples of the tile exist (the image's last, partial tile);
+//                             an anticausal scan then enters at sample T_valid-1, the rest is never touched
 template <typename S>
-inline void scan_tile(S *v, int T, int k, const ScanS<S> &sc, bool clamp_first, const S *carry) {
+inline void scan_tile(S *v, int T, int k, const ScanS<S> &sc, bool clamp_first, const S *carry, int T_valid = -1) {
+    if (T_valid < 0 || T_valid > T) T_valid = T;
     S hist[RF_MAX_ORDER];
     for (int j = 0; j < k; j++) hist[j] = carry ? carry[j] : S(0);
     S y0 = S(0);
-    for (int p = 0; p < T; p++) {
-        int m = sc.causal ? p : T - 1 - p;
+    for (int p = 0; p < T_valid; p++) {
+        int m = sc.causal ? p : T_valid - 1 - p;
         S x = v[m];
         S acc = sc.b * x;
         for (int j = 0; j < k; j++) {
@@ -83,8 +86,11 @@ struct DimTables {
 
 inline bool variant_clamps(int v, bool causal) { return causal ? (v & 1) != 0 : (v & 2) != 0; }
 
+// T_last: number of samples of the dimension's last tile (== T unless the extent is not a multiple of T); the
+// variants with bit1 set describe that tile.
 template <typename S>
-DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, bool clamped) {
+DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, bool clamped, int T_last = -1) {
+    if (T_last < 0 || T_last > T) T_last = T;
     DimTables<S> t;
     t.T = T; t.k = k; t.n = (int)scans.size(); t.scans = scans;
     const int n = t.n;
@@ -93,18 +99,19 @@ DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, 
     t.A.assign(n, std::vector<S>(k * k, S(0)));
     std::vector<S> col(T);
     for (int v = 0; v < 4; v++) {
+        const int Tv = (v & 2) ? T_last : T;      // samples that exist in a tile of this variant
         for (int q = 0; q < n; q++) {
             // R_q: response of an all-zero tile to a unit carry e_o
             std::vector<std::vector<S>> cols(k, std::vector<S>(T, S(0)));
             for (int o = 0; o < k; o++) {
                 S carry[RF_MAX_ORDER];
                 for (int j = 0; j < k; j++) carry[j] = (j == o) ? S(1) : S(0);
-                scan_tile<S>(cols[o].data(), T, k, scans[q], false, carry);
+                scan_tile<S>(cols[o].data(), T, k, scans[q], false, carry, Tv);
             }
             for (int s = q; s < n; s++) {
                 if (s > q) {
                     bool cl = clamped && variant_clamps(v, scans[s].causal);
-                    for (int o = 0; o < k; o++) scan_tile<S>(cols[o].data(), T, k, scans[s], cl, nullptr);
+                    for (int o = 0; o < k; o++) scan_tile<S>(cols[o].data(), T, k, scans[s], cl, nullptr, Tv);
                 }
                 std::vector<S> &P = t.prop[(v * n + q) * n + s];
                 P.assign((size_t)T * k, S(0));
@@ -128,15 +135,17 @@ DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, 
 // Impulse responses of the tile-local tails: H[((v*n + s)*k + r)*T + m] = tail r of scan s (after the
 // tile-local scans 0..s with zero incoming carries) per unit input at memory position m.
 template <typename S>
-std::vector<S> build_tail_responses(const std::vector<ScanS<S>> &scans, int k, int T, bool clamped) {
+std::vector<S> build_tail_responses(const std::vector<ScanS<S>> &scans, int k, int T, bool clamped, int T_last = -1) {
     const int n = (int)scans.size();
+    if (T_last < 0 || T_last > T) T_last = T;
     std::vector<S> H((size_t)4 * n * k * T, S(0));
     std::vector<S> vec(T);
-    for (int v = 0; v < 4; v++)
-        for (int m = 0; m < T; m++) {
+    for (int v = 0; v < 4; v++) {
+        const int Tv = (v & 2) ? T_last : T;      // samples beyond Tv do not exist: their responses stay zero
+        for (int m = 0; m < Tv; m++) {
             for (int i = 0; i < T; i++) vec[i] = (i == m) ? S(1) : S(0);
             for (int s = 0; s < n; s++) {
-                scan_tile<S>(vec.data(), T, k, scans[s], clamped && variant_clamps(v, scans[s].causal), nullptr);
+                scan_tile<S>(vec.data(), T, k, scans[s], clamped && variant_clamps(v, scans[s].causal), nullptr, Tv);
                 for (int r = 0; r < k; r++) {
                     const int p = T - 1 - r;
                     const int mm = scans[s].causal ? p : T - 1 - p;
@@ -144,6 +153,7 @@ std::vector<S> build_tail_responses(const std::vector<ScanS<S>> &scans, int k, i
                 }
             }
         }
+    }
     return H;
 }
 

@@ -47,7 +47,9 @@ class FusedEmu:
             self.Hy = plan.table("H_y").reshape(4, ny, K, self.TY)
 
     # -- x phase of one scan on rows [R, 256], exactly the kernel's decomposition ------------------
-    def xphase(self, rows, s, carry, clamp_first):
+    def xphase(self, rows, s, carry, clamp_first, last_lane=SEG - 1):
+        """last_lane < 15: the tile is a row's partial last tile, its segments beyond last_lane do not exist.  An
+        anticausal scan enters at segment last_lane and the dead segments' exit states are dropped."""
         causal = self.xs[s][0]
         b, a = self.xc[s]
         K = self.K
@@ -55,13 +57,16 @@ class FusedEmu:
         d = rows if causal else rows[:, ::-1]
         seg = d.reshape(R, SEG, SEG).copy()          # [row, lane, sample] in direction coordinates
         S = np.zeros((R, SEG, K))
+        first = 0 if causal else SEG - 1 - last_lane  # direction-lane where the scan enters the row
         for l in range(SEG):
             v = seg[:, l, :].copy()
             c = None
-            if l == 0 and carry is not None:
+            if l == first and carry is not None:
                 c = [carry[j] for j in range(K)]
-            scan_tile(v, True, b, a, K, clamp_first and l == 0, c)
+            scan_tile(v, True, b, a, K, clamp_first and l == first, c)
             seg[:, l, :] = v
+            if not causal and l < first:
+                continue                              # dead lane: exit state stays zero
             for r in range(K):
                 S[:, l, r] = v[:, SEG - 1 - r]
         for step, dist in enumerate((1, 2, 4, 8)):
@@ -76,9 +81,14 @@ class FusedEmu:
 
     def run(self, img):
         img = np.asarray(img, dtype=np.float64)
-        NY, NX = img.shape
+        NY, NX_real = img.shape
         K, TY = self.K, self.TY
-        MX, MY = NX // TX, NY // TY
+        MX = (NX_real + TX - 1) // TX                 # the last tile of a row may be partial: zero padded here,
+        NX = MX * TX                                  # never read back
+        last_lane_of = lambda tx: (NX_real - (MX - 1) * TX) // SEG - 1 if tx == MX - 1 else SEG - 1
+        if NX != NX_real:
+            img = np.concatenate([img, np.zeros((NY, NX - NX_real))], axis=1)
+        MY = NY // TY
         nx, ny = len(self.xs), len(self.ys)
         xt = np.zeros((nx, MX, K, NY))
         yt = np.zeros((ny, MY, K, NX))
@@ -149,7 +159,7 @@ class FusedEmu:
                 for tx in range(MX):
                     rows = np.stack([yt[j, ty, r, tx * TX:(tx + 1) * TX] for j in range(ny) for r in range(K)])
                     for s in range(nx):
-                        rows = self.xphase(rows, s, None, clamped and xfirst(s, tx))
+                        rows = self.xphase(rows, s, None, clamped and xfirst(s, tx), last_lane_of(tx))
                     for j in range(ny):
                         for r in range(K):
                             acc = rows[j * K + r].copy()
@@ -181,9 +191,9 @@ class FusedEmu:
                 t = img[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX].copy()
                 for s in range(nx):
                     c = None if xfirst(s, tx) else xcarry(s, tx)[:, ty * TY:(ty + 1) * TY]
-                    t = self.xphase(t, s, c, clamped and xfirst(s, tx))
+                    t = self.xphase(t, s, c, clamped and xfirst(s, tx), last_lane_of(tx))
                 for j in range(ny):
                     c = None if yfirst(j, ty) else ycarry(j, ty)[:, tx * TX:(tx + 1) * TX]
                     t = yscan(t, j, c, ty)
                 out[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX] = t
-        return out
+        return out[:, :NX_real]

@@ -147,6 +147,14 @@ FUSED_CASES = {
     "x_only": dict(shape=(64, 512), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
     "y_only": dict(shape=(128, 256), scans=[(1, False, [0.5, 0.4, -0.1]), (1, True, [0.5, 0.4])], clamped=True),
     "single_tile": dict(shape=(64, 256), scans=xy_pm(GAUSS2), clamped=True),
+    # widths that are not multiples of 256: the last tile of every row is partial
+    "partial_gauss2_clamped": dict(shape=(64, 320), scans=xy_pm(GAUSS2), clamped=True),
+    "partial_gauss3_clamped": dict(shape=(96, 464), scans=xy_pm(GAUSS3), clamped=True),
+    "partial_mixed_zero": dict(shape=(64, 528), scans=REFERENCE_TESTS["test_generic_xy"]["scans"], clamped=False),
+    "partial_single_tile": dict(shape=(32, 48), scans=xy_pm(GAUSS2), clamped=True),
+    "partial_x_only_causal_then_anti": dict(shape=(64, 272), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.6, 0.3]),
+                                                                    (0, True, [0.9, 0.05]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
+    "partial_sat": dict(shape=(64, 1936), scans=[(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], clamped=False),
 }
 
 

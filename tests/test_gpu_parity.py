@@ -457,3 +457,36 @@ def test_long_1d_signal_int32_prefix_sum_bit_exact_and_fallbacks():
     imgs, outs, (path, _) = _run((8192,), [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], clamped=True)
     assert path == 2
     _check(imgs, outs, [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], True)
+
+
+# ---- partial last tiles: any width that is a multiple of 16 stays on the fused path -----------------------------
+def test_partial_tiles_other_features():
+    import torch
+    import recfilter_amd as rfa
+    g2 = rc.xy_pm(rc.GAUSS2)
+    # int32 bit-exact, in place, two planes
+    imgs, outs, (path, tiles) = _run((64, 336), [(0, True, [1.0, 1.0]), (0, False, [1.0, 2.0]), (1, True, [1.0, 1.0])],
+                                     dtype=np.int32, planes=2, inplace=True)
+    assert path == 3
+    _check(imgs, outs, [(0, True, [1.0, 1.0]), (0, False, [1.0, 2.0]), (1, True, [1.0, 1.0])], False)
+    # 3-D (fused x/y per plane + strided z) and the 1080p-like 1920-wide frame
+    cfg = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]
+    imgs, outs, (path, _) = _run((32, 64, 208), cfg["scans"])
+    assert path == 3
+    _check(imgs, outs, cfg["scans"], False)
+    imgs, outs, (path, tiles) = _run((1088, 1920), g2, clamped=True)
+    assert path == 3 and tiles[0] == 256
+    _check(imgs, outs, g2, True)
+    # pointwise epilogue on a partial width
+    img = rc.random_image((64, 400), np.float32, 5)
+    with rfa.Plan((64, 400), g2, clamped=True, epilogue=(-1.0, 2.0, 0.25)) as plan:
+        out = plan.execute([torch.from_numpy(img).cuda()])[0].cpu().numpy()
+    assert rc.rel_err(out, _pointwise_want(img, g2, True, None, (-1.0, 2.0, 0.25))) < TOL
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_rows_with_partial_width(world):
+    scans = rc.xy_pm(rc.GAUSS2)
+    full, got, (path, nex) = _run_sharded((64 * world, 464), scans, True, world, path=0)
+    assert path == 3 and nex == 2
+    _check(full, got, scans, True)
