@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librecfilter_amd.so")
+# RECFILTER_AMD_LIB: load another build of the same library (A/B timing of kernel changes)
+LIB_PATH = os.environ.get("RECFILTER_AMD_LIB") or os.path.join(_PKG, "librecfilter_amd.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 RF_MAX_DIMS = 3

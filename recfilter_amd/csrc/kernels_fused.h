@@ -46,6 +46,8 @@ struct FusedArgs {
     int64_t NXP;             // MX * 256: pitch of the y tails / y carries (the last tile of a row may be partial)
     int32_t MX, MY;          // tiles along x / y
     int32_t last_lane;       // x phase: lane holding the last existing segment of a row's last tile (15 when full)
+    int64_t NYP;             // MY * TY: pitch of the x tails / x carries (the last tile row may be partial)
+    int32_t last_rows;       // rows that exist in the last tile row (TY when full)
     int32_t nx, ny;          // scans along x / y
     int32_t clamped;
     int32_t y_first_border;  // the slab holds the image's first / last tile row

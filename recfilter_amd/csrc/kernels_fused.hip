@@ -35,7 +35,9 @@ namespace {
 // scans) are requested BEFORE the pixels, so their latency hides behind the 64 KiB pixel load instead of
 // stalling every scan.  (Pass 1 is the contraction of kernels_tails.hip; the scan-everything pass 1 and a
 // persistent, register-prefetching variant of this kernel were measured slower in round 1 and removed.)
-template <typename P, int K, int TY, bool EPI>
+// EDGE: the image has partial tiles (width not a multiple of 256 or height not a multiple of TY); without it the
+// masks below are compile-time constants and the kernel stays lean.
+template <typename P, int K, int TY, bool EPI, bool EDGE>
 __global__ void __launch_bounds__(kFusedThreads, EPI ? 2 : 1)
 fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -50,12 +52,14 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
     const int64_t z = blockIdx.z;
     const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
     const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x phase: segment lane, row slot
-    const int64_t Lx = a.NY * a.NZ, Ly = a.NXP * a.NZ;
-    const int64_t line0 = (int64_t)ty * TY + slot + a.NY * z;          // x phase: row n -> line0 + 16 n
+    const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
+    const int64_t line0 = (int64_t)ty * TY + slot + a.NYP * z;         // x phase: row n -> line0 + 16 n
     const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;       // y phase: this thread's column
     // a row's last tile may be partial: its missing samples are zeros on load, skipped on store, and an anticausal
     // x scan enters at the last existing segment
-    const int last_lane = (tx == a.MX - 1) ? a.last_lane : 15;
+    const int last_lane = (EDGE && tx == a.MX - 1) ? a.last_lane : 15;
+    // ... and so may the last tile row: rows_here of its TY rows exist, an anticausal y scan enters at the last of them
+    const int rows_here = (EDGE && ty == a.MY - 1) ? a.last_rows : TY;
 
     // ---- carries (pass 2) ----
     Acc CX[kFusedMaxScans][NR][K];
@@ -113,14 +117,24 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
         const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
         A4 tmp[TY / 4];
         const bool chunk_in = cc <= 4 * last_lane + 3;        // this thread's 16-byte chunk exists in the image
+        const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+        if (rows_here == TY) {
 #pragma unroll
-        for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? sp[off0 + (uint32_t)(4 * i) * rs4] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+            for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? sp[off0 + (uint32_t)(4 * i) * rs4] : zero4;
+        } else {
+#pragma unroll
+            for (int i = 0; i < TY / 4; i++)
+                tmp[i] = (chunk_in && rg + 4 * i < rows_here) ? sp[off0 + (uint32_t)(4 * i) * rs4] : zero4;
+        }
         if constexpr (!PixelTraits<P>::is_integer) {
             if (a.pw_flags & 1) {
 #pragma unroll
                 for (int i = 0; i < TY / 4; i++) {
-                    tmp[i].x = a.pre_s * tmp[i].x + a.pre_b; tmp[i].y = a.pre_s * tmp[i].y + a.pre_b;
-                    tmp[i].z = a.pre_s * tmp[i].z + a.pre_b; tmp[i].w = a.pre_s * tmp[i].w + a.pre_b;
+                    // samples beyond the image stay zero: they do not exist
+                    const bool in = chunk_in && rg + 4 * i < rows_here;
+                    const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
+                    tmp[i].x = s * tmp[i].x + b; tmp[i].y = s * tmp[i].y + b;
+                    tmp[i].z = s * tmp[i].z + b; tmp[i].w = s * tmp[i].w + b;
                 }
             }
         }
@@ -201,7 +215,8 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
                 for (int q = 1; q < kFusedMaxScans; q++) c[r] = (j == q) ? CY[q][r] : c[r];
             }
             if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
-            else        scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
+            else if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
+            else scan_col_partial_up<Acc, K, TY>(col, sc, clamp_first, rows_here);     // partial last tile row
         }
         if constexpr (!PixelTraits<P>::is_integer) {
             // fused epilogue (compute_at of a pointwise consumer, lib/recfilter.cpp:473-573); x' was applied at the load
@@ -216,8 +231,11 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
                     const uint32_t nxu = (uint32_t)a.NX;
                     const Acc c1 = a.post_i * ((a.pw_flags & 1) ? a.pre_s : Acc(1));
                     const Acc c2 = a.post_b + a.post_i * ((a.pw_flags & 1) ? a.pre_b : Acc(0));
+                    if (t < 16 * (last_lane + 1)) {
 #pragma unroll
-                    for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + (c1 * xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
+                        for (int i = 0; i < TY; i++)
+                            if (i < rows_here) col[i] = a.post_f * col[i] + (c1 * xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < TY; i++) col[i] = a.post_f * col[i] + a.post_b;
@@ -228,25 +246,31 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
             P *dp = dst + tile_off;
             const uint32_t nxu = (uint32_t)a.NX;
             if (t < 16 * (last_lane + 1)) {
+                if (rows_here == TY) {
 #pragma unroll
-                for (int i = 0; i < TY; i++) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+                    for (int i = 0; i < TY; i++) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TY; i++)
+                        if (i < rows_here) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+                }
             }
         }
     }
 }
 
-template <typename P, int K, int TY, bool EPI>
+template <typename P, int K, int TY, bool EPI, bool EDGE>
 int launch_fused_pass2_impl(const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
     static bool attr_set = false;
     if (!attr_set) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -260,12 +284,16 @@ int launch_fused_pass2(int K, int TY, const P *src, P *dst, const FusedArgs<type
     if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
     // the epilogue variant that keeps the input column in registers exists for float pixels only
     bool epi = false;
+    const bool edge = a.last_lane != 15 || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
 #define RF_CASE(KK, TT)                                                                                     \
     if (K == KK && TY == TT) {                                                                              \
-        if constexpr (!PixelTraits<P>::is_integer)                                                          \
-            if (epi) return launch_fused_pass2_impl<P, KK, TT, true>(src, dst, a, stream);                  \
-        return launch_fused_pass2_impl<P, KK, TT, false>(src, dst, a, stream);                              \
+        if constexpr (!PixelTraits<P>::is_integer) {                                                        \
+            if (epi && edge) return launch_fused_pass2_impl<P, KK, TT, true, true>(src, dst, a, stream);    \
+            if (epi) return launch_fused_pass2_impl<P, KK, TT, true, false>(src, dst, a, stream);           \
+        }                                                                                                   \
+        if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true>(src, dst, a, stream);              \
+        return launch_fused_pass2_impl<P, KK, TT, false, false>(src, dst, a, stream);                       \
     }
     RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
     RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)

@@ -61,7 +61,7 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
     const uint32_t rs4 = (uint32_t)(a.NX / 4);
     const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
-    const int64_t Lx = a.NY * a.NZ, Ly = a.NXP * a.NZ;
+    const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (cc <= 4 * a.last_lane + 3);
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
@@ -71,8 +71,20 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     for (int jr = 0; jr < kFusedMaxScans * K; jr++) comb[jr] = Acc(0);
 
     A4 pre[NL];
+    // rows of this half that exist (the last tile row may be partial): the fast path when all of them do
+    const int rows_here = (ty == a.MY - 1) ? a.last_rows : TY;
+    auto load_half = [&](int half) {
+        const int r0 = kTailRows * half + rg;
+        if (rows_here == TY) {
 #pragma unroll
-    for (int i = 0; i < NL; i++) pre[i] = chunk_in ? sp[off0 + (uint32_t)(4 * i) * rs4] : zero4;
+            for (int i = 0; i < NL; i++) pre[i] = chunk_in ? sp[off0 + (uint32_t)(kTailRows * half + 4 * i) * rs4] : zero4;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                pre[i] = (chunk_in && r0 + 4 * i < rows_here) ? sp[off0 + (uint32_t)(kTailRows * half + 4 * i) * rs4] : zero4;
+        }
+    };
+    load_half(0);
     // impulse responses of the x tails for this tile's border variant -> LDS (read back per segment below);
     // 16-byte chunk c of a row is stored at chunk c ^ ((c >> 4) & 3), the same swizzle as the pixels
     if (nxk > 0) {
@@ -87,18 +99,18 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
             if (a.pw_flags & 1) {                                   // fused prologue x' = pre_s * in + pre_b
 #pragma unroll
                 for (int i = 0; i < NL; i++) {
-                    pre[i].x = a.pre_s * pre[i].x + a.pre_b; pre[i].y = a.pre_s * pre[i].y + a.pre_b;
-                    pre[i].z = a.pre_s * pre[i].z + a.pre_b; pre[i].w = a.pre_s * pre[i].w + a.pre_b;
+                    // samples beyond the image stay zero: they do not exist
+                    const bool in = chunk_in && kTailRows * half + rg + 4 * i < rows_here;
+                    const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
+                    pre[i].x = s * pre[i].x + b; pre[i].y = s * pre[i].y + b;
+                    pre[i].z = s * pre[i].z + b; pre[i].w = s * pre[i].w + b;
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NL; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = pre[i];
         __syncthreads();
-        if (half + 1 < NH) {                                    // next half in flight during this one's math
-#pragma unroll
-            for (int i = 0; i < NL; i++) pre[i] = chunk_in ? sp[off0 + (uint32_t)(kTailRows * (half + 1) + 4 * i) * rs4] : zero4;
-        }
+        if (half + 1 < NH) load_half(half + 1);                 // next half in flight during this one's math
 
         // ---- x tails of this half's rows: dot products + reduction over the 16 lanes of a row ----
         if (nxk > 0) {
@@ -111,7 +123,7 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
                     v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
                 }
             }
-            const int64_t line0 = (int64_t)ty * TY + kTailRows * half + slot + a.NY * z;
+            const int64_t line0 = (int64_t)ty * TY + kTailRows * half + slot + a.NYP * z;
 #pragma unroll 1
             for (int sr = 0; sr < nxk; sr++) {
                 Acc h[kFusedSeg];
@@ -262,8 +274,8 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
             const bool lane_in = 4 * l < TY;
             A4 hy = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
             if (lane_in) hy = *reinterpret_cast<const A4 *>(Hy + ((size_t)(vy * a.ny + j) * K + r) * TY + 4 * l);
-            const int64_t Lx = a.NY * a.NZ;
-            const int64_t y0 = (int64_t)ty * TY + a.NY * z + 4 * l;
+            const int64_t Lx = a.NYP * a.NZ;
+            const int64_t y0 = (int64_t)ty * TY + a.NYP * z + 4 * l;
 #pragma unroll
             for (int q = 0; q < kFusedMaxScans; q++) {
                 if (q < a.nx) {

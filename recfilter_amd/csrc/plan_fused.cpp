@@ -46,21 +46,27 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     DimInfo &dy = chained ? no_y : plan->dims[1];
     const int64_t NX = chained ? chained_row_length(dx.N) : dx.N;
     const int64_t NY = chained ? dx.N / NX : dy.N, NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
-    int TY = (NY % 64 == 0) ? 64 : 32;
+    // tile height: 64 rows unless only 32 divides the height; any other height runs 64-row tiles (32 below 33 rows)
+    // with a partial last tile row
+    int TY = (NY % 64 == 0) ? 64 : (NY % 32 == 0 || NY < 32) ? 32 : 64;
     if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
         const int want = atoi(env);
-        if ((want == 32 || want == 64) && NY % want == 0) TY = want;
+        if (want == 32 || want == 64) TY = want;
     }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
     // The width only has to be a multiple of 16 (one x-phase segment): the last tile of a row may be partial.  Its
     // missing samples are loaded as zeros and never stored; the tables of the "last tile" variants are built for the
     // samples that exist (tables.h, T_last), so a clamped anticausal scan enters at the true image border.
-    const int MX = (int)((NX + kFusedTX - 1) / kFusedTX), MY = (int)(NY / TY);
+    // The height is arbitrary: the last tile row may be partial in the same way (rows loaded as zeros, never stored,
+    // an anticausal y scan enters at the last existing row).
+    const int MX = (int)((NX + kFusedTX - 1) / kFusedTX), MY = (int)((NY + TY - 1) / TY);
     const int TVx = (int)(NX - (int64_t)(MX - 1) * kFusedTX);      // samples of the last tile, (0, 256]
+    const int TVy = (int)(NY - (int64_t)(MY - 1) * TY);            // rows of the last tile row, (0, TY]
     const int64_t NXP = (int64_t)MX * kFusedTX;                     // padded width: pitch of everything indexed by column
+    const int64_t NYP = (int64_t)MY * TY;                           // padded height: pitch of everything indexed by row
     dx.T = kFusedTX; dx.M = chained ? dx.N / kFusedTX : MX;
     dy.T = TY;       dy.M = MY;
-    const int64_t Lx = NY * NZ, Ly = NXP * NZ;
+    const int64_t Lx = NYP * NZ, Ly = NXP * NZ;
     const int outer = plan->ndim - 1;
     const bool y_is_exchange_dim = (outer == 1);
     const bool y_sharded = y_is_exchange_dim && plan->shard_world > 1;
@@ -186,10 +192,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->tables["G_x"] = dG;
     }
     if (ny > 0) {
-        DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped);
+        DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped, TVy);
         flatten_W(ty, ny, hWy, hAy, "y");
         {
-            std::vector<S> H = build_tail_responses<S>(table_scans(dy.scan_ids), K, TY, plan->clamped);
+            std::vector<S> H = build_tail_responses<S>(table_scans(dy.scan_ids), K, TY, plan->clamped, TVy);
             std::vector<double> dH(H.size());
             hHy.resize(H.size());
             for (size_t e = 0; e < H.size(); e++) { hHy[e] = table_to_acc<S, Acc>(H[e]); dH[e] = table_to_double<S>(H[e]); }
@@ -231,6 +237,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     FusedArgs<Acc> fbase{};
     fbase.NX = NX; fbase.NY = NY; fbase.NZ = NZ; fbase.MX = MX; fbase.MY = MY; fbase.nx = nx; fbase.ny = ny;
     fbase.NXP = NXP; fbase.last_lane = TVx / kFusedSeg - 1;
+    fbase.NYP = NYP; fbase.last_rows = TVy;
     fbase.clamped = plan->clamped ? 1 : 0;
     fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
     fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
@@ -419,13 +426,14 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
     if (plan->dims[0].N % kFusedSeg != 0) return no("width must be a multiple of 16");
-    if (plan->dims[1].N % 32 != 0) return no("height must be a multiple of 32");
+    if (plan->ndim == 2 && plan->shard_world > 1 && plan->dims[1].N % 32 != 0)
+        return no("row-sharded slabs must be whole tiles (height a multiple of 32)");
     const int K = fused_order(plan);
     if (K > kFusedMaxK) return no("feedback order above 3");
     if ((int)plan->dims[0].scan_ids.size() > kFusedMaxScans || (int)plan->dims[1].scan_ids.size() > kFusedMaxScans)
         return no("more than 4 scans along x or y");
     const int64_t NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
-    if (NZ > 65535 || plan->dims[1].N / 32 > 65535) return no("grid too large");
+    if (NZ > 65535 || (plan->dims[1].N + 31) / 32 > 65535) return no("grid too large");
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
         // the z stage runs on the generic dimension builder
         if (strided_tile(plan, 2) == 0 && pick_generic_tile(plan->dims[2].N, plan->dims[2].k, 0) == 0)

@@ -128,6 +128,37 @@ __device__ __forceinline__ void scan_col(Acc (&col)[TY], const SC &sc, bool clam
     }
 }
 
+// Anticausal scan up a column whose tile row is partial: only rows [0, rows) exist, the scan enters at row rows-1
+// (run-time, wave-uniform) instead of TY-1.  The non-existing rows are cleared first -- an earlier causal scan ran
+// on into them -- so with a zero state they stay zero until the scan reaches the image; the clamped prologue is
+// positioned with run-time (scalar) compares.  Only the last tile row of an image pays for this.
+template <typename Acc, int K, int TY, typename SC>
+__device__ __forceinline__ void scan_col_partial_up(Acc (&col)[TY], const SC &sc, bool clamp_first, int rows) {
+    Acc h[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) h[j] = Acc(0);
+    Acc y0 = Acc(0);
+    const int off = TY - rows;                   // direction positions before the image
+#pragma unroll
+    for (int p = 0; p < TY; p++) {
+        const int m = TY - 1 - p;
+        const int pr = p - off;                  // position counted from the entry row (negative: not in the image)
+        const Acc x = pr < 0 ? Acc(0) : col[m];
+        Acc acc = sc.b * x;
+#pragma unroll
+        for (int j = K - 1; j >= 0; j--) {
+            Acc g = h[j];
+            g = (clamp_first && pr <= j) ? (pr == 0 ? x : y0) : g;
+            acc = acc + sc.a[j] * g;
+        }
+#pragma unroll
+        for (int j = K - 1; j > 0; j--) h[j] = h[j - 1];
+        h[0] = acc;
+        y0 = (pr == 0) ? acc : y0;
+        col[m] = acc;
+    }
+}
+
 template <typename Acc>
 struct Vec4 {
     typedef Acc type __attribute__((ext_vector_type(4)));

@@ -88,7 +88,12 @@ class FusedEmu:
         last_lane_of = lambda tx: (NX_real - (MX - 1) * TX) // SEG - 1 if tx == MX - 1 else SEG - 1
         if NX != NX_real:
             img = np.concatenate([img, np.zeros((NY, NX - NX_real))], axis=1)
-        MY = NY // TY
+        NY_real = NY
+        MY = (NY_real + TY - 1) // TY                 # likewise the last tile row
+        NY = MY * TY
+        rows_of = lambda ty: NY_real - (MY - 1) * TY if ty == MY - 1 else TY
+        if NY != NY_real:
+            img = np.concatenate([img, np.zeros((NY - NY_real, NX))], axis=0)
         nx, ny = len(self.xs), len(self.ys)
         xt = np.zeros((nx, MX, K, NY))
         yt = np.zeros((ny, MY, K, NX))
@@ -111,12 +116,16 @@ class FusedEmu:
             return yt[j, ty - 1 if self.ys[j][0] else ty + 1]
 
         def yscan(tile, j, carry, ty):
-            # tile [TY, W]: scan along axis 0 == scan_tile over transposed rows
-            v = np.ascontiguousarray(tile.T)
+            # tile [TY, W]: scan along axis 0 == scan_tile over transposed rows; only the existing rows of a partial
+            # last tile row are scanned (an anticausal scan enters at the last of them)
+            rows = rows_of(ty)
+            v = np.ascontiguousarray(tile[:rows].T)
             b, a = self.yc[j]
             scan_tile(v, self.ys[j][0], b, a, K, clamped and yfirst(j, ty),
                       None if carry is None else [carry[r] for r in range(K)])
-            return v.T
+            out = tile.copy()
+            out[:rows] = v.T
+            return out
 
         def ytail(tile, j):
             return np.stack([tile[TY - 1 - r] if self.ys[j][0] else tile[r] for r in range(K)])
@@ -196,4 +205,4 @@ class FusedEmu:
                     c = None if yfirst(j, ty) else ycarry(j, ty)[:, tx * TX:(tx + 1) * TX]
                     t = yscan(t, j, c, ty)
                 out[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX] = t
-        return out[:, :NX_real]
+        return out[:NY_real, :NX_real]

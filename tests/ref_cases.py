@@ -155,6 +155,13 @@ FUSED_CASES = {
     "partial_x_only_causal_then_anti": dict(shape=(64, 272), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.6, 0.3]),
                                                                     (0, True, [0.9, 0.05]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
     "partial_sat": dict(shape=(64, 1936), scans=[(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], clamped=False),
+    # heights that are not multiples of 32: the last tile row is partial
+    "partial_y_gauss2_clamped": dict(shape=(100, 512), scans=xy_pm(GAUSS2), clamped=True),
+    "partial_xy_gauss3_clamped": dict(shape=(135, 240), scans=xy_pm(GAUSS3), clamped=True),
+    "partial_y_mixed_zero": dict(shape=(77, 256), scans=REFERENCE_TESTS["test_generic_xy"]["scans"], clamped=False),
+    "partial_y_tiny": dict(shape=(5, 32), scans=xy_pm(GAUSS2), clamped=True),
+    "partial_y_only_scans": dict(shape=(70, 272), scans=[(1, True, [0.5, 0.4, -0.1]), (1, False, [0.6, 0.3]),
+                                                         (1, True, [0.9, 0.05]), (1, False, [0.5, 0.4, -0.1])], clamped=True),
 }
 
 

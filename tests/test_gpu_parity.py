@@ -474,14 +474,25 @@ def test_partial_tiles_other_features():
     imgs, outs, (path, _) = _run((32, 64, 208), cfg["scans"])
     assert path == 3
     _check(imgs, outs, cfg["scans"], False)
-    imgs, outs, (path, tiles) = _run((1088, 1920), g2, clamped=True)
-    assert path == 3 and tiles[0] == 256
-    _check(imgs, outs, g2, True)
+    for shape in [(1088, 1920), (1080, 1920), (2160, 3840)]:       # 1080p / 4K frames: partial in x, in y, in both
+        imgs, outs, (path, tiles) = _run(shape, g2, clamped=True)
+        assert path == 3 and tiles == (256, 64)
+        _check(imgs, outs, g2, True)
+    # partial rows: int32 bit-exact with a clamped border, 3-D with partial x and y, two planes in place
+    sc = [(1, True, [1.0, 1.0]), (1, False, [1.0, 2.0, 1.0]), (0, False, [1.0, 1.0])]
+    imgs, outs, (path, _) = _run((75, 272), sc, dtype=np.int32, clamped=True, planes=2, inplace=True)
+    assert path == 3
+    _check(imgs, outs, sc, True)
+    imgs, outs, (path, _) = _run((32, 50, 208), cfg["scans"])
+    assert path == 3
+    _check(imgs, outs, cfg["scans"], False)
     # pointwise epilogue on a partial width
-    img = rc.random_image((64, 400), np.float32, 5)
-    with rfa.Plan((64, 400), g2, clamped=True, epilogue=(-1.0, 2.0, 0.25)) as plan:
-        out = plan.execute([torch.from_numpy(img).cuda()])[0].cpu().numpy()
-    assert rc.rel_err(out, _pointwise_want(img, g2, True, None, (-1.0, 2.0, 0.25))) < TOL
+    for shape, scans in [((64, 400), g2), ((45, 400), g2), ((45, 400), rc.xy_pm(rc.GAUSS3))]:    # order 3: re-read epilogue
+        img = rc.random_image(shape, np.float32, 5)
+        with rfa.Plan(shape, scans, clamped=True, prologue=(0.5, 0.125), epilogue=(-1.0, 2.0, 0.25)) as plan:
+            assert plan.path_name == "tiled_fused"
+            out = plan.execute([torch.from_numpy(img).cuda()])[0].cpu().numpy()
+        assert rc.rel_err(out, _pointwise_want(img, scans, True, (0.5, 0.125), (-1.0, 2.0, 0.25))) < TOL
 
 
 @pytest.mark.parametrize("world", [2, 3])
