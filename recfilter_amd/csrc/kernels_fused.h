@@ -24,7 +24,8 @@ struct FusedScan {
     Acc b;
     Acc a[kFusedMaxK];
     // x phase only; "direction coordinates": position p counts from where the scan enters
-    Acc R[kFusedSeg][kFusedMaxK];           // effect on position p of the state entering the segment
+    Acc R[kFusedMaxK][kFusedSeg];           // R[j][m]: effect on the segment's sample m (MEMORY order, so that
+                                            // neighbours pair up for packed FMAs) of component j of the entering state
     Acc P[4][kFusedMaxK][kFusedMaxK];       // segment exit-state transfer over 1, 2, 4, 8 segments
 };
 

@@ -93,7 +93,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                 DimTables<S> seg = build_dim_tables<S>({twin}, K, kFusedSeg, false);
                 const std::vector<S> &R = seg.P(0, 0, 0);
                 for (int p = 0; p < kFusedSeg; p++)
-                    for (int j = 0; j < K; j++) f.R[p][j] = table_to_acc<S, Acc>(R[(size_t)p * K + j]);
+                    for (int j = 0; j < K; j++)     // direction position p -> memory position inside the segment
+                        f.R[j][ts.causal ? p : kFusedSeg - 1 - p] = table_to_acc<S, Acc>(R[(size_t)p * K + j]);
                 std::vector<S> Pw = seg.A[0];
                 for (int step = 0; step < 4; step++) {
                     for (int r = 0; r < K; r++)
@@ -142,7 +143,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         std::vector<double> sr, sp;
         for (const auto &f : hxs) {
             for (int p = 0; p < kFusedSeg; p++)
-                for (int j = 0; j < K; j++) sr.push_back((double)f.R[p][j]);
+                for (int j = 0; j < K; j++) sr.push_back((double)f.R[j][f.causal ? p : kFusedSeg - 1 - p]);
             for (int step = 0; step < 4; step++)
                 for (int r = 0; r < K; r++)
                     for (int j = 0; j < K; j++) sp.push_back((double)f.P[step][r][j]);

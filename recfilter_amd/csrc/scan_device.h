@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels_fused.h"
 
 namespace rf {
@@ -90,13 +92,27 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
     for (int n = 0; n < NR; n++)
 #pragma unroll
         for (int j = 0; j < K; j++) C[n][j] = row_shift<CAUSAL, 1>(h[n][j]);
+    if constexpr (std::is_same<Acc, float>::value) {
+        // two neighbouring samples per instruction (v_pk_fma_f32); j outermost so that consecutive packed FMAs are
+        // independent (a dependent pair costs a wait state)
+        typedef float F2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int p = 0; p < kFusedSeg; p++) {
-        const int m = CAUSAL ? p : kFusedSeg - 1 - p;
+        for (int j = 0; j < K; j++)
 #pragma unroll
-        for (int n = 0; n < NR; n++)
+            for (int m = 0; m < kFusedSeg; m += 2)
 #pragma unroll
-            for (int j = 0; j < K; j++) v[n][m] = v[n][m] + sc.R[p][j] * C[n][j];
+                for (int n = 0; n < NR; n++) {
+                    const F2 r = F2{sc.R[j][m], sc.R[j][m + 1]} * F2{C[n][j], C[n][j]} + F2{v[n][m], v[n][m + 1]};
+                    v[n][m] = r.x;
+                    v[n][m + 1] = r.y;
+                }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kFusedSeg; m++)
+#pragma unroll
+            for (int n = 0; n < NR; n++)
+#pragma unroll
+                for (int j = 0; j < K; j++) v[n][m] = v[n][m] + sc.R[j][m] * C[n][j];
     }
 }
 
