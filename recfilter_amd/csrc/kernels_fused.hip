@@ -113,18 +113,20 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
     {
         const int cc = t & 63, rg = t >> 6;
         const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
-        const uint32_t rs4 = (uint32_t)(a.NX / 4);
-        const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
+        // byte offsets inside the tile, kept in 32 bits: scalar base + 32-bit vector offset addressing
+        const char *spb = reinterpret_cast<const char *>(sp);
+        const uint32_t off0 = (uint32_t)rg * a.row_bytes + (uint32_t)cc * 16u;
+        auto ld = [&](int row) { return *reinterpret_cast<const A4 *>(spb + (off0 + (uint32_t)row * a.row_bytes)); };
         A4 tmp[TY / 4];
         const bool chunk_in = cc <= 4 * last_lane + 3;        // this thread's 16-byte chunk exists in the image
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
         if (rows_here == TY) {
 #pragma unroll
-            for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? sp[off0 + (uint32_t)(4 * i) * rs4] : zero4;
+            for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? ld(4 * i) : zero4;
         } else {
 #pragma unroll
             for (int i = 0; i < TY / 4; i++)
-                tmp[i] = (chunk_in && rg + 4 * i < rows_here) ? sp[off0 + (uint32_t)(4 * i) * rs4] : zero4;
+                tmp[i] = (chunk_in && rg + 4 * i < rows_here) ? ld(4 * i) : zero4;
         }
         if constexpr (!PixelTraits<P>::is_integer) {
             if (a.pw_flags & 1) {
@@ -244,15 +246,20 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
         }
         {
             P *dp = dst + tile_off;
-            const uint32_t nxu = (uint32_t)a.NX;
+            // byte offsets kept in 32 bits (a tile spans TY rows: far below 4 GiB): scalar base + one 32-bit add per
+            // row instead of a 64-bit address computation per store
+            char *dpb = reinterpret_cast<char *>(dp);
+            const uint32_t row_bytes = a.row_bytes;
             if (t < 16 * (last_lane + 1)) {
                 if (rows_here == TY) {
 #pragma unroll
-                    for (int i = 0; i < TY; i++) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+                    for (int i = 0; i < TY; i++)
+                        *reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)) = PixelTraits<P>::store(col[i]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < TY; i++)
-                        if (i < rows_here) dp[(uint32_t)t + (uint32_t)i * nxu] = PixelTraits<P>::store(col[i]);
+                        if (i < rows_here)
+                            *reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)) = PixelTraits<P>::store(col[i]);
                 }
             }
         }

@@ -59,8 +59,10 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x part: segment lane, row slot
     const int e = (swz_chunk(t >> 2) << 2) | (t & 3);          // y part: swizzled column offset
     const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
-    const uint32_t rs4 = (uint32_t)(a.NX / 4);
-    const uint32_t off0 = (uint32_t)rg * rs4 + (uint32_t)cc;
+    // byte offsets inside the tile, kept in 32 bits: scalar base + 32-bit vector offset addressing
+    const char *spb = reinterpret_cast<const char *>(sp);
+    const uint32_t off0 = (uint32_t)rg * a.row_bytes + (uint32_t)cc * 16u;
+    auto ld = [&](int row) { return *reinterpret_cast<const A4 *>(spb + (off0 + (uint32_t)row * a.row_bytes)); };
     const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (cc <= 4 * a.last_lane + 3);
@@ -77,11 +79,11 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
         const int r0 = kTailRows * half + rg;
         if (rows_here == TY) {
 #pragma unroll
-            for (int i = 0; i < NL; i++) pre[i] = chunk_in ? sp[off0 + (uint32_t)(kTailRows * half + 4 * i) * rs4] : zero4;
+            for (int i = 0; i < NL; i++) pre[i] = chunk_in ? ld(kTailRows * half + 4 * i) : zero4;
         } else {
 #pragma unroll
             for (int i = 0; i < NL; i++)
-                pre[i] = (chunk_in && r0 + 4 * i < rows_here) ? sp[off0 + (uint32_t)(kTailRows * half + 4 * i) * rs4] : zero4;
+                pre[i] = (chunk_in && r0 + 4 * i < rows_here) ? ld(kTailRows * half + 4 * i) : zero4;
         }
     };
     load_half(0);

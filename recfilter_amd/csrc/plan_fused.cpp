@@ -239,6 +239,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     fbase.NX = NX; fbase.NY = NY; fbase.NZ = NZ; fbase.MX = MX; fbase.MY = MY; fbase.nx = nx; fbase.ny = ny;
     fbase.NXP = NXP; fbase.last_lane = TVx / kFusedSeg - 1;
     fbase.NYP = NYP; fbase.last_rows = TVy;
+    fbase.row_bytes = (uint32_t)(NX * (int64_t)sizeof(P));
     fbase.clamped = plan->clamped ? 1 : 0;
     fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
     fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;

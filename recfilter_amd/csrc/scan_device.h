@@ -43,14 +43,36 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
         for (int j = 0; j < K; j++) h[n][j] = first_lane ? carry[n][j] : Acc(0);
         y0[n] = Acc(0);
     }
+    // feed-forward first, two samples per instruction for f32 (v_pk_mul_f32); the clamped prologue still needs the
+    // unscaled first sample
+    constexpr int m_first = CAUSAL ? 0 : kFusedSeg - 1;
+    Acc x_first[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) x_first[n] = v[n][m_first];
+    if constexpr (std::is_same<Acc, float>::value) {
+        typedef float F2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int m = 0; m < kFusedSeg; m += 2)
+#pragma unroll
+            for (int n = 0; n < NR; n++) {
+                const F2 r = F2{sc.b, sc.b} * F2{v[n][m], v[n][m + 1]};
+                v[n][m] = r.x;
+                v[n][m + 1] = r.y;
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kFusedSeg; m++)
+#pragma unroll
+            for (int n = 0; n < NR; n++) v[n][m] = sc.b * v[n][m];
+    }
     // 1. segment-local recurrence (exact for the first lane, which owns the tile's carry)
 #pragma unroll
     for (int p = 0; p < kFusedSeg; p++) {
         const int m = CAUSAL ? p : kFusedSeg - 1 - p;
 #pragma unroll
         for (int n = 0; n < NR; n++) {
-            Acc x = v[n][m];
-            Acc acc = sc.b * x;
+            const Acc x = x_first[n];       // only read at p == 0
+            Acc acc = v[n][m];
             // oldest tap first: the newest output h[0] enters last, one dependent FMA per sample
 #pragma unroll
             for (int j = K - 1; j >= 0; j--) {
@@ -124,11 +146,26 @@ __device__ __forceinline__ void scan_col(Acc (&col)[TY], const SC &sc, bool clam
 #pragma unroll
     for (int j = 0; j < K; j++) h[j] = carry[j];
     Acc y0 = Acc(0);
+    // feed-forward first, two rows per instruction for f32 (v_pk_mul_f32); the clamped prologue still needs the
+    // unscaled first sample
+    const Acc x_first = col[CAUSAL ? 0 : TY - 1];
+    if constexpr (std::is_same<Acc, float>::value) {
+        typedef float F2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < TY; i += 2) {
+            const F2 r = F2{sc.b, sc.b} * F2{col[i], col[i + 1]};
+            col[i] = r.x;
+            col[i + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TY; i++) col[i] = sc.b * col[i];
+    }
 #pragma unroll
     for (int p = 0; p < TY; p++) {
         const int m = CAUSAL ? p : TY - 1 - p;
-        Acc x = col[m];
-        Acc acc = sc.b * x;
+        const Acc x = x_first;             // only read at p == 0
+        Acc acc = col[m];
         // oldest tap first: the newest output h[0] enters last, one dependent FMA per sample
 #pragma unroll
         for (int j = K - 1; j >= 0; j--) {
