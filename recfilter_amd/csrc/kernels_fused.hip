@@ -14,14 +14,12 @@
 //            LDS reads/writes are ds_read/write_b128, conflict-free thanks to the swizzle.
 //   y phase  thread = column; the TY samples of the column sit in registers, every y scan is
 //            a serial recurrence up or down the registers (no LDS traffic between scans)
-//   pass 1   writes only the k-sample tails of every scan (lib/split.cpp:256-499)
-//   pass 2   injects the completed carries (lib/split.cpp:1008-1130) and stores the tile,
-//            256 B per wave instruction
+//   store    the register column goes straight to HBM, 256 B per wave instruction, after the fused pointwise
+//            epilogue if there is one
 //
-// Between the passes: the x carry recurrence (generic_carry_scan_kernel over the x tails), the
-// cross-dimension residual of lib/split.cpp:1215-1633 split into tau_kernel (run the tile-local
-// y scans on the completed x-carry strips, keep their tails) and carry_block_kernel (kernels_carry.hip:
-// y carry recurrence with the residual sum_o G[x][o] * tau[o] folded into the tail it starts from).
+// This file holds pass 2, the final correction pass (lib/split.cpp:1008-1130, 1647-1780).  Pass 1 (tail extraction as
+// a contraction) and the completion of the y tails are in kernels_tails.hip, the carry recurrences in
+// kernels_carry.hip; plan_fused.cpp strings them together.
 #include "kernels.h"
 #include "kernels_fused.h"
 #include "scan_device.h"

@@ -1,3 +1,4 @@
+"""Run one of tests/ref_cases.FUSED_CASES on the GPU and show where it differs from the oracle (debugging aid)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

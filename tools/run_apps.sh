@@ -1,3 +1,6 @@
+#!/bin/bash
+# Regenerates profiles/r1/apps: every app of the reference at 4096^2 and 16384^2, the audio sweeps at 10 Mi samples and the
+# 64..4096 width sweep (run on a GPU box; results land in gpurun_out/apps).
 mkdir -p gpurun_out/apps
 for w in 4096 16384; do
   for app in summed_table gaussian_3xy gaussian_1xy_2xy gaussian_1xy_1xy_1xy gaussian_1xy_2x_2y gaussian_3x_3y bicubic biquintic_overlapped biquintic_cascaded usm_naive usm_optimized; do
