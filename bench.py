@@ -175,6 +175,17 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": pmc_traffic(dom, args.workload, shape),
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg}
+        # device-to-device copy of the same image with torch's own kernel, timed with HIP events: what a plain
+        # read-once/write-once pass reaches on this box (SURVEY 8d asks for a measured stream-copy ceiling)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outputs[0].copy_(inputs[0])
+        e0.record()
+        for _ in range(5):
+            outputs[0].copy_(inputs[0])
+        e1.record()
+        torch.cuda.synchronize()
+        copy_ms = e0.elapsed_time(e1) / 5
+        roofline["copy_ceiling_gbps"] = round(2 * 4 * (samples_local // planes) / (copy_ms * 1e-3) / 1e9, 1)
         if world > 1:
             plan.close()
 
