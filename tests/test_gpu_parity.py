@@ -501,3 +501,24 @@ def test_sharded_rows_with_partial_width(world):
     full, got, (path, nex) = _run_sharded((64 * world, 464), scans, True, world, path=0)
     assert path == 3 and nex == 2
     _check(full, got, scans, True)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_filters_random_shapes_partial_tiles(seed):
+    """Arbitrary heights and widths that are multiples of 16: partial last tiles in x, y or both; float filters against
+    the oracle, every third case an integer filter bit-exact."""
+    rng = np.random.default_rng(3000 + seed)
+    shape = (int(rng.integers(1, 200)), 16 * int(rng.integers(1, 50)))
+    clamped = bool(rng.integers(0, 2))
+    if seed % 3 == 2:
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(1, 4))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.integers(1, 3))] + [float(rng.integers(-2, 3)) for _ in range(k)]))
+        imgs, outs, (path, _) = _run(shape, scans, dtype=np.int32, clamped=clamped, seed=seed, planes=2)
+    else:
+        scans = _random_filter(rng, 2)
+        imgs, outs, (path, _) = _run(shape, scans, clamped=clamped, seed=seed)
+    assert path == 3, (shape, scans)
+    _check(imgs, outs, scans, clamped)
