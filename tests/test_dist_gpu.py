@@ -1,0 +1,68 @@
+"""Two real processes drive the product's GPU plans through recfilter_amd.dist.ShardedFilter.
+
+The pool's GPU boxes have one device, so both ranks share cuda:0 and the process group is gloo (RCCL refuses two
+ranks on one device); everything else -- the HIP kernels, the stepping API, the exchange buffers, the all-gather
+of device tensors -- is the code path `bench.py --gpus N` runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, shape, scans, clamped, planes, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    import ref_cases as rc
+    from recfilter_amd.dist import ShardedFilter
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = [rc.random_image(shape, np.float32, 91 + p) for p in range(planes)]
+        n = shape[0] // world
+        local = (n,) + tuple(shape[1:])
+        inputs = [torch.from_numpy(np.ascontiguousarray(f[rank * n:(rank + 1) * n])).cuda() for f in full]
+        outputs = [torch.empty_like(t) for t in inputs]
+        filt = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world)
+        assert filt.plan.path_name == "tiled_fused"
+        for _ in range(2):                     # the second execute reuses the exchange buffers
+            filt.execute(inputs, outputs)
+        torch.cuda.synchronize()
+        for p in range(planes):
+            want = oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[rank * n:(rank + 1) * n]
+            err = rc.rel_err(outputs[p].cpu().numpy(), want)
+            assert err < 1e-4, f"rank {rank} plane {p}: rel err {err}"
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d"])
+def test_two_processes_one_gpu(case, tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    import ref_cases as rc
+    if case == "rows_2d":
+        shape, scans, clamped, planes = (256, 768), rc.xy_pm(rc.GAUSS2), True, 2
+    else:
+        shape, scans, clamped, planes = (32, 96, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
