@@ -17,6 +17,8 @@
 // All scans of the dimension run inside ONE launch (a workgroup owns its lines completely, so a
 // barrier orders scan s+1's chaining loads after scan s's stores).  Results are identical to the
 // serial recurrence up to f32 rounding; integer pixel types stay bit-exact (ring arithmetic).
+#include <cstdlib>
+
 #include "kernels.h"
 #include "kernels_fused.h"
 
@@ -184,6 +186,170 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     }
 }
 
+// completes one scan of the pair in registers (the chaining terms must already be in t) and stores it
+template <typename Acc, int K, bool CAUSAL>
+__device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][K], int s, const CarryGeom &g, Acc *__restrict__ tails,
+                                          const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
+                                          Acc (*exits)[kCarryLines][K], int ln, int ch, int n_chunks, int t0, int nvalid,
+                                          uint32_t line, bool line_ok) {
+    const int M = g.M;
+    const uint32_t L = g.lines;
+    const uint32_t tile_stride = (uint32_t)K * L;
+    constexpr bool causal = CAUSAL;     // compile time: the owned tiles stay statically indexed registers
+    const Acc *Am = Atab + s * K * K;
+    const Acc *ACm = AC + s * K * K;
+    Acc x[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) x[r] = Acc(0);
+    // chunk-local recurrence in scan direction, zero entering state
+#pragma unroll
+    for (int p = 0; p < kCarryMaxC; p++) {
+        const int ii = causal ? p : kCarryMaxC - 1 - p;
+        if (ii < nvalid) {
+            matvec_acc<Acc, K>(Am, x, t[ii]);
+#pragma unroll
+            for (int r = 0; r < K; r++) x[r] = t[ii][r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < K; r++) exits[ch][ln][r] = x[r];
+    __syncthreads();
+    // state entering this chunk: the chunks before it in scan direction (all of them full chunks of C tiles)
+    Acc inc[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) inc[r] = Acc(0);
+    if (causal) {
+#pragma unroll 1
+        for (int c = 0; c < ch; c++) {
+            Acc nx[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) nx[r] = exits[c][ln][r];
+            matvec_acc<Acc, K>(ACm, inc, nx);
+#pragma unroll
+            for (int r = 0; r < K; r++) inc[r] = nx[r];
+        }
+    } else {
+#pragma unroll 1
+        for (int c = n_chunks - 1; c > ch; c--) {
+            Acc nx[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) nx[r] = exits[c][ln][r];
+            // the chunk at the high end may be partial or empty: an empty one hands over nothing and the
+            // transfer across the partial one is folded into its own exit state, so AC applies from the
+            // second chunk (in scan direction) on
+            const int nv_c = M - c * C;
+            if (nv_c >= C) matvec_acc<Acc, K>(ACm, inc, nx);
+#pragma unroll
+            for (int r = 0; r < K; r++) inc[r] = nx[r];
+        }
+    }
+    // propagate through the chunk and store
+    const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
+#pragma unroll
+    for (int p = 0; p < kCarryMaxC; p++) {
+        const int ii = causal ? p : kCarryMaxC - 1 - p;
+        if (ii < nvalid) {
+            Acc y[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) y[r] = Acc(0);
+            matvec_acc<Acc, K>(Am, inc, y);
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                inc[r] = y[r];
+                t[ii][r] = t[ii][r] + y[r];
+                if (line_ok) tails[base + (uint32_t)(t0 + ii) * tile_stride + (uint32_t)r * L] = t[ii][r];
+            }
+        }
+    }
+}
+
+// ---- two scans of one dimension in one pass over registers -----------------------------------------------------
+// The common case -- a causal/anticausal pair (or any two scans) of a dimension whose tiles fit one block of chunks --
+// gets a kernel without the second scan's trip through memory.  Every thread owns the SAME C tiles (memory order)
+// of its line for both scans, requests both scans' tails up front, completes the first scan, and takes the chaining
+// terms of the second scan (create_tail_residual_term, lib/split.cpp:912-1004) from its own registers plus one
+// halo tile from each neighbouring chunk (through LDS).  The general kernel above re-reads the first scan's
+// completed tails from memory behind a barrier instead.
+template <typename Acc, int K>
+__global__ void __launch_bounds__(kCarryLines * kCarryChunks)
+carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
+                  const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C) {
+    __shared__ Acc exits[kCarryChunks][kCarryLines][K];
+    __shared__ Acc edge[kCarryChunks][2][kCarryLines][K];      // first / last completed tail of every chunk (scan s0)
+
+    const int ln = threadIdx.x & (kCarryLines - 1);
+    const int ch = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kCarryLines);    // wave-uniform
+    const uint32_t L = g.lines;
+    const uint32_t line_raw = blockIdx.x * kCarryLines + ln;
+    const bool line_ok = line_raw < L;
+    const uint32_t line = line_ok ? line_raw : L - 1;
+    const int M = g.M;
+    const uint32_t tile_stride = (uint32_t)K * L;
+    const int n_chunks = (int)blockDim.x / kCarryLines;
+    const int t0 = ch * C;                                   // first owned tile (memory order)
+    int nvalid = M - t0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);     // wave-uniform
+
+    Acc ta[kCarryMaxC][K], tb[kCarryMaxC][K];                // owned tiles of scan s0 / s0+1
+    auto load_scan = [&](Acc (&t)[kCarryMaxC][K], int s) {
+        const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
+#pragma unroll
+        for (int ii = 0; ii < kCarryMaxC; ii++) {
+#pragma unroll
+            for (int r = 0; r < K; r++) t[ii][r] = Acc(0);
+            if (ii < nvalid) {
+#pragma unroll
+                for (int r = 0; r < K; r++) t[ii][r] = tails[base + (uint32_t)(t0 + ii) * tile_stride + (uint32_t)r * L];
+            }
+        }
+    };
+    load_scan(ta, s0);
+    load_scan(tb, s0 + 1);
+
+    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, true>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    else                            pair_run_scan<Acc, K, false>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+
+    // ---- chaining of scan s0+1 on the completed scan s0 ----
+    {
+        const int q = s0, s = s0 + 1;
+        const bool qc = ((g.causal_mask >> q) & 1u) != 0;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            edge[ch][0][ln][r] = ta[0][r];
+            Acc last = ta[0][r];
+#pragma unroll
+            for (int ii = 1; ii < kCarryMaxC; ii++) last = (ii < nvalid) ? ta[ii][r] : last;
+            edge[ch][1][ln][r] = last;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < kCarryMaxC; ii++) {
+            if (ii < nvalid) {
+                const int tt = t0 + ii;
+                const int v = ((tt == 0 && g.first_is_border) ? 1 : 0) | ((tt == M - 1 && g.last_is_border) ? 2 : 0);
+                const bool q_first = qc ? (tt == 0) : (tt == M - 1);
+                Acc c[K];
+                if (q_first) {
+#pragma unroll
+                    for (int o = 0; o < K; o++) c[o] = incoming[(uint32_t)(q * K + o) * L + line];
+                } else if (qc) {           // carry of a causal scan comes from the tile before
+#pragma unroll
+                    for (int o = 0; o < K; o++) c[o] = (ii > 0) ? ta[ii > 0 ? ii - 1 : 0][o] : edge[ch - 1][1][ln][o];
+                } else {                   // ... of an anticausal scan from the tile after
+#pragma unroll
+                    for (int o = 0; o < K; o++)
+                        c[o] = (ii + 1 < nvalid) ? ta[ii + 1 < kCarryMaxC ? ii + 1 : 0][o] : edge[ch + 1][0][ln][o];
+                }
+                const Acc *Wm = Wtab + (((v * g.n_scans + q) * g.n_scans + s) * K) * K;
+                matvec_acc<Acc, K>(Wm, c, tb[ii]);
+            }
+        }
+    }
+    __syncthreads();          // exits[] is reused by the second scan
+    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, true>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    else                                  pair_run_scan<Acc, K, false>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+}
+
 // Row chaining for a long 1-D signal folded into NY rows of MX tiles (plan_fused.cpp, "chained rows"): the
 // blocked scan above completes every row with a zero entering state; this kernel walks the rows' exit states
 // (NY k-vectors -- tiny) and produces the state entering every row.  One wave; lane l owns rows
@@ -283,6 +449,17 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
     int n_chunks = carry_chunk_count(a.M, a.g.lines, C, K);
     const unsigned threads = (unsigned)(kCarryLines * n_chunks);
+    // two order-2 scans, nothing to send, every line's tiles in one block of chunks: the register-chained pair kernel
+    // (order 1 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
+    if constexpr (sizeof(Acc) == 4) {
+        if (s_end - s_begin == 2 && send == nullptr && K == 2 && (int64_t)n_chunks * C >= a.M &&
+            getenv("RF_CARRY_NO_PAIR") == nullptr) {
+            hipLaunchKernelGGL((carry_pair_kernel<Acc, 2>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+                               (const Acc *)a.incoming, a.W, a.A, AC, C);
+            RF_HIP_CHECK(hipGetLastError());
+            return RF_OK;
+        }
+    }
 #define RF_CASE(KK, MC) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK, MC, (KK <= 3 ? kCarryChunks : kCarryChunksHigh)>), dim3(grid), dim3(threads), 0, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, a.W, a.A, AC, send, C); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
     RF_CASE(1, kCarryMaxC) RF_CASE(2, kCarryMaxC) RF_CASE(3, kCarryMaxC)
     RF_CASE(4, kCarryMaxCHigh) RF_CASE(5, kCarryMaxCHigh) RF_CASE(6, kCarryMaxCHigh) RF_CASE(7, kCarryMaxCHigh)
