@@ -187,8 +187,18 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
 }
 
 // completes one scan of the pair in registers (the chaining terms must already be in t) and stores it
-template <typename Acc, int K, bool CAUSAL>
-__device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][K], int s, const CarryGeom &g, Acc *__restrict__ tails,
+// (the owned-tile arrays are [16][KP] with KP = max(K, 2): as [16][1] the compiler turns them into one 16-wide vector
+// and every guarded element update into a whole-vector copy through scratch)
+template <typename Acc, int K, int KP>
+__device__ __forceinline__ void pair_matvec(const Acc *__restrict__ m, const Acc (&x)[K], Acc (&y)[KP]) {
+#pragma unroll
+    for (int r = 0; r < K; r++)
+#pragma unroll
+        for (int j = 0; j < K; j++) y[r] = y[r] + m[r * K + j] * x[j];
+}
+
+template <typename Acc, int K, int KP, bool CAUSAL>
+__device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, const CarryGeom &g, Acc *__restrict__ tails,
                                           const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
                                           Acc (*exits)[kCarryLines][K], int ln, int ch, int n_chunks, int t0, int nvalid,
                                           uint32_t line, bool line_ok) {
@@ -206,7 +216,7 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][K], int s, co
     for (int p = 0; p < kCarryMaxC; p++) {
         const int ii = causal ? p : kCarryMaxC - 1 - p;
         if (ii < nvalid) {
-            matvec_acc<Acc, K>(Am, x, t[ii]);
+            pair_matvec<Acc, K, KP>(Am, x, t[ii]);
 #pragma unroll
             for (int r = 0; r < K; r++) x[r] = t[ii][r];
         }
@@ -290,13 +300,14 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     int nvalid = M - t0;
     nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);     // wave-uniform
 
-    Acc ta[kCarryMaxC][K], tb[kCarryMaxC][K];                // owned tiles of scan s0 / s0+1
-    auto load_scan = [&](Acc (&t)[kCarryMaxC][K], int s) {
+    constexpr int KP = K < 2 ? 2 : K;
+    Acc ta[kCarryMaxC][KP], tb[kCarryMaxC][KP];              // owned tiles of scan s0 / s0+1
+    auto load_scan = [&](Acc (&t)[kCarryMaxC][KP], int s) {
         const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
 #pragma unroll
         for (int ii = 0; ii < kCarryMaxC; ii++) {
 #pragma unroll
-            for (int r = 0; r < K; r++) t[ii][r] = Acc(0);
+            for (int r = 0; r < KP; r++) t[ii][r] = Acc(0);
             if (ii < nvalid) {
 #pragma unroll
                 for (int r = 0; r < K; r++) t[ii][r] = tails[base + (uint32_t)(t0 + ii) * tile_stride + (uint32_t)r * L];
@@ -306,8 +317,8 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     load_scan(ta, s0);
     load_scan(tb, s0 + 1);
 
-    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, true>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
-    else                            pair_run_scan<Acc, K, false>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, KP, true>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    else                            pair_run_scan<Acc, K, KP, false>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
 
     // ---- chaining of scan s0+1 on the completed scan s0 ----
     {
@@ -341,13 +352,13 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
                         c[o] = (ii + 1 < nvalid) ? ta[ii + 1 < kCarryMaxC ? ii + 1 : 0][o] : edge[ch + 1][0][ln][o];
                 }
                 const Acc *Wm = Wtab + (((v * g.n_scans + q) * g.n_scans + s) * K) * K;
-                matvec_acc<Acc, K>(Wm, c, tb[ii]);
+                pair_matvec<Acc, K, KP>(Wm, c, tb[ii]);
             }
         }
     }
     __syncthreads();          // exits[] is reused by the second scan
-    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, true>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
-    else                                  pair_run_scan<Acc, K, false>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, KP, true>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    else                                  pair_run_scan<Acc, K, KP, false>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
 }
 
 // Row chaining for a long 1-D signal folded into NY rows of MX tiles (plan_fused.cpp, "chained rows"): the
@@ -449,13 +460,15 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
     int n_chunks = carry_chunk_count(a.M, a.g.lines, C, K);
     const unsigned threads = (unsigned)(kCarryLines * n_chunks);
-    // two order-2 scans, nothing to send, every line's tiles in one block of chunks: the register-chained pair kernel
-    // (order 1 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
+    // two scans of order <= 2, nothing to send, every line's tiles in one block of chunks: the register-chained pair kernel
+    // (order 3 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
     if constexpr (sizeof(Acc) == 4) {
-        if (s_end - s_begin == 2 && send == nullptr && K == 2 && (int64_t)n_chunks * C >= a.M &&
+        if (s_end - s_begin == 2 && send == nullptr && K <= 2 && (int64_t)n_chunks * C >= a.M &&
             getenv("RF_CARRY_NO_PAIR") == nullptr) {
-            hipLaunchKernelGGL((carry_pair_kernel<Acc, 2>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
-                               (const Acc *)a.incoming, a.W, a.A, AC, C);
+            if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+                                           (const Acc *)a.incoming, a.W, a.A, AC, C);
+            else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+                                           (const Acc *)a.incoming, a.W, a.A, AC, C);
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
         }
