@@ -170,6 +170,16 @@ int rf_integral_image_coeff(int n, float *coeff_out /* n+1 */);
 int rf_overlap_feedback_coeff(const float *a, int na, const float *b, int nb, float *c_out /* na+nb */);
 int rf_gaussian_box_filter(int k, float sigma, int *width_out);
 
+/* ---- finite differences of summed-area tables (iterated box filters) --------------------- */
+/* The consumer of the reference's box-filter apps (apps/box/box_filter.h:36-39, 128-139; apps/DoG/diff_gauss.cpp:
+ * 132-150): along every dimension d, order[d] times,
+ *     out(i) = (s(min(i + radius, N-1)) - s(max(i - radius - 1, 0))) / (2*radius + 1)
+ * with s a summed-area table of matching order (rf_integral_image_coeff).  The nested clamps are evaluated exactly
+ * as written there.  order[d] in 0..2.  One elementwise kernel over dense x-fastest device planes; float pixel types.
+ * in == out is NOT allowed (the operator gathers). */
+int rf_box_difference(const void *in, void *out, int ndim, const int64_t *extent, int dtype, int radius,
+                      const int32_t *order, void *stream);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 const char *rf_last_error_string(void);
 const char *rf_version(void);

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "rf_plan_exchange_bytes",
     "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_finish",
     "rf_plan_table", "rf_plan_debug_buffer", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
-    "rf_gaussian_box_filter", "rf_last_error_string", "rf_version", "rf_device_count",
+    "rf_gaussian_box_filter", "rf_box_difference", "rf_last_error_string", "rf_version", "rf_device_count",
 ]
 
 
@@ -117,6 +117,8 @@ def lib() -> ctypes.CDLL:
     L.rf_integral_image_coeff.argtypes = [ctypes.c_int, fp]
     L.rf_overlap_feedback_coeff.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, fp]
     L.rf_gaussian_box_filter.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
+    L.rf_box_difference.argtypes = [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_int32), vp]
     L.rf_last_error_string.restype = ctypes.c_char_p
     L.rf_version.restype = ctypes.c_char_p
     _lib = L

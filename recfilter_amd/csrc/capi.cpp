@@ -267,6 +267,28 @@ int rf_gaussian_box_filter(int k, float sigma, int *width_out) {
     return RF_OK;
 }
 
+int rf_box_difference(const void *in, void *out, int ndim, const int64_t *extent, int dtype, int radius, const int32_t *order,
+                      void *stream) {
+    if (!in || !out || !extent || !order) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    if (in == out) { set_error("box_difference gathers: out must differ from in"); return RF_ERR_INVALID_ARG; }
+    if (ndim < 1 || ndim > RF_MAX_DIMS) { set_error("ndim must be 1..%d", RF_MAX_DIMS); return RF_ERR_INVALID_ARG; }
+    if (radius < 0) { set_error("radius must be >= 0"); return RF_ERR_INVALID_ARG; }
+    BoxDiffArgs a{};
+    for (int d = 0; d < RF_MAX_DIMS; d++) {
+        a.n[d] = d < ndim ? extent[d] : 1;
+        a.order[d] = d < ndim ? order[d] : 0;
+        if (a.n[d] < 1) { set_error("extent[%d] must be positive", d); return RF_ERR_INVALID_ARG; }
+        if (a.order[d] < 0 || a.order[d] > 2) { set_error("order[%d] must be 0..2", d); return RF_ERR_INVALID_ARG; }
+    }
+    a.radius = radius;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (this library has no CPU fallback)"); return RF_ERR_HIP; }
+    if (dtype == RF_F32) return launch_box_difference<float>((const float *)in, (float *)out, a, (hipStream_t)stream);
+    if (dtype == RF_F64) return launch_box_difference<double>((const double *)in, (double *)out, a, (hipStream_t)stream);
+    set_error("box_difference needs a floating-point pixel type");
+    return RF_ERR_UNSUPPORTED;
+}
+
 const char *rf_last_error_string(void) { return g_last_error.c_str(); }
 const char *rf_version(void) { return "recfilter_amd 0.1 (gfx950)"; }
 

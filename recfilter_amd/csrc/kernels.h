@@ -36,6 +36,15 @@ int launch_untiled_scan(const P *in, P *out, LineGeom g, const DevScan<typename 
 template <typename P>
 int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream);
 
+// ---- finite differences of summed-area tables (rf_box_difference) ----
+struct BoxDiffArgs {
+    int64_t n[RF_MAX_DIMS];       // extents, x first (1 for missing dimensions)
+    int32_t order[RF_MAX_DIMS];   // 0..2 applications per dimension
+    int32_t radius;
+};
+template <typename P>
+int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t stream);
+
 // ---- generic tiled path, any tile width T <= kGenericMaxTile dividing n -------------------
 constexpr int kGenericMaxTile = 128;
 

@@ -87,6 +87,50 @@ pointwise_kernel(const P *f, const P *x, P *dst, int64_t n, P c0, P c1, P c2) {
 }
 
 // ---------------------------------------------------------------------------------------
+// rf_box_difference: out = D_z^oz D_y^oy D_x^ox s with D(i) = (s(min(i+B, N-1)) - s(max(i-B-1, 0))) / (2B+1) and the
+// nested clamps of apps/box/box_filter.h:128-139 kept as written.  Every application of D doubles the number of
+// taps: per dimension up to four (position, sign) pairs, combined as a product over the dimensions.  A gather over a
+// summed-area table: the taps of neighbouring outputs are neighbouring table entries, so the reads coalesce and hit
+// L2; the kernel is bound by its one write per sample.
+template <typename P>
+__global__ void __launch_bounds__(kBlock)
+box_difference_kernel(const P *__restrict__ in, P *__restrict__ out, BoxDiffArgs a) {
+    const int64_t total = a.n[0] * a.n[1] * a.n[2];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t B = a.radius;
+    P scale = P(1);
+    for (int d = 0; d < RF_MAX_DIMS; d++)
+        for (int o = 0; o < a.order[d]; o++) scale = scale * P(2 * B + 1);
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += stride) {
+        const int64_t c0 = idx % a.n[0], c1 = (idx / a.n[0]) % a.n[1], c2 = idx / (a.n[0] * a.n[1]);
+        // tap k of a dimension: order 0 -> the sample itself; order 1 -> (up, dn); order 2 -> (up up, dn up, up dn, dn dn)
+        // with signs (+), (+,-), (+,-,-,+)
+        auto tap = [&](int64_t c, int64_t N, int order, int k) -> int64_t {
+            auto up = [&](int64_t i) { return i + B < N - 1 ? i + B : N - 1; };
+            auto dn = [&](int64_t i) { return i - B - 1 > 0 ? i - B - 1 : (int64_t)0; };
+            if (order == 0) return c;
+            if (order == 1) return k == 0 ? up(c) : dn(c);
+            const int64_t first = (k & 2) ? dn(c) : up(c);          // inner application
+            return (k & 1) ? dn(first) : up(first);                  // outer application
+        };
+        P acc = P(0);
+        for (int kz = 0; kz < (1 << a.order[2]); kz++) {
+            const int64_t p2 = tap(c2, a.n[2], a.order[2], kz);
+            for (int ky = 0; ky < (1 << a.order[1]); ky++) {
+                const int64_t p1 = tap(c1, a.n[1], a.order[1], ky);
+                for (int kx = 0; kx < (1 << a.order[0]); kx++) {
+                    const int64_t p0 = tap(c0, a.n[0], a.order[0], kx);
+                    const int neg = ((kx == 1 || kx == 2) ? 1 : 0) ^ ((ky == 1 || ky == 2) ? 1 : 0) ^ ((kz == 1 || kz == 2) ? 1 : 0);
+                    const P v = in[(p2 * a.n[1] + p1) * a.n[0] + p0];
+                    acc = neg ? acc - v : acc + v;
+                }
+            }
+        }
+        out[idx] = acc / scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Generic tiled path.  tails index: ((s*M + t)*k + r)*lines + line
 template <typename Acc>
 __device__ __forceinline__ int64_t tail_idx(const GenericDimArgs<Acc> &a, int s, int t, int r, int64_t line) {
@@ -275,6 +319,19 @@ int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, doubl
 }
 template int launch_pointwise<float>(const float *, const float *, float *, int64_t, double, double, double, hipStream_t);
 template int launch_pointwise<double>(const double *, const double *, double *, int64_t, double, double, double, hipStream_t);
+
+template <typename P>
+int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t stream) {
+    const int64_t total = a.n[0] * a.n[1] * a.n[2];
+    if (total <= 0) return RF_OK;
+    const int64_t want = (total + kBlock - 1) / kBlock;
+    const unsigned blocks = (unsigned)(want < 256 * 64 ? want : 256 * 64);
+    hipLaunchKernelGGL((box_difference_kernel<P>), dim3(blocks), dim3(kBlock), 0, stream, in, out, a);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+template int launch_box_difference<float>(const float *, float *, const BoxDiffArgs &, hipStream_t);
+template int launch_box_difference<double>(const double *, double *, const BoxDiffArgs &, hipStream_t);
 
 // explicit instantiations ----------------------------------------------------------------
 #define RF_INSTANTIATE_PIXEL(P)                                                                                    \

@@ -234,3 +234,20 @@ def gaussian_box_filter(k: int, sigma: float) -> int:
     w = ctypes.c_int()
     capi.check(capi.lib().rf_gaussian_box_filter(int(k), float(sigma), ctypes.byref(w)))
     return int(w.value)
+
+
+def box_difference(table, radius: int, order: Sequence[int], out=None, stream=None):
+    """rf_box_difference: finite differences that turn a (higher-order) summed-area table into an iterated box filter
+    (apps/box/box_filter.h).  `table` is a device tensor (..., y, x); `order` is per dimension in (x, y, z) order."""
+    import torch
+    if out is None:
+        out = torch.empty_like(table)
+    shape = tuple(table.shape)
+    ext = (ctypes.c_int64 * len(shape))(*reversed(shape))
+    order = list(order) + [0] * (len(shape) - len(order))
+    ords = (ctypes.c_int32 * len(shape))(*order[:len(shape)])
+    if not table.is_cuda or not table.is_contiguous() or not out.is_contiguous():
+        raise ValueError("box_difference needs contiguous device tensors")
+    capi.check(capi.lib().rf_box_difference(ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(out.data_ptr()), len(shape), ext,
+                                            _dtype_code(table.dtype), int(radius), ords, Plan._stream(stream)))
+    return out

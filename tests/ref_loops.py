@@ -89,3 +89,18 @@ def clamped_xy_loops(image: np.ndarray, coeff) -> np.ndarray:
             ref[h - 1 - y, x] = (b0 * ref[h - 1 - y, x] + a1 * ref[h - 1 - max(y - 1, 0), x]
                                  + a2 * ref[h - 1 - max(y - 2, 0), x])
     return ref
+
+
+def box_difference(table, radius, order):
+    """apps/box/box_filter.h:36-39,128-139 restated: along every dimension d (order given in x, y, z order, numpy axes
+    reversed), order[d] times, out(i) = (s(min(i+B, N-1)) - s(max(i-B-1, 0))) / (2B+1)."""
+    out = np.asarray(table, dtype=np.float64)
+    nd = out.ndim
+    for d, o in enumerate(order):
+        axis = nd - 1 - d
+        n = out.shape[axis]
+        i = np.arange(n)
+        hi, lo = np.minimum(i + radius, n - 1), np.maximum(i - radius - 1, 0)
+        for _ in range(o):
+            out = (np.take(out, hi, axis=axis) - np.take(out, lo, axis=axis)) / (2 * radius + 1)
+    return out

@@ -522,3 +522,41 @@ def test_random_filters_random_shapes_partial_tiles(seed):
         imgs, outs, (path, _) = _run(shape, scans, clamped=clamped, seed=seed)
     assert path == 3, (shape, scans)
     _check(imgs, outs, scans, clamped)
+
+
+# ---- rf_box_difference: the finite-difference consumer of the box-filter apps ------------------------------------
+@pytest.mark.parametrize("shape,order,radius", [((64, 96), [1, 1], 5), ((40, 130), [2, 0], 3), ((70, 33), [0, 2], 5),
+                                                ((50, 64), [2, 2], 1), ((12, 20, 24), [1, 2, 1], 2), ((300,), [2], 7)])
+def test_box_difference_matches_reference_expression(shape, order, radius):
+    import torch
+    import recfilter_amd as rfa
+    import ref_loops
+    for dtype in (np.float32, np.float64):
+        tab = np.cumsum(rc.random_image(shape, dtype, 3), axis=-1).astype(dtype)
+        out = rfa.box_difference(torch.from_numpy(tab).cuda(), radius, order).cpu().numpy()
+        assert rc.rel_err(out, ref_loops.box_difference(tab, radius, order)) < (1e-4 if dtype == np.float32 else 1e-12)
+
+
+def test_box_filter_app_is_a_box_filter():
+    """apps/box/box_filter_1.cpp: summed-area table + differences = mean over the (2B+1)^2 window (interior pixels)."""
+    import torch
+    import recfilter_amd as rfa
+    B, n = 5, 256
+    img = rc.random_image((n, n), np.float64, 9)
+    img[:B + 2], img[-B - 2:], img[:, :B + 2], img[:, -B - 2:] = 0, 0, 0, 0      # the apps pad the image with zeros
+    x, y = rfa.RecFilterDim("x", n), rfa.RecFilterDim("y", n)
+    F = rfa.RecFilter("Box1_Sat")
+    F[x, y] = torch.from_numpy(img).cuda()
+    F.add_filter(+x, [1.0, 1.0]); F.add_filter(+y, [1.0, 1.0])
+    F.split(x, 32, y, 32)
+    out = rfa.box_difference(F.realize()[0], B, [1, 1]).cpu().numpy()
+    want = np.zeros_like(img)
+    for dy in range(-B, B + 1):
+        for dx in range(-B, B + 1):
+            want += np.roll(np.roll(img, dy, axis=0), dx, axis=1)
+    want /= (2 * B + 1) ** 2
+    inner = (slice(2 * B + 2, n - 2 * B - 2),) * 2
+    assert np.max(np.abs(out[inner] - want[inner])) < 1e-9
+    with pytest.raises(rfa.RecFilterError):
+        t = torch.zeros((8, 8), device="cuda")
+        rfa.box_difference(t, 1, [1, 1], out=t)

@@ -154,6 +154,67 @@ def _usm(optimized):
     return build
 
 
+def _box(stages):
+    """apps/box/box_filter_{1,3,6}.cpp: stages of box_filter_order_1 (summed-area table + xy differences) and
+    box_filter_order_2 (second-order prefix sums along x, differences, then the same along y), radius 5."""
+    def build(rfa, w, t):
+        B = 5
+        img = _image((w, w))
+        pad = 3 * (B + 1) + 1
+        img[:pad], img[-pad:], img[:, :pad], img[:, -pad:] = 0, 0, 0, 0
+        x, y = rfa.RecFilterDim("x", w), rfa.RecFilterDim("y", w)
+        I2 = rfa.integral_image_coeff(2)
+
+        import torch
+        bufs = [img] + [torch.empty_like(img) for _ in stages]       # bufs[i + 1] = result of stage i
+        runs = []
+        for i, kind in enumerate(stages):
+            src, dst = bufs[i], bufs[i + 1]
+            if kind == 1:
+                F = rfa.RecFilter("Box1_Sat"); F[x, y] = src
+                F.add_filter(+x, [1.0, 1.0]); F.add_filter(+y, [1.0, 1.0]); F.split(x, t, y, t)
+                runs.append(lambda F=F, dst=dst: rfa.box_difference(F.realize()[0], B, [1, 1], out=dst))
+            else:
+                mid = torch.empty_like(img)
+                Fx = rfa.RecFilter("Box2_Satx"); Fx[x, y] = src; Fx.add_filter(+x, I2); Fx.split_all_dimensions(t)
+                Fy = rfa.RecFilter("Box2_Saty"); Fy[x, y] = mid; Fy.add_filter(+y, I2); Fy.split_all_dimensions(t)
+                runs.append(lambda Fx=Fx, Fy=Fy, mid=mid, dst=dst: (
+                    rfa.box_difference(Fx.realize()[0], B, [2, 0], out=mid),
+                    rfa.box_difference(Fy.realize()[0], B, [0, 2], out=dst)))
+
+        class Chain:
+            def realize(self):
+                for r in runs:
+                    r()
+                return [bufs[-1]]
+
+            def profile(self, iterations):
+                import time
+                self.realize(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iterations):
+                    self.realize()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) * 1000.0 / iterations
+
+        def expect_fn(_unused, im):
+            import ref_loops
+            import oracle
+            cur = im
+            for kind in stages:
+                if kind == 1:
+                    sat = oracle.apply_filter(cur, [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], False)
+                    cur = ref_loops.box_difference(sat, B, [1, 1])
+                else:
+                    sx = oracle.apply_filter(cur, [(0, True, [float(v) for v in I2])], False)
+                    dx = ref_loops.box_difference(sx, B, [2, 0])
+                    sy = oracle.apply_filter(dx, [(1, True, [float(v) for v in I2])], False)
+                    cur = ref_loops.box_difference(sy, B, [0, 2])
+            return cur
+        return Chain(), img, [], False, expect_fn
+    return build
+
+
 def _audio(kind):
     def build(rfa, w, t, param):                  # apps/audio/audio_filter_{high_order,biquads}.cpp
         img = _image((w,))
@@ -188,6 +249,7 @@ APPS = {
     "bicubic": _bspline(BICUBIC, False), "biquintic_overlapped": _bspline(BIQUINTIC, False),
     "biquintic_cascaded": _bspline(BIQUINTIC, True),
     "usm_naive": _usm(False), "usm_optimized": _usm(True),
+    "box_filter_1": _box([1]), "box_filter_3": _box([1, 2]), "box_filter_6": _box([2, 2, 2]),
 }
 SWEEP_APPS = {      # the 1-D apps sweep a filter parameter at one width instead (apps/audio/*.cpp)
     "audio_high_order": (_audio("high_order"), lambda rfa: range(1, min(30, rfa.capi.RF_MAX_ORDER + 1), 2)),
