@@ -56,7 +56,9 @@ int orc_max_threads(void) {
     static void NAME(T *base, int64_t n, int64_t stride, int64_t w, int causal, int order,   \
                      const ACC *c, int clamp) {                                              \
         ACC tmp[PANEL];                                                                      \
-        for (int64_t r = 0; r < n; r++) {                                                    \
+        int64_t r_end = n;                                                                   \
+        if (w == 1 && n > order) r_end = order;   /* single line: only the border samples need the general form */ \
+        for (int64_t r = 0; r < r_end; r++) {                                                \
             int64_t i = causal ? r : n - 1 - r;                                              \
             T *cur = base + i * stride;                                                      \
             for (int64_t v = 0; v < w; v++) tmp[v] = (ACC)(c[0] * (ACC)cur[v]);              \
@@ -73,6 +75,14 @@ int orc_max_threads(void) {
                 for (int64_t v = 0; v < w; v++) tmp[v] = (ACC)(tmp[v] + (ACC)(a * (ACC)tap[v])); \
             }                                                                                \
             for (int64_t v = 0; v < w; v++) cur[v] = (T)tmp[v];                              \
+        }                                                                                    \
+        /* same arithmetic in the same order for the samples whose taps are all inside the line (r >= order) */ \
+        const int64_t step = causal ? stride : -stride;                                      \
+        T *cur = base + (causal ? r_end : n - 1 - r_end) * stride;                           \
+        for (int64_t r = r_end; r < n; r++, cur += step) {                                   \
+            ACC acc = (ACC)(c[0] * (ACC)cur[0]);                                             \
+            for (int j = 0; j < order; j++) acc = (ACC)(acc + (ACC)(c[1 + j] * (ACC)cur[-(j + 1) * step])); \
+            cur[0] = (T)acc;                                                                 \
         }                                                                                    \
     }
 
@@ -117,7 +127,17 @@ int orc_apply_scan(void *data, int dtype, int ndim, const int64_t *extent,
         else                  cu[j] = (uint32_t)(int32_t)scan->coeff[j];
     }
 
-    int64_t panels_per_outer = (inner + PANEL - 1) / PANEL;
+    /* panel width: PANEL lines when there are plenty of panels, narrower (>= 16 lines, one cache line of floats)
+     * when the threads would otherwise idle -- e.g. a 4096-wide image gives only 16 panels of 256 columns */
+    int64_t pw = PANEL;
+    {
+        int nthr = threads > 1 ? threads : 1;
+        int64_t want = inner / (4 * (int64_t)nthr);
+        want &= ~(int64_t)15;
+        if (want < 16) want = 16;
+        if (want < pw) pw = want;
+    }
+    int64_t panels_per_outer = (inner + pw - 1) / pw;
     int64_t n_tasks = outer * panels_per_outer;
     int clamp = (border == ORC_BORDER_CLAMP);
     int causal = scan->causal ? 1 : 0;
@@ -132,8 +152,8 @@ int orc_apply_scan(void *data, int dtype, int ndim, const int64_t *extent,
     for (int64_t task = 0; task < n_tasks; task++) {
         int64_t o = task / panels_per_outer;
         int64_t p = task % panels_per_outer;
-        int64_t x0 = p * PANEL;
-        int64_t w = inner - x0 < PANEL ? inner - x0 : PANEL;
+        int64_t x0 = p * pw;
+        int64_t w = inner - x0 < pw ? inner - x0 : pw;
         size_t off = (size_t)(o * n * inner + x0);
         switch (dtype) {
             case ORC_F32: scan_panel_f32((float *)bytes + off, n, inner, w, causal, order, cf, clamp); break;
