@@ -75,17 +75,25 @@ def cpu_baseline(cfg, budget_px=16 * 1024 * 1024):
         i = int(np.argmax(shape))
         shape[i] //= 2
     img = np.random.default_rng(1).random(tuple(shape), dtype=np.float32)
-    threads = max(1, min(oracle.max_threads(), os.cpu_count() or 1))
-    oracle.apply_filter(img[..., :64], cfg["scans"], cfg["clamped"], threads=threads)   # warm the library
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        oracle.apply_filter(img, cfg["scans"], cfg["clamped"], threads=threads)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    avail = max(1, min(oracle.max_threads(), avail))
+    oracle.apply_filter(img[..., :64], cfg["scans"], cfg["clamped"], threads=avail)   # warm the library
+    # the box may expose more hardware threads than the container is allowed to use: take the best thread count
+    best, best_threads = None, avail
+    for threads in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 16), min(avail, 8)}, reverse=True):
+        for _ in range(2):
+            t0 = time.perf_counter()
+            oracle.apply_filter(img, cfg["scans"], cfg["clamped"], threads=threads)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, best_threads = dt, threads
     px = float(np.prod(shape))
-    return {"value": round(px / best / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": f"{'x'.join(map(str, shape))} f32 crop of the workload, 1 plane, best of 2"}
+    return {"value": round(px / best / 1e6, 2), "unit": "Mpixels/s", "cores": best_threads, "kind": "port",
+            "sample": f"{'x'.join(map(str, shape))} f32 crop of the workload, 1 plane, best run over "
+                      f"{avail} / {avail // 2} / {avail // 4} / 16 / 8 threads"}
 
 
 def main():
