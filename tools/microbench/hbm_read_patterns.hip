@@ -3,6 +3,7 @@
 //   linear   : every workgroup reads one contiguous 64 KiB block (16 B per lane, 16 loads per thread)
 //   tile64   : every workgroup reads a 256-float x 64-row tile of a 16384-wide image (1 KiB rows, 64 KiB apart)
 //   tile32x2 : same tile as two 32-row halves, second half requested while the first is consumed (fused_tails)
+//   segment  : same tile in the x-phase register layout (64 B per lane and row, four loads of 16 B)
 // The loaded values are summed into one float per thread and written once (negligible traffic).
 #include <hip/hip_runtime.h>
 
@@ -66,6 +67,23 @@ __global__ void __launch_bounds__(256) wide_tile_kernel(const f4 *src, float *ou
     if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the x-phase register layout loaded straight from memory: thread = (row slot, 16-sample segment), four 16-byte loads
+// per row with a 64-byte stride between lanes (every load instruction touches a quarter of each 64-byte piece)
+__global__ void __launch_bounds__(256) segment_kernel(const f4 *src, float *out, int nx4, int mx) {
+    const int tx = blockIdx.x % mx, ty = blockIdx.x / mx;
+    const int l = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const size_t base = ((size_t)ty * 64 + slot) * nx4 + (size_t)tx * 64 + 4 * l;
+    f4 v[16];
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[4 * n + j] = src[base + (size_t)(16 * n) * nx4 + j];
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main() {
@@ -93,5 +111,6 @@ int main() {
     time("tile 256x64, 2x8 loads", [&] { hipLaunchKernelGGL(tile_kernel<32>, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
     time("tile, rows per wave", [&] { hipLaunchKernelGGL(tile_rows_per_wave_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
     time("tile 1024x16", [&] { hipLaunchKernelGGL(wide_tile_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, n / 1024); });
+    time("tile, segment layout", [&] { hipLaunchKernelGGL(segment_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
     return 0;
 }
