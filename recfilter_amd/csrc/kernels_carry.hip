@@ -463,8 +463,8 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     // two scans of order <= 2, nothing to send, every line's tiles in one block of chunks: the register-chained pair kernel
     // (order 3 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
     if constexpr (sizeof(Acc) == 4) {
-        if (s_end - s_begin == 2 && send == nullptr && K <= 2 && (int64_t)n_chunks * C >= a.M &&
-            getenv("RF_CARRY_NO_PAIR") == nullptr) {
+        static const bool pair_off = getenv("RF_CARRY_NO_PAIR") != nullptr;     // tuning knob: always the general kernel
+        if (s_end - s_begin == 2 && send == nullptr && K <= 2 && (int64_t)n_chunks * C >= a.M && !pair_off) {
             if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
                                            (const Acc *)a.incoming, a.W, a.A, AC, C);
             else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,

@@ -268,11 +268,15 @@ template <typename P, int K, int TY, bool EPI, bool EDGE>
 int launch_fused_pass2_impl(const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the 64 KiB of dynamic LDS has to be opted into once per device
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    RF_HIP_CHECK(hipGetDevice(&dev));
+    bool &done = attr_set[dev & 63];
+    if (!done) {
         RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        done = true;
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
     hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
