@@ -86,10 +86,15 @@ typedef struct {
  * elementwise kernels.  RF_POINTWISE_POST with post_input != 0 needs out != in. */
 #define RF_POINTWISE_PRE   1
 #define RF_POINTWISE_POST  2
+/* element type of the INPUT planes: the pixel type (default), or unsigned bytes converted on load -- the
+ * `cast<float>(input(x,y,c)) / 255.0f` of demo/demo_gaussian_filter.cpp:51-53 with the uint8 image read directly
+ * (1 byte per sample instead of 4 in both passes).  RF_IN_U8 needs dtype RF_F32; outputs stay f32. */
+typedef enum { RF_IN_PIXEL = 0, RF_IN_U8 = 1 } rf_input_dtype;
 typedef struct {
     int32_t flags;                    /* RF_POINTWISE_PRE | RF_POINTWISE_POST */
     float   pre_scale, pre_bias;
     float   post_filtered, post_input, post_bias;
+    int32_t in_dtype;                 /* rf_input_dtype */
 } rf_pointwise_desc;
 
 typedef struct {

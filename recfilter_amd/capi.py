@@ -25,6 +25,7 @@ RF_OK, RF_ERR_INVALID_ARG, RF_ERR_UNSUPPORTED, RF_ERR_HIP, RF_ERR_NOMEM, RF_ERR_
 RF_F32, RF_F64, RF_I32, RF_I16 = range(4)
 RF_BORDER_ZERO, RF_BORDER_CLAMP = 0, 1
 RF_POINTWISE_PRE, RF_POINTWISE_POST = 1, 2
+RF_IN_PIXEL, RF_IN_U8 = 0, 1
 RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED = range(4)
 PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
               RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused"}
@@ -47,7 +48,8 @@ class ScanDesc(ctypes.Structure):
 
 class PointwiseDesc(ctypes.Structure):
     _fields_ = [("flags", ctypes.c_int32), ("pre_scale", ctypes.c_float), ("pre_bias", ctypes.c_float),
-                ("post_filtered", ctypes.c_float), ("post_input", ctypes.c_float), ("post_bias", ctypes.c_float)]
+                ("post_filtered", ctypes.c_float), ("post_input", ctypes.c_float), ("post_bias", ctypes.c_float),
+                ("in_dtype", ctypes.c_int32)]
 
 
 class FilterDesc(ctypes.Structure):

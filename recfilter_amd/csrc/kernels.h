@@ -35,6 +35,9 @@ int launch_untiled_scan(const P *in, P *out, LineGeom g, const DevScan<typename 
 // ---- stand-alone pointwise stage: dst = c0*f + c1*x + c2 (float pixel types; x ignored when c1 == 0) ----
 template <typename P>
 int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream);
+// same with the x operand of another element type (unsigned-byte input planes); f may be null when c0 == 0
+template <typename P, typename X>
+int launch_pointwise_from(const P *f, const X *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream);
 
 // ---- finite differences of summed-area tables (rf_box_difference) ----
 struct BoxDiffArgs {

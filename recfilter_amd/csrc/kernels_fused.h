@@ -98,12 +98,13 @@ int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool 
 int carry_chunk_count(int64_t M, int64_t lines, int C, int K = 1);
 
 // pass 2: the final correction pass (kernels_fused.hip)
+// (src_u8: the input plane holds unsigned bytes, rf_pointwise_desc.in_dtype == RF_IN_U8; float pixels only)
 template <typename P>
-int launch_fused_pass2(int K, int TY, const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+int launch_fused_pass2(int K, int TY, const void *src, bool src_u8, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                        hipStream_t stream);
 // pass 1 as a contraction with precomputed impulse responses (kernels_tails.hip)
 template <typename P>
-int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                        const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy,
                        hipStream_t stream);
 // tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)

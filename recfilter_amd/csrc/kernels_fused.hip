@@ -20,6 +20,8 @@
 // This file holds pass 2, the final correction pass (lib/split.cpp:1008-1130, 1647-1780).  Pass 1 (tail extraction as
 // a contraction) and the completion of the y tails are in kernels_tails.hip, the carry recurrences in
 // kernels_carry.hip; plan_fused.cpp strings them together.
+#include <type_traits>
+
 #include "kernels.h"
 #include "kernels_fused.h"
 #include "scan_device.h"
@@ -35,9 +37,9 @@ namespace {
 // persistent, register-prefetching variant of this kernel were measured slower in round 1 and removed.)
 // EDGE: the image has partial tiles (width not a multiple of 256 or height not a multiple of TY); without it the
 // masks below are compile-time constants and the kernel stays lean.
-template <typename P, int K, int TY, bool EPI, bool EDGE>
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI>
 __global__ void __launch_bounds__(kFusedThreads, EPI ? 2 : 1)
-fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
+fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
     using A4 = typename Vec4<Acc>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -110,11 +112,11 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
     // ---- load: wave w streams rows w, w+4, ...; one 1 KiB row per instruction ----
     {
         const int cc = t & 63, rg = t >> 6;
-        const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
         // byte offsets inside the tile, kept in 32 bits: scalar base + 32-bit vector offset addressing
-        const char *spb = reinterpret_cast<const char *>(sp);
-        const uint32_t off0 = (uint32_t)rg * a.row_bytes + (uint32_t)cc * 16u;
-        auto ld = [&](int row) { return *reinterpret_cast<const A4 *>(spb + (off0 + (uint32_t)row * a.row_bytes)); };
+        const char *spb = reinterpret_cast<const char *>(src + tile_off);
+        const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
+        const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
+        auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
         A4 tmp[TY / 4];
         const bool chunk_in = cc <= 4 * last_lane + 3;        // this thread's 16-byte chunk exists in the image
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
@@ -227,14 +229,14 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
                 if (a.post_i != Acc(0)) {
                     // order 3 has no registers to spare at two workgroups per CU: its input column comes back through
                     // L2 / the Infinity Cache instead, 64 coalesced dword loads per thread
-                    const P *xp = src + tile_off;
+                    const PI *xp = src + tile_off;
                     const uint32_t nxu = (uint32_t)a.NX;
                     const Acc c1 = a.post_i * ((a.pw_flags & 1) ? a.pre_s : Acc(1));
                     const Acc c2 = a.post_b + a.post_i * ((a.pw_flags & 1) ? a.pre_b : Acc(0));
                     if (t < 16 * (last_lane + 1)) {
 #pragma unroll
                         for (int i = 0; i < TY; i++)
-                            if (i < rows_here) col[i] = a.post_f * col[i] + (c1 * xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
+                            if (i < rows_here) col[i] = a.post_f * col[i] + (c1 * (Acc)xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
                     }
                 } else {
 #pragma unroll
@@ -264,8 +266,8 @@ fused_pass2_kernel(const P *__restrict__ src, P *__restrict__ dst, FusedArgs<typ
     }
 }
 
-template <typename P, int K, int TY, bool EPI, bool EDGE>
-int launch_fused_pass2_impl(const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI>
+int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
     // the 64 KiB of dynamic LDS has to be opted into once per device
@@ -274,35 +276,33 @@ int launch_fused_pass2_impl(const P *src, P *dst, const FusedArgs<typename Pixel
     RF_HIP_CHECK(hipGetDevice(&dev));
     bool &done = attr_set[dev & 63];
     if (!done) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done = true;
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
 
 }  // namespace
 
-template <typename P>
-int launch_fused_pass2(int K, int TY, const P *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
-                       hipStream_t stream) {
-    if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
-    if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
+template <typename P, typename PI>
+static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                                    hipStream_t stream) {
     // the epilogue variant that keeps the input column in registers exists for float pixels only
     bool epi = false;
     const bool edge = a.last_lane != 15 || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
-#define RF_CASE(KK, TT)                                                                                     \
-    if (K == KK && TY == TT) {                                                                              \
-        if constexpr (!PixelTraits<P>::is_integer) {                                                        \
-            if (epi && edge) return launch_fused_pass2_impl<P, KK, TT, true, true>(src, dst, a, stream);    \
-            if (epi) return launch_fused_pass2_impl<P, KK, TT, true, false>(src, dst, a, stream);           \
-        }                                                                                                   \
-        if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true>(src, dst, a, stream);              \
-        return launch_fused_pass2_impl<P, KK, TT, false, false>(src, dst, a, stream);                       \
+#define RF_CASE(KK, TT)                                                                                         \
+    if (K == KK && TY == TT) {                                                                                  \
+        if constexpr (!PixelTraits<P>::is_integer) {                                                            \
+            if (epi && edge) return launch_fused_pass2_impl<P, KK, TT, true, true, PI>(src, dst, a, stream);    \
+            if (epi) return launch_fused_pass2_impl<P, KK, TT, true, false, PI>(src, dst, a, stream);           \
+        }                                                                                                       \
+        if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true, PI>(src, dst, a, stream);              \
+        return launch_fused_pass2_impl<P, KK, TT, false, false, PI>(src, dst, a, stream);                       \
     }
     RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
     RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
@@ -311,7 +311,18 @@ int launch_fused_pass2(int K, int TY, const P *src, P *dst, const FusedArgs<type
     return RF_ERR_UNSUPPORTED;
 }
 
-template int launch_fused_pass2<float>(int, int, const float *, float *, const FusedArgs<float> &, hipStream_t);
-template int launch_fused_pass2<int32_t>(int, int, const int32_t *, int32_t *, const FusedArgs<uint32_t> &, hipStream_t);
+template <typename P>
+int launch_fused_pass2(int K, int TY, const void *src, bool src_u8, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                       hipStream_t stream) {
+    if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
+    if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
+    if constexpr (std::is_same<P, float>::value) {
+        if (src_u8) return launch_fused_pass2_typed<P, uint8_t>(K, TY, (const uint8_t *)src, dst, a, stream);
+    }
+    return launch_fused_pass2_typed<P, P>(K, TY, (const P *)src, dst, a, stream);
+}
+
+template int launch_fused_pass2<float>(int, int, const void *, bool, float *, const FusedArgs<float> &, hipStream_t);
+template int launch_fused_pass2<int32_t>(int, int, const void *, bool, int32_t *, const FusedArgs<uint32_t> &, hipStream_t);
 
 }  // namespace rf

@@ -75,13 +75,14 @@ untiled_scan_kernel(const P *__restrict__ in, P *__restrict__ out, LineGeom g,
 // ---------------------------------------------------------------------------------------
 // Stand-alone pointwise stage (rf_pointwise_desc) for the paths that do not fuse it:
 //   dst = c0 * f + c1 * x + c2          (x may be null when c1 == 0)
-template <typename P>
+template <typename P, typename X>
 __global__ void __launch_bounds__(kBlock)
-pointwise_kernel(const P *f, const P *x, P *dst, int64_t n, P c0, P c1, P c2) {
+pointwise_kernel(const P *f, const X *x, P *dst, int64_t n, P c0, P c1, P c2) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        P v = c0 * f[i] + c2;
-        if (x) v = v + c1 * x[i];
+        P v = c2;
+        if (f) v = v + c0 * f[i];
+        if (x) v = v + c1 * (P)x[i];
         dst[i] = v;
     }
 }
@@ -312,11 +313,22 @@ int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, doubl
     if (n <= 0) return RF_OK;
     const int64_t want = (n + kBlock - 1) / kBlock;
     const unsigned blocks = (unsigned)(want < 256 * 64 ? want : 256 * 64);
-    hipLaunchKernelGGL((pointwise_kernel<P>), dim3(blocks), dim3(kBlock), 0, stream, f, c1 != 0.0 ? x : (const P *)nullptr, dst, n,
+    hipLaunchKernelGGL((pointwise_kernel<P, P>), dim3(blocks), dim3(kBlock), 0, stream, f, c1 != 0.0 ? x : (const P *)nullptr, dst, n,
                        (P)c0, (P)c1, (P)c2);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
+template <typename P, typename X>
+int launch_pointwise_from(const P *f, const X *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream) {
+    if (n <= 0) return RF_OK;
+    const int64_t want = (n + kBlock - 1) / kBlock;
+    const unsigned blocks = (unsigned)(want < 256 * 64 ? want : 256 * 64);
+    hipLaunchKernelGGL((pointwise_kernel<P, X>), dim3(blocks), dim3(kBlock), 0, stream, c0 != 0.0 ? f : (const P *)nullptr, x, dst, n,
+                       (P)c0, (P)c1, (P)c2);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+template int launch_pointwise_from<float, uint8_t>(const float *, const uint8_t *, float *, int64_t, double, double, double, hipStream_t);
 template int launch_pointwise<float>(const float *, const float *, float *, int64_t, double, double, double, hipStream_t);
 template int launch_pointwise<double>(const double *, const double *, double *, int64_t, double, double, double, hipStream_t);
 

@@ -32,9 +32,9 @@ constexpr int kTailRows = 32;     // rows staged per step
 
 typedef float F2 __attribute__((ext_vector_type(2)));     // operands of the packed f32 instructions
 
-template <typename P, int K, int TY>
+template <typename P, int K, int TY, typename PI>
 __global__ void __launch_bounds__(kFusedThreads)
-fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>::Acc> a,
+fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>::Acc> a,
                    const typename PixelTraits<P>::Acc *__restrict__ Hx,     // [vx][s][r][256]
                    const typename PixelTraits<P>::Acc *__restrict__ Hy) {   // [vy][j][r][TY]
     using Acc = typename PixelTraits<P>::Acc;
@@ -58,11 +58,11 @@ fused_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>:
     const int cc = t & 63, rg = t >> 6;                        // load: 16-byte chunk, row group
     const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x part: segment lane, row slot
     const int e = (swz_chunk(t >> 2) << 2) | (t & 3);          // y part: swizzled column offset
-    const A4 *sp = reinterpret_cast<const A4 *>(src + tile_off);
     // byte offsets inside the tile, kept in 32 bits: scalar base + 32-bit vector offset addressing
-    const char *spb = reinterpret_cast<const char *>(sp);
-    const uint32_t off0 = (uint32_t)rg * a.row_bytes + (uint32_t)cc * 16u;
-    auto ld = [&](int row) { return *reinterpret_cast<const A4 *>(spb + (off0 + (uint32_t)row * a.row_bytes)); };
+    const char *spb = reinterpret_cast<const char *>(src + tile_off);
+    const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
+    const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
+    auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
     const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (cc <= 4 * a.last_lane + 3);
@@ -372,7 +372,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
 }  // namespace
 
 template <typename P>
-int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                        const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy,
                        hipStream_t stream) {
     if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
@@ -380,7 +380,16 @@ int launch_fused_tails(int K, int TY, const P *src, const FusedArgs<typename Pix
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
 #define RF_CASE(KK, TT)                                                                                             \
     if (K == KK && TY == TT) {                                                                                       \
-        hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT>), grid, dim3(kFusedThreads), 0, stream, src, a, Hx, Hy);   \
+        if constexpr (std::is_same<P, float>::value) {                                                               \
+            if (src_u8) {                                                                                            \
+                hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, uint8_t>), grid, dim3(kFusedThreads), 0, stream,   \
+                                   (const uint8_t *)src, a, Hx, Hy);                                                 \
+                RF_HIP_CHECK(hipGetLastError());                                                                     \
+                return RF_OK;                                                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P>), grid, dim3(kFusedThreads), 0, stream, (const P *)src, \
+                           a, Hx, Hy);                                                                               \
         RF_HIP_CHECK(hipGetLastError());                                                                             \
         return RF_OK;                                                                                                \
     }
@@ -404,8 +413,8 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
     return RF_ERR_UNSUPPORTED;
 }
 
-template int launch_fused_tails<float>(int, int, const float *, const FusedArgs<float> &, const float *, const float *, hipStream_t);
-template int launch_fused_tails<int32_t>(int, int, const int32_t *, const FusedArgs<uint32_t> &, const uint32_t *,
+template int launch_fused_tails<float>(int, int, const void *, bool, const FusedArgs<float> &, const float *, const float *, hipStream_t);
+template int launch_fused_tails<int32_t>(int, int, const void *, bool, const FusedArgs<uint32_t> &, const uint32_t *,
                                          const uint32_t *, hipStream_t);
 template int launch_xscan_rows<float>(int, int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
 template int launch_xscan_rows<uint32_t>(int, int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);

@@ -9,6 +9,7 @@
 #include "plan_generic.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 
@@ -103,8 +104,13 @@ void add_pointwise_steps_typed(rf_plan *plan) {
         Step st;
         st.name = "pointwise_pre";
         st.run = [plan, pw](int pl) {
-            int rc = launch_pointwise<P>((const P *)plan->orig_in[pl], (const P *)nullptr, (P *)plan->out[pl], plan->total,
-                                         pw.pre_s, 0.0, pw.pre_b, plan->stream);
+            int rc = RF_OK;
+            if constexpr (std::is_same<P, float>::value) {
+                if (pw.in_u8) rc = launch_pointwise_from<P, uint8_t>(nullptr, (const uint8_t *)plan->orig_in[pl], (P *)plan->out[pl],
+                                                                     plan->total, 0.0, pw.pre_s, pw.pre_b, plan->stream);
+            }
+            if (!pw.in_u8) rc = launch_pointwise<P>((const P *)plan->orig_in[pl], (const P *)nullptr, (P *)plan->out[pl], plan->total,
+                                                    pw.pre_s, 0.0, pw.pre_b, plan->stream);
             plan->in[pl] = plan->out[pl];
             return rc;
         };
@@ -117,6 +123,10 @@ void add_pointwise_steps_typed(rf_plan *plan) {
         const double c1 = pw.post_i * (pw.pre ? pw.pre_s : 1.0);
         const double c2 = pw.post_b + pw.post_i * (pw.pre ? pw.pre_b : 0.0);
         st.run = [plan, pw, c1, c2](int pl) {
+            if constexpr (std::is_same<P, float>::value) {
+                if (pw.in_u8) return launch_pointwise_from<P, uint8_t>((const P *)plan->out[pl], (const uint8_t *)plan->orig_in[pl],
+                                                                       (P *)plan->out[pl], plan->total, pw.post_f, c1, c2, plan->stream);
+            }
             return launch_pointwise<P>((const P *)plan->out[pl], (const P *)plan->orig_in[pl], (P *)plan->out[pl], plan->total,
                                        pw.post_f, c1, c2, plan->stream);
         };
@@ -171,6 +181,8 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     }
     const rf_pointwise_desc &pwd = desc->pointwise;
     if (pwd.flags & ~(RF_POINTWISE_PRE | RF_POINTWISE_POST)) { set_error("unknown pointwise flags 0x%x", pwd.flags); return RF_ERR_INVALID_ARG; }
+    if (pwd.in_dtype != RF_IN_PIXEL && pwd.in_dtype != RF_IN_U8) { set_error("unknown pointwise input type %d", pwd.in_dtype); return RF_ERR_INVALID_ARG; }
+    if (pwd.in_dtype == RF_IN_U8 && desc->dtype != RF_F32) { set_error("unsigned-byte input needs f32 pixels"); return RF_ERR_UNSUPPORTED; }
     if (pwd.flags != 0 && desc->dtype != RF_F32 && desc->dtype != RF_F64) {
         set_error("pointwise stages need a floating-point pixel type");
         return RF_ERR_UNSUPPORTED;
@@ -202,7 +214,9 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     plan->shard_world = world;
     plan->pw.pre = (pwd.flags & RF_POINTWISE_PRE) != 0;
     plan->pw.post = (pwd.flags & RF_POINTWISE_POST) != 0;
+    plan->pw.in_u8 = pwd.in_dtype == RF_IN_U8;
     if (plan->pw.pre) { plan->pw.pre_s = pwd.pre_scale; plan->pw.pre_b = pwd.pre_bias; }
+    if (plan->pw.in_u8) plan->pw.pre = true;        // the conversion is a prologue (scale 1, bias 0 unless given)
     if (plan->pw.post) { plan->pw.post_f = pwd.post_filtered; plan->pw.post_i = pwd.post_input; plan->pw.post_b = pwd.post_bias; }
     plan->total = 1;
     for (int d = 0; d < desc->ndim; d++) {

@@ -33,6 +33,7 @@ struct Step {
 // stand-alone elementwise step runs it (pointwise_pre first, pointwise_post last).
 struct Pointwise {
     bool pre = false, post = false;
+    bool in_u8 = false;            // input planes are unsigned bytes, converted on load (implies a prologue)
     bool pre_fused = false, post_fused = false;
     double pre_s = 1.0, pre_b = 0.0, post_f = 1.0, post_i = 0.0, post_b = 0.0;
 };

@@ -299,7 +299,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Step p1;
     p1.name = "fused_tails";
     p1.run = [plan, fargs, K, TY, d_Hx, d_Hy](int pl) {
-        return launch_fused_tails<P>(K, TY, (const P *)plan->in[pl], fargs(pl), d_Hx, d_Hy, plan->stream);
+        return launch_fused_tails<P>(K, TY, plan->in[pl], plan->pw.in_u8, fargs(pl), d_Hx, d_Hy, plan->stream);
     };
     plan->begin_steps.push_back(p1);
     if (nx > 0 && !chained) {
@@ -397,7 +397,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Step p2;
     p2.name = "fused_pass2";
     p2.run = [plan, fargs, K, TY](int pl) {
-        return launch_fused_pass2<P>(K, TY, (const P *)plan->in[pl], (P *)plan->out[pl], fargs(pl), plan->stream);
+        return launch_fused_pass2<P>(K, TY, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], fargs(pl), plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
     else plan->begin_steps.push_back(p2);

@@ -42,10 +42,11 @@ class Plan:
                  planes: int = 1, tile: Optional[Sequence[int]] = None, path: int = capi.RF_PATH_AUTO,
                  device: int = -1, shard_rank: int = 0, shard_world: int = 1,
                  prologue: Optional[Tuple[float, float]] = None,
-                 epilogue: Optional[Tuple[float, float, float]] = None):
+                 epilogue: Optional[Tuple[float, float, float]] = None, input_dtype=None):
         """prologue = (scale, bias): x' = scale*in + bias before the first scan;
         epilogue = (w_filtered, w_input, bias): out = w_filtered*F(x') + w_input*x' + bias
-        (rf_pointwise_desc; fused into pass 1 / pass 2 on the fused path)."""
+        (rf_pointwise_desc; fused into pass 1 / pass 2 on the fused path).  input_dtype=np.uint8 (with dtype float32):
+        the input planes are unsigned bytes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8)."""
         L = capi.lib()
         shape = tuple(int(s) for s in shape)
         if not 1 <= len(shape) <= capi.RF_MAX_DIMS:
@@ -87,6 +88,13 @@ class Plan:
         if epilogue is not None:
             d.pointwise.flags |= capi.RF_POINTWISE_POST
             d.pointwise.post_filtered, d.pointwise.post_input, d.pointwise.post_bias = (float(v) for v in epilogue)
+        self.input_np_dtype = None
+        if input_dtype is not None and np.dtype(input_dtype if not hasattr(input_dtype, "is_floating_point") else
+                                                 str(input_dtype).replace("torch.", "")) == np.dtype(np.uint8):
+            d.pointwise.in_dtype = capi.RF_IN_U8
+            self.input_np_dtype = np.dtype(np.uint8)
+        elif input_dtype is not None and _dtype_code(input_dtype) != d.dtype:
+            raise TypeError(f"unsupported input type {input_dtype} for pixel type {dtype}")
         self._desc = d
         self.shape = shape
         self.planes = int(planes)
@@ -150,7 +158,7 @@ class Plan:
         return out
 
     # -- execution --------------------------------------------------------------------------
-    def _pointers(self, tensors) -> ctypes.Array:
+    def _pointers(self, tensors, inputs: bool = False) -> ctypes.Array:
         if len(tensors) != self.planes:
             raise ValueError(f"expected {self.planes} planes, got {len(tensors)}")
         arr = (ctypes.c_void_p * self.planes)()
@@ -159,10 +167,20 @@ class Plan:
                 raise ValueError(f"plane {i}: shape {tuple(t.shape)} != plan shape {self.shape}")
             if not t.is_cuda or not t.is_contiguous():
                 raise ValueError("planes must be contiguous device tensors")
-            if _dtype_code(t.dtype) != self._desc.dtype:
+            if inputs and self.input_np_dtype is not None:
+                import torch
+                if t.dtype != torch.uint8:
+                    raise TypeError(f"plane {i}: the plan expects unsigned-byte input planes, got {t.dtype}")
+            elif _dtype_code(t.dtype) != self._desc.dtype:
                 raise TypeError(f"plane {i}: dtype {t.dtype} does not match the plan")
             arr[i] = t.data_ptr()
         return arr
+
+    def _new_outputs(self, inputs):
+        import torch
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32,
+               np.dtype(np.int16): torch.int16}[self.np_dtype]
+        return [torch.empty(t.shape, dtype=tdt, device=t.device) for t in inputs]
 
     @staticmethod
     def _stream(stream) -> ctypes.c_void_p:
@@ -174,8 +192,8 @@ class Plan:
         """rf_plan_execute: asynchronous on `stream` (default: torch's current stream)."""
         import torch
         if outputs is None:
-            outputs = [torch.empty_like(t) for t in inputs]
-        pin, pout = self._pointers(inputs), self._pointers(outputs)
+            outputs = self._new_outputs(inputs)
+        pin, pout = self._pointers(inputs, True), self._pointers(outputs)
         capi.check(capi.lib().rf_plan_execute(self._h, pin, pout, self._stream(stream)))
         return outputs
 
@@ -183,8 +201,8 @@ class Plan:
         """rf_plan_execute_timed: returns (outputs, [(kernel name, ms), ...]) measured with HIP events."""
         import torch
         if outputs is None:
-            outputs = [torch.empty_like(t) for t in inputs]
-        pin, pout = self._pointers(inputs), self._pointers(outputs)
+            outputs = self._new_outputs(inputs)
+        pin, pout = self._pointers(inputs, True), self._pointers(outputs)
         n = self.num_kernels
         ms = (ctypes.c_float * max(n, 1))()
         names = (ctypes.c_char_p * max(n, 1))()
@@ -193,7 +211,7 @@ class Plan:
 
     # stepping API (sharded execution) ---------------------------------------------------------
     def begin(self, inputs, outputs, stream=None):
-        pin, pout = self._pointers(inputs), self._pointers(outputs)
+        pin, pout = self._pointers(inputs, True), self._pointers(outputs)
         capi.check(capi.lib().rf_plan_begin(self._h, pin, pout, self._stream(stream)))
 
     def exchange_bytes(self, i: int) -> int:

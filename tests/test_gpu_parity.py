@@ -560,3 +560,44 @@ def test_box_filter_app_is_a_box_filter():
     with pytest.raises(rfa.RecFilterError):
         t = torch.zeros((8, 8), device="cuda")
         rfa.box_difference(t, 1, [1, 1], out=t)
+
+
+# ---- unsigned-byte input planes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8) -------------------------
+@pytest.mark.parametrize("shape,path", [((128, 512), 0), ((75, 464), 0), ((64, 250), 0), ((64, 256), 1), ((40, 16, 272), 0)],
+                         ids=["fused", "fused_partial", "generic_auto", "untiled", "fused_3d"])
+@pytest.mark.parametrize("post", [None, (-1.0, 2.0, 0.1)], ids=["plain", "unsharp"])
+def test_uint8_input_planes(shape, path, post):
+    import torch
+    import recfilter_amd as rfa
+    scans = rc.xy_pm(rc.GAUSS2) if len(shape) == 2 else rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    clamped = len(shape) == 2
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(2)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    with rfa.Plan(shape, scans, clamped=clamped, planes=2, path=path, input_dtype=np.uint8, prologue=(1.0 / 255.0, 0.0),
+                  epilogue=post) as plan:
+        outs = [o.cpu().numpy() for o in plan.execute(dev)]
+        assert outs[0].dtype == np.float32
+        with pytest.raises(TypeError):
+            plan.execute([d.float() for d in dev])                    # the plan wants byte planes
+    for im, out in zip(imgs, outs):
+        x = (np.float32(1.0 / 255.0) * im.astype(np.float32)).astype(np.float64)
+        want = oracle.apply_filter(x, scans, clamped)
+        if post is not None:
+            want = post[0] * want + post[1] * x + post[2]
+        assert rc.rel_err(out, want) < TOL
+
+
+def test_uint8_input_without_scale_and_order3_epilogue():
+    import torch
+    import recfilter_amd as rfa
+    scans = rc.xy_pm(rc.GAUSS3)
+    im = np.random.default_rng(6).integers(0, 256, size=(70, 400), dtype=np.uint8)
+    with rfa.Plan((70, 400), scans, clamped=True, input_dtype=np.uint8, epilogue=(1.0, -1.0, 0.0)) as plan:
+        assert plan.path_name == "tiled_fused"
+        out = plan.execute([torch.from_numpy(im).cuda()])[0].cpu().numpy()
+    x = im.astype(np.float64)
+    blur = oracle.apply_filter(x, scans, True)
+    # a difference of two O(255) terms: the bar is relative to the terms (see test_unsharp_mask_front_end)
+    scale = np.abs(blur) + np.abs(x)
+    assert np.max(np.abs(out - (blur - x)) / np.maximum(scale, 1e-2 * scale.max())) < TOL

@@ -270,4 +270,19 @@ def test_pointwise_desc_validation_and_kernel_count():
                         prologue=(2.0, 1.0), epilogue=(1.0, -1.0, 0.0))
     assert gen_pw.num_kernels == gen.num_kernels + 2
     # layout of the descriptor the binding fills must match the header's struct
-    assert ctypes.sizeof(capi.PointwiseDesc) == 24
+    assert ctypes.sizeof(capi.PointwiseDesc) == 28
+
+
+def test_unsigned_byte_input_planes_are_a_prologue():
+    """rf_pointwise_desc.in_dtype = RF_IN_U8: f32 pixels only; fused into the passes on the fused path, one conversion
+    kernel in front of the others."""
+    scans = rc.BASELINE_CONFIGS["cfg3_gaussian2_xy"]["scans"]
+    with pytest.raises(rfa.RecFilterError) as e:
+        _host_plan((64, 256), scans, dtype=np.float64, input_dtype=np.uint8)
+    assert e.value.status == capi.RF_ERR_UNSUPPORTED
+    plain = _host_plan((64, 256), scans, clamped=True)
+    u8 = _host_plan((64, 256), scans, clamped=True, input_dtype=np.uint8, prologue=(1 / 255.0, 0.0))
+    assert u8.path_name == "tiled_fused" and u8.num_kernels == plain.num_kernels
+    gen = _host_plan((64, 250), scans, clamped=True)
+    gen_u8 = _host_plan((64, 250), scans, clamped=True, input_dtype=np.uint8)
+    assert gen.path_name == "tiled_generic" and gen_u8.num_kernels == gen.num_kernels + 1
