@@ -70,6 +70,9 @@ struct RecFilterImageRef {
     /** affine defining expression, e.g. `cast<float>(in)/255` (demo/demo_gaussian_filter.cpp:51-53): the filter
      *  runs on scale*image + bias, applied when the passes load pixels.  Shared by all Tuple elements. */
     float scale = 1.0f, bias = 0.0f;
+    /** the buffer holds unsigned bytes that are converted to float on load (rf_pointwise_desc.in_dtype = RF_IN_U8);
+     *  the filter itself is a float filter */
+    bool bytes = false;
     RecFilterImageRef operator*(float s) const { RecFilterImageRef r = *this; r.scale *= s; r.bias *= s; return r; }
     RecFilterImageRef operator/(float s) const { return *this * (1.0f / s); }
     RecFilterImageRef operator+(float b) const { RecFilterImageRef r = *this; r.bias += b; return r; }
@@ -82,6 +85,13 @@ struct RecFilterPointwise {
 };
 template <typename T>
 RecFilterImageRef RecFilterImage(const T *device_ptr) { return RecFilterImageRef{device_ptr, RecFilterPixel<T>::dtype}; }
+/** `cast<float>(input(x,y))` of a uint8 image (demo/demo_gaussian_filter.cpp:51-53): the bytes are read directly by
+ *  the passes; combine with `/ 255.0f`. */
+inline RecFilterImageRef RecFilterImage(const uint8_t *device_ptr) {
+    RecFilterImageRef r{device_ptr, RF_F32};
+    r.bytes = true;
+    return r;
+}
 
 /** Result of realize(): one device buffer per Tuple element, owned by the filter. */
 struct RecFilterRealization {
@@ -368,6 +378,7 @@ public:
         d.n_scans = (int)sd.size(); d.scans = sd.data();
         d.path = c->tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
         d.device = -1; d.shard_rank = 0; d.shard_world = 1;
+        if (!c->source && !c->inputs.empty() && c->inputs[0].bytes) d.pointwise.in_dtype = RF_IN_U8;
         if (!c->source && !c->inputs.empty() && (c->inputs[0].scale != 1.0f || c->inputs[0].bias != 0.0f)) {
             d.pointwise.flags |= RF_POINTWISE_PRE;
             d.pointwise.pre_scale = c->inputs[0].scale; d.pointwise.pre_bias = c->inputs[0].bias;

@@ -208,8 +208,9 @@ int main() {
         const int width = 512, height = 256;
         const float weight = 1.0f;
         std::vector<float> image = random_image((size_t)width * height, 5);
-        for (auto &v : image) v *= 255.0f;
-        float *d = upload(image);
+        std::vector<uint8_t> bytes(image.size());
+        for (size_t i = 0; i < image.size(); i++) { bytes[i] = (uint8_t)(image[i] * 255.0f); image[i] = (float)bytes[i]; }
+        uint8_t *d = upload(bytes);          // the filters read the uint8 image directly
         RecFilterDim x("x", width), y("y", height);
         std::vector<float> W3 = gaussian_weights(5.0f, 3);
         RecFilter B("Blur"), U("Blur_untiled");
