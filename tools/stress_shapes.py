@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Random large shapes and filters: the fused path against the untiled GPU path (the literal add_filter recurrence),
+both through the C ABI.  A one-off robustness sweep for index arithmetic at sizes the oracle is too slow for."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import recfilter_amd as rfa
+import ref_cases as rc
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+worst = 0.0
+for case in range(n_cases):
+    ndim = 2 if case % 4 else 3
+    if ndim == 2:
+        shape = (int(rng.integers(1, 9000)), 16 * int(rng.integers(1, 600)))
+    else:
+        shape = (int(rng.choice([32, 64, 96])), int(rng.integers(1, 700)), 16 * int(rng.integers(1, 80)))
+    scans = []
+    for d in range(ndim):
+        for _ in range(int(rng.integers(0, 3 if d < 2 else 2)) + (1 if d == 0 else 0)):
+            k = int(rng.integers(1, 4))
+            a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+            scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+    clamped = bool(rng.integers(0, 2))
+    dtype = torch.int32 if case % 5 == 4 else torch.float32
+    if dtype == torch.int32:
+        scans = [(d, c, [float(int(rng.integers(1, 3)))] + [float(int(rng.integers(-2, 3))) for _ in co[1:]]) for d, c, co in scans]
+        img = torch.randint(0, 256, shape, dtype=torch.int32, device="cuda")
+    else:
+        img = torch.rand(shape, device="cuda")
+    npdt = np.int32 if dtype == torch.int32 else np.float32
+    with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped) as pf, rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1) as pu:
+        of, ou = pf.execute([img])[0], pu.execute([img])[0]
+        torch.cuda.synchronize()
+        if dtype == torch.int32:
+            err = float((of != ou).sum().item())
+        else:
+            peak = float(ou.abs().max().item())
+            err = float(((of - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
+        worst = max(worst, err)
+        print(f"{case:3d} {pf.path_name:13s} {str(shape):22s} scans={len(scans)} clamped={int(clamped)} {str(dtype)[6:]:8s} err={err:.3e}",
+              "" if err < (1 if dtype == torch.int32 else 2e-4) else "  <-- CHECK", flush=True)
+print("worst", worst)
