@@ -93,41 +93,53 @@ pointwise_kernel(const P *f, const X *x, P *dst, int64_t n, P c0, P c1, P c2) {
 // taps: per dimension up to four (position, sign) pairs, combined as a product over the dimensions.  A gather over a
 // summed-area table: the taps of neighbouring outputs are neighbouring table entries, so the reads coalesce and hit
 // L2; the kernel is bound by its one write per sample.
+constexpr int kBoxRows = 16;      // rows one workgroup walks (amortises its setup; a row per workgroup is launch-bound)
+
 template <typename P>
 __global__ void __launch_bounds__(kBlock)
 box_difference_kernel(const P *__restrict__ in, P *__restrict__ out, BoxDiffArgs a) {
-    const int64_t total = a.n[0] * a.n[1] * a.n[2];
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t B = a.radius;
-    P scale = P(1);
+    // grid = (x blocks, groups of kBoxRows rows, z): no index division in the kernel; the x taps are computed once per
+    // thread, the y / z taps are wave-uniform (scalar), all in 32 bits (extents are checked on the host)
+    const int c0 = (int)(blockIdx.x * kBlock + threadIdx.x), c2 = (int)blockIdx.z;
+    const int n0 = (int)a.n[0], n1 = (int)a.n[1], n2 = (int)a.n[2];
+    if (c0 >= n0) return;
+    const int B = a.radius;
+    P inv = P(1);
     for (int d = 0; d < RF_MAX_DIMS; d++)
-        for (int o = 0; o < a.order[d]; o++) scale = scale * P(2 * B + 1);
-    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += stride) {
-        const int64_t c0 = idx % a.n[0], c1 = (idx / a.n[0]) % a.n[1], c2 = idx / (a.n[0] * a.n[1]);
-        // tap k of a dimension: order 0 -> the sample itself; order 1 -> (up, dn); order 2 -> (up up, dn up, up dn, dn dn)
-        // with signs (+), (+,-), (+,-,-,+)
-        auto tap = [&](int64_t c, int64_t N, int order, int k) -> int64_t {
-            auto up = [&](int64_t i) { return i + B < N - 1 ? i + B : N - 1; };
-            auto dn = [&](int64_t i) { return i - B - 1 > 0 ? i - B - 1 : (int64_t)0; };
-            if (order == 0) return c;
-            if (order == 1) return k == 0 ? up(c) : dn(c);
-            const int64_t first = (k & 2) ? dn(c) : up(c);          // inner application
-            return (k & 1) ? dn(first) : up(first);                  // outer application
-        };
+        for (int o = 0; o < a.order[d]; o++) inv = inv / P(2 * B + 1);
+    // tap k of a dimension: order 0 -> the sample itself; order 1 -> (up, dn); order 2 -> (up up, dn up, up dn, dn dn)
+    // with signs (+), (+,-), (+,-,-,+)
+    auto tap = [&](int c, int N, int order, int k) -> int {
+        auto up = [&](int i) { return i + B < N - 1 ? i + B : N - 1; };
+        auto dn = [&](int i) { return i - B - 1 > 0 ? i - B - 1 : 0; };
+        if (order == 0) return c;
+        if (order == 1) return k == 0 ? up(c) : dn(c);
+        const int first = (k & 2) ? dn(c) : up(c);              // inner application
+        return (k & 1) ? dn(first) : up(first);                  // outer application
+    };
+    const int nkx = 1 << a.order[0], nky = 1 << a.order[1], nkz = 1 << a.order[2];
+    uint32_t px[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; kx++) px[kx] = (uint32_t)tap(c0, n0, a.order[0], kx < nkx ? kx : 0);
+    const int row_begin = (int)blockIdx.y * kBoxRows;
+#pragma unroll 4
+    for (int rr = 0; rr < kBoxRows; rr++) {
+        const int c1 = row_begin + rr;
+        if (c1 >= n1) break;
         P acc = P(0);
-        for (int kz = 0; kz < (1 << a.order[2]); kz++) {
-            const int64_t p2 = tap(c2, a.n[2], a.order[2], kz);
-            for (int ky = 0; ky < (1 << a.order[1]); ky++) {
-                const int64_t p1 = tap(c1, a.n[1], a.order[1], ky);
-                for (int kx = 0; kx < (1 << a.order[0]); kx++) {
-                    const int64_t p0 = tap(c0, a.n[0], a.order[0], kx);
-                    const int neg = ((kx == 1 || kx == 2) ? 1 : 0) ^ ((ky == 1 || ky == 2) ? 1 : 0) ^ ((kz == 1 || kz == 2) ? 1 : 0);
-                    const P v = in[(p2 * a.n[1] + p1) * a.n[0] + p0];
-                    acc = neg ? acc - v : acc + v;
-                }
+        for (int kz = 0; kz < nkz; kz++) {
+            const int64_t p2 = tap(c2, n2, a.order[2], kz);
+            for (int ky = 0; ky < nky; ky++) {
+                const int64_t p1 = tap(c1, n1, a.order[1], ky);
+                const P *row = in + (p2 * n1 + p1) * n0;         // wave-uniform
+                const bool negyz = ((ky == 1 || ky == 2) ? 1 : 0) ^ ((kz == 1 || kz == 2) ? 1 : 0);
+                P part = row[px[0]];
+                if (nkx > 1) part = part - row[px[1]];
+                if (nkx > 2) part = part - row[px[2]] + row[px[3]];
+                acc = negyz ? acc - part : acc + part;
             }
         }
-        out[idx] = acc / scale;
+        out[((int64_t)c2 * n1 + c1) * n0 + c0] = acc * inv;
     }
 }
 
@@ -334,11 +346,13 @@ template int launch_pointwise<double>(const double *, const double *, double *, 
 
 template <typename P>
 int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t stream) {
-    const int64_t total = a.n[0] * a.n[1] * a.n[2];
-    if (total <= 0) return RF_OK;
-    const int64_t want = (total + kBlock - 1) / kBlock;
-    const unsigned blocks = (unsigned)(want < 256 * 64 ? want : 256 * 64);
-    hipLaunchKernelGGL((box_difference_kernel<P>), dim3(blocks), dim3(kBlock), 0, stream, in, out, a);
+    if (a.n[0] <= 0 || a.n[1] <= 0 || a.n[2] <= 0) return RF_OK;
+    if ((a.n[1] + kBoxRows - 1) / kBoxRows > 65535 || a.n[2] > 65535 || a.n[0] >= (1ll << 31) || a.n[1] >= (1ll << 31)) {
+        set_error("box_difference: extents too large");
+        return RF_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)((a.n[0] + kBlock - 1) / kBlock), (unsigned)((a.n[1] + kBoxRows - 1) / kBoxRows), (unsigned)a.n[2]);
+    hipLaunchKernelGGL((box_difference_kernel<P>), grid, dim3(kBlock), 0, stream, in, out, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
