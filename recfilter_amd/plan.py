@@ -269,3 +269,27 @@ def box_difference(table, radius: int, order: Sequence[int], out=None, stream=No
     capi.check(capi.lib().rf_box_difference(ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(out.data_ptr()), len(shape), ext,
                                             _dtype_code(table.dtype), int(radius), ords, Plan._stream(stream)))
     return out
+
+
+def second_order_sections(coeff: Sequence[float]) -> List[List[float]]:
+    """Factors one scan {b, a1..ak} (y[i] = b x[i] + sum_j a_j y[i-j-1]) into first/second-order scans with the same
+    transfer function: the poles (roots of z^k - a1 z^(k-1) - ... - ak) are paired into conjugate pairs / pairs of real
+    poles, b goes to the first section.  Applied one after the other in the same direction with a ZERO border the
+    sections reproduce the original scan exactly (up to rounding); this is how orders above 3 reach the fused kernels
+    (the reference's audio apps sweep orders up to 29, apps/audio/audio_filter_high_order.cpp).  The inverse of
+    overlap_feedback_coeff (lib/iir_coeff.cpp:236-263)."""
+    coeff = [float(c) for c in coeff]
+    k = len(coeff) - 1
+    if k <= 2:
+        return [coeff]
+    poles = np.roots([1.0] + [-c for c in coeff[1:]])
+    cplx = sorted([p for p in poles if p.imag > 1e-12 * max(1.0, abs(p))], key=lambda p: -abs(p))
+    real = sorted([p.real for p in poles if abs(p.imag) <= 1e-12 * max(1.0, abs(p))], key=lambda p: -abs(p))
+    sections = [[1.0, float(2.0 * p.real), float(-(abs(p) ** 2))] for p in cplx]
+    while len(real) >= 2:
+        p, q = real.pop(0), real.pop(0)
+        sections.append([1.0, float(p + q), float(-p * q)])
+    if real:
+        sections.append([1.0, float(real[0])])
+    sections[0][0] = coeff[0]
+    return sections

@@ -286,3 +286,17 @@ def test_unsigned_byte_input_planes_are_a_prologue():
     gen = _host_plan((64, 250), scans, clamped=True)
     gen_u8 = _host_plan((64, 250), scans, clamped=True, input_dtype=np.uint8)
     assert gen.path_name == "tiled_generic" and gen_u8.num_kernels == gen.num_kernels + 1
+
+
+def test_second_order_sections_reproduce_the_scan():
+    """recfilter_amd.second_order_sections: the sections' cascade (zero border) is the original scan."""
+    rng = np.random.default_rng(3)
+    x = rng.random(4000)
+    for coeff in ([1.0] + [0.01] * 9, rfa.gaussian_weights(5.0, 3), [0.7, 0.5, -0.3, 0.1, 0.05], [1.0, 0.5]):
+        secs = rfa.second_order_sections(coeff)
+        assert all(len(s) <= 3 for s in secs)
+        y = x.copy()
+        for s in secs:
+            y = oracle.apply_filter(y, [(0, True, s)], False)
+        want = oracle.apply_filter(x, [(0, True, list(coeff))], False)
+        assert rc.rel_err(y, want) < 1e-5
