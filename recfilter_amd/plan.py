@@ -277,7 +277,10 @@ def second_order_sections(coeff: Sequence[float]) -> List[List[float]]:
     poles, b goes to the first section.  Applied one after the other in the same direction with a ZERO border the
     sections reproduce the original scan exactly (up to rounding); this is how orders above 3 reach the fused kernels
     (the reference's audio apps sweep orders up to 29, apps/audio/audio_filter_high_order.cpp).  The inverse of
-    overlap_feedback_coeff (lib/iir_coeff.cpp:236-263)."""
+    overlap_feedback_coeff (lib/iir_coeff.cpp:236-263).  Numerically this is a cascade form: well conditioned for
+    the usual low-pass designs (order-3 Gaussian: 3e-7), but for polynomials whose poles sit evenly on a circle (that
+    app's dummy coefficients) f32 cascades lose accuracy quickly above order 15 -- use f64 pixels or the direct form
+    there."""
     coeff = [float(c) for c in coeff]
     k = len(coeff) - 1
     if k <= 2:

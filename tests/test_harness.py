@@ -46,6 +46,7 @@ def test_audio_sweeps_and_width_sweep(tmp_path, capsys):
     assert "max rel err" in out
     for line in out.strip().splitlines():
         order = int(line.split()[0])
-        # orders above 3 run as f32 first/second-order sections: the rounding of their coefficients moves the poles of
-        # the app's high-order dummy polynomial (ill-conditioned) -- up to 1e-3 (order 21) against the f64 direct form
-        assert float(line.split()[-1]) < (1e-4 if order <= 9 else 5e-3), line
+        # Orders above 3 run as f32 first/second-order sections.  The app's dummy polynomial (all feedback 0.01) has its
+        # poles spread over a circle: a cascade of sharp resonators whose product is nearly flat, ill-conditioned in
+        # f32 (5e-5 at order 15 against the f64 direct form, 4e-2 at order 29, which is why the sweep stops at 15).
+        assert float(line.split()[-1]) < (1e-4 if order <= 9 else 1e-3), line

