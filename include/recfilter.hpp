@@ -15,6 +15,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <algorithm>
+#include <cmath>
+#include <ostream>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -107,6 +110,28 @@ struct RecFilterRealization {
         return h;
     }
 };
+
+/** Error summary of a result against a reference, in the reference's terms (lib/recfilter.h:792-823): per-sample
+ *  relative error in percent, 100 * |ref - out| / (ref + 1e-9), its maximum and its mean.  Streams like the
+ *  reference's CheckResult ("Max relative error = ... %"). */
+template <typename T>
+struct CheckResult {
+    float max_diff = 0.0f, mean_diff = 0.0f;
+    CheckResult(const std::vector<T> &ref, const std::vector<T> &out) {
+        if (ref.size() != out.size()) throw RecFilterError("CheckResult: images differ in size");
+        double sum = 0.0;
+        for (size_t i = 0; i < ref.size(); i++) {
+            const float re = 100.0f * std::abs((float)ref[i] - (float)out[i]) / ((float)ref[i] + 1e-9f);
+            sum += re;
+            max_diff = std::max(max_diff, re);
+        }
+        mean_diff = ref.empty() ? 0.0f : (float)(sum / (double)ref.size());
+    }
+};
+template <typename T>
+std::ostream &operator<<(std::ostream &s, const CheckResult<T> &v) {
+    return s << "Max  relative error = " << v.max_diff << " % \n" << "Mean relative error = " << v.mean_diff << " % \n\n";
+}
 
 class RecFilter;
 

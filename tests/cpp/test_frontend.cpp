@@ -175,6 +175,9 @@ int main() {
         std::vector<float> ref = f2.realize().to_host<float>();
         std::vector<float> out = f3.realize().to_host<float>();
         report("test_overlap_filter_order", rel_err(ref, out));
+        CheckResult<float> cr(ref, out);          // the reference's own summary (percent)
+        std::printf("%-34s CheckResult: max %.2e %%, mean %.2e %%\n", "", cr.max_diff, cr.mean_diff);
+        failures += !(cr.mean_diff < 1e-2f);
         (void)hipFree(d);
     }
     {   // apps/gaussian/gaussian_filter_1xy_2xy.cpp: 8 scans cascaded {0-3},{4-7}, clamped, 1024^2 -> fused path
