@@ -58,6 +58,8 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     // a row's last tile may be partial: its missing samples are zeros on load, skipped on store, and an anticausal
     // x scan enters at the last existing segment
     const int last_lane = (EDGE && tx == a.MX - 1) ? a.last_lane : 15;
+    const int last_cols = (EDGE && tx == a.MX - 1) ? a.last_cols : kFusedTX;       // columns of this tile that exist
+    const int entry_valid = last_cols - 16 * last_lane;                             // ... in the last existing segment
     // ... and so may the last tile row: rows_here of its TY rows exist, an anticausal y scan enters at the last of them
     const int rows_here = (EDGE && ty == a.MY - 1) ? a.last_rows : TY;
 
@@ -118,7 +120,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
         auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
         A4 tmp[TY / 4];
-        const bool chunk_in = cc <= 4 * last_lane + 3;        // this thread's 16-byte chunk exists in the image
+        const bool chunk_in = 4 * cc < last_cols;            // this thread's 16-byte chunk exists in the image
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
         if (rows_here == TY) {
 #pragma unroll
@@ -183,7 +185,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                     for (int q = 1; q < kFusedMaxScans; q++) cx[n][j] = (s == q) ? CX[q][n][j] : cx[n][j];
                 }
             if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
-            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane);
+            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
         }
 #pragma unroll
         for (int n = 0; n < NR; n++) {
@@ -233,7 +235,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                     const uint32_t nxu = (uint32_t)a.NX;
                     const Acc c1 = a.post_i * ((a.pw_flags & 1) ? a.pre_s : Acc(1));
                     const Acc c2 = a.post_b + a.post_i * ((a.pw_flags & 1) ? a.pre_b : Acc(0));
-                    if (t < 16 * (last_lane + 1)) {
+                    if (t < last_cols) {
 #pragma unroll
                         for (int i = 0; i < TY; i++)
                             if (i < rows_here) col[i] = a.post_f * col[i] + (c1 * (Acc)xp[(uint32_t)t + (uint32_t)i * nxu] + c2);
@@ -250,7 +252,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
             // row instead of a 64-bit address computation per store
             char *dpb = reinterpret_cast<char *>(dp);
             const uint32_t row_bytes = a.row_bytes;
-            if (t < 16 * (last_lane + 1)) {
+            if (t < last_cols) {
                 if (rows_here == TY) {
 #pragma unroll
                     for (int i = 0; i < TY; i++)
@@ -293,7 +295,7 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
                                     hipStream_t stream) {
     // the epilogue variant that keeps the input column in registers exists for float pixels only
     bool epi = false;
-    const bool edge = a.last_lane != 15 || a.last_rows != TY;
+    const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
 #define RF_CASE(KK, TT)                                                                                         \
     if (K == KK && TY == TT) {                                                                                  \

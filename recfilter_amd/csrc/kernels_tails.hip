@@ -65,7 +65,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
     const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
-    const bool chunk_in = (tx != a.MX - 1) || (cc <= 4 * a.last_lane + 3);
+    const bool chunk_in = (tx != a.MX - 1) || (4 * cc < a.last_cols);
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
 
     Acc comb[kFusedMaxScans * K];
@@ -232,7 +232,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // touches every tail sample anyway; the y carry scan then needs no knowledge of x.  The G table of the
 // interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
 // border tiles read their variant from memory.
-template <typename Acc, int K>
+template <typename Acc, int K, bool EDGE>
 __global__ void __launch_bounds__(256)
 xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
@@ -327,11 +327,12 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
             const FusedScan<Acc> &sc = a.xs[s];
             const bool causal = sc.causal != 0;
             const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-            const int last_lane = (tx == a.MX - 1) ? a.last_lane : 15;       // a row's last tile may be partial
+            const int last_lane = (EDGE && tx == a.MX - 1) ? a.last_lane : 15;       // a row's last tile may be partial
             const bool first_lane = causal ? (l == 0) : (l == last_lane);
             const bool clamp_first = a.clamped && tile_first && first_lane;
             if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, clamp_first, zero);
-            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero, l > last_lane);
+            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero, l > last_lane,
+                                                          (EDGE && tx == a.MX - 1) ? a.last_cols - 16 * a.last_lane : kFusedSeg);
         }
         if (residual) {
 #pragma unroll
@@ -406,7 +407,14 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
     const int64_t n_row_tiles = (int64_t)a.ny * a.MY * K * a.NZ * a.MX;
     if (n_row_tiles <= 0 || a.nx == 0) return RF_OK;
     const unsigned grid = (unsigned)((n_row_tiles + 15) / 16);
-#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, TY, Hy, G); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    const bool edge = a.last_cols != kFusedTX;       // images of whole tiles keep the lean kernel
+#define RF_CASE(KK)                                                                                                        \
+    if (K == KK) {                                                                                                         \
+        if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, TY, Hy, G);  \
+        else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, TY, Hy, G); \
+        RF_HIP_CHECK(hipGetLastError());                                                                                   \
+        return RF_OK;                                                                                                      \
+    }
     RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
     set_error("xscan rows: unsupported order %d", K);

@@ -54,7 +54,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         if (want == 32 || want == 64) TY = want;
     }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
-    // The width only has to be a multiple of 16 (one x-phase segment): the last tile of a row may be partial.  Its
+    // The width only has to be a multiple of 4 (rows stay 16-byte aligned): the last tile of a row may be partial.  Its
     // missing samples are loaded as zeros and never stored; the tables of the "last tile" variants are built for the
     // samples that exist (tables.h, T_last), so a clamped anticausal scan enters at the true image border.
     // The height is arbitrary: the last tile row may be partial in the same way (rows loaded as zeros, never stored,
@@ -237,7 +237,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     FusedArgs<Acc> fbase{};
     fbase.NX = NX; fbase.NY = NY; fbase.NZ = NZ; fbase.MX = MX; fbase.MY = MY; fbase.nx = nx; fbase.ny = ny;
-    fbase.NXP = NXP; fbase.last_lane = TVx / kFusedSeg - 1;
+    fbase.NXP = NXP; fbase.last_lane = (TVx - 1) / kFusedSeg; fbase.last_cols = TVx;
     fbase.NYP = NYP; fbase.last_rows = TVy;
     fbase.row_bytes = (uint32_t)(NX * (int64_t)sizeof(P));
     fbase.clamped = plan->clamped ? 1 : 0;
@@ -427,7 +427,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
         return true;
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
-    if (plan->dims[0].N % kFusedSeg != 0) return no("width must be a multiple of 16");
+    if (plan->dims[0].N % 4 != 0) return no("width must be a multiple of 4 (16-byte rows)");
     if (plan->ndim == 2 && plan->shard_world > 1 && plan->dims[1].N % 32 != 0)
         return no("row-sharded slabs must be whole tiles (height a multiple of 32)");
     const int K = fused_order(plan);

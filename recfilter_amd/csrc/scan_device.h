@@ -34,7 +34,8 @@ __device__ __forceinline__ int swz_chunk(int c) { return c ^ ((c >> 4) & 3); }
 // interleaves them (ILP = NR) and the dependent-FMA latency of one row hides behind the others.
 template <typename Acc, bool CAUSAL, int K, int NR>
 __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const FusedScan<Acc> &sc, bool first_lane,
-                                            bool clamp_first, const Acc (&carry)[NR][K], bool dead_lane = false) {
+                                            bool clamp_first, const Acc (&carry)[NR][K], bool dead_lane = false,
+                                            int entry_valid = kFusedSeg) {
     Acc h[NR][K];
     Acc y0[NR];
 #pragma unroll
@@ -48,7 +49,17 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
     constexpr int m_first = CAUSAL ? 0 : kFusedSeg - 1;
     Acc x_first[NR];
 #pragma unroll
-    for (int n = 0; n < NR; n++) x_first[n] = v[n][m_first];
+    for (int n = 0; n < NR; n++) {
+        x_first[n] = v[n][m_first];
+        if (!CAUSAL && entry_valid < kFusedSeg) {                    // partial entry segment: its last existing sample
+            // (three plain registers behind an opaque asm: left alone the compiler folds the select chain into
+            // v[n][entry_valid - 1], a run-time index that sends the whole register array to scratch)
+            Acc s3 = v[n][3], s7 = v[n][7], s11 = v[n][11];
+            asm volatile("" : "+v"(s3), "+v"(s7), "+v"(s11));
+            const Acc pick = entry_valid == 4 ? s3 : (entry_valid == 8 ? s7 : s11);
+            x_first[n] = first_lane ? pick : x_first[n];
+        }
+    }
     if constexpr (std::is_same<Acc, float>::value) {
         typedef float F2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -65,6 +76,33 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
 #pragma unroll
             for (int n = 0; n < NR; n++) v[n][m] = sc.b * v[n][m];
     }
+    // An anticausal scan of a row's partial last tile enters inside the entry lane's segment when the width is not a
+    // multiple of 16: only its first entry_valid (4, 8 or 12; wave-uniform) samples exist.  The dead ones are cleared --
+    // an earlier causal scan ran on into them -- and the clamped prologue is positioned per lane; with a zero state
+    // the dead positions then stay zero until the scan reaches the image.  Only those tiles take this path.
+    if (!CAUSAL && entry_valid < kFusedSeg) {
+        const int off = first_lane ? kFusedSeg - entry_valid : 0;           // direction positions before the image
+#pragma unroll
+        for (int p = 0; p < kFusedSeg; p++) {
+            const int m = kFusedSeg - 1 - p;
+            const int pr = p - off;
+#pragma unroll
+            for (int n = 0; n < NR; n++) {
+                Acc acc = pr < 0 ? Acc(0) : v[n][m];
+#pragma unroll
+                for (int j = K - 1; j >= 0; j--) {
+                    Acc g = h[n][j];
+                    g = (clamp_first && pr >= 0 && pr <= j) ? (pr == 0 ? x_first[n] : y0[n]) : g;
+                    acc = acc + sc.a[j] * g;
+                }
+#pragma unroll
+                for (int j = K - 1; j > 0; j--) h[n][j] = h[n][j - 1];
+                h[n][0] = acc;
+                y0[n] = (pr == 0) ? acc : y0[n];
+                v[n][m] = acc;
+            }
+        }
+    } else
     // 1. segment-local recurrence (exact for the first lane, which owns the tile's carry)
 #pragma unroll
     for (int p = 0; p < kFusedSeg; p++) {

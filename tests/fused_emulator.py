@@ -47,9 +47,10 @@ class FusedEmu:
             self.Hy = plan.table("H_y").reshape(4, ny, K, self.TY)
 
     # -- x phase of one scan on rows [R, 256], exactly the kernel's decomposition ------------------
-    def xphase(self, rows, s, carry, clamp_first, last_lane=SEG - 1):
-        """last_lane < 15: the tile is a row's partial last tile, its segments beyond last_lane do not exist.  An
-        anticausal scan enters at segment last_lane and the dead segments' exit states are dropped."""
+    def xphase(self, rows, s, carry, clamp_first, last_lane=SEG - 1, entry_valid=SEG):
+        """last_lane < 15 or entry_valid < 16: the tile is a row's partial last tile; its segments beyond last_lane and the
+        samples beyond entry_valid of segment last_lane do not exist.  An anticausal scan enters at the last existing
+        sample, the dead samples are cleared and the dead segments' exit states are dropped."""
         causal = self.xs[s][0]
         b, a = self.xc[s]
         K = self.K
@@ -63,7 +64,14 @@ class FusedEmu:
             c = None
             if l == first and carry is not None:
                 c = [carry[j] for j in range(K)]
-            scan_tile(v, True, b, a, K, clamp_first and l == first, c)
+            if not causal and l == first and entry_valid < SEG:
+                off = SEG - entry_valid                 # direction positions before the image
+                v[:, :off] = 0.0
+                w = np.ascontiguousarray(v[:, off:])
+                scan_tile(w, True, b, a, K, clamp_first, c)
+                v[:, off:] = w
+            else:
+                scan_tile(v, True, b, a, K, clamp_first and l == first, c)
             seg[:, l, :] = v
             if not causal and l < first:
                 continue                              # dead lane: exit state stays zero
@@ -85,7 +93,9 @@ class FusedEmu:
         K, TY = self.K, self.TY
         MX = (NX_real + TX - 1) // TX                 # the last tile of a row may be partial: zero padded here,
         NX = MX * TX                                  # never read back
-        last_lane_of = lambda tx: (NX_real - (MX - 1) * TX) // SEG - 1 if tx == MX - 1 else SEG - 1
+        TV = NX_real - (MX - 1) * TX                  # columns of the last tile
+        last_lane_of = lambda tx: (TV - 1) // SEG if tx == MX - 1 else SEG - 1
+        entry_of = lambda tx: TV - SEG * ((TV - 1) // SEG) if tx == MX - 1 else SEG
         if NX != NX_real:
             img = np.concatenate([img, np.zeros((NY, NX - NX_real))], axis=1)
         NY_real = NY
@@ -168,7 +178,7 @@ class FusedEmu:
                 for tx in range(MX):
                     rows = np.stack([yt[j, ty, r, tx * TX:(tx + 1) * TX] for j in range(ny) for r in range(K)])
                     for s in range(nx):
-                        rows = self.xphase(rows, s, None, clamped and xfirst(s, tx), last_lane_of(tx))
+                        rows = self.xphase(rows, s, None, clamped and xfirst(s, tx), last_lane_of(tx), entry_of(tx))
                     for j in range(ny):
                         for r in range(K):
                             acc = rows[j * K + r].copy()
@@ -200,7 +210,7 @@ class FusedEmu:
                 t = img[ty * TY:(ty + 1) * TY, tx * TX:(tx + 1) * TX].copy()
                 for s in range(nx):
                     c = None if xfirst(s, tx) else xcarry(s, tx)[:, ty * TY:(ty + 1) * TY]
-                    t = self.xphase(t, s, c, clamped and xfirst(s, tx), last_lane_of(tx))
+                    t = self.xphase(t, s, c, clamped and xfirst(s, tx), last_lane_of(tx), entry_of(tx))
                 for j in range(ny):
                     c = None if yfirst(j, ty) else ycarry(j, ty)[:, tx * TX:(tx + 1) * TX]
                     t = yscan(t, j, c, ty)

@@ -155,6 +155,12 @@ FUSED_CASES = {
     "partial_x_only_causal_then_anti": dict(shape=(64, 272), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.6, 0.3]),
                                                                     (0, True, [0.9, 0.05]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
     "partial_sat": dict(shape=(64, 1936), scans=[(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], clamped=False),
+    # widths that are multiples of 4 only: the scan enters inside a 16-sample segment
+    "partial_w4_gauss2_clamped": dict(shape=(64, 300), scans=xy_pm(GAUSS2), clamped=True),
+    "partial_w4_gauss3_clamped": dict(shape=(50, 1000), scans=xy_pm(GAUSS3), clamped=True),
+    "partial_w4_mixed_zero": dict(shape=(33, 20), scans=REFERENCE_TESTS["test_generic_xy"]["scans"], clamped=False),
+    "partial_w4_x_scans": dict(shape=(32, 268), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.6, 0.3]),
+                                                       (0, True, [0.9, 0.05]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
     # heights that are not multiples of 32: the last tile row is partial
     "partial_y_gauss2_clamped": dict(shape=(100, 512), scans=xy_pm(GAUSS2), clamped=True),
     "partial_xy_gauss3_clamped": dict(shape=(135, 240), scans=xy_pm(GAUSS3), clamped=True),

@@ -220,10 +220,10 @@ def test_fused_plan_tables_reproduce_oracle(name):
 
 
 def test_fused_not_applicable_falls_back_in_auto_mode():
-    p = _host_plan((100, 300), rc.xy_pm(rc.GAUSS2), clamped=True)       # width not a multiple of 256
+    p = _host_plan((100, 302), rc.xy_pm(rc.GAUSS2), clamped=True)       # width not a multiple of 4: rows not 16-byte aligned
     assert p.path == capi.RF_PATH_TILED_GENERIC
     with pytest.raises(rfa.RecFilterError) as e:
-        _host_plan((100, 300), rc.xy_pm(rc.GAUSS2), clamped=True, path=capi.RF_PATH_TILED_FUSED)
+        _host_plan((100, 302), rc.xy_pm(rc.GAUSS2), clamped=True, path=capi.RF_PATH_TILED_FUSED)
     assert e.value.status == capi.RF_ERR_UNSUPPORTED
     p = _host_plan((64, 512), rc.xy_pm(rc.GAUSS2), clamped=True)
     assert p.path == capi.RF_PATH_TILED_FUSED

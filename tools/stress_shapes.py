@@ -14,9 +14,9 @@ worst = 0.0
 for case in range(n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
-        shape = (int(rng.integers(1, 9000)), 16 * int(rng.integers(1, 600)))
+        shape = (int(rng.integers(1, 9000)), 4 * int(rng.integers(1, 2400)))
     else:
-        shape = (int(rng.choice([32, 64, 96])), int(rng.integers(1, 700)), 16 * int(rng.integers(1, 80)))
+        shape = (int(rng.choice([32, 64, 96])), int(rng.integers(1, 700)), 4 * int(rng.integers(1, 320)))
     scans = []
     for d in range(ndim):
         for _ in range(int(rng.integers(0, 3 if d < 2 else 2)) + (1 if d == 0 else 0)):
