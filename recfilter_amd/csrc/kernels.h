@@ -66,6 +66,8 @@ struct GenericDimArgs {
     Acc *incoming;             // [scan][r][line]   carry entering the slab (zeros at the image border)
     const Acc *W;              // [variant 4][q][s][r][o]   (q < s used)
     const Acc *A;              // [s][r][j]
+    const Acc *Apow;           // [s][i][r][j] = (A[s])^(i+1), i = 0..M-1: what the carry entering the slab adds to the
+                               // tail of the i-th tile in scan direction (carry_apply); may be null (serial fallback)
 };
 
 template <typename P>

@@ -246,6 +246,36 @@ generic_carry_apply_kernel(GenericDimArgs<Acc> a, int s) {
     }
 }
 
+// The same update with every tile independent: tail(t) += A^(i+1) * incoming, the powers tabulated on the host
+// (GenericDimArgs::Apow).  Thread = line, blockIdx.y = a chunk of kApplyTiles tiles; the matrix of a tile is
+// wave-uniform (scalar loads), the tails are read and written once, coalesced across lines.  The serial kernel above
+// walks the tiles of a line in one thread -- a chain of dependent read-modify-writes that took 0.33 ms per scan on a
+// cfg3 slab; this one is bound by the tails' traffic.
+constexpr int kApplyTiles = 8;
+template <typename Acc>
+__global__ void __launch_bounds__(kBlock)
+carry_apply_parallel_kernel(GenericDimArgs<Acc> a, int s) {
+    const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int k = a.k;
+    const bool causal = a.scans[s].causal != 0;
+    Acc x[RF_MAX_ORDER];
+#pragma unroll
+    for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
+    for (int j = 0; j < k; j++) x[j] = a.incoming[((int64_t)s * k + j) * a.g.lines + line];
+    const int i0 = (int)blockIdx.y * kApplyTiles;
+    for (int i = i0; i < i0 + kApplyTiles && i < a.M; i++) {
+        const int t = causal ? i : a.M - 1 - i;
+        const Acc *Ap = a.Apow + ((int64_t)s * a.M + i) * k * k;          // wave-uniform
+        for (int r = 0; r < k; r++) {
+            Acc add = Acc(0);
+            for (int j = 0; j < k; j++) add = add + Ap[r * k + j] * x[j];
+            const int64_t idx = tail_idx(a, s, t, r, line);
+            a.tails[idx] = a.tails[idx] + add;
+        }
+    }
+}
+
 template <typename Acc>
 __global__ void __launch_bounds__(kBlock)
 gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gathered, int64_t rank_stride,
@@ -306,7 +336,12 @@ int launch_generic_pass2(const P *src, P *dst, GenericDimArgs<typename PixelTrai
 
 template <typename Acc>
 int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream) {
-    hipLaunchKernelGGL(generic_carry_apply_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
+    if (a.Apow != nullptr && a.M > 0) {
+        dim3 grid(grid_for(a.g.lines), (unsigned)((a.M + kApplyTiles - 1) / kApplyTiles));
+        hipLaunchKernelGGL(carry_apply_parallel_kernel<Acc>, grid, dim3(kBlock), 0, stream, a, s);
+    } else {
+        hipLaunchKernelGGL(generic_carry_apply_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
+    }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }

@@ -152,12 +152,13 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->tables["seg_P_x"] = sp;
     }
     std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
-    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy, hHx, hHy, hAMx, hAMSx;
+    std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy, hHx, hHy, hAMx, hAMSx, hApowX, hApowY;
     const int chain_S = (int)((NY + 63) / 64);     // rows per lane of the row-chain kernel
     const int Cx = carry_chunk_length(MX, Lx), Cy = carry_chunk_length(MY, Ly);
     if (nx > 0) {
         DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped, TVx);
         flatten_W(tx, nx, hWx, hAx, "x");
+        if (chained) hApowX = carry_apply_powers<S, Acc>(tx.A, MX, K);
         {
             std::vector<S> H = build_tail_responses<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped, TVx);
             std::vector<double> dH(H.size());
@@ -195,6 +196,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (ny > 0) {
         DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped, TVy);
         flatten_W(ty, ny, hWy, hAy, "y");
+        if (y_sharded) hApowY = carry_apply_powers<S, Acc>(ty.A, MY, K);
         {
             std::vector<S> H = build_tail_responses<S>(table_scans(dy.scan_ids), K, TY, plan->clamped, TVy);
             std::vector<double> dH(H.size());
@@ -224,6 +226,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const Acc *d_Wx = up(hWx), *d_Ax = up(hAx), *d_Wy = up(hWy), *d_Ay = up(hAy), *d_G = up(hG), *d_AMy = up(hAMy);
     const Acc *d_ACx = up(hACx), *d_ACy = up(hACy), *d_Hx = up(hHx), *d_Hy = up(hHy);
     const Acc *d_AMx = up(hAMx), *d_AMSx = up(hAMSx);
+    const Acc *d_ApowX = up(hApowX), *d_ApowY = up(hApowY);      // only filled when carry_apply runs (chained rows, row shards)
 
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
@@ -271,7 +274,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     gx.g = LineGeom{NX, 1, Lx};
     gx.T = kFusedTX; gx.M = MX; gx.k = K; gx.n_scans = nx; gx.clamped = fbase.clamped;
     gx.first_is_border = 1; gx.last_is_border = 1;
-    gx.scans = d_xd; gx.W = d_Wx; gx.A = d_Ax;
+    gx.scans = d_xd; gx.W = d_Wx; gx.A = d_Ax; gx.Apow = hApowX.empty() ? nullptr : d_ApowX;
     auto gxargs = [=](int pl) {
         GenericDimArgs<Acc> a = gx;
         a.tails = xt + (size_t)pl * xt_pp;
@@ -282,7 +285,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     gy.g = LineGeom{NY, NXP, Ly};
     gy.T = TY; gy.M = MY; gy.k = K; gy.n_scans = ny; gy.clamped = fbase.clamped;
     gy.first_is_border = fbase.y_first_border; gy.last_is_border = fbase.y_last_border;
-    gy.scans = d_yd; gy.W = d_Wy; gy.A = d_Ay;
+    gy.scans = d_yd; gy.W = d_Wy; gy.A = d_Ay; gy.Apow = hApowY.empty() ? nullptr : d_ApowY;
     auto gyargs = [=](int pl) {
         GenericDimArgs<Acc> a = gy;
         a.tails = yt + (size_t)pl * yt_pp;

@@ -52,6 +52,20 @@ double table_to_double(S v) {
     else return (double)v;
 }
 
+// (A[s])^(i+1) for i = 0..M-1, flattened [s][i][r][j] in the kernels' arithmetic type (GenericDimArgs::Apow)
+template <typename S, typename Acc>
+std::vector<Acc> carry_apply_powers(const std::vector<std::vector<S>> &A, int64_t M, int k) {
+    std::vector<Acc> out((size_t)A.size() * M * k * k);
+    for (size_t s = 0; s < A.size(); s++) {
+        std::vector<S> pw = A[s];
+        for (int64_t i = 0; i < M; i++) {
+            for (int e = 0; e < k * k; e++) out[((size_t)s * M + i) * k * k + e] = table_to_acc<S, Acc>(pw[e]);
+            pw = mat_mul<S>(pw, A[s], k);
+        }
+    }
+    return out;
+}
+
 inline int pick_generic_tile(int64_t N, int k, int hint) {
     if (hint > 0 && hint <= kGenericMaxTile && N % hint == 0 && hint >= k) return hint;
     int cap = hint > 0 ? kGenericMaxTile : 64;
@@ -138,6 +152,11 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
         const Acc *dAp = (const Acc *)plan->upload(hA.data(), hA.size() * sizeof(Acc), &status);
         const Acc *dAMp = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
         const Acc *dACp = (const Acc *)plan->upload(hAC.data(), hAC.size() * sizeof(Acc), &status);
+        const Acc *dApow = nullptr;
+        if (d == outer && plan->shard_world > 1) {
+            std::vector<Acc> hApow = carry_apply_powers<S, Acc>(tab.A, di.M, k);
+            dApow = (const Acc *)plan->upload(hApow.data(), hApow.size() * sizeof(Acc), &status);
+        }
         size_t tails_per_plane = (size_t)n * di.M * k * di.lines;
         size_t inc_per_plane = (size_t)n * k * di.lines;
         Acc *tails = (Acc *)plan->alloc(tails_per_plane * plan->n_planes * sizeof(Acc), false, &status);
@@ -151,7 +170,7 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
         base.clamped = plan->clamped ? 1 : 0;
         base.first_is_border = (!sharded_dim || plan->shard_rank == 0) ? 1 : 0;
         base.last_is_border = (!sharded_dim || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
-        base.scans = dScans; base.W = dWp; base.A = dAp;
+        base.scans = dScans; base.W = dWp; base.A = dAp; base.Apow = dApow;
         auto args_for = [base, tails, incoming, tails_per_plane, inc_per_plane](int pl) {
             GenericDimArgs<Acc> a = base;
             a.tails = tails + (size_t)pl * tails_per_plane;

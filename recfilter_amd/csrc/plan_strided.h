@@ -81,6 +81,11 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     const Acc *d_A = (const Acc *)plan->upload(hA.data(), hA.size() * sizeof(Acc), &status);
     const Acc *d_AC = (const Acc *)plan->upload(hAC.data(), hAC.size() * sizeof(Acc), &status);
     const Acc *d_AM = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
+    const Acc *d_Apow = nullptr;
+    if (sharded) {
+        std::vector<Acc> hApow = carry_apply_powers<S, Acc>(tab.A, M, K);
+        d_Apow = (const Acc *)plan->upload(hApow.data(), hApow.size() * sizeof(Acc), &status);
+    }
     const size_t tails_pp = (size_t)n * M * K * di.lines, inc_pp = (size_t)n * K * di.lines;
     Acc *tails = (Acc *)plan->alloc(tails_pp * np * sizeof(Acc), false, &status);
     Acc *incoming = (Acc *)plan->alloc(inc_pp * np * sizeof(Acc), true, &status);
@@ -100,7 +105,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     gb.g = LineGeom{di.N, di.stride, di.lines};
     gb.T = TZ; gb.M = M; gb.k = K; gb.n_scans = n; gb.clamped = base.clamped;
     gb.first_is_border = base.first_is_border; gb.last_is_border = base.last_is_border;
-    gb.scans = d_scans; gb.W = d_W; gb.A = d_A;
+    gb.scans = d_scans; gb.W = d_W; gb.A = d_A; gb.Apow = d_Apow;
     auto gargs = [=](int pl) {
         GenericDimArgs<Acc> a = gb;
         a.tails = tails + (size_t)pl * tails_pp;
