@@ -264,14 +264,25 @@ carry_apply_parallel_kernel(GenericDimArgs<Acc> a, int s) {
     for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
     for (int j = 0; j < k; j++) x[j] = a.incoming[((int64_t)s * k + j) * a.g.lines + line];
     const int i0 = (int)blockIdx.y * kApplyTiles;
-    for (int i = i0; i < i0 + kApplyTiles && i < a.M; i++) {
-        const int t = causal ? i : a.M - 1 - i;
-        const Acc *Ap = a.Apow + ((int64_t)s * a.M + i) * k * k;          // wave-uniform
-        for (int r = 0; r < k; r++) {
-            Acc add = Acc(0);
-            for (int j = 0; j < k; j++) add = add + Ap[r * k + j] * x[j];
-            const int64_t idx = tail_idx(a, s, t, r, line);
-            a.tails[idx] = a.tails[idx] + add;
+    // all loads of the chunk first, then the stores: interleaved, every store could alias the next load and the
+    // read-modify-writes would run one after the other
+    for (int r = 0; r < k; r++) {
+        Acc cur[kApplyTiles];
+#pragma unroll
+        for (int u = 0; u < kApplyTiles; u++) {
+            const int i = i0 + u;
+            cur[u] = Acc(0);
+            if (i < a.M) cur[u] = a.tails[tail_idx(a, s, causal ? i : a.M - 1 - i, r, line)];
+        }
+#pragma unroll
+        for (int u = 0; u < kApplyTiles; u++) {
+            const int i = i0 + u;
+            if (i < a.M) {
+                const Acc *Ap = a.Apow + ((int64_t)s * a.M + i) * k * k;          // wave-uniform
+                Acc add = Acc(0);
+                for (int j = 0; j < k; j++) add = add + Ap[r * k + j] * x[j];
+                a.tails[tail_idx(a, s, causal ? i : a.M - 1 - i, r, line)] = cur[u] + add;
+            }
         }
     }
 }
