@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
     ap.add_argument("--path", type=int, default=0, help="rf_path override (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
+                    "multi-rank path on a box with one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="device ordinal for every rank (debug; default LOCAL_RANK)")
     args = ap.parse_args()
 
     import numpy as np
@@ -116,12 +119,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = workload(args.workload, args.size)
     shape, planes = cfg["shape"], cfg["planes"]

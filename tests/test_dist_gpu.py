@@ -66,3 +66,20 @@ def test_two_processes_one_gpu(case, tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_bench_two_ranks_over_gloo():
+    """bench.py's multi-rank flow (rendezvous, sharded steps with one all-gather per y scan, barriers, max-over-ranks
+    timing, one JSON line from rank 0) with two ranks on this box's one GPU; the driver runs the same script over RCCL."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--device", "0", "--size", "1024"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["path"] == "tiled_fused"
+    assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] == "fused_pass2"
