@@ -144,15 +144,18 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
 /* For a plan with shard_world > 1 the scans along the outermost dimension need the carry of
  * the neighbouring slab.  Protocol, per execute (all calls asynchronous on the begin() stream):
  *     rf_plan_begin(...)                         pass 1 + every slab-local carry stage
- *     for e in 0 .. rf_plan_num_exchanges()-1:   one per scan along the sharded dimension
+ *     for e in 0 .. rf_plan_num_exchanges()-1:   ONE for all scans of the sharded dimension (orders <= 3, at most
+ *                                                4 scans, scans * world * order <= 128), else one per scan
  *         rf_plan_exchange_local(e, send)        slab-local recurrence; writes this slab's exit
- *                                                carry (rf_plan_exchange_bytes(e) bytes) to `send`
+ *                                                carries (rf_plan_exchange_bytes(e) bytes) to `send`
  *         -- caller all-gathers `send` over the ranks into `gathered` (world * bytes, rank-major;
  *            RCCL all-gather on the same stream) --
  *         rf_plan_exchange_apply(e, gathered)    forms the incoming carry, fixes the slab's tails
  *     rf_plan_finish(...)                        final correction pass
  * `send` and `gathered` are caller-owned device buffers.  With shard_world == 1 the apply step
- * is a no-op and may be skipped. */
+ * is a no-op and may be skipped.  Every slab must have the same extent along the sharded dimension
+ * (a slab's exit carry is propagated across the slabs between it and the receiver with tables built
+ * from the local tile count). */
 int rf_plan_num_exchanges(const rf_plan *plan);
 size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange);
 int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream);

@@ -80,6 +80,13 @@ template <typename Acc>
 int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, int64_t rank_stride,
                            int64_t plane_offset, int rank, int world, const Acc *AM /* k*k device */,
                            hipStream_t stream);
+// merged exchange (all scans of the sharded dimension behind one all-gather): gathered[h][plane][s][r][line] holds
+// every slab's zero-entering-carry exits; X[type][q][s] / Y[q][s][t] are the cross-scan transfers of plan_generic.h
+template <typename Acc>
+int launch_merged_gather(GenericDimArgs<Acc> a, const Acc *gathered, int64_t rank_stride, int64_t plane_offset, int rank,
+                         int world, const Acc *X, hipStream_t stream);
+template <typename Acc>
+int launch_merged_apply(GenericDimArgs<Acc> a, const Acc *Y, hipStream_t stream);
 template <typename P>
 int launch_generic_pass2(const P *src, P *dst, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream);
 

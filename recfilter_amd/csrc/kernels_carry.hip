@@ -175,7 +175,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                 for (int r = 0; r < K; r++) carry_in[ln][r] = last_tail[r];
                 if (send != nullptr && last_i == M - 1 && line_ok) {
 #pragma unroll
-                    for (int r = 0; r < K; r++) send[(uint32_t)r * L + line] = last_tail[r];
+                    for (int r = 0; r < K; r++) send[(uint32_t)((s - s_begin) * K + r) * L + line] = last_tail[r];
                 }
             }
             __syncthreads();
@@ -201,7 +201,7 @@ template <typename Acc, int K, int KP, bool CAUSAL>
 __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, const CarryGeom &g, Acc *__restrict__ tails,
                                           const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
                                           Acc (*exits)[kCarryLines][K], int ln, int ch, int n_chunks, int t0, int nvalid,
-                                          uint32_t line, bool line_ok) {
+                                          uint32_t line, bool line_ok, Acc *__restrict__ send) {
     const int M = g.M;
     const uint32_t L = g.lines;
     const uint32_t tile_stride = (uint32_t)K * L;
@@ -268,6 +268,8 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, c
                 inc[r] = y[r];
                 t[ii][r] = t[ii][r] + y[r];
                 if (line_ok) tails[base + (uint32_t)(t0 + ii) * tile_stride + (uint32_t)r * L] = t[ii][r];
+                // the slab's exit carry: the completed tail of the last tile in scan direction
+                if (send != nullptr && line_ok && t0 + ii == (causal ? M - 1 : 0)) send[(uint32_t)r * L + line] = t[ii][r];
             }
         }
     }
@@ -283,7 +285,8 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, c
 template <typename Acc, int K>
 __global__ void __launch_bounds__(kCarryLines * kCarryChunks)
 carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
-                  const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C) {
+                  const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
+                  Acc *__restrict__ send) {
     __shared__ Acc exits[kCarryChunks][kCarryLines][K];
     __shared__ Acc edge[kCarryChunks][2][kCarryLines][K];      // first / last completed tail of every chunk (scan s0)
 
@@ -317,8 +320,8 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     load_scan(ta, s0);
     load_scan(tb, s0 + 1);
 
-    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, KP, true>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
-    else                            pair_run_scan<Acc, K, KP, false>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, KP, true>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send);
+    else                            pair_run_scan<Acc, K, KP, false>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send);
 
     // ---- chaining of scan s0+1 on the completed scan s0 ----
     {
@@ -357,8 +360,9 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
         }
     }
     __syncthreads();          // exits[] is reused by the second scan
-    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, KP, true>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
-    else                                  pair_run_scan<Acc, K, KP, false>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok);
+    Acc *send2 = send != nullptr ? send + (uint32_t)K * L : nullptr;
+    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, KP, true>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send2);
+    else                                  pair_run_scan<Acc, K, KP, false>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send2);
 }
 
 // Row chaining for a long 1-D signal folded into NY rows of MX tiles (plan_fused.cpp, "chained rows"): the
@@ -460,15 +464,15 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
     int n_chunks = carry_chunk_count(a.M, a.g.lines, C, K);
     const unsigned threads = (unsigned)(kCarryLines * n_chunks);
-    // two scans of order <= 2, nothing to send, every line's tiles in one block of chunks: the register-chained pair kernel
+    // two scans of order <= 2, every line's tiles in one block of chunks: the register-chained pair kernel
     // (order 3 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
     if constexpr (sizeof(Acc) == 4) {
         static const bool pair_off = getenv("RF_CARRY_NO_PAIR") != nullptr;     // tuning knob: always the general kernel
-        if (s_end - s_begin == 2 && send == nullptr && K <= 2 && (int64_t)n_chunks * C >= a.M && !pair_off) {
+        if (s_end - s_begin == 2 && K <= 2 && (int64_t)n_chunks * C >= a.M && !pair_off) {
             if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
-                                           (const Acc *)a.incoming, a.W, a.A, AC, C);
+                                           (const Acc *)a.incoming, a.W, a.A, AC, C, send);
             else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
-                                           (const Acc *)a.incoming, a.W, a.A, AC, C);
+                                           (const Acc *)a.incoming, a.W, a.A, AC, C, send);
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
         }

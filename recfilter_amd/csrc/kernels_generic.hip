@@ -315,6 +315,91 @@ gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gat
     for (int r = 0; r < k; r++) a.incoming[((int64_t)s * k + r) * a.g.lines + line] = x[r];
 }
 
+// ---- merged exchange: one all-gather for all scans of the sharded dimension ---------------------------------
+// Every slab has completed its scans with zero entering carries and published the exit carry of each
+// (gathered[h][plane][s][r][line]).  The true exit of slab h for scan s is
+//     E_s[h] = E_s^local[h] + sum_{q <= s} X[type(h)][q][s] * in_q[h]
+// (X = the exit-tile rows of the cross-scan transfer Y, plan_generic.h), and in_s of the next slab in scan
+// direction is E_s[h].  One thread per line walks the slabs for every scan in order; the carries entering EVERY
+// slab are kept (the cross terms of later scans need them), n * world * k values in a private array.
+constexpr int kMergeMaxState = 128;
+template <typename Acc>
+__global__ void __launch_bounds__(kBlock)
+merged_gather_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered, int64_t rank_stride, int64_t plane_offset,
+                     int rank, int world, const Acc *__restrict__ X) {
+    const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int k = a.k, n = a.n_scans;
+    const int64_t L = a.g.lines;
+    Acc in[kMergeMaxState];
+    for (int s = 0; s < n; s++) {
+        const bool causal = a.scans[s].causal != 0;
+        Acc prev[RF_MAX_ORDER];
+        for (int j = 0; j < k; j++) prev[j] = Acc(0);
+        for (int i = 0; i < world; i++) {
+            const int h = causal ? i : world - 1 - i;
+            for (int j = 0; j < k; j++) in[(s * world + h) * k + j] = prev[j];
+            if (i == world - 1) break;        // nobody follows the last slab
+            const int type = (h == 0 ? 1 : 0) | (h == world - 1 ? 2 : 0);
+            Acc e[RF_MAX_ORDER];
+            for (int r = 0; r < k; r++) {
+                Acc acc = gathered[h * rank_stride + plane_offset + ((int64_t)s * k + r) * L + line];
+                for (int q = 0; q <= s; q++) {
+                    const Acc *Xm = X + (((int64_t)type * n + q) * n + s) * k * k;
+                    for (int j = 0; j < k; j++) acc = acc + Xm[r * k + j] * in[(q * world + h) * k + j];
+                }
+                e[r] = acc;
+            }
+            for (int r = 0; r < k; r++) prev[r] = e[r];
+        }
+        for (int r = 0; r < k; r++) a.incoming[((int64_t)s * k + r) * L + line] = in[(s * world + rank) * k + r];
+    }
+}
+
+// tails_s[t] += sum_{q <= s} Y[q][s][t] * in_q for every scan and tile of the slab: one pass over the tails, parallel
+// over lines and chunks of tiles (memory order).  K and the scan count are compile-time so the entering carries stay
+// in registers.
+template <typename Acc, int K, int NS>
+__global__ void __launch_bounds__(kBlock)
+merged_apply_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ Y) {
+    const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int64_t L = a.g.lines;
+    const int M = a.M;
+    Acc in[NS][K];
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int j = 0; j < K; j++) in[q][j] = a.incoming[((int64_t)q * K + j) * L + line];
+    const int t0 = (int)blockIdx.y * kApplyTiles;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            Acc cur[kApplyTiles];
+#pragma unroll
+            for (int u = 0; u < kApplyTiles; u++) {
+                cur[u] = Acc(0);
+                if (t0 + u < M) cur[u] = a.tails[tail_idx(a, s, t0 + u, r, line)];
+            }
+#pragma unroll
+            for (int u = 0; u < kApplyTiles; u++) {
+                const int t = t0 + u;
+                if (t < M) {
+                    Acc add = Acc(0);
+#pragma unroll
+                    for (int q = 0; q <= s; q++) {
+                        const Acc *Ym = Y + ((((int64_t)q * NS + s) * M + t) * K + r) * K;      // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < K; j++) add = add + Ym[j] * in[q][j];
+                    }
+                    a.tails[tail_idx(a, s, t, r, line)] = cur[u] + add;
+                }
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -364,6 +449,34 @@ int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, in
                        rank_stride, plane_offset, rank, world, AM);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
+}
+
+template <typename Acc>
+int launch_merged_gather(GenericDimArgs<Acc> a, const Acc *gathered, int64_t rank_stride, int64_t plane_offset, int rank,
+                         int world, const Acc *X, hipStream_t stream) {
+    if (a.n_scans * world * a.k > kMergeMaxState) { set_error("merged exchange: too many carries per line"); return RF_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(merged_gather_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, gathered,
+                       rank_stride, plane_offset, rank, world, X);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename Acc>
+int launch_merged_apply(GenericDimArgs<Acc> a, const Acc *Y, hipStream_t stream) {
+    if (a.M <= 0) return RF_OK;
+    dim3 grid(grid_for(a.g.lines), (unsigned)((a.M + kApplyTiles - 1) / kApplyTiles));
+#define RF_CASE(KK, NN)                                                                                            \
+    if (a.k == KK && a.n_scans == NN) {                                                                            \
+        hipLaunchKernelGGL((merged_apply_kernel<Acc, KK, NN>), grid, dim3(kBlock), 0, stream, a, Y);               \
+        RF_HIP_CHECK(hipGetLastError());                                                                           \
+        return RF_OK;                                                                                              \
+    }
+    RF_CASE(1, 1) RF_CASE(1, 2) RF_CASE(1, 3) RF_CASE(1, 4)
+    RF_CASE(2, 1) RF_CASE(2, 2) RF_CASE(2, 3) RF_CASE(2, 4)
+    RF_CASE(3, 1) RF_CASE(3, 2) RF_CASE(3, 3) RF_CASE(3, 4)
+#undef RF_CASE
+    set_error("merged exchange: order %d with %d scans not instantiated", a.k, a.n_scans);
+    return RF_ERR_UNSUPPORTED;
 }
 
 template <typename P>
@@ -419,7 +532,10 @@ RF_INSTANTIATE_PIXEL(int16_t)
 #define RF_INSTANTIATE_ACC(Acc)                                                                                    \
     template int launch_generic_carry_apply<Acc>(GenericDimArgs<Acc>, int, hipStream_t);                           \
     template int launch_gather_incoming<Acc>(GenericDimArgs<Acc>, int, const Acc *, int64_t, int64_t, int, int,    \
-                                             const Acc *, hipStream_t);
+                                             const Acc *, hipStream_t);                                            \
+    template int launch_merged_gather<Acc>(GenericDimArgs<Acc>, const Acc *, int64_t, int64_t, int, int, const Acc *, \
+                                           hipStream_t);                                                           \
+    template int launch_merged_apply<Acc>(GenericDimArgs<Acc>, const Acc *, hipStream_t);
 RF_INSTANTIATE_ACC(float)
 RF_INSTANTIATE_ACC(double)
 RF_INSTANTIATE_ACC(uint32_t)

@@ -193,8 +193,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             }
         plan->tables["G_x"] = dG;
     }
+    DimTables<S> ty;
     if (ny > 0) {
-        DimTables<S> ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped, TVy);
+        ty = build_dim_tables<S>(table_scans(dy.scan_ids), K, TY, plan->clamped, TVy);
         flatten_W(ty, ny, hWy, hAy, "y");
         if (y_sharded) hApowY = carry_apply_powers<S, Acc>(ty.A, MY, K);
         {
@@ -362,6 +363,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             };
             plan->begin_steps.push_back(cy);
         }
+    } else if (merged_exchange_applies(ny, K, plan->shard_world)) {
+        // one all-gather for all y scans (plan_generic.h, "merged exchange")
+        int rc = add_merged_exchange<S, Acc>(plan, ty, "y", MY, Ly, ymask, gyargs, yin, yin_pp, d_ACy, Cy, "carry_y");
+        if (rc != RF_OK) return rc;
     } else {
         for (int j = 0; j < ny; j++) {
             const int64_t plane_stride = (int64_t)K * Ly;

@@ -66,6 +66,140 @@ std::vector<Acc> carry_apply_powers(const std::vector<std::vector<S>> &A, int64_
     return out;
 }
 
+// ---- merged exchange (one all-gather per sharded dimension) ------------------------------------------------
+// With zero entering carries every slab completes ALL its scans locally; what the true entering carries in_q add
+// afterwards is linear in them.  Y[q][s][t] (k x k, q <= s, t in memory order) is what a unit carry entering scan q
+// adds to the completed tail of scan s at tile t: for q == s the plain propagation A_s^(i+1), for q < s the chaining
+// terms W (create_tail_residual_term, lib/split.cpp:912-1004) followed by scan s's own recurrence.  The tables
+// depend on which ends of the slab are image borders.  Flattened [q][s][t][r][o]; entries with q > s are zero.
+template <typename S>
+std::vector<S> cross_scan_transfer(const DimTables<S> &tab, int64_t M, bool first_is_border, bool last_is_border) {
+    const int n = tab.n, k = tab.k, kk = k * k;
+    std::vector<S> Y((size_t)n * n * M * kk, S(0));
+    auto causal = [&](int s) { return tab.scans[s].causal; };
+    auto variant = [&](int64_t t) { return ((t == 0 && first_is_border) ? 1 : 0) | ((t == M - 1 && last_is_border) ? 2 : 0); };
+    std::vector<std::vector<S>> C(n, std::vector<S>((size_t)M * k));     // C[s][t*k + r]: effect on scan s, tile t
+    for (int q = 0; q < n; q++)
+        for (int o = 0; o < k; o++) {
+            for (int s = q; s < n; s++) {
+                std::vector<S> &Cs = C[s];
+                std::fill(Cs.begin(), Cs.end(), S(0));
+                if (s > q) {      // chaining on the scans q .. s-1 (their effects are already in C)
+                    for (int64_t t = 0; t < M; t++) {
+                        const int v = variant(t);
+                        for (int qq = q; qq < s; qq++) {
+                            const bool first = causal(qq) ? (t == 0) : (t == M - 1);
+                            const std::vector<S> &Wm = tab.Wm(v, qq, s);
+                            for (int r = 0; r < k; r++) {
+                                S acc = S(0);
+                                for (int j = 0; j < k; j++) {
+                                    S c;
+                                    if (first) c = (qq == q && j == o) ? S(1) : S(0);
+                                    else c = C[qq][(size_t)(causal(qq) ? t - 1 : t + 1) * k + j];
+                                    acc = acc + Wm[r * k + j] * c;
+                                }
+                                Cs[(size_t)t * k + r] = Cs[(size_t)t * k + r] + acc;
+                            }
+                        }
+                    }
+                }
+                // scan s's own recurrence over the tiles; for s == q the entering state is the unit carry
+                std::vector<S> x(k, S(0));
+                if (s == q) x[o] = S(1);
+                for (int64_t i = 0; i < M; i++) {
+                    const int64_t t = causal(s) ? i : M - 1 - i;
+                    for (int r = 0; r < k; r++) {
+                        S acc = Cs[(size_t)t * k + r];
+                        for (int j = 0; j < k; j++) acc = acc + tab.A[s][r * k + j] * x[j];
+                        Cs[(size_t)t * k + r] = acc;
+                    }
+                    for (int r = 0; r < k; r++) x[r] = Cs[(size_t)t * k + r];
+                }
+                for (int64_t t = 0; t < M; t++)
+                    for (int r = 0; r < k; r++)
+                        Y[(((size_t)q * n + s) * M + t) * kk + r * k + o] = Cs[(size_t)t * k + r];
+            }
+        }
+    return Y;
+}
+
+inline bool merged_exchange_applies(int n_scans, int k, int world) {
+    return world > 1 && n_scans >= 1 && n_scans <= 4 && k >= 1 && k <= 3 && n_scans * world * k <= 128;
+}
+
+// Exchange structure of a sharded dimension with ONE all-gather: the local step completes every scan with zero
+// entering carries and publishes all exit carries ([plane][s][r][line]); the apply step derives every scan's true
+// entering carry from the gathered exits and corrects all tails in one pass.
+// (The slabs must have the same number of tiles: the exit transfers of the other slabs are computed from M.)
+template <typename S, typename Acc, typename ArgsFn>
+int add_merged_exchange(rf_plan *plan, const DimTables<S> &tab, const std::string &dn, int64_t M, int64_t lines,
+                        uint32_t causal_mask, ArgsFn gargs, Acc *incoming, size_t inc_pp, const Acc *d_AC, int C,
+                        const std::string &carry_name) {
+    int status = RF_OK;
+    const int n = tab.n, K = tab.k, kk = K * K, np = plan->n_planes;
+    const int world = plan->shard_world, rank = plan->shard_rank;
+    const int own_type = (rank == 0 ? 1 : 0) | (rank == world - 1 ? 2 : 0);
+    std::vector<Acc> hY, hX((size_t)4 * n * n * kk, Acc(0));
+    std::vector<double> dY, dX(hX.size(), 0.0);
+    for (int type = 0; type < 4; type++) {
+        std::vector<S> Y = cross_scan_transfer<S>(tab, M, (type & 1) != 0, (type & 2) != 0);
+        for (int q = 0; q < n; q++)
+            for (int s = q; s < n; s++) {
+                const int64_t t_exit = tab.scans[s].causal ? M - 1 : 0;
+                for (int e = 0; e < kk; e++) {
+                    const S v = Y[(((size_t)q * n + s) * M + t_exit) * kk + e];
+                    hX[(((size_t)type * n + q) * n + s) * kk + e] = table_to_acc<S, Acc>(v);
+                    dX[(((size_t)type * n + q) * n + s) * kk + e] = table_to_double<S>(v);
+                }
+            }
+        if (type == own_type) {
+            hY.resize(Y.size());
+            dY.resize(Y.size());
+            for (size_t e = 0; e < Y.size(); e++) { hY[e] = table_to_acc<S, Acc>(Y[e]); dY[e] = table_to_double<S>(Y[e]); }
+        }
+    }
+    plan->tables["Y_" + dn] = dY;
+    plan->tables["X_" + dn] = dX;
+    const Acc *d_Y = (const Acc *)plan->upload(hY.data(), hY.size() * sizeof(Acc), &status);
+    const Acc *d_X = (const Acc *)plan->upload(hX.data(), hX.size() * sizeof(Acc), &status);
+
+    const int64_t plane_stride = (int64_t)n * K * lines, rank_stride = (int64_t)np * plane_stride;
+    const int ex_index = (int)plan->exchanges.size();
+    rf_plan::Exchange ex;
+    ex.bytes = (size_t)rank_stride * sizeof(Acc);
+    ex.scratch = plan->alloc(ex.bytes, true, &status);
+    if (status != RF_OK) return status;
+    ex.send = ex.scratch;
+    ex.form_incoming = [plan, gargs, rank_stride, plane_stride, d_X](const void *gathered) {
+        for (int pl = 0; pl < plan->n_planes; pl++) {
+            int rc = launch_merged_gather<Acc>(gargs(pl), (const Acc *)gathered, rank_stride, pl * plane_stride,
+                                               plan->shard_rank, plan->shard_world, d_X, plan->stream);
+            if (rc) return rc;
+        }
+        return (int)RF_OK;
+    };
+    plan->exchanges.push_back(ex);
+
+    Step cs;
+    cs.name = carry_name;
+    cs.run = [plan, gargs, K, n, causal_mask, d_AC, C, ex_index, plane_stride, incoming, inc_pp](int pl) {
+        // the local pass sees zero entering carries (the buffer holds the previous execute's)
+        if (hipMemsetAsync(incoming + (size_t)pl * inc_pp, 0, inc_pp * sizeof(Acc), plan->stream) != hipSuccess) {
+            set_error("hipMemsetAsync failed");
+            return (int)RF_ERR_HIP;
+        }
+        Acc *send = (Acc *)plan->exchanges[ex_index].send;
+        return launch_carry_block<Acc>(K, gargs(pl), causal_mask, 0, n, send ? send + pl * plane_stride : nullptr, d_AC, C,
+                                       plan->stream);
+    };
+    plan->exchange_local_steps.push_back({cs});
+    Step ap;
+    ap.name = carry_name + "_apply";
+    ap.run = [plan, gargs, d_Y](int pl) { return launch_merged_apply<Acc>(gargs(pl), d_Y, plan->stream); };
+    plan->exchange_apply_steps.push_back({ap});
+    return status;
+}
+
 inline int pick_generic_tile(int64_t N, int k, int hint) {
     if (hint > 0 && hint <= kGenericMaxTile && N % hint == 0 && hint >= k) return hint;
     int cap = hint > 0 ? kGenericMaxTile : 64;
@@ -189,7 +323,13 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
         };
         plan->begin_steps.push_back(p1);
 
-        for (int s = 0; s < n; s++) {
+        const bool merged = is_exchange_dim && merged_exchange_applies(n, k, plan->shard_world);
+        if (merged) {
+            int rc = add_merged_exchange<S, Acc>(plan, tab, dn, di.M, di.lines, causal_mask, args_for, incoming, inc_per_plane,
+                                                 dACp, C, "generic_carry_" + dn);
+            if (rc != RF_OK) return rc;
+        }
+        for (int s = 0; s < n && !merged; s++) {
             int ex_index = -1;
             if (is_exchange_dim) {
                 ex_index = (int)plan->exchanges.size();

@@ -128,6 +128,9 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
             return launch_carry_block<Acc>(K, gargs(pl), mask, 0, n, (Acc *)nullptr, d_AC, C, plan->stream);
         };
         plan->begin_steps.push_back(cs);
+    } else if (merged_exchange_applies(n, K, plan->shard_world)) {
+        int rc = add_merged_exchange<S, Acc>(plan, tab, dn, M, di.lines, mask, gargs, incoming, inc_pp, d_AC, C, "carry_" + dn);
+        if (rc != RF_OK) return rc;
     } else {
         for (int s = 0; s < n; s++) {
             const int64_t plane_stride = (int64_t)K * di.lines, rank_stride = (int64_t)np * K * di.lines;

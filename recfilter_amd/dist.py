@@ -3,10 +3,12 @@
 The image is partitioned along its outermost dimension (y for 2-D, z for 3-D) into `world`
 contiguous slabs of whole tiles.  Scans along inner dimensions are slab-local.  For every scan
 along the sharded dimension the only cross-GPU dependency is the k-row carry at the slab
-boundary; because the carry recurrence is linear with a known k x k matrix per slab, each rank
-publishes the exit carry of its slab computed with a zero incoming carry and ONE all-gather per
-scan lets every rank form its true incoming carry locally.  The reference has no
-multi-device path; this is the MI355X-native addition BASELINE.json asks for.
+boundary; because the carry recurrence is linear with known k x k matrices per slab, each rank
+publishes the exit carries of its slab computed with zero incoming carries and ONE all-gather
+(for all scans of the dimension together; one per scan for orders > 3 or more than 4 scans) lets
+every rank form its true incoming carries locally.  Slabs must have
+equal extents.  The reference has no multi-device path; this is the MI355X-native addition
+BASELINE.json asks for.
 
 The driver is backend-agnostic: `engine` is anything with the stepping API of
 recfilter_amd.Plan (begin / num_exchanges / exchange_bytes / exchange_local / exchange_apply /

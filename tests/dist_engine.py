@@ -47,14 +47,24 @@ class NumpySlabEngine:
         self.T = self.tiles[self.outer] if self.n else self.N
         self.M = self.N // self.T if self.n else 1
         self.lines = int(np.prod(self.shape[1:])) if nd > 1 else 1
+        # merged exchange (one all-gather for all scans): the plan publishes the cross-scan transfers Y / X
+        self.merged = False
+        if self.n and world > 1:
+            try:
+                name = "xyz"[self.outer]
+                self.Y = self.plan.table("Y_" + name).reshape(self.n, self.n, self.M, self.k, self.k)
+                self.X = self.plan.table("X_" + name).reshape(4, self.n, self.n, self.k, self.k)
+                self.merged = True
+            except Exception:
+                self.merged = False
 
     # ---- protocol ---------------------------------------------------------------------------
     @property
     def num_exchanges(self):
-        return self.n
+        return 1 if self.merged else self.n
 
     def exchange_bytes(self, i):
-        return self.planes * self.k * self.lines * 4
+        return self.planes * (self.n if self.merged else 1) * self.k * self.lines * 4
 
     def _first(self, s, t):
         return t == 0 if self.outer_scans[s][0] else t == self.M - 1
@@ -112,8 +122,24 @@ class NumpySlabEngine:
                         self.tails[pl][s, t, r] = v[:, p if c else T - 1 - p]
 
     def exchange_local(self, s, send_ptr):
+        if self.merged:
+            return self._merged_local(send_ptr)
         k, M = self.k, self.M
         send = _view(send_ptr, self.planes * k * self.lines).reshape(self.planes, k, self.lines)
+        self._local_scan(s, send)
+
+    def _merged_local(self, send_ptr):
+        k = self.k
+        send = _view(send_ptr, self.planes * self.n * k * self.lines).reshape(self.planes, self.n, k, self.lines)
+        for pl in range(self.planes):
+            for s in range(self.n):
+                for j in range(k):
+                    self.incoming[pl][s][j] = np.zeros(self.lines)
+        for s in range(self.n):
+            self._local_scan(s, send[:, s])
+
+    def _local_scan(self, s, send):
+        k, M = self.k, self.M
         causal = self.outer_scans[s][0]
         for pl in range(self.planes):
             prev = None
@@ -135,7 +161,35 @@ class NumpySlabEngine:
             for r in range(k):
                 send[pl, r] = prev[r]
 
+    def _merged_apply(self, gathered_ptr):
+        k, M, n, W = self.k, self.M, self.n, self.world
+        gathered = _view(gathered_ptr, W * self.planes * n * k * self.lines).reshape(
+            W, self.planes, n, k, self.lines).astype(np.float64)
+        for pl in range(self.planes):
+            ins = np.zeros((n, W, k, self.lines))              # carry entering every slab, every scan
+            for s in range(n):
+                causal = self.outer_scans[s][0]
+                prev = np.zeros((k, self.lines))
+                for i in range(W):
+                    h = i if causal else W - 1 - i
+                    ins[s, h] = prev
+                    if i == W - 1:
+                        break
+                    typ = (1 if h == 0 else 0) | (2 if h == W - 1 else 0)
+                    e = gathered[h, pl, s].copy()
+                    for q in range(s + 1):
+                        e += self.X[typ, q, s] @ ins[q, h]
+                    prev = e
+                for j in range(k):
+                    self.incoming[pl][s][j] = ins[s, self.rank, j].copy()
+            for s in range(n):
+                for t in range(M):
+                    for q in range(s + 1):
+                        self.tails[pl][s, t] += self.Y[q, s, t] @ ins[q, self.rank]
+
     def exchange_apply(self, s, gathered_ptr):
+        if self.merged:
+            return self._merged_apply(gathered_ptr)
         k, M = self.k, self.M
         gathered = _view(gathered_ptr, self.world * self.planes * k * self.lines).reshape(
             self.world, self.planes, k, self.lines).astype(np.float64)
@@ -174,7 +228,7 @@ class NumpySlabEngine:
     def execute(self, inputs, outputs, stream=None):      # world == 1 path of ShardedFilter
         self.begin(inputs, outputs)
         import torch
-        for i in range(self.n):
+        for i in range(self.num_exchanges):
             send = torch.empty(self.exchange_bytes(i), dtype=torch.uint8)
             self.exchange_local(i, send.data_ptr())
         self.finish()

@@ -211,13 +211,16 @@ def test_fused_matches_untiled_gpu_at_full_size_properties():
 
 
 # ---- sharded execution (stepping API of the C ABI), all "ranks" emulated on the one GPU of the test box ----
-def _run_sharded(shape, scans, clamped, world, path, planes=1):
+def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32):
     import torch
     import recfilter_amd as rfa
-    full = [rc.random_image(shape, np.float32, 31 + p) for p in range(planes)]
+    if np.issubdtype(dtype, np.integer):
+        full = [np.random.default_rng(31 + p).integers(0, 4, size=shape).astype(dtype) for p in range(planes)]
+    else:
+        full = [rc.random_image(shape, np.float32, 31 + p) for p in range(planes)]
     n = shape[0] // world
     local = (n,) + tuple(shape[1:])
-    plans = [rfa.Plan(local, scans, clamped=clamped, planes=planes, path=path, shard_rank=r, shard_world=world)
+    plans = [rfa.Plan(local, scans, dtype=dtype, clamped=clamped, planes=planes, path=path, shard_rank=r, shard_world=world)
              for r in range(world)]
     ins = [[torch.from_numpy(np.ascontiguousarray(f[r * n:(r + 1) * n])).cuda() for f in full] for r in range(world)]
     outs = [[torch.empty_like(t) for t in ins[r]] for r in range(world)]
@@ -243,10 +246,10 @@ def _run_sharded(shape, scans, clamped, world, path, planes=1):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_fused_2d_rows(world):
-    """cfg3's filter, rows sharded over `world` slabs: one exchange per y scan."""
+    """cfg3's filter, rows sharded over `world` slabs: ONE exchange for both y scans (merged exchange)."""
     scans = rc.xy_pm(rc.GAUSS2)
     full, got, (path, nex) = _run_sharded((64 * 2 * world, 512), scans, True, world, path=0, planes=2)
-    assert path == 3 and nex == 2
+    assert path == 3 and nex == 1
     _check(full, got, scans, True)
 
 
@@ -255,14 +258,14 @@ def test_sharded_3d_z_slabs(world):
     """cfg5's filter (tests/test_generic_xyz.cpp), z sharded: fused x/y per plane, exchanges on the z scans."""
     scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
     full, got, (path, nex) = _run_sharded((16 * world, 64, 256), scans, False, world, path=0)
-    assert path == 3 and nex == 2
+    assert path == 3 and nex == 1
     _check(full, got, scans, False)
 
 
 def test_sharded_generic_path_uneven_scans():
     scans = rc.REFERENCE_TESTS["test_generic_xy"]["scans"]      # 4 x scans, 3 y scans
     full, got, (path, nex) = _run_sharded((48, 40), scans, False, 3, path=2)
-    assert path == 2 and nex == 3
+    assert path == 2 and nex == 1
     _check(full, got, scans, False)
     with pytest.raises(Exception):                                # a sharded plan refuses the one-shot execute
         import torch
@@ -499,8 +502,40 @@ def test_partial_tiles_other_features():
 def test_sharded_rows_with_partial_width(world):
     scans = rc.xy_pm(rc.GAUSS2)
     full, got, (path, nex) = _run_sharded((64 * world, 464), scans, True, world, path=0)
-    assert path == 3 and nex == 2
+    assert path == 3 and nex == 1
     _check(full, got, scans, True)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sharded_random_filters_merged_exchange(seed):
+    """Row / z-slab shards with random scans of orders 1-3 along every dimension (up to 4 per dimension, any mix of
+    directions) and 2-5 slabs: one all-gather carries every scan of the sharded dimension, the cross-scan transfers
+    Y / X (plan_generic.h) do the rest.  Every third case is an integer filter, checked bit-exact."""
+    rng = np.random.default_rng(7000 + seed)
+    world = int(rng.integers(2, 6))
+    ndim = 2 if seed % 4 else 3
+    integer = seed % 3 == 2
+    path = 0 if seed % 2 == 0 else 2                              # fused / strided builders and the generic one
+    if integer:
+        scans = []
+        for d in range(ndim):
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(1, 4))
+                scans.append((d, bool(rng.integers(0, 2)), [1.0] + [float(v) for v in rng.integers(-1, 2, size=k)]))
+    else:
+        scans = _random_filter(rng, ndim)
+        if not any(d == ndim - 1 for d, _, _ in scans):
+            scans.append((ndim - 1, True, [0.7, 0.4, -0.2]))
+    clamped = bool(rng.integers(0, 2))
+    if ndim == 2:
+        shape = (32 * int(rng.integers(1, 4)) * world, 4 * int(rng.integers(8, 120)))
+    else:
+        shape = (32 * world, 32 * int(rng.integers(1, 3)), 64 * int(rng.integers(1, 4)))
+    dtype = np.int32 if integer else np.float32
+    full, got, (got_path, nex) = _run_sharded(shape, scans, clamped, world, path=path, dtype=dtype)
+    n_outer = sum(1 for d, _, _ in scans if d == ndim - 1)
+    assert nex == (1 if n_outer <= 4 else n_outer)
+    _check(full, got, scans, clamped)
 
 
 @pytest.mark.parametrize("seed", range(32))
