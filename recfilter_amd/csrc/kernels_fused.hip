@@ -251,19 +251,20 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         {
             P *dp = dst + tile_off;
             // byte offsets kept in 32 bits (a tile spans TY rows: far below 4 GiB): scalar base + one 32-bit add per
-            // row instead of a 64-bit address computation per store
+            // row instead of a 64-bit address computation per store; the output is written once and not read again
+            // by this filter: non-temporal stores
             char *dpb = reinterpret_cast<char *>(dp);
             const uint32_t row_bytes = a.row_bytes;
             if (t < last_cols) {
                 if (rows_here == TY) {
 #pragma unroll
                     for (int i = 0; i < TY; i++)
-                        *reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)) = PixelTraits<P>::store(col[i]);
+                        __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)));
                 } else {
 #pragma unroll
                     for (int i = 0; i < TY; i++)
                         if (i < rows_here)
-                            *reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)) = PixelTraits<P>::store(col[i]);
+                            __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)));
                 }
             }
         }

@@ -51,7 +51,7 @@ strided_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, StridedArgs<
     const int64_t base = (line / a.inner) * a.n * a.inner + (line % a.inner) + (int64_t)t * TZ * a.inner;
     Acc col[TZ];
 #pragma unroll
-    for (int i = 0; i < TZ; i++) col[i] = PixelTraits<P>::load(src[base + (int64_t)i * a.inner]);
+    for (int i = 0; i < TZ; i++) col[i] = PixelTraits<P>::load(__builtin_nontemporal_load(src + base + (int64_t)i * a.inner));
 #pragma unroll 1
     for (int s = 0; s < a.n_scans; s++) {
         const FusedScanY<Acc> &sc = a.scans[s];
@@ -82,7 +82,7 @@ strided_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, StridedArgs<
     }
     if (FINAL) {
 #pragma unroll
-        for (int i = 0; i < TZ; i++) dst[base + (int64_t)i * a.inner] = PixelTraits<P>::store(col[i]);
+        for (int i = 0; i < TZ; i++) __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), dst + base + (int64_t)i * a.inner);
     }
 }
 
