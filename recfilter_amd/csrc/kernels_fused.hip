@@ -48,9 +48,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     constexpr int NR = TY / 16;
 
     const int t = threadIdx.x;
-    // pass 1 walked the tiles first to last; walking them last to first here finds the end of the image (and of the
-    // tails) still in the memory-side cache: +0.5-1 % on cfg3, free
-    const int tx = gridDim.x - 1 - blockIdx.x, ty = gridDim.y - 1 - blockIdx.y;
+    const int tx = blockIdx.x, ty = blockIdx.y;
     const int64_t z = blockIdx.z;
     const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
     const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x phase: segment lane, row slot

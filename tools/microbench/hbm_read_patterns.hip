@@ -84,6 +84,53 @@ __global__ void __launch_bounds__(256) segment_kernel(const f4 *src, float *out,
     if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// tile-shaped copy (what pass 2 moves): 16-byte loads of a 256 x 64 tile, 4-byte column stores like the kernel's, with
+// and without the non-temporal hint on either side
+// MAP: 0 = tiles in launch order (x fastest); 1 = every XCD (launch index mod 8) gets a contiguous eighth of the tiles;
+// 2 = y fastest (consecutive workgroups walk down a tile column); 3 = 8 x 8 blocks of tiles per group of 64 workgroups
+template <bool NT_LD, bool NT_ST, int MAP = 0>
+__global__ void __launch_bounds__(256) tile_copy_kernel(const f4 *src, float *dst, int nx4, int mx) {
+    __shared__ f4 tile[64 * 64];
+    int b = blockIdx.x;
+    const int total = gridDim.x, my = total / mx;
+    int tx, ty;
+    if (MAP == 1) b = (b & 7) * (total >> 3) + (b >> 3);
+    if (MAP == 2) { ty = b % my; tx = b / my; }
+    else if (MAP == 3) { const int g = b >> 6, i = b & 63; const int gx = g % (mx >> 3), gy = g / (mx >> 3); tx = gx * 8 + (i & 7); ty = gy * 8 + (i >> 3); }
+    else { tx = b % mx; ty = b / mx; }
+    const int cc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const size_t base = ((size_t)ty * 64 + rg) * nx4 + (size_t)tx * 64 + cc;
+    f4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = NT_LD ? __builtin_nontemporal_load(src + base + (size_t)(4 * i) * nx4) : src[base + (size_t)(4 * i) * nx4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) tile[(rg + 4 * i) * 64 + (cc ^ ((rg + 4 * i) & 63))] = v[i];
+    __syncthreads();
+    const float *tf = reinterpret_cast<const float *>(tile);
+    const int t = threadIdx.x;
+    float *dp = dst + ((size_t)ty * 64) * (size_t)(4 * nx4) + (size_t)tx * 256 + t;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const float val = tf[i * 256 + ((((t >> 2) ^ (i & 63)) << 2) | (t & 3))];
+        if (NT_ST) __builtin_nontemporal_store(val, dp + (size_t)i * (size_t)(4 * nx4));
+        else dp[(size_t)i * (size_t)(4 * nx4)] = val;
+    }
+}
+
+// plain streaming copy, 16 bytes per lane both ways
+template <bool NT>
+__global__ void __launch_bounds__(256) linear_copy_kernel(const f4 *src, f4 *dst) {
+    const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
+    f4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = NT ? __builtin_nontemporal_load(src + base + 256 * i) : src[base + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (NT) __builtin_nontemporal_store(v[i], dst + base + 256 * i);
+        else dst[base + 256 * i] = v[i];
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main() {
@@ -112,5 +159,29 @@ int main() {
     time("tile, rows per wave", [&] { hipLaunchKernelGGL(tile_rows_per_wave_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
     time("tile 1024x16", [&] { hipLaunchKernelGGL(wide_tile_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, n / 1024); });
     time("tile, segment layout", [&] { hipLaunchKernelGGL(segment_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
+    float *dst;
+    CK(hipMalloc(&dst, bytes));
+    std::printf("copies (rates count read + write bytes):\n");
+    auto time2 = [&](const char *name, auto launch) {
+        for (int i = 0; i < 3; i++) launch();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 20; i++) launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= 20;
+        std::printf("%-30s %.4f ms  %.2f TB/s\n", name, ms, 2.0 * bytes / (ms * 1e-3) / 1e12);
+    };
+    time2("linear copy", [&] { hipLaunchKernelGGL(linear_copy_kernel<false>, dim3(tiles), dim3(256), 0, 0, src, (f4 *)dst); });
+    time2("linear copy, nt", [&] { hipLaunchKernelGGL(linear_copy_kernel<true>, dim3(tiles), dim3(256), 0, 0, src, (f4 *)dst); });
+    time2("tile copy", [&] { hipLaunchKernelGGL((tile_copy_kernel<false, false>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy, nt loads", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, false>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy, nt stores", [&] { hipLaunchKernelGGL((tile_copy_kernel<false, true>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy, nt both", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy nt, XCD-contiguous", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 1>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy nt, y fastest", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 2>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy nt, 8x8 groups", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 3>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0);
+    time2("hipMemcpyDtoD", [&] { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0); });
     return 0;
 }
