@@ -99,8 +99,8 @@ def cpu_baseline(cfg, budget_px=16 * 1024 * 1024):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
     ap.add_argument("--path", type=int, default=0, help="rf_path override (debug)")
