@@ -234,27 +234,40 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // border tiles read their variant from memory.
 template <typename Acc, int K, bool EDGE>
 __global__ void __launch_bounds__(256)
-xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
+xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
     __shared__ __attribute__((aligned(16))) Acc g_lds[kFusedMaxScans * kFusedTX * K];      // G[variant 0][q][o][x]
     A4 *rows4 = reinterpret_cast<A4 *>(rows);
     const int t = threadIdx.x;
-    const int64_t rt0 = (int64_t)blockIdx.x * 16;
     const int cc = t & 63, rg = t >> 6;
     const int l = t & 15, row = t >> 4, sw = (l >> 2) & 3;
     const int nxk = a.nx * K;
-    A4 *g4 = reinterpret_cast<A4 *>(a.yt + rt0 * kFusedTX);
+    // The workgroup's 16 row tiles: gj combined rows (j, r) x 16/gj consecutive x tiles of one tile row ty -- the rows of
+    // one x tile need the same carry strips (tau below), so they sit in the same wave and fetch them once.
+    // block -> (ty, z, group of combined rows, group of x tiles), x groups fastest
+    const int txp = 16 / gj;
+    const int n_xg = (a.MX + txp - 1) / txp, n_jg = a.ny * K / gj;
+    int b = blockIdx.x;
+    const int xg = b % n_xg; b /= n_xg;
+    const int jg = b % n_jg; b /= n_jg;
+    const int64_t z = b % a.NZ;
+    const int ty = (int)(b / a.NZ);
+    auto tile_of = [&](int r, int &jr, int &tx_out) { jr = jg * gj + r % gj; tx_out = xg * txp + r / gj; };
+    auto row_tile_index = [&](int jr, int tx_i) {      // yt is [j][ty][r][z][tx][256]
+        return ((((int64_t)(jr / K) * a.MY + ty) * K + jr % K) * a.NZ + z) * a.MX + tx_i;
+    };
+    A4 *yt4 = reinterpret_cast<A4 *>(a.yt);
     A4 tmp[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int r = rg + 4 * i;
-        tmp[i] = (rt0 + r < n_row_tiles) ? g4[r * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+        int jr_i, tx_i;
+        tile_of(rg + 4 * i, jr_i, tx_i);
+        tmp[i] = (tx_i < a.MX) ? yt4[row_tile_index(jr_i, tx_i) * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
     }
-    // this thread's row tile: index = ((((j*MY + ty)*K + r)*NZ + z)*MX + tx)
-    const int64_t rt = rt0 + row;
-    const bool row_ok = rt < n_row_tiles;
-    const int tx = (int)(rt % a.MX);
+    int jr, tx;
+    tile_of(row, jr, tx);
+    const bool row_ok = tx < a.MX;
     const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
     Acc tv[kFusedMaxScans * K];
 #pragma unroll
@@ -265,13 +278,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
     const bool residual = (G != nullptr);
     if (residual) {
         if (row_ok) {
-            int64_t rest = rt / a.MX;
-            const int64_t z = rest % a.NZ;
-            rest /= a.NZ;
-            const int r = (int)(rest % K);
-            rest /= K;
-            const int ty = (int)(rest % a.MY);
-            const int j = (int)(rest / a.MY);
+            const int r = jr % K, j = jr / K;
             const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
             const bool lane_in = 4 * l < TY;
             A4 hy = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
@@ -366,7 +373,9 @@ xscan_rows_kernel(FusedArgs<Acc> a, int64_t n_row_tiles, int TY, const Acc *__re
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = rg + 4 * i;
-        if (rt0 + r < n_row_tiles) g4[r * 64 + cc] = rows4[r * 64 + swz_chunk(cc)];
+        int jr_i, tx_i;
+        tile_of(r, jr_i, tx_i);
+        if (tx_i < a.MX) yt4[row_tile_index(jr_i, tx_i) * 64 + cc] = rows4[r * 64 + swz_chunk(cc)];
     }
 }
 
@@ -404,14 +413,21 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
 template <typename Acc>
 int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream) {
     // yt is [j][ty][r][x + NX*z]: every run of 256 consecutive samples is one combined row of one x tile
-    const int64_t n_row_tiles = (int64_t)a.ny * a.MY * K * a.NZ * a.MX;
-    if (n_row_tiles <= 0 || a.nx == 0) return RF_OK;
-    const unsigned grid = (unsigned)((n_row_tiles + 15) / 16);
+    const int n_jr = a.ny * K;
+    if (n_jr <= 0 || a.MY <= 0 || a.MX <= 0 || a.NZ <= 0 || a.nx == 0) return RF_OK;
+    // combined rows per workgroup: the largest power of two (<= 16) dividing their number; the rest of the 16 row
+    // tiles are consecutive x tiles
+    int gj = 1;
+    while (gj < 16 && n_jr % (2 * gj) == 0) gj *= 2;
+    const int txp = 16 / gj;
+    const int64_t blocks = (int64_t)a.MY * a.NZ * (n_jr / gj) * ((a.MX + txp - 1) / txp);
+    if (blocks >= (1ll << 31)) { set_error("xscan rows: grid too large"); return RF_ERR_UNSUPPORTED; }
+    const unsigned grid = (unsigned)blocks;
     const bool edge = a.last_cols != kFusedTX;       // images of whole tiles keep the lean kernel
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \
-        if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, TY, Hy, G);  \
-        else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false>), dim3(grid), dim3(256), 0, stream, a, n_row_tiles, TY, Hy, G); \
+        if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true>), dim3(grid), dim3(256), 0, stream, a, gj, TY, Hy, G);  \
+        else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false>), dim3(grid), dim3(256), 0, stream, a, gj, TY, Hy, G); \
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }
