@@ -159,8 +159,9 @@ int main() {
     time("tile, rows per wave", [&] { hipLaunchKernelGGL(tile_rows_per_wave_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
     time("tile 1024x16", [&] { hipLaunchKernelGGL(wide_tile_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, n / 1024); });
     time("tile, segment layout", [&] { hipLaunchKernelGGL(segment_kernel, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
-    float *dst;
-    CK(hipMalloc(&dst, bytes));
+    float *dst_base, *dst;
+    CK(hipMalloc(&dst_base, bytes + (64u << 20)));
+    dst = dst_base;
     std::printf("copies (rates count read + write bytes):\n");
     auto time2 = [&](const char *name, auto launch) {
         for (int i = 0; i < 3; i++) launch();
@@ -181,6 +182,13 @@ int main() {
     time2("tile copy nt, XCD-contiguous", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 1>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
     time2("tile copy nt, y fastest", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 2>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
     time2("tile copy nt, 8x8 groups", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 3>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    // does the distance between the two streams matter (same channel/bank for the tile being read and written)?
+    for (size_t off : {(size_t)4096, (size_t)65536, (size_t)(1u << 20) + 8192, (size_t)(16u << 20) + 4096 * 37}) {
+        float *d2 = dst_base + off / 4;
+        char name[64];
+        std::snprintf(name, sizeof name, "tile copy nt, dst + %zu KiB", off >> 10);
+        time2(name, [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true>), dim3(tiles), dim3(256), 0, 0, src, d2, nx4, mx); });
+    }
     (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0);
     time2("hipMemcpyDtoD", [&] { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0); });
     return 0;
