@@ -41,6 +41,8 @@ struct FusedScanY {
 // space), so a run-time scan index still compiles to scalar loads.  Behind a pointer the persistent
 // kernel's own stores make them "possibly clobbered" and the compiler falls back to per-lane vector
 // loads that cost ~50 VGPRs.
+constexpr int kFusedMaxPlanes = 16;     // == RF_MAX_PLANES
+
 template <typename Acc>
 struct FusedArgs {
     int64_t NX, NY, NZ;      // extents (NZ = batch of planes along z, 1 for 2-D)
@@ -66,6 +68,11 @@ struct FusedArgs {
     // on every pixel load, bit 1 = out = post_f*F + post_i*x' + post_b on the final store of pass 2
     int32_t pw_flags;
     Acc pre_s, pre_b, post_f, post_i, post_b;
+    // Tuple planes of a 2-D filter batched into one launch: plane z of the "volume" is its own buffer (the kernels'
+    // src/dst arguments are unused); the tails treat the planes exactly like the z planes of a 3-D image
+    int32_t plane_batch;
+    const void *in_planes[kFusedMaxPlanes];
+    void *out_planes[kFusedMaxPlanes];
 };
 
 // Register-column scans along a strided dimension (kernels_strided.hip), by value like FusedArgs.

@@ -50,7 +50,12 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     const int t = threadIdx.x;
     const int tx = blockIdx.x, ty = blockIdx.y;
     const int64_t z = blockIdx.z;
-    const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
+    // batched Tuple planes: plane z is its own buffer (wave-uniform pointer pick from the kernel arguments)
+    if (a.plane_batch) {
+        src = reinterpret_cast<const PI *>(a.in_planes[z]);
+        dst = reinterpret_cast<P *>(a.out_planes[z]);
+    }
+    const int64_t tile_off = (a.plane_batch ? 0 : z * a.NX * a.NY) + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
     const int l = t & 15, slot = t >> 4, sw = (l >> 2) & 3;    // x phase: segment lane, row slot
     const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
     const int64_t line0 = (int64_t)ty * TY + slot + a.NYP * z;         // x phase: row n -> line0 + 16 n

@@ -50,7 +50,8 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const int t = threadIdx.x;
     const int tx = blockIdx.x, ty = blockIdx.y;
     const int64_t z = blockIdx.z;
-    const int64_t tile_off = z * a.NX * a.NY + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
+    if (a.plane_batch) src = reinterpret_cast<const PI *>(a.in_planes[z]);     // batched Tuple planes: own buffers
+    const int64_t tile_off = (a.plane_batch ? 0 : z * a.NX * a.NY) + (int64_t)ty * TY * a.NX + (int64_t)tx * kFusedTX;
     const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
     const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
     const int nxk = a.nx * K, nyk = a.ny * K;

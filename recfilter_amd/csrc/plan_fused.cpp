@@ -45,7 +45,12 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     DimInfo no_y;
     DimInfo &dy = chained ? no_y : plan->dims[1];
     const int64_t NX = chained ? chained_row_length(dx.N) : dx.N;
-    const int64_t NY = chained ? dx.N / NX : dy.N, NZ = plan->ndim > 2 ? plan->dims[2].N : 1;
+    // Tuple planes of a 2-D filter ride in ONE launch per step, as the z planes of a volume whose planes are separate
+    // buffers (FusedArgs::plane_batch): 5 launches instead of 5 per plane, which is most of the time of a small RGB image.
+    const bool batch = plan->ndim == 2 && plan->n_planes > 1 && plan->n_planes <= kFusedMaxPlanes && plan->shard_world <= 1 &&
+                       getenv("RF_NO_PLANE_BATCH") == nullptr;
+    const int64_t NY = chained ? dx.N / NX : dy.N, NZ = batch ? plan->n_planes : (plan->ndim > 2 ? plan->dims[2].N : 1);
+    const size_t first_begin_step = plan->begin_steps.size(), first_finish_step = plan->finish_steps.size();
     // tile height: 64 rows unless only 32 divides the height; any other height runs 64-row tiles (32 below 33 rows)
     // with a partial last tile row
     int TY = (NY % 64 == 0) ? 64 : (NY % 32 == 0 || NY < 32) ? 32 : 64;
@@ -231,7 +236,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
-    const int np = plan->n_planes;
+    const int np = batch ? 1 : plan->n_planes;         // batched planes are inside Lx / Ly already (NZ)
     Acc *xt = (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status);
     Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);
     Acc *xin = (Acc *)plan->alloc(xin_pp * np * sizeof(Acc), true, &status);
@@ -269,6 +274,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         a.yt = yt + (size_t)pl * yt_pp;
         a.y_incoming = yin + (size_t)pl * yin_pp;
         a.x_incoming = xin + (size_t)pl * xin_pp;
+        a.plane_batch = batch ? 1 : 0;
+        if (batch)
+            for (int i = 0; i < plan->n_planes; i++) { a.in_planes[i] = plan->in[i]; a.out_planes[i] = plan->out[i]; }
         return a;
     };
     GenericDimArgs<Acc> gx{};
@@ -415,6 +423,17 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         int rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false)
                                            : add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
         if (rc != RF_OK) return rc;
+    }
+    if (batch) {
+        // every step above covers all planes in its one launch: it runs for plane 0 and is skipped for the others
+        auto once = [](std::vector<Step> &steps, size_t first) {
+            for (size_t i = first; i < steps.size(); i++) {
+                auto inner = steps[i].run;
+                steps[i].run = [inner](int pl) { return pl > 0 ? (int)RF_OK : inner(0); };
+            }
+        };
+        once(plan->begin_steps, first_begin_step);
+        once(plan->finish_steps, first_finish_step);
     }
     return status;
 }

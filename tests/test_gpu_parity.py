@@ -597,6 +597,38 @@ def test_box_filter_app_is_a_box_filter():
         rfa.box_difference(t, 1, [1, 1], out=t)
 
 
+# ---- Tuple planes batched into one launch per step (FusedArgs::plane_batch) ------------------------------------------
+@pytest.mark.parametrize("planes,shape,dtype", [(3, (128, 512), np.float32), (5, (75, 464), np.float32),
+                                                (4, (96, 300), np.int32), (16, (64, 256), np.float32)],
+                         ids=["rgb", "five_partial", "int_partial", "max_planes"])
+def test_batched_planes_match_the_per_plane_launches(planes, shape, dtype, monkeypatch):
+    """All planes of a 2-D filter ride in one launch per step, as the z planes of a volume whose planes are separate
+    buffers: same results bit for bit as one launch per plane, the oracle's within tolerance, in place too."""
+    import torch
+    import recfilter_amd as rfa
+    integer = np.issubdtype(dtype, np.integer)
+    scans = [(0, True, [1.0, 1.0]), (0, False, [1.0, 1.0, -1.0]), (1, True, [1.0, 2.0, -1.0])] if integer else rc.xy_pm(rc.GAUSS2)
+    rng = np.random.default_rng(77)
+    imgs = [rng.integers(0, 5, size=shape).astype(dtype) if integer else rc.random_image(shape, np.float32, 90 + p)
+            for p in range(planes)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=not integer, planes=planes) as plan:
+        assert plan.path_name == "tiled_fused"
+        outs, timed = plan.execute_timed(dev)
+        assert len(timed) == 5                                       # launches per step, not per plane
+        batched = [o.cpu().numpy() for o in outs]
+        inplace = [d.clone() for d in dev]
+        plan.execute(inplace, inplace)
+        for a, b in zip(batched, inplace):
+            assert np.array_equal(a, b.cpu().numpy())
+    monkeypatch.setenv("RF_NO_PLANE_BATCH", "1")
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=not integer, planes=planes) as plan:
+        single = [o.cpu().numpy() for o in plan.execute(dev)]
+    for a, b in zip(batched, single):
+        assert np.array_equal(a, b)
+    _check(imgs, batched, scans, not integer)
+
+
 # ---- unsigned-byte input planes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8) -------------------------
 @pytest.mark.parametrize("shape,path", [((128, 512), 0), ((75, 464), 0), ((64, 250), 0), ((64, 256), 1), ((40, 16, 272), 0)],
                          ids=["fused", "fused_partial", "generic_auto", "untiled", "fused_3d"])
