@@ -69,7 +69,7 @@ def test_two_processes_one_gpu(case, tmp_path):
 
 
 def test_bench_two_ranks_over_gloo():
-    """bench.py's multi-rank flow (rendezvous, sharded steps with one all-gather per y scan, barriers, max-over-ranks
+    """bench.py's multi-rank flow (rendezvous, sharded steps with one all-gather each, barriers, max-over-ranks
     timing, one JSON line from rank 0) with two ranks on this box's one GPU; the driver runs the same script over RCCL."""
     import json
     import subprocess
