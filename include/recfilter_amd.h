@@ -130,7 +130,9 @@ int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]);
 int rf_plan_num_kernels(const rf_plan *plan);
 
 /* ---- execution (replaces Func::realize) --------------------------------------------------- */
-/* in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed. */
+/* in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan on the fused
+ * path (rf_plan_path() == RF_PATH_TILED_FUSED) needs 16-byte aligned planes (4-byte for RF_IN_U8 input planes) and
+ * returns RF_ERR_INVALID_ARG otherwise; the other paths take any element-aligned pointer. */
 int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes,
                     void *stream);
 

@@ -1,4 +1,5 @@
 // capi.cpp -- extern "C" entry points declared in include/recfilter_amd.h.
+#include <cstdint>
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -37,6 +38,14 @@ int set_context(rf_plan *plan, const void *const *in_planes, void *const *out_pl
         if (plan->pw.post && plan->pw.post_i != 0.0 && in_planes[pl] == out_planes[pl]) {
             set_error("plane %d: a pointwise epilogue that reads the input needs out != in", pl);
             return RF_ERR_INVALID_ARG;
+        }
+        // the fused kernels move 16 bytes per lane (4 for unsigned-byte input planes)
+        if (plan->path == RF_PATH_TILED_FUSED) {
+            const uintptr_t in_mask = plan->pw.in_u8 ? 3u : 15u;
+            if (((uintptr_t)in_planes[pl] & in_mask) != 0 || ((uintptr_t)out_planes[pl] & 15u) != 0) {
+                set_error("plane %d: the fused path needs 16-byte aligned image pointers (4-byte for uint8 inputs)", pl);
+                return RF_ERR_INVALID_ARG;
+            }
         }
         plan->in[pl] = plan->orig_in[pl] = in_planes[pl];
         plan->out[pl] = out_planes[pl];

@@ -597,6 +597,30 @@ def test_box_filter_app_is_a_box_filter():
         rfa.box_difference(t, 1, [1, 1], out=t)
 
 
+def test_fused_path_rejects_misaligned_planes():
+    """The fused kernels move 16 bytes per lane: an image pointer that is not 16-byte aligned is refused with an error
+    code instead of being handed to the kernels (the generic path takes any element-aligned pointer)."""
+    import torch
+    import recfilter_amd as rfa
+    n = 256
+    buf = torch.rand(n * n + 8, device="cuda")
+    shifted = buf[1:1 + n * n].view(n, n)                       # contiguous, 4 bytes off a 16-byte boundary
+    aligned = buf[4:4 + n * n].view(n, n)
+    scans = rc.xy_pm(rc.GAUSS2)
+    with rfa.Plan((n, n), scans, clamped=True) as plan:
+        assert plan.path_name == "tiled_fused"
+        with pytest.raises(rfa.RecFilterError, match="aligned"):
+            plan.execute([shifted])
+        with pytest.raises(rfa.RecFilterError, match="aligned"):
+            plan.execute([aligned], [torch.empty(n * n + 8, device="cuda")[1:1 + n * n].view(n, n)])
+        out = plan.execute([aligned])[0].cpu().numpy()
+    want = oracle.apply_filter(aligned.cpu().numpy().astype(np.float64), scans, True)
+    assert rc.rel_err(out, want) < TOL
+    with rfa.Plan((n, n), scans, clamped=True, path=2) as plan:          # the generic path has no such requirement
+        out = plan.execute([shifted])[0].cpu().numpy()
+    assert rc.rel_err(out, oracle.apply_filter(shifted.cpu().numpy().astype(np.float64), scans, True)) < TOL
+
+
 # ---- Tuple planes batched into one launch per step (FusedArgs::plane_batch) ------------------------------------------
 @pytest.mark.parametrize("planes,shape,dtype", [(3, (128, 512), np.float32), (5, (75, 464), np.float32),
                                                 (4, (96, 300), np.int32), (16, (64, 256), np.float32)],
