@@ -93,7 +93,8 @@ pointwise_kernel(const P *f, const X *x, P *dst, int64_t n, P c0, P c1, P c2) {
 // taps: per dimension up to four (position, sign) pairs, combined as a product over the dimensions.  A gather over a
 // summed-area table: the taps of neighbouring outputs are neighbouring table entries, so the reads coalesce and hit
 // L2; the kernel is bound by its one write per sample.
-constexpr int kBoxRows = 16;      // rows one workgroup walks (amortises its setup; a row per workgroup is launch-bound)
+constexpr int kBoxRows = 16;      // rows one workgroup walks (amortises its setup; a row per workgroup is launch-bound;
+                                  // taller strips measured no faster: the re-read rows miss L1/L2 either way)
 
 template <typename P>
 __global__ void __launch_bounds__(kBlock)
@@ -139,7 +140,125 @@ box_difference_kernel(const P *__restrict__ in, P *__restrict__ out, BoxDiffArgs
                 acc = negyz ? acc - part : acc + part;
             }
         }
-        out[((int64_t)c2 * n1 + c1) * n0 + c0] = acc * inv;
+        __builtin_nontemporal_store(acc * inv, out + (((int64_t)c2 * n1 + c1) * n0 + c0));      // written once, streamed
+    }
+}
+
+// The same operator for 2-D tables as a stream: a workgroup owns 256 columns, walks a strip of rows top to bottom and
+// keeps the last few table rows in an LDS ring -- the raw row, every sample loaded ONCE (aligned, coalesced), plus a
+// halo of order_x * (2B + 1) columns fetched by the first threads.  The x taps of a sample are ring entries a few
+// columns to the left and right (what other threads loaded), the y taps are other ring rows; an output is a signed sum
+// of 1..16 ring entries.  One barrier per block of rows.  The gather kernel above reads every table row once per tap:
+// rows 2B+1 apart do not survive in L1/L2 between their uses at 16384^2 (PMC: 2.1 GB fetched per launch for the 1.07 GB
+// table) and every x tap is a separate, misaligned load.  [1,1] 0.86 -> 0.61 ms, [0,2] 1.34 -> 0.70 ms at 16384^2.
+// The rows of the next block are requested before the current block's outputs are computed.
+// barrier that orders the workgroup's LDS traffic only: __syncthreads() also drains the outstanding global loads
+// (s_waitcnt vmcnt(0)), which here are the next block's rows, requested early precisely to stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename P, int BATCH, bool SHARED>      // SHARED: x taps -> threads read columns other threads loaded
+__global__ void __launch_bounds__(kBlock)
+box_difference_stream_kernel(const P *__restrict__ in, P *__restrict__ out, BoxDiffArgs a, int strip_rows, int ring_mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char box_lds[];
+    P *ring = reinterpret_cast<P *>(box_lds);
+    const int t = (int)threadIdx.x;
+    const int n0 = (int)a.n[0], n1 = (int)a.n[1];
+    const int x0 = (int)(blockIdx.x * kBlock), c2 = (int)blockIdx.z;
+    const bool active = x0 + t < n0;
+    const int c0 = active ? x0 + t : n0 - 1;                      // idle lanes shadow the last column (they take part in the barriers)
+    const int B = a.radius;
+    P inv = P(1);
+    for (int d = 0; d < 2; d++)
+        for (int o = 0; o < a.order[d]; o++) inv = inv / P(2 * B + 1);
+    auto tap = [&](int c, int N, int order, int k) -> int {
+        auto up = [&](int i) { return i + B < N - 1 ? i + B : N - 1; };
+        auto dn = [&](int i) { return i - B - 1 > 0 ? i - B - 1 : 0; };
+        if (order == 0) return c;
+        if (order == 1) return k == 0 ? up(c) : dn(c);
+        const int first = (k & 2) ? dn(c) : up(c);
+        return (k & 1) ? dn(first) : up(first);
+    };
+    const int ordx = a.order[0], ord = a.order[1];
+    const int nkx = 1 << ordx, nky = 1 << ord;
+    // ring row = [left halo | the workgroup's 256 columns | right halo]; column c sits at c - x0 + halo_l
+    const int halo_l = ordx * (B + 1), halo_r = ordx * B;
+    const int pitch = SHARED ? kBlock + halo_l + halo_r : kBlock;
+    int ix[4];                                                    // ring positions of this sample's x taps
+#pragma unroll
+    for (int kx = 0; kx < 4; kx++) ix[kx] = tap(c0, n0, ordx, kx < nkx ? kx : 0) - x0 + halo_l;
+    // the halo column this thread fetches besides its own (clamped into the image; never referenced when outside)
+    const bool has_halo = t < halo_l + halo_r;
+    int hc = t < halo_l ? x0 - halo_l + t : x0 + kBlock + (t - halo_l);
+    const int hslot = t < halo_l ? t : kBlock + t;                // = hc - x0 + halo_l
+    hc = hc < 0 ? 0 : (hc > n0 - 1 ? n0 - 1 : hc);
+    const P *plane = in + (int64_t)c2 * n1 * n0;
+    P *oplane = out + (int64_t)c2 * n1 * n0;
+    auto load_row = [&](int r, P &main, P &halo) {
+        const P *row = plane + (int64_t)r * n0;                      // wave-uniform
+        main = row[c0];
+        halo = P(0);
+        if constexpr (SHARED) {
+            if (has_halo) halo = row[hc];
+        }
+    };
+    auto store_row = [&](int r, P main, P halo) {
+        P *dst = ring + (size_t)(r & ring_mask) * pitch;
+        dst[halo_l + t] = main;
+        if constexpr (SHARED) {
+            if (has_halo) dst[hslot] = halo;
+        }
+    };
+    auto h_of = [&](int r) -> P {                                    // x difference of table row r at this column
+        const P *src = ring + (size_t)(r & ring_mask) * pitch;
+        if constexpr (!SHARED) return src[t];
+        P part = src[ix[0]];
+        if (nkx > 1) part = part - src[ix[1]];
+        if (nkx > 2) part = part - src[ix[2]] + src[ix[3]];
+        return part;
+    };
+    const int reach_up = ord * B, reach_dn = ord * (B + 1);          // how far the nested y taps of a row can lie
+    const int y0 = (int)blockIdx.y * strip_rows;
+    const int y1 = y0 + strip_rows < n1 ? y0 + strip_rows : n1;
+    int next = y0 - reach_dn > 0 ? y0 - reach_dn : 0;                 // first table row not yet in the ring
+    auto need_hi_of = [&](int cb) {                                    // last table row the outputs [cb, cb + BATCH) read
+        const int ce = cb + BATCH < y1 ? cb + BATCH : y1;
+        return ce - 1 + reach_up < n1 - 1 ? ce - 1 + reach_up : n1 - 1;
+    };
+    // prime the ring with everything the first block of outputs needs
+    {
+        const int need_hi = need_hi_of(y0);
+        while (next <= need_hi) {
+            P v[BATCH], w[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; i++) load_row(next + i <= need_hi ? next + i : need_hi, v[i], w[i]);
+#pragma unroll
+            for (int i = 0; i < BATCH; i++)
+                if (next + i <= need_hi) store_row(next + i, v[i], w[i]);
+            next = next + BATCH <= need_hi ? next + BATCH : need_hi + 1;
+        }
+    }
+    if (SHARED) lds_barrier();                 // without x taps a thread only reads its own column: no barriers
+    for (int cb = y0; cb < y1; cb += BATCH) {
+        const int ce = cb + BATCH < y1 ? cb + BATCH : y1;
+        // request the rows of the NEXT block now (at most BATCH new ones), use them after this block's outputs
+        const int next_hi = cb + BATCH < y1 ? need_hi_of(cb + BATCH) : next - 1;
+        P v[BATCH], w[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; i++) load_row(next + i <= next_hi ? next + i : next - 1, v[i], w[i]);   // next >= 1 here; the filler row is cached
+        for (int c1 = cb; c1 < ce; c1++) {
+            P acc = P(0);
+            for (int ky = 0; ky < nky; ky++) {
+                const P h = h_of(tap(c1, n1, ord, ky));
+                acc = (ky == 1 || ky == 2) ? acc - h : acc + h;
+            }
+            if (active) __builtin_nontemporal_store(acc * inv, oplane + ((int64_t)c1 * n0 + c0));
+        }
+        if (SHARED) lds_barrier();      // the new rows replace rows other threads may still be reading for this block
+#pragma unroll
+        for (int i = 0; i < BATCH; i++)
+            if (next + i <= next_hi) store_row(next + i, v[i], w[i]);
+        next = next_hi + 1 > next ? next_hi + 1 : next;
+        if (SHARED) lds_barrier();
     }
 }
 
@@ -509,6 +628,31 @@ int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t
     if ((a.n[1] + kBoxRows - 1) / kBoxRows > 65535 || a.n[2] > 65535 || a.n[0] >= (1ll << 31) || a.n[1] >= (1ll << 31)) {
         set_error("box_difference: extents too large");
         return RF_ERR_UNSUPPORTED;
+    }
+    // 2-D tables: the streaming kernel, when its ring of table rows fits 64 KiB of LDS and a thread has at most one
+    // halo column to fetch
+    if (a.order[2] == 0 && (a.order[0] > 0 || a.order[1] > 0) && getenv("RF_BOX_GATHER") == nullptr) {
+        const int halo = a.order[0] * (2 * a.radius + 1);
+        const int batch = a.order[1] <= 1 ? 16 : 8;      // rows in flight; the second-order window is twice as tall
+        const int window = a.order[1] * (2 * a.radius + 1) + batch;
+        int ring = 16;
+        while (ring < window) ring *= 2;
+        const size_t lds = (size_t)ring * (kBlock + halo) * sizeof(P);
+        if (halo <= kBlock && lds <= 64 * 1024) {
+            // strips as tall as possible (the reach_up + reach_dn rows around a strip are read again by its neighbours)
+            // that still give the chip ~1024 workgroups
+            const int64_t xb = (a.n[0] + kBlock - 1) / kBlock;
+            int strip = 256;
+            while (strip > 32 && xb * ((a.n[1] + strip - 1) / strip) * a.n[2] < 1024) strip /= 2;
+            dim3 grid((unsigned)xb, (unsigned)((a.n[1] + strip - 1) / strip), (unsigned)a.n[2]);
+            const bool shared = a.order[0] > 0;
+            if (batch == 16 && shared) hipLaunchKernelGGL((box_difference_stream_kernel<P, 16, true>), grid, dim3(kBlock), lds, stream, in, out, a, strip, ring - 1);
+            else if (batch == 16)      hipLaunchKernelGGL((box_difference_stream_kernel<P, 16, false>), grid, dim3(kBlock), lds, stream, in, out, a, strip, ring - 1);
+            else if (shared)           hipLaunchKernelGGL((box_difference_stream_kernel<P, 8, true>), grid, dim3(kBlock), lds, stream, in, out, a, strip, ring - 1);
+            else                       hipLaunchKernelGGL((box_difference_stream_kernel<P, 8, false>), grid, dim3(kBlock), lds, stream, in, out, a, strip, ring - 1);
+            RF_HIP_CHECK(hipGetLastError());
+            return RF_OK;
+        }
     }
     dim3 grid((unsigned)((a.n[0] + kBlock - 1) / kBlock), (unsigned)((a.n[1] + kBoxRows - 1) / kBoxRows), (unsigned)a.n[2]);
     hipLaunchKernelGGL((box_difference_kernel<P>), grid, dim3(kBlock), 0, stream, in, out, a);

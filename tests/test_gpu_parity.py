@@ -561,7 +561,12 @@ def test_random_filters_random_shapes_partial_tiles(seed):
 
 # ---- rf_box_difference: the finite-difference consumer of the box-filter apps ------------------------------------
 @pytest.mark.parametrize("shape,order,radius", [((64, 96), [1, 1], 5), ((40, 130), [2, 0], 3), ((70, 33), [0, 2], 5),
-                                                ((50, 64), [2, 2], 1), ((12, 20, 24), [1, 2, 1], 2), ((300,), [2], 7)])
+                                                ((50, 64), [2, 2], 1), ((12, 20, 24), [1, 2, 1], 2), ((300,), [2], 7),
+                                                # the streaming kernel: several strips, strips shorter than the reach of
+                                                # the taps, a radius beyond the image, a ring too large for LDS (gather)
+                                                ((700, 300), [1, 1], 5), ((1000, 260), [0, 2], 7), ((520, 512), [2, 2], 3),
+                                                ((20, 64), [1, 1], 30), ((90, 70), [1, 2], 14), ((300, 100), [1, 1], 40),
+                                                ((3, 40, 300), [1, 1, 0], 4)])
 def test_box_difference_matches_reference_expression(shape, order, radius):
     import torch
     import recfilter_amd as rfa
