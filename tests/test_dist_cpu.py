@@ -75,7 +75,7 @@ def _scans(name):
     return [(1, False, [0.6, 0.5, -0.1]), (1, True, [0.6, 0.5, -0.1]), (1, False, [1.0, 0.25])]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_sharded_filter_over_gloo(name, world, tmp_path):
     import torch.multiprocessing as mp
