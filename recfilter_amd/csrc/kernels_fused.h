@@ -62,6 +62,10 @@ struct FusedArgs {
     Acc *xt;                 // x tails   [s][tx][r][y + NY*z]
     Acc *yt;                 // y tails   [j][ty][r][x + NX*z]
     const Acc *y_incoming;   // carry entering the slab along y, [j][r][x + NX*z]
+    const Acc *y_apply;      // row shards with the merged exchange: Y[q][j][ty][r][o] (cross_scan_transfer, plan_generic.h).
+                             // The slab's y tails were completed with ZERO entering carries; pass 2 adds what the true
+                             // ones (y_incoming) contribute, Y * in, as it loads a carry, so the tails are not rewritten
+                             // by a separate launch.  Null otherwise.
     const Acc *x_incoming;   // carry entering each row along x, [s][r][y + NY*z]: zeros for an image; for a long
                              // 1-D signal folded into rows it is the state the previous row hands over
     // pointwise stages fused into the passes (rf_pointwise_desc; float pixels only): bit 0 = x' = pre_s*in + pre_b

@@ -114,6 +114,37 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                 }
             }
         }
+        if (a.y_apply != nullptr) {
+            // row shard: tails completed with zero entering carries + Y * (true entering carries), in the summation
+            // order of merged_apply_kernel (kernels_generic.hip).  Y is uniform per workgroup: scalar loads.
+            Acc yin[kFusedMaxScans][K];
+#pragma unroll
+            for (int q = 0; q < kFusedMaxScans; q++)
+#pragma unroll
+                for (int o = 0; o < K; o++)
+                    yin[q][o] = q < a.ny ? a.y_incoming[((int64_t)q * K + o) * Ly + line] : Acc(0);
+#pragma unroll
+            for (int j = 0; j < kFusedMaxScans; j++) {
+                if (j < a.ny) {
+                    const bool causal = a.ys[j].causal != 0;
+                    const bool tile_first = causal ? (ty == 0) : (ty == a.MY - 1);
+                    if (!tile_first) {
+                        const int tp = causal ? ty - 1 : ty + 1;
+#pragma unroll
+                        for (int r = 0; r < K; r++) {
+                            Acc add = Acc(0);
+#pragma unroll
+                            for (int q = 0; q <= j; q++) {
+                                const Acc *Ym = a.y_apply + ((((int64_t)q * a.ny + j) * a.MY + tp) * K + r) * K;
+#pragma unroll
+                                for (int o = 0; o < K; o++) add = add + Ym[o] * yin[q][o];
+                            }
+                            CY[j][r] = CY[j][r] + add;
+                        }
+                    }
+                }
+            }
+        }
     }
 
     // ---- load: wave w streams rows w, w+4, ...; one 1 KiB row per instruction ----

@@ -15,6 +15,8 @@
 //
 // These are the always-correct paths (any extent, any tile that divides it, any pixel type,
 // order <= RF_MAX_ORDER).  The bandwidth-tuned path is kernels_fused.hip.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace rf {
@@ -475,6 +477,75 @@ merged_gather_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered, in
     }
 }
 
+// The same walk with order, scan count and a bound on the slab count known at compile time (one node: world <= 8):
+// every index is static, so the entering carries of all slabs stay in registers (the kernel above keeps them in a
+// dynamically indexed private array, i.e. scratch memory: 25 us on a cfg3 slab), and all exits are requested before
+// the first dependent multiply.  Same summation order as above.
+constexpr int kMergeRegWorld = 8;
+template <typename Acc, int K, int NS>
+__global__ void __launch_bounds__(kBlock)
+merged_gather_reg_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered, int64_t rank_stride, int64_t plane_offset,
+                         int rank, int world, const Acc *__restrict__ X) {
+    constexpr int W = kMergeRegWorld;
+    const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int64_t L = a.g.lines;
+    Acc ex[NS][W][K], in[NS][W][K];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int h = 0; h < W; h++)
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                in[s][h][r] = Acc(0);
+                ex[s][h][r] = h < world ? gathered[h * rank_stride + plane_offset + ((int64_t)s * K + r) * L + line] : Acc(0);
+            }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const bool causal = a.scans[s].causal != 0;
+        Acc prev[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) prev[j] = Acc(0);
+        // slab h of the walk (ascending for a causal scan, descending otherwise; h is a constant after unrolling): the
+        // carry entering it is what the slabs before it in scan direction handed on
+        auto walk = [&](auto ascending) {
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+                const int h = decltype(ascending)::value ? i : W - 1 - i;
+                if (h < world) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) in[s][h][j] = prev[j];
+                    const int type = (h == 0 ? 1 : 0) | (h == world - 1 ? 2 : 0);
+                    Acc e[K];
+#pragma unroll
+                    for (int r = 0; r < K; r++) {
+                        Acc acc = ex[s][h][r];
+#pragma unroll
+                        for (int q = 0; q <= s; q++) {
+                            const Acc *Xm = X + (((int64_t)type * NS + q) * NS + s) * K * K;
+#pragma unroll
+                            for (int j = 0; j < K; j++) acc = acc + Xm[r * K + j] * in[q][h][j];
+                        }
+                        e[r] = acc;
+                    }
+                    // (the exit of the last slab in scan direction enters nobody: prev is not read again)
+#pragma unroll
+                    for (int r = 0; r < K; r++) prev[r] = e[r];
+                }
+            }
+        };
+        if (causal) walk(std::true_type{});
+        else walk(std::false_type{});
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            Acc mine = Acc(0);
+#pragma unroll
+            for (int h = 0; h < W; h++) mine = (h == rank) ? in[s][h][r] : mine;
+            a.incoming[((int64_t)s * K + r) * L + line] = mine;
+        }
+    }
+}
+
 // tails_s[t] += sum_{q <= s} Y[q][s][t] * in_q for every scan and tile of the slab: one pass over the tails, parallel
 // over lines and chunks of tiles (memory order).  K and the scan count are compile-time so the entering carries stay
 // in registers.
@@ -573,6 +644,19 @@ int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, in
 template <typename Acc>
 int launch_merged_gather(GenericDimArgs<Acc> a, const Acc *gathered, int64_t rank_stride, int64_t plane_offset, int rank,
                          int world, const Acc *X, hipStream_t stream) {
+    if (world <= kMergeRegWorld) {
+#define RF_CASE(KK, NN)                                                                                            \
+    if (a.k == KK && a.n_scans == NN) {                                                                            \
+        hipLaunchKernelGGL((merged_gather_reg_kernel<Acc, KK, NN>), dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, \
+                           gathered, rank_stride, plane_offset, rank, world, X);                                   \
+        RF_HIP_CHECK(hipGetLastError());                                                                           \
+        return RF_OK;                                                                                              \
+    }
+        RF_CASE(1, 1) RF_CASE(1, 2) RF_CASE(1, 3) RF_CASE(1, 4)
+        RF_CASE(2, 1) RF_CASE(2, 2) RF_CASE(2, 3) RF_CASE(2, 4)
+        RF_CASE(3, 1) RF_CASE(3, 2) RF_CASE(3, 3) RF_CASE(3, 4)
+#undef RF_CASE
+    }
     if (a.n_scans * world * a.k > kMergeMaxState) { set_error("merged exchange: too many carries per line"); return RF_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(merged_gather_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, gathered,
                        rank_stride, plane_offset, rank, world, X);

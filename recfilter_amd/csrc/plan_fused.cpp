@@ -365,6 +365,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         };
         plan->begin_steps.push_back(xs);
     }
+    const Acc *d_Yapply = nullptr;
     if (!y_sharded) {   // one launch for every y scan; per-scan launches only around the exchanges
         if (ny > 0) {
             Step cy;
@@ -376,7 +377,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         }
     } else if (merged_exchange_applies(ny, K, plan->shard_world)) {
         // one all-gather for all y scans (plan_generic.h, "merged exchange")
-        int rc = add_merged_exchange<S, Acc>(plan, ty, "y", MY, Ly, ymask, gyargs, yin, yin_pp, d_ACy, Cy, "carry_y");
+        // ... whose correction of the tails is left to pass 2 (FusedArgs::y_apply): no launch between gather and pass 2
+        static const bool separate_apply = getenv("RF_SHARD_SEPARATE_APPLY") != nullptr;     // A/B runs
+        int rc = add_merged_exchange<S, Acc>(plan, ty, "y", MY, Ly, ymask, gyargs, yin, yin_pp, d_ACy, Cy, "carry_y",
+                                             separate_apply ? nullptr : &d_Yapply);
         if (rc != RF_OK) return rc;
     } else {
         for (int j = 0; j < ny; j++) {
@@ -415,8 +419,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     }
     Step p2;
     p2.name = "fused_pass2";
-    p2.run = [plan, fargs, K, TY](int pl) {
-        return launch_fused_pass2<P>(K, TY, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], fargs(pl), plan->stream);
+    p2.run = [plan, fargs, K, TY, d_Yapply](int pl) {
+        FusedArgs<Acc> a = fargs(pl);
+        a.y_apply = d_Yapply;
+        return launch_fused_pass2<P>(K, TY, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
     else plan->begin_steps.push_back(p2);

@@ -134,7 +134,7 @@ inline bool merged_exchange_applies(int n_scans, int k, int world) {
 template <typename S, typename Acc, typename ArgsFn>
 int add_merged_exchange(rf_plan *plan, const DimTables<S> &tab, const std::string &dn, int64_t M, int64_t lines,
                         uint32_t causal_mask, ArgsFn gargs, Acc *incoming, size_t inc_pp, const Acc *d_AC, int C,
-                        const std::string &carry_name) {
+                        const std::string &carry_name, const Acc **apply_in_final_pass = nullptr) {
     int status = RF_OK;
     const int n = tab.n, K = tab.k, kk = K * K, np = plan->n_planes;
     const int world = plan->shard_world, rank = plan->shard_rank;
@@ -180,19 +180,26 @@ int add_merged_exchange(rf_plan *plan, const DimTables<S> &tab, const std::strin
     };
     plan->exchanges.push_back(ex);
 
+    // the local pass sees zero entering carries: a buffer of zeros of its own (the plan's `incoming` holds the true
+    // carries of the previous execute until the gather overwrites them)
+    const Acc *zeros = (const Acc *)plan->alloc(inc_pp * np * sizeof(Acc), true, &status);
+    if (status != RF_OK) return status;
     Step cs;
     cs.name = carry_name;
-    cs.run = [plan, gargs, K, n, causal_mask, d_AC, C, ex_index, plane_stride, incoming, inc_pp](int pl) {
-        // the local pass sees zero entering carries (the buffer holds the previous execute's)
-        if (hipMemsetAsync(incoming + (size_t)pl * inc_pp, 0, inc_pp * sizeof(Acc), plan->stream) != hipSuccess) {
-            set_error("hipMemsetAsync failed");
-            return (int)RF_ERR_HIP;
-        }
+    cs.run = [plan, gargs, K, n, causal_mask, d_AC, C, ex_index, plane_stride, zeros, inc_pp](int pl) {
         Acc *send = (Acc *)plan->exchanges[ex_index].send;
-        return launch_carry_block<Acc>(K, gargs(pl), causal_mask, 0, n, send ? send + pl * plane_stride : nullptr, d_AC, C,
+        auto a = gargs(pl);
+        a.incoming = const_cast<Acc *>(zeros) + (size_t)pl * inc_pp;
+        return launch_carry_block<Acc>(K, a, causal_mask, 0, n, send ? send + pl * plane_stride : nullptr, d_AC, C,
                                        plan->stream);
     };
     plan->exchange_local_steps.push_back({cs});
+    if (apply_in_final_pass != nullptr) {
+        // the caller's final pass adds Y * in as it loads a carry (fused pass 2): the tails are not rewritten
+        *apply_in_final_pass = d_Y;
+        plan->exchange_apply_steps.push_back({});
+        return status;
+    }
     Step ap;
     ap.name = carry_name + "_apply";
     ap.run = [plan, gargs, d_Y](int pl) { return launch_merged_apply<Acc>(gargs(pl), d_Y, plan->stream); };

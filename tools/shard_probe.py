@@ -39,3 +39,19 @@ for it in range(12):
             acc.setdefault(name, []).append(a.elapsed_time(b))
 res = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
 print(f"world={world} rank={rank} n={n}: total {sum(res.values()):.4f} ms", res)
+
+# whole steps back to back, no events inside (what a rank's stream sees between two collectives)
+def step():
+    plan.begin([img], [out])
+    for e in range(nex):
+        send, gath = bufs[e]
+        plan.exchange_local(e, send.data_ptr())
+        gath.view(world, -1).copy_(send.view(1, -1).expand(world, -1))          # one copy kernel stands in for the all-gather
+        plan.exchange_apply(e, gath.data_ptr())
+    plan.finish()
+for _ in range(5): step()
+torch.cuda.synchronize()
+a = ev()
+for _ in range(40): step()
+b = ev(); torch.cuda.synchronize()
+print(f"back to back: {a.elapsed_time(b) / 40:.4f} ms per step")
