@@ -152,7 +152,8 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
  *                                                carries (rf_plan_exchange_bytes(e) bytes) to `send`
  *         -- caller all-gathers `send` over the ranks into `gathered` (world * bytes, rank-major;
  *            RCCL all-gather on the same stream) --
- *         rf_plan_exchange_apply(e, gathered)    forms the incoming carry, fixes the slab's tails
+ *         rf_plan_exchange_apply(e, gathered)    forms the incoming carry; what it adds to the slab's tails is
+ *                                                applied here, or by the final pass as it loads a carry (fused 2-D)
  *     rf_plan_finish(...)                        final correction pass
  * `send` and `gathered` are caller-owned device buffers.  With shard_world == 1 the apply step
  * is a no-op and may be skipped.  Every slab must have the same extent along the sharded dimension

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) tails_regs_kernel(const f4 *__restrict__ 
     const size_t base = ((size_t)ty * 64 + 16 * w) * nx4 + (size_t)tx * 64 + lane;
     f4 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = src[base + (size_t)i * nx4];
+    for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load(src + base + (size_t)i * nx4);
     F2 hx[4][NXK / 2];
 #pragma unroll
     for (int c = 0; c < 4; c++)
