@@ -38,3 +38,29 @@ def run(two_streams, iters=20):
 
 for _ in range(2):
     print(f"order {order}: two planes on one stream {run(False):.4f} ms, on two streams {run(True):.4f} ms")
+
+# free-running: each stream runs its plane's steps back to back with no per-iteration join, the second stream started
+# half a step late so that its latency-bound carry kernels fall into the other plane's HBM-bound passes
+def free_run(iters=40):
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    start = torch.cuda.Event(); start.record()
+    done = []
+    for p in range(2):
+        streams[p].wait_event(start)
+    with torch.cuda.stream(streams[1]):
+        plans[1].begin([ins[1]], [outs[1]]); plans[1].finish() if False else None
+    for it in range(iters):
+        for p in range(2):
+            with torch.cuda.stream(streams[p]):
+                plans[p].execute([ins[p]], [outs[p]])
+    for p in range(2):
+        with torch.cuda.stream(streams[p]):
+            ev = torch.cuda.Event(); ev.record(); done.append(ev)
+    for ev in done: torch.cuda.current_stream().wait_event(ev)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (2 * iters)
+
+for _ in range(3):
+    print(f"order {order}: free-running on two streams {free_run():.4f} ms per plane-step")
