@@ -10,6 +10,11 @@ on.  N>1 (launched by torch.distributed.run, one rank per GPU) shards the image 
 owns a 16384-row slab of a (N*16384) x 16384 image (weak scaling) and the ranks exchange the k-row
 boundary carry of the two y scans with one RCCL all-gather per scan.
 
+Steps are submitted round robin to `--inflight` HIP streams (default 2), each with its own plan (workspace), exchange
+buffers and output planes, so that one step's latency-bound carry kernels and its all-gather run beside another
+step's HBM-bound passes; `value` is throughput over the K timed steps, `ms_per_step` its inverse.  `--inflight 1`
+runs the steps strictly one after the other on one stream (what `kernels_ms` adds up to).
+
 Prints ONE JSON line (rank 0).  `value` = Mpixels/s over all GPUs; `roofline` prices the dominant
 kernel against the 8 TB/s HBM peak with HIP-event timing of that kernel; `cpu_baseline` is the CPU
 oracle (a port of the reference's scan operator, OpenMP over all host cores) on a bounded sample.
@@ -108,6 +113,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="device ordinal for every rank (debug; default LOCAL_RANK)")
+    ap.add_argument("--inflight", type=int, default=2, help="steps in flight per GPU, each on its own HIP stream with its own "
+                    "plan and output planes (1 = strictly one after the other on one stream)")
     args = ap.parse_args()
 
     import numpy as np
@@ -135,25 +142,31 @@ def main():
     dtype = torch.float32
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     inputs = [torch.rand(shape, generator=gen, device="cuda", dtype=dtype) for _ in range(planes)]
-    outputs = [torch.empty_like(t) for t in inputs]
+    inflight = max(1, args.inflight)
+    # steps in flight at the same time write distinct output planes
+    output_sets = [[torch.empty_like(t) for t in inputs] for _ in range(inflight)]
+    outputs = output_sets[0]
     samples_local = int(np.prod(shape)) * planes
 
     from recfilter_amd.dist import ShardedFilter
     filt = ShardedFilter(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, rank=rank, world=world,
-                         path=args.path, dtype=np.float32, group=None)
+                         path=args.path, dtype=np.float32, group=None, inflight=inflight)
 
     def barrier():
+        filt.drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        filt.execute(inputs, outputs)
+    # A step = one execute of the whole filter on the resident image.  With --inflight D the steps are submitted round
+    # robin to D streams (recfilter_amd/dist.py): step i+1's pass 1 runs beside step i's carry kernels / all-gather.
+    for i in range(args.warmup):
+        filt.submit(inputs, output_sets[i % inflight])
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        filt.execute(inputs, outputs)
+    for i in range(args.steps):
+        filt.submit(inputs, output_sets[i % inflight])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -218,7 +231,8 @@ def main():
             "config": {"workload": f"{args.workload}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
                                    f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
                        "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
-                       "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else "none"},
+                       "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else "none",
+                       "steps_in_flight": inflight},
             "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / world, 4),
             "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
             "roofline": roofline,

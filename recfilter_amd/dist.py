@@ -26,35 +26,77 @@ from .plan import Plan
 
 
 class ShardedFilter:
+    """`inflight` > 1 keeps that many executions in flight, each on its own HIP stream with its own plan (workspace)
+    and exchange buffers: the latency-bound carry kernels and the all-gather of one execution then run beside the
+    HBM-bound passes of another ("steps in flight").  Use `submit` + `drain` for that; `execute` stays
+    the one-at-a-time call on the current stream."""
+
     def __init__(self, local_shape: Sequence[int], scans, clamped: bool = False, planes: int = 1,
                  rank: int = 0, world: int = 1, path: int = capi.RF_PATH_AUTO, dtype=np.float32,
-                 tile=None, group=None, engine=None):
+                 tile=None, group=None, engine=None, inflight: int = 1):
         self.rank, self.world, self.group = int(rank), int(world), group
-        self.plan = engine if engine is not None else Plan(
-            local_shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path,
-            shard_rank=rank, shard_world=world)
+        self.inflight = max(1, int(inflight))
+        if engine is not None and self.inflight > 1:
+            raise ValueError("inflight > 1 builds its own plans: pass no engine")
+
+        def make():
+            return Plan(local_shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path,
+                        shard_rank=rank, shard_world=world)
+        self.plans = [engine if engine is not None else make()]
+        self.plans += [make() for _ in range(self.inflight - 1)]
+        self.plan = self.plans[0]
         self._send = {}
         self._gathered = {}
+        self._streams = None          # one per slot, created on the first submit
+        self._next = 0
 
-    def _buffers(self, i: int, like):
+    def _buffers(self, key, plan, like):
         import torch
-        if i not in self._send:
-            nbytes = self.plan.exchange_bytes(i)
-            self._send[i] = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
-            self._gathered[i] = torch.empty(nbytes * self.world, dtype=torch.uint8, device=like.device)
-        return self._send[i], self._gathered[i]
+        if key not in self._send:
+            nbytes = plan.exchange_bytes(key[1])
+            self._send[key] = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+            self._gathered[key] = torch.empty(nbytes * self.world, dtype=torch.uint8, device=like.device)
+        return self._send[key], self._gathered[key]
+
+    def _run(self, slot, inputs, outputs, stream=None):
+        plan = self.plans[slot]
+        kw = {} if stream is None else {"stream": stream}       # (the numpy stand-in of the CPU tests has no streams)
+        if self.world == 1:
+            return plan.execute(inputs, outputs, **kw)
+        import torch.distributed as dist
+        plan.begin(inputs, outputs, **kw)
+        for i in range(plan.num_exchanges):
+            send, gathered = self._buffers((slot, i), plan, inputs[0])
+            plan.exchange_local(i, send.data_ptr())
+            dist.all_gather_into_tensor(gathered, send, group=self.group)      # ordered after / before the current stream
+            plan.exchange_apply(i, gathered.data_ptr())
+        plan.finish()
+        return outputs
 
     def execute(self, inputs, outputs):
         """One filter execution on this rank's slab.  Asynchronous on the current stream for a
         GPU engine; the all-gathers run on the same stream (torch.distributed orders them)."""
-        if self.world == 1:
-            return self.plan.execute(inputs, outputs)
-        import torch.distributed as dist
-        self.plan.begin(inputs, outputs)
-        for i in range(self.plan.num_exchanges):
-            send, gathered = self._buffers(i, inputs[0])
-            self.plan.exchange_local(i, send.data_ptr())
-            dist.all_gather_into_tensor(gathered, send, group=self.group)
-            self.plan.exchange_apply(i, gathered.data_ptr())
-        self.plan.finish()
+        return self._run(0, inputs, outputs)
+
+    def submit(self, inputs, outputs):
+        """Like execute, on the next slot's stream (round robin over `inflight` slots): it starts after what the current
+        stream holds now (the inputs are ready) and after the slot's previous execution, and runs beside the other
+        slots.  Executions in flight at the same time need distinct output planes.  Call drain() before reading."""
+        import torch
+        if self.inflight == 1:
+            return self._run(0, inputs, outputs)
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=inputs[0].device) for _ in range(self.inflight)]
+        slot, self._next = self._next, (self._next + 1) % self.inflight
+        st = self._streams[slot]
+        st.wait_stream(torch.cuda.current_stream(inputs[0].device))
+        with torch.cuda.stream(st):
+            self._run(slot, inputs, outputs, stream=st)
         return outputs
+
+    def drain(self):
+        """The current stream waits for every execution submitted so far."""
+        import torch
+        if self._streams is not None:
+            for st in self._streams:
+                torch.cuda.current_stream(st.device).wait_stream(st)

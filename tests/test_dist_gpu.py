@@ -45,10 +45,21 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir):
         for _ in range(2):                     # the second execute reuses the exchange buffers
             filt.execute(inputs, outputs)
         torch.cuda.synchronize()
+        wants = [oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[rank * n:(rank + 1) * n] for p in range(planes)]
         for p in range(planes):
-            want = oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[rank * n:(rank + 1) * n]
-            err = rc.rel_err(outputs[p].cpu().numpy(), want)
+            err = rc.rel_err(outputs[p].cpu().numpy(), wants[p])
             assert err < 1e-4, f"rank {rank} plane {p}: rel err {err}"
+        # steps in flight: two slots (own stream, plan, exchange buffers, output planes), five submits, one drain
+        piped = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, inflight=2)
+        sets = [[torch.zeros_like(t) for t in inputs] for _ in range(2)]
+        for i in range(5):
+            piped.submit(inputs, sets[i % 2])
+        piped.drain()
+        torch.cuda.synchronize()
+        for k in range(2):
+            for p in range(planes):
+                err = rc.rel_err(sets[k][p].cpu().numpy(), wants[p])
+                assert err < 1e-4, f"rank {rank} slot {k} plane {p}: rel err {err}"
         open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
