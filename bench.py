@@ -10,10 +10,12 @@ on.  N>1 (launched by torch.distributed.run, one rank per GPU) shards the image 
 owns a 16384-row slab of a (N*16384) x 16384 image (weak scaling) and the ranks exchange the k-row
 boundary carry of the two y scans with one RCCL all-gather per scan.
 
-Steps are submitted round robin to `--inflight` HIP streams (default 2), each with its own plan (workspace), exchange
-buffers and output planes, so that one step's latency-bound carry kernels and its all-gather run beside another
-step's HBM-bound passes; `value` is throughput over the K timed steps, `ms_per_step` its inverse.  `--inflight 1`
-runs the steps strictly one after the other on one stream (what `kernels_ms` adds up to).
+Steps are submitted round robin to `--inflight` HIP streams, each with its own plan (workspace), exchange buffers and
+output planes, so that one step's latency-bound carry kernels and its all-gather run beside another step's HBM-bound
+passes; `value` is throughput over the K timed steps, `ms_per_step` its inverse.  Default: ONE step at a time on one
+GPU (strictly one after the other on one stream: what `kernels_ms` adds up to and what the rocprofv3 summaries under
+profiles/ show), two in flight on N > 1 GPUs, where the second step keeps the all-gather's latency off the critical
+path (`config.steps_in_flight` says which; on one GPU two in flight are worth 2 %).
 
 Prints ONE JSON line (rank 0).  `value` = Mpixels/s over all GPUs; `roofline` prices the dominant
 kernel against the 8 TB/s HBM peak with HIP-event timing of that kernel; `cpu_baseline` is the CPU
@@ -113,8 +115,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="device ordinal for every rank (debug; default LOCAL_RANK)")
-    ap.add_argument("--inflight", type=int, default=2, help="steps in flight per GPU, each on its own HIP stream with its own "
-                    "plan and output planes (1 = strictly one after the other on one stream)")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU, each on its own HIP stream with its own "
+                    "plan and output planes (1 = strictly one after the other on one stream; 0 = auto: 1 on one GPU, so "
+                    "that per-kernel durations under rocprofv3 are those of kernels running alone, 2 on several GPUs, "
+                    "where the second step hides the all-gather)")
     args = ap.parse_args()
 
     import numpy as np
@@ -142,7 +146,7 @@ def main():
     dtype = torch.float32
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     inputs = [torch.rand(shape, generator=gen, device="cuda", dtype=dtype) for _ in range(planes)]
-    inflight = max(1, args.inflight)
+    inflight = args.inflight if args.inflight > 0 else (1 if world == 1 else 2)
     # steps in flight at the same time write distinct output planes
     output_sets = [[torch.empty_like(t) for t in inputs] for _ in range(inflight)]
     outputs = output_sets[0]
