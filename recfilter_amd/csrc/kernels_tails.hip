@@ -40,7 +40,10 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     using Acc = typename PixelTraits<P>::Acc;
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc tile[kTailRows * kFusedTX];
-    __shared__ __attribute__((aligned(16))) Acc hx_lds[kFusedMaxScans * K * kFusedTX];   // Hx of this tile's variant
+    // Hx of this tile's variant: nx * K rows of 256, dynamic so that a filter with two x scans of order 3 (6 KiB instead
+    // of 12) still fits four workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) unsigned char hx_raw[];
+    Acc *hx_lds = reinterpret_cast<Acc *>(hx_raw);
     A4 *tile4 = reinterpret_cast<A4 *>(tile);
     A4 *hx4 = reinterpret_cast<A4 *>(hx_lds);
     constexpr int NH = TY / kTailRows;            // steps per tile (2 for TY = 64)
@@ -238,7 +241,9 @@ __global__ void __launch_bounds__(256)
 xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
-    __shared__ __attribute__((aligned(16))) Acc g_lds[kFusedMaxScans * kFusedTX * K];      // G[variant 0][q][o][x]
+    extern __shared__ __attribute__((aligned(16))) unsigned char g_raw[];                  // G[variant 0][q][o][x]: nx * K
+    Acc *g_lds = reinterpret_cast<Acc *>(g_raw);                                           // rows of 256 (dynamic: more
+                                                                                           // workgroups per CU with few scans)
     A4 *rows4 = reinterpret_cast<A4 *>(rows);
     const int t = threadIdx.x;
     const int cc = t & 63, rg = t >> 6;
@@ -389,17 +394,18 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
     if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
+    const size_t hx_bytes = (size_t)(a.nx > 0 ? a.nx : 1) * K * kFusedTX * sizeof(typename PixelTraits<P>::Acc);
 #define RF_CASE(KK, TT)                                                                                             \
     if (K == KK && TY == TT) {                                                                                       \
         if constexpr (std::is_same<P, float>::value) {                                                               \
             if (src_u8) {                                                                                            \
-                hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, uint8_t>), grid, dim3(kFusedThreads), 0, stream,   \
+                hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, uint8_t>), grid, dim3(kFusedThreads), hx_bytes, stream, \
                                    (const uint8_t *)src, a, Hx, Hy);                                                 \
                 RF_HIP_CHECK(hipGetLastError());                                                                     \
                 return RF_OK;                                                                                        \
             }                                                                                                        \
         }                                                                                                            \
-        hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P>), grid, dim3(kFusedThreads), 0, stream, (const P *)src, \
+        hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P>), grid, dim3(kFusedThreads), hx_bytes, stream, (const P *)src, \
                            a, Hx, Hy);                                                                               \
         RF_HIP_CHECK(hipGetLastError());                                                                             \
         return RF_OK;                                                                                                \
@@ -425,10 +431,11 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
     if (blocks >= (1ll << 31)) { set_error("xscan rows: grid too large"); return RF_ERR_UNSUPPORTED; }
     const unsigned grid = (unsigned)blocks;
     const bool edge = a.last_cols != kFusedTX;       // images of whole tiles keep the lean kernel
+    const size_t g_bytes = (size_t)a.nx * K * kFusedTX * sizeof(Acc);
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \
-        if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true>), dim3(grid), dim3(256), 0, stream, a, gj, TY, Hy, G);  \
-        else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false>), dim3(grid), dim3(256), 0, stream, a, gj, TY, Hy, G); \
+        if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
+        else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }
