@@ -697,3 +697,24 @@ def test_uint8_input_without_scale_and_order3_epilogue():
     # a difference of two O(255) terms: the bar is relative to the terms (see test_unsharp_mask_front_end)
     scale = np.abs(blur) + np.abs(x)
     assert np.max(np.abs(out - (blur - x)) / np.maximum(scale, 1e-2 * scale.max())) < TOL
+
+
+def test_steps_in_flight_keep_their_images_apart():
+    """ShardedFilter(inflight=3).submit on one GPU: seven different images through three slots (own stream, plan and
+    workspace each), every output against the oracle -- a slot must never see another slot's tails."""
+    import torch
+    from recfilter_amd.dist import ShardedFilter
+    scans = rc.xy_pm(rc.GAUSS2)
+    shape = (320, 1024)
+    filt = ShardedFilter(shape, scans, clamped=True, inflight=3)
+    assert filt.plan.path_name == "tiled_fused"
+    imgs = [rc.random_image(shape, np.float32, 300 + i) for i in range(7)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    outs = [torch.empty_like(d) for d in dev]
+    for d, o in zip(dev, outs):
+        filt.submit([d], [o])
+    filt.drain()
+    torch.cuda.synchronize()
+    for im, o in zip(imgs, outs):
+        want = oracle.apply_filter(im.astype(np.float64), scans, True)
+        assert rc.rel_err(o.cpu().numpy(), want) < 1e-4
