@@ -246,6 +246,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()                  # rank 0 was still timing single kernels: leave the group together
         dist.destroy_process_group()
 
 
