@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                     "multi-rank path on a box with one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="device ordinal for every rank (debug; default LOCAL_RANK)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's shape is the GLOBAL image, every rank "
+                    "owns 1/N of its outermost dimension (BASELINE config 5: 2048^3 z-sharded over 8 GPUs); default is weak "
+                    "scaling, every rank owns a full-size slab")
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU, each on its own HIP stream with its own "
                     "plan and output planes (1 = strictly one after the other on one stream; 0 = auto: 1 on one GPU, so "
                     "that per-kernel durations under rocprofv3 are those of kernels running alone, 2 on several GPUs, "
@@ -143,6 +146,10 @@ def main():
 
     cfg = workload(args.workload, args.size)
     shape, planes = cfg["shape"], cfg["planes"]
+    if args.strong and world > 1:
+        if shape[0] % (world * 64) != 0:
+            raise SystemExit(f"--strong: outermost extent {shape[0]} is not a multiple of {world} slabs of whole tiles")
+        shape = (shape[0] // world,) + tuple(shape[1:])
     dtype = torch.float32
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     inputs = [torch.rand(shape, generator=gen, device="cuda", dtype=dtype) for _ in range(planes)]
@@ -231,7 +238,7 @@ def main():
             "metric": "Mpixels/s + achieved HBM GB/s, 16384^2 order-2 x/y Gaussian IIR",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
                                    f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
                        "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
