@@ -174,6 +174,7 @@ class RecFilter {
         bool clamped = false, tiled = false, compiled = false, has_consumer = false;
         RecFilterPointwise consumer;
         rf_plan *plan = nullptr;
+        void *stream = nullptr;                  // HIP stream of enqueue() / realize() (set_stream); null = default stream
         std::vector<void *> out;                 // device buffers of the last realization
         std::shared_ptr<std::vector<std::string>> schedule_log = std::make_shared<std::vector<std::string>>();
         ~Contents() {
@@ -430,7 +431,22 @@ public:
             c->out.assign(in.size(), nullptr);
             for (auto &p : c->out) if (hipMalloc(&p, bytes) != hipSuccess) fail("hipMalloc failed");
         }
-        if (rf_plan_execute(c->plan, in.data(), c->out.data(), nullptr) != RF_OK) fail(rf_last_error_string());
+        if (rf_plan_execute(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
+    }
+
+    /** Not in the reference (Halide owns its streams): the HIP stream this filter's kernels run on (a hipStream_t).  Every
+     *  stage of a cascade launches on its own setting: give all stages the same stream. */
+    void set_stream(void *hip_stream) { c->stream = hip_stream; }
+
+    /** realize() without the device synchronisation: launches the filter (and its upstream cascade stages) on its stream
+     *  and returns the output planes, valid once the stream has drained.  Several RecFilter objects enqueued on
+     *  different streams run beside each other -- the carry kernels of one under the passes of another. */
+    RecFilterRealization enqueue() {
+        execute_chain();
+        RecFilterRealization r;
+        r.planes = c->out; r.dtype = dtype(); r.bytes_per_plane = plane_elems() * dtype_size(dtype());
+        for (auto &dm : c->dims) r.extent.push_back(dm.num_pixels());
+        return r;
     }
 
     /** lib/recfilter.cpp:984-989 */

@@ -265,6 +265,54 @@ int main() {
         failures += caught != 10;
         (void)hipFree(d);
     }
+    {   // two filters enqueued on two streams (set_stream / enqueue): each keeps its own result
+        const int width = 512, height = 256;
+        const std::vector<float> W = gaussian_weights(5.0f, 2);
+        hipStream_t st[2];
+        std::vector<float> images[2] = {random_image((size_t)width * height, 31), random_image((size_t)width * height, 32)};
+        float *d[2];
+        RecFilterDim x("x", width), y("y", height);
+        std::vector<RecFilter> filters;
+        for (int i = 0; i < 2; i++) {
+            if (hipStreamCreate(&st[i]) != hipSuccess) { std::fprintf(stderr, "hipStreamCreate failed\n"); return 2; }
+            d[i] = upload(images[i]);
+            RecFilter f;
+            f.set_clamped_image_border();
+            f(x, y) = RecFilterImage(d[i]);
+            f.add_filter(+x, W); f.add_filter(-x, W); f.add_filter(+y, W); f.add_filter(-y, W);
+            f.split_all_dimensions(32);
+            f.set_stream(st[i]);
+            filters.push_back(f);
+        }
+        RecFilterRealization r[2];
+        for (int rep = 0; rep < 3; rep++)
+            for (int i = 0; i < 2; i++) r[i] = filters[i].enqueue();
+        for (int i = 0; i < 2; i++) {
+            if (hipStreamSynchronize(st[i]) != hipSuccess) { std::fprintf(stderr, "hipStreamSynchronize failed\n"); return 2; }
+            std::vector<float> ref = images[i];
+            // the clamped loops of the reference's apps: taps before the first sample read the sample itself
+            for (int dim = 0; dim < 2; dim++)
+                for (int causal = 1; causal >= 0; causal--) {
+                    const int n = dim == 0 ? width : height, lines = dim == 0 ? height : width;
+                    for (int ln = 0; ln < lines; ln++)
+                        for (int p = 0; p < n; p++) {
+                            const int i0 = causal ? p : n - 1 - p;
+                            auto at = [&](int q) -> float & { return dim == 0 ? ref[(size_t)ln * width + q] : ref[(size_t)q * width + ln]; };
+                            float acc = W[0] * at(i0);
+                            for (int j = 1; j <= 2; j++) {
+                                int q = causal ? i0 - j : i0 + j;
+                                q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+                                acc += W[j] * at(q);
+                            }
+                            at(i0) = acc;
+                        }
+                }
+            report(i == 0 ? "enqueue on stream 0" : "enqueue on stream 1", rel_err(ref, r[i].to_host<float>()));
+            (void)hipFree(d[i]);
+        }
+        filters.clear();
+        for (int i = 0; i < 2; i++) (void)hipStreamDestroy(st[i]);
+    }
     std::printf("%s\n", failures ? "SOME TESTS FAILED" : "all front-end tests passed");
     return failures ? 1 : 0;
 }
