@@ -237,7 +237,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
 // border tiles read their variant from memory.
 template <typename Acc, int K, bool EDGE>
-__global__ void __launch_bounds__(256, K <= 2 ? 6 : 4)
+__global__ void __launch_bounds__(256, 6)
 xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
