@@ -72,7 +72,7 @@ def pmc_traffic(kernel_name, workload, shape):
     return table[key]["fetch_bytes_corrected"] + table[key]["write_bytes"]
 
 
-def cpu_baseline(cfg, budget_px=16 * 1024 * 1024):
+def cpu_baseline(cfg, budget_px=64 * 1024 * 1024):      # 8192^2 of cfg3: like the workload it does not fit the host's caches
     """Times the CPU oracle (oracle/, a port of lib/recfilter.cpp:302-343 with OpenMP over lines --
     the shape of the reference's cpu_auto_full_schedule) on a bounded sample of the same workload."""
     import numpy as np
