@@ -58,18 +58,21 @@ def algorithmic_bytes_per_launch(kernel_name, samples, itemsize):
 def pmc_traffic(kernel_name, workload, shape):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950).
-    Only valid for the exact workload the counters were collected on (cfg3 at full size); else None."""
+    rocprofv3 cannot run inside the bench, so this is a LOOKUP in the newest committed summary, not a measurement of
+    the run that prints it -- the bench line names the file (`traffic_source`).  Only valid for the exact workload the
+    counters were collected on (cfg3 at full size); else (None, None)."""
     if workload != "cfg3" or tuple(shape) != (16384, 16384):
-        return None
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
-    try:
-        table = json.load(open(path))["kernels"]
-    except Exception:
-        return None
-    key = {"fused_pass2": "fused_pass2_kernel", "fused_tails": "fused_tails_kernel"}.get(kernel_name)
-    if key not in table:
-        return None
-    return table[key]["fetch_bytes_corrected"] + table[key]["write_bytes"]
+        return None, None
+    for rnd in ("r2", "r1"):
+        rel = os.path.join("profiles", rnd, "pmc_traffic.json")
+        try:
+            table = json.load(open(os.path.join(ROOT, rel)))["kernels"]
+        except Exception:
+            continue
+        for key, entry in table.items():
+            if key.startswith(kernel_name):
+                return entry["fetch_bytes_corrected"] + entry["write_bytes"], rel
+    return None, None
 
 
 def cpu_baseline(cfg, budget_px=64 * 1024 * 1024):      # 8192^2 of cfg3: like the workload it does not fit the host's caches
@@ -103,6 +106,36 @@ def cpu_baseline(cfg, budget_px=64 * 1024 * 1024):      # 8192^2 of cfg3: like t
                       f"{avail} / {avail // 2} / {avail // 4} / 16 / 8 threads"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run (one per GPU, rendezvous
+    on 127.0.0.1) and return its exit code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()                 # does not initialise the GPU
+    if args.device < 0 and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible devices, found {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def metric_name(workload_name, shape, planes):
+    """BASELINE.json's metric string for the configuration it is quoted on (cfg3 at full size); other workloads and
+    debug sizes say what they ran."""
+    if workload_name == "cfg3" and tuple(shape) == (16384, 16384) and planes == 1:
+        return "Mpixels/s + achieved HBM GB/s, 16384^2 order-2 x/y Gaussian IIR"
+    what = {"cfg2": "order-1 summed-area table", "cfg3": "order-2 x/y Gaussian IIR", "cfg4a": "bicubic B-spline prefilter",
+            "cfg4b": "order-3 x/y Gaussian IIR", "cfg5": "order-2 x/y/z filter (test_generic_xyz)"}[workload_name]
+    return f"Mpixels/s + achieved HBM GB/s, {'x'.join(map(str, shape))} x{planes} {what}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +157,12 @@ def main():
                     "where the second step hides the all-gather)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not launched by torch.distributed.run: become the launcher.  Nothing in this process has touched the GPU yet
+        # (torch.cuda.device_count() does not initialise it) and it never will: the ranks are CHILD processes, this one
+        # only waits and passes their exit code on.
+        sys.exit(spawn_ranks(args))
+
     import numpy as np
     import torch
     import recfilter_amd as rfa
@@ -131,8 +170,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.device < 0 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()}")
     device = local_rank if args.device < 0 else args.device
     torch.cuda.set_device(device)
     dist = None
@@ -184,8 +225,9 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    joined = dist.get_world_size() if dist is not None else 1      # ranks that actually took part
     ms_per_step = elapsed * 1000.0 / args.steps
-    total_px = samples_local * world
+    total_px = samples_local * joined
     value = total_px / (ms_per_step * 1e-3) / 1e6
 
     # --- per-kernel timing with HIP events on the launch stream (rank 0, single-device plan) --------
@@ -214,9 +256,10 @@ def main():
         alg = algorithmic_bytes_per_launch(dom, samples_local // launches, 4)
         avg_ms = kernels[dom] / launches
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_source = pmc_traffic(dom, args.workload, shape)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": pmc_traffic(dom, args.workload, shape),
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg}
         # device-to-device copy of the same image with torch's own kernel, timed with HIP events: what a plain
         # read-once/write-once pass reaches on this box (SURVEY 8d asks for a measured stream-copy ceiling)
@@ -235,16 +278,18 @@ def main():
     if rank == 0:
         whole = 8.0 * total_px / (ms_per_step * 1e-3) / 1e9      # 8 B per f32 sample per filter
         line = {
-            "metric": "Mpixels/s + achieved HBM GB/s, 16384^2 order-2 x/y Gaussian IIR",
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "metric": metric_name(args.workload, cfg["shape"], planes),
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": joined, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
                                    f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
                        "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
                        "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else "none",
-                       "steps_in_flight": inflight},
-            "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / world, 4),
+                       "steps_in_flight": inflight,
+                       "backend": (args.backend if joined > 1 else "none"),
+                       "rccl_ranks": (joined if (joined > 1 and args.backend == "nccl") else 0)},
+            "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / joined, 4),
             "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
             "roofline": roofline,
             "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},

@@ -130,7 +130,14 @@ int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]);
 int rf_plan_num_kernels(const rf_plan *plan);
 
 /* ---- execution (replaces Func::realize) --------------------------------------------------- */
-/* in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan on the fused
+/* One execution in flight per plan: a plan owns ONE tail/carry workspace and keeps the per-execute context (plane
+ * pointers, stream, stepping phase) inside the handle, so two executes of the same plan may only overlap when the
+ * second is enqueued on the SAME stream (stream order then separates them).  To run executions concurrently -- on
+ * different streams or from different host threads -- create one plan per stream; plans are cheap (tables are a few
+ * hundred KB, the workspace ~8 % of one image) and independent.  recfilter_amd.dist.ShardedFilter(inflight=D) does
+ * exactly that.  The C entry points are not re-entrant per plan; distinct plans may be used from distinct threads.
+ *
+ * in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan on the fused
  * path (rf_plan_path() == RF_PATH_TILED_FUSED) needs 16-byte aligned planes (4-byte for RF_IN_U8 input planes) and
  * returns RF_ERR_INVALID_ARG otherwise; the other paths take any element-aligned pointer. */
 int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes,

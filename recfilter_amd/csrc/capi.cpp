@@ -113,19 +113,29 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
     for (auto &ex : plan->exchanges) ex.send = ex.scratch;
     auto steps = flat_steps(plan);
     if (capacity < (int)steps.size() || !ms_out) { set_error("ms_out too small: need %zu", steps.size()); return RF_ERR_INVALID_ARG; }
-    std::vector<hipEvent_t> ev(steps.size() + 1);
-    for (auto &e : ev) RF_HIP_CHECK(hipEventCreate(&e));
+    // events are destroyed on every return path; outputs are fully written even when a step fails
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    } events;
+    for (size_t i = 0; i < steps.size(); i++) {
+        ms_out[i] = 0.0f;
+        if (names_out) names_out[i] = steps[i]->name.c_str();
+    }
+    for (size_t i = 0; i < steps.size() + 1; i++) {
+        hipEvent_t e;
+        RF_HIP_CHECK(hipEventCreate(&e));
+        events.ev.push_back(e);
+    }
+    std::vector<hipEvent_t> &ev = events.ev;
     RF_HIP_CHECK(hipEventRecord(ev[0], plan->stream));
     for (size_t i = 0; i < steps.size() && rc == RF_OK; i++) {
         for (int pl = 0; pl < plan->n_planes && rc == RF_OK; pl++) rc = steps[i]->run(pl);
         if (rc == RF_OK && hipEventRecord(ev[i + 1], plan->stream) != hipSuccess) rc = RF_ERR_HIP;
     }
     if (rc == RF_OK && hipEventSynchronize(ev.back()) != hipSuccess) rc = RF_ERR_HIP;
-    for (size_t i = 0; i < steps.size() && rc == RF_OK; i++) {
+    for (size_t i = 0; i < steps.size() && rc == RF_OK; i++)
         if (hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]) != hipSuccess) rc = RF_ERR_HIP;
-        if (names_out) names_out[i] = steps[i]->name.c_str();
-    }
-    for (auto &e : ev) (void)hipEventDestroy(e);
     if (rc == RF_ERR_HIP) set_error("HIP event timing failed: %s", hipGetErrorString(hipGetLastError()));
     return rc;
 }

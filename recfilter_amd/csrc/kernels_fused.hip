@@ -20,6 +20,7 @@
 // This file holds pass 2, the final correction pass (lib/split.cpp:1008-1130, 1647-1780).  Pass 1 (tail extraction as
 // a contraction) and the completion of the y tails are in kernels_tails.hip, the carry recurrences in
 // kernels_carry.hip; plan_fused.cpp strings them together.
+#include <atomic>
 #include <type_traits>
 
 #include "kernels.h"
@@ -310,14 +311,16 @@ int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename Pixe
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
     // the 64 KiB of dynamic LDS has to be opted into once per device
-    static bool attr_set[64] = {false};
+    // (concurrent plan creators/executors on different host threads may race to set it: the flag is atomic and the
+    // attribute call itself is idempotent)
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
-    bool &done = attr_set[dev & 63];
-    if (!done) {
+    std::atomic<bool> &done = attr_set[dev & 63];
+    if (!done.load(std::memory_order_acquire)) {
         RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done = true;
+        done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
     hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);

@@ -120,8 +120,6 @@ class RecFilter:
         affine defining expression such as `in(x,y)/255` (demo/demo_gaussian_filter.cpp:51-53); they are
         applied on the fly when the passes load pixels."""
         c = self._contents
-        if float(scale) != 1.0 or float(bias) != 0.0:
-            c["prologue"] = (float(scale), float(bias))
         if c["dims"]:
             raise RecFilterUsageError(f"Recursive filter {self.name()} already defined")
         if not pure_args:
@@ -142,6 +140,10 @@ class RecFilter:
                     raise RecFilterUsageError(f"input shape {tuple(t.shape)} does not match dimensions {want}")
         c["dims"] = list(pure_args)
         c["inputs"] = inputs
+        # only a definition that passed every check above may set the prologue (a rejected re-definition must not
+        # change the filter it was rejected for)
+        if float(scale) != 1.0 or float(bias) != 0.0:
+            c["prologue"] = (float(scale), float(bias))
 
     def __setitem__(self, dims, value):      # R[x, y] = image
         dims = dims if isinstance(dims, tuple) else (dims,)
@@ -227,6 +229,10 @@ class RecFilter:
             if c["clamped"]:
                 rf.set_clamped_image_border()
             rf.define(c["dims"], (c["inputs"] if c["source"] is None else c["source"]) if i == 0 else out[i - 1])
+            if i == 0:
+                # the affine defining expression (`in/255`) belongs to the image, so it stays with the stage that
+                # reads the image (lib/reorder.cpp:118-133: stage 0 keeps the original pure definition)
+                rf._contents["prologue"] = c["prologue"]
             for s in group:
                 rf._contents["scans"].append(c["scans"][s])
             out.append(rf)
@@ -258,6 +264,7 @@ class RecFilter:
         if a["clamped"]:
             rf.set_clamped_image_border()
         rf.define(a["dims"], a["inputs"] if a["source"] is None else a["source"])
+        rf._contents["prologue"] = a["prologue"]       # fA's defining expression is the merged filter's (reorder.cpp:231-381)
         for d in range(len(a["dims"])):
             sa = [s for s in a["scans"] if s[0] == d]
             sb = [s for s in b["scans"] if s[0] == d]
@@ -315,17 +322,20 @@ class RecFilter:
         cls._vectorization_width = int(v)
 
     # -- compile and run (lib/recfilter.cpp:918-1016) -------------------------------------------
-    def _resolve_inputs(self):
+    def _root_inputs(self):
+        """The tensors at the head of the cascade this filter belongs to.  A stage's planes have the shape, device and
+        plane count of the head's inputs and the head's PIXEL type (float32 when the head reads unsigned bytes), so a
+        plan can be built without launching the upstream stages."""
         c = self._contents
-        if c["source"] is not None:
-            return c["source"].realize()
+        while c["source"] is not None:
+            c = c["source"]._contents
         return c["inputs"]
 
     def compile_jit(self, filename: str = "", path: Optional[int] = None) -> None:
         c = self._contents
         if not c["dims"]:
             raise RecFilterUsageError("filter has no definition")
-        inputs = self._resolve_inputs()
+        inputs = self._root_inputs()
         shape = tuple(d.num_pixels() for d in reversed(c["dims"]))
         tile = [c["tile"].get(d.var(), 0) for d in c["dims"]]
         if path is None:

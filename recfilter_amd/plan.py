@@ -189,7 +189,9 @@ class Plan:
         return ctypes.c_void_p(s.cuda_stream)
 
     def execute(self, inputs, outputs=None, stream=None):
-        """rf_plan_execute: asynchronous on `stream` (default: torch's current stream)."""
+        """rf_plan_execute: asynchronous on `stream` (default: torch's current stream).  One execution in flight per
+        plan (it owns one workspace): overlapping executes must share the stream; use one Plan per stream otherwise
+        (include/recfilter_amd.h)."""
         import torch
         if outputs is None:
             outputs = self._new_outputs(inputs)

@@ -79,18 +79,39 @@ def test_two_processes_one_gpu(case, tmp_path):
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
-def test_bench_two_ranks_over_gloo():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_over_gloo(launcher):
     """bench.py's multi-rank flow (rendezvous, sharded steps with one all-gather each, barriers, max-over-ranks
-    timing, one JSON line from rank 0) with two ranks on this box's one GPU; the driver runs the same script over RCCL."""
+    timing, one JSON line from rank 0) with two ranks on this box's one GPU.  "self": `python bench.py --gpus 2` with
+    no launcher around it -- bench.py starts its own ranks as child processes before anything touches the GPU;
+    "torchrun": the way the driver launches it.  The driver runs the same script over RCCL."""
     import json
     import subprocess
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--backend", "gloo", "--device", "0", "--size", "1024"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--device", "0",
+            "--size", "1024"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["path"] == "tiled_fused"
+    assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0
     assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] == "fused_pass2"
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`--gpus N` on a box with fewer than N devices must fail loudly, not benchmark one GPU and print n_gpus = 1."""
+    import subprocess
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "visible devices" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
