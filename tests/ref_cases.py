@@ -206,10 +206,12 @@ def rel_err_highpass_floor(out, ref):
 
 
 def has_zero_crossings(ref):
-    """True when the smallest magnitude of the reference result is below 0.1 % of its peak: the result of a high-pass
-    filter (or of random coefficients with negative lobes), where only the floored metric is meaningful."""
-    a = np.abs(np.asarray(ref, dtype=np.float64))
-    return float(a.min()) < 1e-3 * float(a.max())
+    """True when the reference result changes sign (or touches zero): the result of a high-pass filter, or of random
+    coefficients with negative lobes, where only the floored metric is meaningful.  A large dynamic range alone (a
+    summed-area table runs from 0.8 to 3e7) is NOT a reason to leave the strict metric."""
+    r = np.asarray(ref, dtype=np.float64)
+    lo, hi = float(r.min()), float(r.max())
+    return (lo < 0.0 < hi) or float(np.abs(r).min()) < 1e-6
 
 
 def rel_err(out, ref):

@@ -1,0 +1,235 @@
+"""Full-size parity: every BASELINE.json configuration at the size the bench runs it, HIP path (C ABI) against the
+CPU oracle in f64 with the STRICT metric of SURVEY 8d, max |out-ref| / max(|ref|, 1e-6) <= 1e-4 (bit-exact for the
+integer summed-area table).
+
+The oracle runs on all host cores (OpenMP over independent lines); 16384^2 takes seconds.  2048^3 (32 GiB per
+volume) does not fit a host-side f64 reference, so it is pinned through inputs whose exact result is cheap:
+separable (rank-1 / rank-2) volumes, for which the 3-D filter factors into three 1-D filters the oracle evaluates
+exactly, with index ranges beyond 2^32, plus equality with the z-sharded execution."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import ref_cases as rc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, oracle.max_threads(), 64))
+
+
+def _strict_err(out, want, rows=512):
+    """rel_err_strict, evaluated in row blocks (the temporaries of a 16384^2 f64 comparison are 2 GiB each)."""
+    out2 = out.reshape(-1, out.shape[-1])
+    want2 = want.reshape(-1, want.shape[-1])
+    worst = 0.0
+    for r in range(0, out2.shape[0], rows):
+        worst = max(worst, rc.rel_err_strict(out2[r:r + rows], want2[r:r + rows]))
+    return worst
+
+
+def _floor_err(out, want, rows=512):
+    out2 = out.reshape(-1, out.shape[-1])
+    want2 = want.reshape(-1, want.shape[-1])
+    peak = float(np.max(np.abs(want2)))
+    worst = 0.0
+    for r in range(0, out2.shape[0], rows):
+        d = np.abs(out2[r:r + rows].astype(np.float64) - want2[r:r + rows])
+        worst = max(worst, float(np.max(d / np.maximum(np.abs(want2[r:r + rows]), 1e-2 * peak))))
+    return worst
+
+
+def _gpu(shape, scans, clamped, img, dtype=np.float32):
+    import torch
+    import recfilter_amd as rfa
+    dev = torch.from_numpy(img).cuda()
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped) as plan:
+        assert plan.path == 3, plan.path_name                 # the fused kernels, i.e. what bench.py times
+        out = plan.execute([dev])[0]
+        torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    del out, dev
+    torch.cuda.empty_cache()
+    return got
+
+
+def test_cfg2_summed_table_8192_f32_strict():
+    c = rc.BASELINE_CONFIGS["cfg2_summed_table"]
+    img = rc.random_image(c["shape"], np.float32, 2)
+    got = _gpu(c["shape"], c["scans"], c["clamped"], img)
+    want = oracle.apply_filter(img.astype(np.float64), c["scans"], c["clamped"], threads=_threads())
+    assert not rc.has_zero_crossings(want)
+    assert _strict_err(got, want) < TOL
+
+
+def test_cfg2_summed_table_8192_int32_bit_exact():
+    c = rc.BASELINE_CONFIGS["cfg2_summed_table"]
+    img = rc.random_image(c["shape"], np.int32, 3)            # [0, 255]: the table wraps around 2^31 -- still bit-exact
+    got = _gpu(c["shape"], c["scans"], c["clamped"], img, dtype=np.int32)
+    want = oracle.apply_filter(img, c["scans"], c["clamped"], threads=_threads())
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got, img.astype(np.int64).cumsum(0).cumsum(1).astype(np.int32))
+
+
+def test_cfg3_gaussian_16384_strict():
+    """The headline configuration at the size bench.py times it, every pixel against the f64 oracle."""
+    c = rc.BASELINE_CONFIGS["cfg3_gaussian2_xy"]
+    img = rc.random_image(c["shape"], np.float32, 4)
+    got = _gpu(c["shape"], c["scans"], c["clamped"], img)
+    want = oracle.apply_filter(img.astype(np.float64), c["scans"], c["clamped"], threads=_threads())
+    assert not rc.has_zero_crossings(want)
+    assert _strict_err(got, want) < TOL
+
+
+def test_cfg4b_gaussian3_16384_one_plane_strict():
+    c = rc.BASELINE_CONFIGS["cfg4b_gaussian3_rgb"]
+    img = rc.random_image(c["shape"], np.float32, 5)
+    got = _gpu(c["shape"], c["scans"], c["clamped"], img)
+    want = oracle.apply_filter(img.astype(np.float64), c["scans"], c["clamped"], threads=_threads())
+    assert not rc.has_zero_crossings(want)
+    assert _strict_err(got, want) < TOL
+
+
+def test_cfg4a_bicubic_16384_one_plane_highpass_floor_metric():
+    """The B-spline prefilter is a high-pass: its result on noise crosses zero, where a pointwise relative error is
+    meaningless; this is the ONE configuration checked with the floored metric (1 % of the peak), and it also has to
+    meet the strict metric on the pixels that stay away from zero."""
+    c = rc.BASELINE_CONFIGS["cfg4a_bicubic_rgb"]
+    img = rc.random_image(c["shape"], np.float32, 6)
+    got = _gpu(c["shape"], c["scans"], c["clamped"], img)
+    want = oracle.apply_filter(img.astype(np.float64), c["scans"], c["clamped"], threads=_threads())
+    assert rc.has_zero_crossings(want)
+    assert _floor_err(got, want) < TOL
+    far = np.abs(want) > 0.05
+    assert float(np.max(np.abs(got[far] - want[far]) / np.abs(want[far]))) < TOL
+
+
+def test_cfg4_three_planes_16384_batched_equals_single_plane():
+    """cfg4's three planes ride in one launch per step: every plane must equal the single-plane result bit for bit
+    (same kernels, same tables), which the two tests above pin against the oracle."""
+    import torch
+    import recfilter_amd as rfa
+    c = rc.BASELINE_CONFIGS["cfg4b_gaussian3_rgb"]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    planes = [torch.rand(c["shape"], device="cuda", generator=g) for _ in range(3)]
+    with rfa.Plan(c["shape"], c["scans"], clamped=True, planes=3) as p3, rfa.Plan(c["shape"], c["scans"], clamped=True) as p1:
+        outs = p3.execute(planes)
+        for i in range(3):
+            one = p1.execute([planes[i]])[0]
+            assert torch.equal(one, outs[i])
+            del one
+
+
+def _separable_volume(n, seed, terms):
+    """sum over `terms` of a(z) b(y) c(x) with factors that are multiples of 1/64 in [0.5, 1.5): every product is
+    exact in f32, so the f32 volume IS the separable function and F(volume) = sum Fz(a) Fy(b) Fx(c) exactly."""
+    rng = np.random.default_rng(seed)
+    return [[(rng.integers(32, 96, size=n) / 64.0) for _ in range(3)] for _ in range(terms)]
+
+
+def _check_separable_3d(n, terms, tol=TOL):
+    import torch
+    import recfilter_amd as rfa
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    fac = _separable_volume(n, 17 + n, terms)
+    vol = torch.zeros((n, n, n), device="cuda")
+    for a, b, c in fac:
+        ta, tb, tc = (torch.from_numpy(v.astype(np.float32)).cuda() for v in (a, b, c))
+        vol += ta[:, None, None] * tb[None, :, None] * tc[None, None, :]
+    with rfa.Plan((n, n, n), scans) as plan:
+        assert plan.path == 3
+        out = plan.execute([vol])[0]
+        torch.cuda.synchronize()
+    # the oracle filters the 1-D factors (dimension d of the volume filter = the scans of dimension d, as dim 0 of a line)
+    want = []
+    for a, b, c in fac:
+        fz = oracle.apply_filter(a.astype(np.float64), [(0, s[1], s[2]) for s in scans if s[0] == 2])
+        fy = oracle.apply_filter(b.astype(np.float64), [(0, s[1], s[2]) for s in scans if s[0] == 1])
+        fx = oracle.apply_filter(c.astype(np.float64), [(0, s[1], s[2]) for s in scans if s[0] == 0])
+        want.append(tuple(torch.from_numpy(v).cuda() for v in (fz, fy, fx)))
+    worst = 0.0
+    step = max(1, (1 << 27) // (n * n))                      # z slabs of <= 1 GiB of f64
+    for z0 in range(0, n, step):
+        ref = torch.zeros((min(step, n - z0), n, n), device="cuda", dtype=torch.float64)
+        for fz, fy, fx in want:
+            ref += fz[z0:z0 + step, None, None] * fy[None, :, None] * fx[None, None, :]
+        err = ((out[z0:z0 + step].double() - ref).abs() / ref.abs().clamp_min(1e-6)).max()
+        worst = max(worst, float(err))
+        del ref
+    assert worst < tol, f"separable {n}^3, {terms} term(s): strict rel err {worst}"
+    return vol, out
+
+
+def test_cfg5_1024_cubed_against_the_oracle_strict():
+    """cfg5's filter at 1024^3 (1 Gi samples) against the f64 oracle on a uniform random volume."""
+    import torch
+    import recfilter_amd as rfa
+    import psutil
+    n = 1024
+    if psutil.virtual_memory().available < 30 * 2 ** 30:
+        pytest.skip("the f64 oracle of 1024^3 needs ~24 GiB of host memory")
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    img = np.random.default_rng(8).random((n, n, n), dtype=np.float32)
+    got = _gpu((n, n, n), scans, False, img)
+    want = img.astype(np.float64)
+    del img
+    ext = (oracle.ctypes.c_int64 * 3)(n, n, n)
+    arr, ns = oracle._scan_array(scans)
+    rcode = oracle.lib().orc_apply_filter(want.ctypes.data_as(oracle.ctypes.c_void_p), oracle.F64, 3, ext, arr, ns,
+                                          oracle.BORDER_ZERO, _threads())            # in place: no second 8 GiB copy
+    assert rcode == 0
+    assert _strict_err(got, want, rows=4096) < TOL
+
+
+def test_cfg5_2048_cubed_separable_volumes_and_sharded_equality():
+    """cfg5 at its full size, 2048^3 = 8.6 G samples (indices beyond 2^32): (i) rank-2 separable volume against the
+    exact factorised reference, every sample, strict metric; (ii) the z-sharded execution over 8 emulated ranks
+    (stepping API, the exchange as bench.py --gpus 8 --strong drives it) reproduces the single-GPU result."""
+    import torch
+    import recfilter_amd as rfa
+    n = 2048
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2 ** 30:
+        pytest.skip("needs ~130 GiB of device memory")
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    vol, out = _check_separable_3d(n, terms=2)
+    world = 8
+    nz = n // world
+    plans = [rfa.Plan((nz, n, n), scans, shard_rank=r, shard_world=world) for r in range(world)]
+    outs = [torch.empty((nz, n, n), device="cuda") for _ in range(world)]
+    for r in range(world):
+        plans[r].begin([vol[r * nz:(r + 1) * nz]], [outs[r]])
+    for e in range(plans[0].num_exchanges):
+        nbytes = plans[0].exchange_bytes(e)
+        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            plans[r].exchange_local(e, gathered.data_ptr() + r * nbytes)
+        for r in range(world):
+            plans[r].exchange_apply(e, gathered.data_ptr())
+    for r in range(world):
+        plans[r].finish()
+    torch.cuda.synchronize()
+    for r in range(world):
+        d = ((outs[r] - out[r * nz:(r + 1) * nz]).abs() / out[r * nz:(r + 1) * nz].abs().clamp_min(1e-6)).max()
+        assert float(d) < 1e-5, f"slab {r}: sharded vs single-GPU {float(d)}"
+    for p in plans:
+        p.close()
+
+
+def test_cfg5_256_cubed_separable_matches_direct_oracle():
+    """Sanity of the separable reference itself at a size where the direct oracle is cheap: both must agree."""
+    import torch
+    n = 256
+    vol, out = _check_separable_3d(n, terms=2)
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    want = oracle.apply_filter(vol.cpu().numpy().astype(np.float64), scans, False, threads=_threads())
+    assert rc.rel_err_strict(out.cpu().numpy(), want) < TOL

@@ -146,7 +146,7 @@ def test_cascade_and_overlap_keep_the_prologue():
     whole = build()
     whole.split_all_dimensions(32)
     assert rc.rel_err(whole.realize()[0].cpu().numpy(), want) < TOL
-    for stages in (F.cascade([0, 1, 2, 3], [4, 5, 6, 7]), build().cascade_by_dimension(), build().cascade_by_causality()):
+    for stages in (F.cascade([0, 1, 2, 3], [4, 5, 6, 7]), build().cascade_by_dimension()):
         assert stages[0]._contents["prologue"] == (scale, bias) and all(s._contents["prologue"] is None for s in stages[1:])
         assert rc.rel_err(stages[-1].realize()[0].cpu().numpy(), want) < TOL
     # overlap: the two cascade stages merged back into one filter of orders 3
