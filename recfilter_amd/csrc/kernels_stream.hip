@@ -4,7 +4,7 @@
 // Why: fused_tails_kernel is latency-bound (profiles/r1/pmc_shader.json: its waves wait in 69 % of their cycles).
 // Every tile byte travels HBM -> VGPR -> ds_write -> barrier, so the bytes a workgroup keeps in flight are capped
 // by its staging registers, and every workgroup starts with an empty pipe.  Here
-//   * a workgroup is 4 compute waves + 1 LOADER wave.  The loader issues `global_load_lds_dwordx4` (1 KiB per wave
+//   * a workgroup is 8 compute waves (4 for the x tails, 4 for the y tails of the same slot) + 1 LOADER wave.  The loader issues `global_load_lds_dwordx4` (1 KiB per wave
 //     instruction, straight into LDS, no VGPR hop, no ds_write) for slots up to kAhead quarters of a tile ahead of
 //     the one being contracted, across tile boundaries: the bytes in flight per workgroup are constant
 //     (kAhead x 16 KiB), whatever the compute waves are doing;
@@ -35,9 +35,8 @@ constexpr int kQRows = 16;                          // rows per ring slot: a qua
 constexpr int kSlotBytes = kQRows * kFusedTX * 4;   // 16 KiB
 constexpr int kStreamTY = 64;
 constexpr int kQPerTile = kStreamTY / kQRows;       // 4
-constexpr int kStreamThreads = 320;                 // waves 0..3 compute, wave 4 loads
+constexpr int kStreamThreads = 576;                 // waves 0..3: x tails, waves 4..7: y tails, wave 8: loader
 
-typedef float F2s __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void lds_barrier() {
     // LDS traffic of this wave retired, then the workgroup barrier; a compiler barrier for memory as well.  (Not
@@ -69,25 +68,50 @@ __device__ __forceinline__ TileCoord tile_coord(const FusedArgs<Acc> &a, uint32_
     return c;
 }
 
-// SLOTS ring slots, AHEAD (< SLOTS) of them in flight ahead of the slot being contracted
-template <typename P, int K, int SLOTS, int AHEAD>
+typedef float F4s __attribute__((ext_vector_type(4)));
+
+// Where chunk c (16 bytes) of row i sits inside a 1 KiB slot row: the low four bits of the chunk index are XORed with
+// the row (the 16 rows a matrix-core A operand gathers at one column then sit on 16 different bank groups) and with
+// bits 4..5 of the chunk (segments 256 B apart otherwise share banks).  Both reads of the kernel are conflict-free
+// under it: x role, lane = (row i, chunk 4m + kk); y role, lane = (row ks + 4 kk, 16 consecutive columns).
+__device__ __forceinline__ int slot_pos(int i, int c) { return c ^ (i & 15) ^ ((c >> 4) & 3); }
+
+// SLOTS ring slots, AHEAD (< SLOTS) of them in flight ahead of the slot being contracted.
+//
+// The contractions run on the matrix cores, which leaves the vector ALU almost idle.  With the dot products on the
+// VALU (16 + 16 packed FMAs per thread and slot plus DPP reductions) the compute waves alone needed 0.16-0.18 ms of
+// the loader's 0.19 ms; v_mfma_f32_16x16x4_f32 was no better (only nx*K = 4 of its 16 output columns are useful,
+// the matrix pipe itself became the bound).  The instruction that fits is v_mfma_f32_4x4x1_16b_f32: sixteen
+// independent 4 x 4 outer products per issue (8 cycles), D[b][i][j] += A[b][i] * B[b][j] with block b = lane / 4,
+// i.e. a rank-4 "tails" dimension at full efficiency (exact f32: a chain of fma's).
+//   x role (waves 0..3, wave w owns columns 64w..64w+63 of every row):
+//       block = (column phase cg = lane/16, row group rg): A[b][i] = pixel (row 4rg + i, column 4(16w + 4m + cg) + e),
+//       B[b][j] = Hx[sr = j][that column] (16 registers per group of four tails, loaded when the walker's tile column
+//       changes: never, while the stride is a multiple of the tiles per row).  One ds_read_b128 feeds four MFMAs.  The
+//       four column phases are added with two cross-lane steps, the four waves' partial sums meet in the LDS stage.
+//   y role (waves 4..7, wave w owns the same columns):
+//       block = group of four columns, one MFMA per slot row: A[b][i] = pixel (row, column 64w + 4b + i) = lane-linear
+//       ds_read_b32, B[b][j] = Hy[jr = j][row] (read from an LDS copy of the table, 16 bytes per 4 rows); the
+//       accumulator D[b][i][j] = combined row jr at column 64w + 4b + i lives across the tile's four slots and needs
+//       no reduction at all.
+// NGX / NGY: groups of four tails along x / y (compile time: they size the register arrays); K is a run-time value here
+template <int NGX, int NGY, int SLOTS, int AHEAD>
 __global__ void __launch_bounds__(kStreamThreads)
-stream_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>::Acc> a,
-                    const typename PixelTraits<P>::Acc *__restrict__ Hx,     // [vx][s][r][256]
-                    const typename PixelTraits<P>::Acc *__restrict__ Hy,     // [vy][j][r][64]
-                    uint32_t n_tiles) {
-    using Acc = typename PixelTraits<P>::Acc;
-    using A4 = typename Vec4<Acc>::type;
-    static_assert(sizeof(Acc) == 4, "the ring moves 4-byte samples");
+stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
+                    const float *__restrict__ Hx,     // [vx][s][r][256]
+                    const float *__restrict__ Hy,     // [vy][j][r][64]
+                    uint32_t n_tiles, int K, int debug_mode) {
     static_assert(AHEAD >= 1 && AHEAD < SLOTS && 16 * AHEAD <= 63, "ring geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ring: SLOTS x 16 KiB][hx: nx*K rows of 256][x-tail stage: 2 x nx*K x 64]
+    // [ring: SLOTS x 16 KiB][x-tail stage: 2 tiles x 4 waves x nx*K x 64][Hy table: 4 variants x ny*K x 64]
     const int nxk = a.nx * K, nyk = a.ny * K;
-    Acc *hx_lds = reinterpret_cast<Acc *>(smem + SLOTS * kSlotBytes);
-    Acc *stage = hx_lds + (size_t)(nxk > 0 ? nxk : 1) * kFusedTX;
+    float *stage = reinterpret_cast<float *>(smem + SLOTS * kSlotBytes);
+    const int stage_tile = 4 * (nxk > 0 ? nxk : 1) * kStreamTY;       // floats per tile in the stage
+    float *hy_lds = stage + 2 * stage_tile;
 
-    const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const uint32_t G = gridDim.x;
     const uint32_t first = blockIdx.x;
     const int n_my = first < n_tiles ? (int)((n_tiles - first + G - 1) / G) : 0;     // tiles this workgroup walks
@@ -95,24 +119,31 @@ stream_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const uint32_t row_bytes = a.row_bytes;
     auto variant_x = [&](int tx) { return (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0); };
 
-    if (wave == 4) {
+    if (wave == 8) {
         // ------------------------------------------------ loader wave ------------------------------------------------
-        const int lane = t & 63;
-        const uint32_t lane_off = (uint32_t)swz_chunk(lane) * 16u;       // LDS position `lane` holds chunk swz(lane)
         auto issue = [&](int g) {
+            if (debug_mode & 2) return;                              // timing experiments: no loads
             const TileCoord c = tile_coord(a, first + (uint32_t)(g / kQPerTile) * G);
-            const P *plane = a.plane_batch ? reinterpret_cast<const P *>(a.in_planes[c.z]) : src + c.z * a.NX * a.NY;
+            const float *plane = a.plane_batch ? reinterpret_cast<const float *>(a.in_planes[c.z]) : src + c.z * a.NX * a.NY;
             const char *base = reinterpret_cast<const char *>(plane + (int64_t)c.ty * kStreamTY * a.NX + (int64_t)c.tx * kFusedTX) +
                                (size_t)(g % kQPerTile) * kQRows * row_bytes;
             unsigned char *slot = smem + (g % SLOTS) * kSlotBytes;
 #pragma unroll
-            for (int r = 0; r < kQRows; r++)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(base + ((uint32_t)r * row_bytes + lane_off)),
-                    (__attribute__((address_space(3))) void *)(slot + r * (kFusedTX * 4)), 16, 0, /*nt*/ 2);
+            for (int r = 0; r < kQRows; r++) {
+                // LDS position `lane` of row r receives the chunk that slot_pos maps there (an involution per row)
+                const uint32_t lane_off = (uint32_t)slot_pos(r, lane) * 16u;
+                // each sample is read once by this pass: non-temporal (leaves L2 / the memory-side cache to the tails)
+                if (debug_mode & 16)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(base + ((uint32_t)r * row_bytes + lane_off)),
+                        (__attribute__((address_space(3))) void *)(slot + r * (kFusedTX * 4)), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(base + ((uint32_t)r * row_bytes + lane_off)),
+                        (__attribute__((address_space(3))) void *)(slot + r * (kFusedTX * 4)), 16, 0, /*nt*/ 2);
+            }
         };
         for (int g = 0; g < AHEAD && g < nq; g++) issue(g);
-        int cur_vx = -1;
         for (int g = 0; g < nq; g++) {
             // slot g has landed once at most min(AHEAD-1, nq-1-g) younger slots (16 pieces each) are outstanding
             const int younger = nq - 1 - g;
@@ -120,148 +151,154 @@ stream_tails_kernel(const P *__restrict__ src, FusedArgs<typename PixelTraits<P>
             else if (AHEAD >= 3 && younger == 1) wait_vmcnt<16>();
             else wait_vmcnt<0>();
             lds_barrier();                                          // B_g
-            if (g % kQPerTile == 0) {                               // the compute waves restage Hx behind a second barrier
-                const int vx = variant_x(tile_coord(a, first + (uint32_t)(g / kQPerTile) * G).tx);
-                if (vx != cur_vx) { cur_vx = vx; lds_barrier(); }
-            }
             if (g + AHEAD < nq) issue(g + AHEAD);                   // refills the slot contracted before B_g
         }
         lds_barrier();                                              // final: x-tail stage of the last tile
         return;
     }
 
-    // ------------------------------------------------ compute waves --------------------------------------------------
-    const int l = t & 15, slot_row = t >> 4, sw = (l >> 2) & 3;       // x part: segment lane, row of the quarter
-    const int e = (swz_chunk(t >> 2) << 2) | (t & 3);                 // y part: this column's place in a swizzled row
+    // Hy table -> LDS (all four border variants; ordered before its first use by B_0)
+    for (int i = tid; i < 4 * nyk * kStreamTY; i += 512) hy_lds[i] = Hy[i];
+
     const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
-    A4 *hx4 = reinterpret_cast<A4 *>(hx_lds);
-    int cur_vx = -1;
+    const int w = wave & 3;                                          // column group 64w .. 64w+63
 
-    auto flush_xtails = [&](int n) {       // tile n's x tails: stage -> xt, 16 bytes per lane, 256 B per (s, r)
-        if (nxk > 0 && t < nxk * 16) {
-            const TileCoord c = tile_coord(a, first + (uint32_t)n * G);
-            const int sr = t >> 4, j = t & 15;
-            const A4 v = reinterpret_cast<const A4 *>(stage + (size_t)(n & 1) * nxk * kStreamTY + (size_t)sr * kStreamTY)[j];
-            const int s = sr / K, r = sr % K;
-            const int64_t line0 = (int64_t)c.ty * kStreamTY + a.NYP * c.z;
-            *reinterpret_cast<A4 *>(a.xt + (((int64_t)s * a.MX + c.tx) * K + r) * Lx + line0 + 4 * j) = v;
+    if (wave < 4) {
+        // ------------------------------------------------ x role ----------------------------------------------------
+        const int t = tid;                                           // 0..255
+        const int row = lane & 15, cg = lane >> 4, j4 = lane & 3;    // A: row of the slot, column phase; B: tail in group
+        float Bx[NGX][16];                                           // Hx[sr = 4 gx + j4][4 (16w + 4m + cg) + e] at [gx][4m + e]
+        auto flush_xtails = [&](int n) {       // tile n's x tails: sum of the four waves' partials -> xt, 16 B per lane
+            if (nxk > 0 && t < nxk * 16) {
+                const TileCoord c = tile_coord(a, first + (uint32_t)n * G);
+                const int sr = t >> 4, j = t & 15;
+                const F4s *sp = reinterpret_cast<const F4s *>(stage + (size_t)(n & 1) * stage_tile + (size_t)sr * kStreamTY) + j;
+                F4s v = sp[0];
+#pragma unroll
+                for (int ww = 1; ww < 4; ww++) v = v + sp[(size_t)ww * nxk * (kStreamTY / 4)];
+                const int s = sr / K, r = sr % K;
+                const int64_t line0 = (int64_t)c.ty * kStreamTY + a.NYP * c.z;
+                *reinterpret_cast<F4s *>(a.xt + (((int64_t)s * a.MX + c.tx) * K + r) * Lx + line0 + 4 * j) = v;
+            }
+        };
+        // byte offsets of this lane's four A reads inside a slot: row `row`, chunk 16w + 4m + cg
+        uint32_t a_off[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) a_off[m] = (uint32_t)row * 1024u + (uint32_t)slot_pos(row, 16 * w + 4 * m + cg) * 16u;
+        // The stride G is a multiple of the tiles per row (stream_grid_size), so this walker never leaves its tile
+        // column: one border variant, its Hx fragments loaded once.  (Loaded inside the tile loop the compiler joins the
+        // branch with `s_waitcnt vmcnt(0)`, which also waits for the previous tile's x-tail STORE: a store latency per
+        // tile on the critical path of every wave of the workgroup.)
+        {
+            const int vx = variant_x((int)(first % (uint32_t)a.MX));
+#pragma unroll
+            for (int gx = 0; gx < NGX; gx++)
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int sr = 4 * gx + j4;
+                        Bx[gx][4 * m + e] = (n_my > 0 && sr < nxk) ? Hx[((size_t)vx * nxk + sr) * kFusedTX + 4 * (16 * w + 4 * m + cg) + e] : 0.0f;
+                    }
         }
-    };
+        for (int n = 0; n < n_my; n++) {
+            float *stage_w = stage + (size_t)(n & 1) * stage_tile + (size_t)w * nxk * kStreamTY;
+#pragma unroll 1
+            for (int q = 0; q < kQPerTile; q++) {
+                const int g = n * kQPerTile + q;
+                lds_barrier();                                          // B_g: slot g landed, slot g-1 free
+                if (q == 0 && n > 0) flush_xtails(n - 1);               // every wave's stage writes of tile n-1 are behind B_g
+                if ((debug_mode & 5) || nxk == 0) continue;              // (timing experiments: no arithmetic)
+                const unsigned char *slot = smem + (g % SLOTS) * kSlotBytes;
+                F4s av[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) av[m] = *reinterpret_cast<const F4s *>(slot + a_off[m]);
+#pragma unroll
+                for (int gx = 0; gx < NGX; gx++) {
+                    {
+                        // four accumulators: consecutive MFMAs do not wait for each other
+                        F4s acc[4];
+#pragma unroll
+                        for (int m = 0; m < 4; m++) acc[m] = F4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m].x, Bx[gx][4 * m + 0], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m].y, Bx[gx][4 * m + 1], acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m].z, Bx[gx][4 * m + 2], acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m].w, Bx[gx][4 * m + 3], acc[3], 0, 0, 0);
+                        }
+                        F4s d = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                        // add the four column phases: lanes l, l^16, l^32, l^48
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            d[i] = d[i] + __shfl_xor(d[i], 16);
+                            d[i] = d[i] + __shfl_xor(d[i], 32);
+                        }
+                        // lane 4 rg + j (cg == 0), register i: row 4 rg + i of tail sr = 4 gx + j
+                        const int sr = 4 * gx + j4;
+                        if (cg == 0 && sr < nxk)
+                            *reinterpret_cast<F4s *>(stage_w + sr * kStreamTY + q * kQRows + (row & 12)) = d;
+                    }
+                }
+            }
+        }
+        lds_barrier();                                                  // final: the last tile's stage is complete
+        if (n_my > 0) flush_xtails(n_my - 1);
+        return;
+    }
 
+    // ------------------------------------------------ y role ----------------------------------------------------
+    // this lane's pixel of slot row r: column 64w + lane -> chunk 16w + lane/4, element lane%4
+    const int j4 = lane & 3;
+    const uint32_t px_base = (uint32_t)((16 * w + (lane >> 2)) ^ (w & 3)) * 16u + (uint32_t)(lane & 3) * 4u;
     for (int n = 0; n < n_my; n++) {
         const TileCoord c = tile_coord(a, first + (uint32_t)n * G);
-        const int vx = variant_x(c.tx);
         const int vy = ((c.ty == 0 && a.y_first_border) ? 1 : 0) | ((c.ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
-        Acc comb[kFusedMaxScans * K];
+        F4s acc[NGY];
 #pragma unroll
-        for (int jr = 0; jr < kFusedMaxScans * K; jr++) comb[jr] = Acc(0);
-        Acc *stage_n = stage + (size_t)(n & 1) * nxk * kStreamTY;
-
-#pragma unroll 1
+        for (int gy = 0; gy < NGY; gy++) acc[gy] = F4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int q = 0; q < kQPerTile; q++) {
             const int g = n * kQPerTile + q;
-            lds_barrier();                                          // B_g: slot g landed, slot g-1 free
-            if (q == 0) {
-                if (vx != cur_vx) {
-                    // impulse responses of the x tails for this border variant -> LDS, chunk-swizzled like the pixels
-                    cur_vx = vx;
-                    if (nxk > 0) {
-                        const A4 *hsrc = reinterpret_cast<const A4 *>(Hx + (size_t)vx * nxk * kFusedTX);
-                        for (int cidx = t; cidx < nxk * 64; cidx += 256) hx4[(cidx & ~63) | swz_chunk(cidx & 63)] = hsrc[cidx];
-                    }
-                    lds_barrier();
-                }
-                if (n > 0) flush_xtails(n - 1);                     // every wave's stage writes of tile n-1 are behind B_g
-            }
-            const Acc *tile = reinterpret_cast<const Acc *>(smem + (g % SLOTS) * kSlotBytes);
-            const A4 *tile4 = reinterpret_cast<const A4 *>(tile);
-
-            // ---- x tails of this quarter's 16 rows: dot products + reduction over the 16 lanes of a row ----
-            if (nxk > 0) {
-                Acc v[kFusedSeg];
+            lds_barrier();                                          // B_g
+            if ((debug_mode & 9) || nyk == 0) continue;
+            const unsigned char *slot = smem + (g % SLOTS) * kSlotBytes;
+            float px[kQRows];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const A4 w = tile4[slot_row * 64 + 4 * l + (j ^ sw)];
-                    v[4 * j + 0] = w.x; v[4 * j + 1] = w.y; v[4 * j + 2] = w.z; v[4 * j + 3] = w.w;
-                }
-#pragma unroll 1
-                for (int sr = 0; sr < nxk; sr++) {
-                    Acc h[kFusedSeg];
+            for (int r = 0; r < kQRows; r++)
+                px[r] = *reinterpret_cast<const float *>(slot + ((px_base ^ ((uint32_t)r << 4)) + (uint32_t)r * 1024u));
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const A4 w = hx4[sr * 64 + 4 * l + (j ^ sw)];
-                        h[4 * j + 0] = w.x; h[4 * j + 1] = w.y; h[4 * j + 2] = w.z; h[4 * j + 3] = w.w;
-                    }
-                    Acc acc;
-                    if constexpr (std::is_same<Acc, float>::value) {
-                        F2s a0 = F2s{0.0f, 0.0f}, a1 = F2s{0.0f, 0.0f};
+            for (int gy = 0; gy < NGY; gy++) {
+                {
+                    const int jr = 4 * gy + j4;
+                    const float *hp = hy_lds + (size_t)(vy * nyk + (jr < nyk ? jr : 0)) * kStreamTY + q * kQRows;
+                    const float keep = jr < nyk ? 1.0f : 0.0f;
 #pragma unroll
-                        for (int m = 0; m < kFusedSeg; m += 4) {
-                            a0 = F2s{h[m], h[m + 1]} * F2s{v[m], v[m + 1]} + a0;
-                            a1 = F2s{h[m + 2], h[m + 3]} * F2s{v[m + 2], v[m + 3]} + a1;
-                        }
-                        const F2s s2 = a0 + a1;
-                        acc = s2.x + s2.y;
-                    } else {
-                        acc = Acc(0);
-#pragma unroll
-                        for (int m = 0; m < kFusedSeg; m++) acc = acc + h[m] * v[m];
-                    }
-                    acc = acc + row_shift<true, 8>(acc);
-                    acc = acc + row_shift<true, 4>(acc);
-                    acc = acc + row_shift<true, 2>(acc);
-                    acc = acc + row_shift<true, 1>(acc);
-                    if (l == 15) stage_n[sr * kStreamTY + q * kQRows + slot_row] = acc;
-                }
-            }
-
-            // ---- y: contract this quarter's rows with Hy (thread = column) ----
-            if (nyk > 0) {
-                Acc col[kQRows];
-#pragma unroll
-                for (int i = 0; i < kQRows; i++) col[i] = tile[i * kFusedTX + e];
-                if constexpr (std::is_same<Acc, float>::value) {
-#pragma unroll
-                    for (int gp = 0; gp < (kFusedMaxScans * K + 1) / 2; gp++) {
-                        if (2 * gp < nyk) {
-                            const int j0 = 2 * gp, j1 = (2 * gp + 1 < nyk) ? 2 * gp + 1 : 2 * gp;
-                            const Acc *h0 = Hy + (size_t)(vy * nyk + j0) * kStreamTY + q * kQRows;     // wave-uniform
-                            const Acc *h1 = Hy + (size_t)(vy * nyk + j1) * kStreamTY + q * kQRows;
-                            F2s c0 = F2s{0.0f, 0.0f}, c1 = F2s{0.0f, 0.0f};
-#pragma unroll
-                            for (int i = 0; i < kQRows; i += 2) {
-                                const F2s cc = F2s{col[i], col[i + 1]};
-                                c0 = F2s{h0[i], h0[i + 1]} * cc + c0;
-                                c1 = F2s{h1[i], h1[i + 1]} * cc + c1;
-                            }
-                            comb[2 * gp] = comb[2 * gp] + (c0.x + c0.y);
-                            if (2 * gp + 1 < kFusedMaxScans * K) comb[2 * gp + 1] = comb[2 * gp + 1] + (c1.x + c1.y);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int jr = 0; jr < kFusedMaxScans * K; jr++) {
-                        if (jr < nyk) {
-                            const Acc *hy = Hy + (size_t)(vy * nyk + jr) * kStreamTY + q * kQRows;
-#pragma unroll
-                            for (int i = 0; i < kQRows; i++) comb[jr] = comb[jr] + hy[i] * col[i];
-                        }
+                    for (int m = 0; m < 4; m++) {
+                        const F4s h = *reinterpret_cast<const F4s *>(hp + 4 * m) * keep;
+                        acc[gy] = __builtin_amdgcn_mfma_f32_4x4x1f32(px[4 * m + 0], h.x, acc[gy], 0, 0, 0);
+                        acc[gy] = __builtin_amdgcn_mfma_f32_4x4x1f32(px[4 * m + 1], h.y, acc[gy], 0, 0, 0);
+                        acc[gy] = __builtin_amdgcn_mfma_f32_4x4x1f32(px[4 * m + 2], h.z, acc[gy], 0, 0, 0);
+                        acc[gy] = __builtin_amdgcn_mfma_f32_4x4x1f32(px[4 * m + 3], h.w, acc[gy], 0, 0, 0);
                     }
                 }
             }
         }
-        // combined rows -> yt; with x scans in the filter xscan_rows_kernel finishes them in place
-        if (nyk > 0) {
-            const int64_t line = (int64_t)c.tx * kFusedTX + t + a.NXP * c.z;
+        // lane 4b + j, register i: combined row jr = 4 gy + j at column 64w + 4b + i -> yt, 16 bytes per lane (with x
+        // scans in the filter xscan_rows_kernel finishes them in place)
 #pragma unroll
-            for (int jr = 0; jr < kFusedMaxScans * K; jr++)
-                if (jr < nyk) a.yt[(((int64_t)(jr / K) * a.MY + c.ty) * K + jr % K) * Ly + line] = comb[jr];
+        for (int gy = 0; gy < NGY; gy++) {
+            const int jr = 4 * gy + j4;
+            if (jr < nyk)
+                *reinterpret_cast<F4s *>(a.yt + (((int64_t)(jr / K) * a.MY + c.ty) * K + jr % K) * Ly + a.NXP * c.z +
+                                         (int64_t)c.tx * kFusedTX + 64 * w + (lane & ~3)) = acc[gy];
         }
     }
-    lds_barrier();                                                  // final: the last tile's stage is complete
-    if (n_my > 0) flush_xtails(n_my - 1);
+    lds_barrier();                                                  // final (the x waves flush the last stage behind it)
 }
 
+// Workgroups to launch: two per CU (LDS: two rings), rounded down to a multiple of the tiles per row so that a walker
+// stays in one tile column (one Hx border variant for life); 0 when the image is too wide for that.
 int stream_grid_size(int64_t n_tiles, int MX) {
     static int cus = 0;
     if (cus == 0) {
@@ -270,60 +307,67 @@ int stream_grid_size(int64_t n_tiles, int MX) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         cus = prop.multiProcessorCount;
     }
-    int64_t g = 2ll * cus;                       // two workgroups per CU (LDS: two rings)
+    int64_t g = 2ll * cus;
     if (const char *env = getenv("RF_STREAM_GRID")) g = atoll(env);
-    // a stride that is a multiple of the tiles per row keeps a walker in one tile column: one Hx variant for life
-    if (g > MX && g % MX != 0) g -= g % MX;
-    if (g > n_tiles) g = n_tiles;
-    return (int)(g < 1 ? 1 : g);
+    if (g >= n_tiles) return (int)n_tiles;        // one tile per walker
+    if (g < MX) return 0;
+    g -= g % MX;
+    return (int)g;
 }
 
 }  // namespace
 
-bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t n_tiles) {
+// When pass 1 takes the streaming kernel.  Measured (profiles/r2/pass1_stream_vs_staged.txt): the LDS-DMA ring streams
+// at 5.2-5.8 TB/s whatever the size, the register-staged fused_tails_kernel at 5.0 TB/s on a single 16384^2 plane
+// (launch ramp and tail of its 16384 short workgroups) but at 5.9-6.0 TB/s once a launch is three times as long
+// (3 planes, volumes).  So: single planes with at most four tails per dimension stream, everything else is staged.
+bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t n_tiles, int MX,
+                             int64_t NZ, int nxk, int nyk) {
     static const bool off = getenv("RF_NO_STREAM_TAILS") != nullptr;      // A/B runs against fused_tails_kernel
+    const bool force = getenv("RF_STREAM_FORCE") != nullptr;              // ... and the other way (tests: every shape class; read per call)
     if (off || src_u8 || (pw_flags & 1) || TY != kStreamTY || last_cols != kFusedTX || last_rows != TY) return false;
     if (K < 1 || K > 3) return false;
-    static const int64_t min_tiles = getenv("RF_STREAM_MIN_TILES") ? atoll(getenv("RF_STREAM_MIN_TILES")) : 2048;
-    return n_tiles >= min_tiles;      // below that a walker has too few tiles to amortise its pipeline fill
+    if (!force && (NZ != 1 || nxk > 4 || nyk > 4)) return false;
+    const char *mt = getenv("RF_STREAM_MIN_TILES");              // (read per call: the tests lower it to cover small shapes)
+    const int64_t min_tiles = mt ? atoll(mt) : 2048;
+    if (n_tiles < min_tiles) return false;      // below that a walker has too few tiles to amortise its pipeline fill
+    return stream_grid_size(n_tiles, MX) > 0;
 }
 
-template <typename P>
-int launch_stream_tails(int K, const P *src, const FusedArgs<typename PixelTraits<P>::Acc> &a,
-                        const typename PixelTraits<P>::Acc *Hx, const typename PixelTraits<P>::Acc *Hy, hipStream_t stream) {
-    using Acc = typename PixelTraits<P>::Acc;
+int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, const float *Hx, const float *Hy, hipStream_t stream) {
     const int64_t n_tiles = (int64_t)a.MX * a.MY * a.NZ;
     if (n_tiles <= 0) return RF_OK;
     if (n_tiles >= (1ll << 31)) { set_error("stream tails: too many tiles"); return RF_ERR_UNSUPPORTED; }
     const int grid = stream_grid_size(n_tiles, a.MX);
     if (grid <= 0) { set_error("stream tails: no device properties"); return RF_ERR_HIP; }
-    constexpr int SLOTS = 4, AHEAD = 3;
+    static const int debug_mode = getenv("RF_STREAM_DEBUG") ? atoi(getenv("RF_STREAM_DEBUG")) : 0;   // timing experiments
+    static const int ring = getenv("RF_STREAM_RING") ? atoi(getenv("RF_STREAM_RING")) : 4;           // ring slots (tuning)
     const int nxk = a.nx * K;
-    const size_t lds = (size_t)SLOTS * kSlotBytes + (size_t)(nxk > 0 ? nxk : 1) * kFusedTX * sizeof(Acc) +
-                       (size_t)2 * (nxk > 0 ? nxk : 1) * kStreamTY * sizeof(Acc);
-#define RF_CASE(KK)                                                                                                      \
-    if (K == KK) {                                                                                                       \
-        auto kern = &stream_tails_kernel<P, KK, SLOTS, AHEAD>;                                                           \
+    const size_t lds_rest = (size_t)2 * 4 * (nxk > 0 ? nxk : 1) * kStreamTY * sizeof(float) +
+                            (size_t)4 * (a.ny * K > 0 ? a.ny * K : 1) * kStreamTY * sizeof(float);
+    const int ngx = nxk > 0 ? (nxk + 3) / 4 : 1, ngy = a.ny * K > 0 ? (a.ny * K + 3) / 4 : 1;
+#define RF_CASE(GX, GY, SLOTS, AHEAD)                                                                                    \
+    if (ngx == GX && ngy == GY && ring == SLOTS) {                                                                       \
+        auto kern = &stream_tails_kernel<GX, GY, SLOTS, AHEAD>;                                                          \
         static std::atomic<bool> attr_set[64];                                                                           \
         int dev = 0;                                                                                                     \
         RF_HIP_CHECK(hipGetDevice(&dev));                                                                                \
         if (!attr_set[dev & 63].load(std::memory_order_acquire)) {                                                       \
             RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                             (int)(SLOTS * kSlotBytes + 3 * kFusedMaxScans * KK * kFusedTX * sizeof(Acc)))); \
+                                             (int)(SLOTS * kSlotBytes + (8 * 4 * GX + 4 * 4 * GY) * kStreamTY * sizeof(float)))); \
             attr_set[dev & 63].store(true, std::memory_order_release);                                                   \
         }                                                                                                                \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, src, a, Hx, Hy, (uint32_t)n_tiles);      \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kStreamThreads), (size_t)SLOTS * kSlotBytes + lds_rest, stream, src, a, Hx, \
+                           Hy, (uint32_t)n_tiles, K, debug_mode);                                                        \
         RF_HIP_CHECK(hipGetLastError());                                                                                 \
         return RF_OK;                                                                                                    \
     }
-    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+    RF_CASE(1, 1, 4, 3) RF_CASE(1, 2, 4, 3) RF_CASE(1, 3, 4, 3) RF_CASE(2, 1, 4, 3) RF_CASE(2, 2, 4, 3) RF_CASE(2, 3, 4, 3)
+    RF_CASE(3, 1, 4, 3) RF_CASE(3, 2, 4, 3) RF_CASE(3, 3, 4, 3)
+    RF_CASE(1, 1, 3, 2)       // RF_STREAM_RING=3: the shallower ring (A/B runs on cfg3's shape)
 #undef RF_CASE
     set_error("stream tails: unsupported order %d", K);
     return RF_ERR_UNSUPPORTED;
 }
-
-template int launch_stream_tails<float>(int, const float *, const FusedArgs<float> &, const float *, const float *, hipStream_t);
-template int launch_stream_tails<int32_t>(int, const int32_t *, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *,
-                                          hipStream_t);
 
 }  // namespace rf

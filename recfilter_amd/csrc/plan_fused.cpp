@@ -316,8 +316,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     p1.run = [plan, fargs, K, TY, d_Hx, d_Hy](int pl) {
         const FusedArgs<Acc> a = fargs(pl);
         // images of whole 256 x 64 tiles stream through the LDS-DMA ring (kernels_stream.hip)
-        if (stream_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, (int64_t)a.MX * a.MY * a.NZ))
-            return launch_stream_tails<P>(K, (const P *)plan->in[pl], a, d_Hx, d_Hy, plan->stream);
+        if constexpr (std::is_same<P, float>::value) {
+            if (stream_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, (int64_t)a.MX * a.MY * a.NZ, a.MX,
+                                        a.NZ, a.nx * K, a.ny * K))
+                return launch_stream_tails(K, (const float *)plan->in[pl], a, d_Hx, d_Hy, plan->stream);
+        }
         return launch_fused_tails<P>(K, TY, plan->in[pl], plan->pw.in_u8, a, d_Hx, d_Hy, plan->stream);
     };
     plan->begin_steps.push_back(p1);
