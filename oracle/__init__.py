@@ -34,8 +34,9 @@ class _Scan(ctypes.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
     src = os.path.join(_HERE, "recfilter_oracle.c")
+    src2 = os.path.join(_HERE, "recfilter_cpu_tiled.c")
     stale = (not os.path.exists(_LIB_PATH)
-             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src))
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(src2)))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "librecfilter_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -45,16 +46,40 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
-def lib() -> ctypes.CDLL:
+def use_native_build(cache_dir: str = None) -> bool:
+    """For TIMING the CPU baseline: rebuild the two C files with `-O3 -march=native` for the host this runs on (into a
+    scratch directory, the in-tree checker build stays as it is) and use that library from now on.  The arithmetic is
+    the same (`-ffp-contract=off` kept); returns False and keeps the portable build when the compile fails."""
+    global _lib
+    import tempfile
+    cache_dir = cache_dir or os.path.join(tempfile.gettempdir(), f"recfilter_oracle_native_{os.getuid()}")
+    os.makedirs(cache_dir, exist_ok=True)
+    out = os.path.join(cache_dir, "librecfilter_oracle_native.so")
+    cmd = ["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fopenmp", "-shared", "-o", out,
+           os.path.join(_HERE, "recfilter_oracle.c"), os.path.join(_HERE, "recfilter_cpu_tiled.c"), "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    _lib = None
+    lib(out)
+    return True
+
+
+def lib(path: str = None) -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_LIB_PATH)
+        if path is None:
+            build()
+        L = ctypes.CDLL(path or _LIB_PATH)
         i64p = ctypes.POINTER(ctypes.c_int64)
         fp = ctypes.POINTER(ctypes.c_float)
         L.orc_apply_filter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, i64p,
                                        ctypes.POINTER(_Scan), ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.orc_apply_filter.restype = ctypes.c_int
+        L.orc_apply_filter_tiled_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, i64p, ctypes.POINTER(_Scan), ctypes.c_int,
+                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        L.orc_apply_filter_tiled_f32.restype = ctypes.c_int
         L.orc_gaussian_weights.argtypes = [ctypes.c_float, ctypes.c_int, fp]
         L.orc_integral_image_coeff.argtypes = [ctypes.c_int, fp]
         L.orc_overlap_feedback_coeff.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, fp]
@@ -86,18 +111,38 @@ def _scan_array(scans: Iterable[Scan]):
 
 
 def apply_filter(image: np.ndarray, scans: Iterable[Scan], clamped: bool = False,
-                 threads: int = 1) -> np.ndarray:
+                 threads: int = 1, inplace: bool = False) -> np.ndarray:
     """Untiled reference result.  `image` is indexed [..., z, y, x] (numpy C order, x fastest),
-    scan dim 0 = x = last numpy axis.  Returns a new array of the same dtype."""
+    scan dim 0 = x = last numpy axis.  Returns a new array of the same dtype (inplace=True: filters a C-contiguous
+    `image` itself, for volumes too large to copy)."""
     if image.dtype not in _NP2ORC:
         raise TypeError(f"unsupported dtype {image.dtype}")
-    out = np.ascontiguousarray(image).copy()
+    out = image if (inplace and image.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(image).copy()
     ext = (ctypes.c_int64 * out.ndim)(*reversed(out.shape))
     arr, n = _scan_array(scans)
     rc = lib().orc_apply_filter(out.ctypes.data_as(ctypes.c_void_p), _NP2ORC[out.dtype], out.ndim,
                                 ext, arr, n, BORDER_CLAMP if clamped else BORDER_ZERO, int(threads))
     if rc:
         raise RuntimeError(f"orc_apply_filter failed with {rc}")
+    return out
+
+
+def apply_filter_tiled(image: np.ndarray, scans: Iterable[Scan], clamped: bool = False, tile=32, threads: int = 1,
+                       inplace: bool = False) -> np.ndarray:
+    """The tiled CPU schedule's counterpart (recfilter_cpu_tiled.c): pass 1 / carry / pass 2 per dimension, tiles in
+    parallel.  f32 only; `tile` = one width for every filtered dimension, or a list per dimension in (x, y, z) order
+    (0 = untiled).  Same result as apply_filter up to f32 rounding."""
+    if image.dtype != np.float32:
+        raise TypeError("the tiled CPU counterpart is f32 only")
+    out = image if (inplace and image.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(image).copy()
+    ext = (ctypes.c_int64 * out.ndim)(*reversed(out.shape))
+    arr, n = _scan_array(scans)
+    tiles = [int(tile)] * out.ndim if np.isscalar(tile) else [int(t) for t in tile]
+    tl = (ctypes.c_int * out.ndim)(*tiles)
+    rc = lib().orc_apply_filter_tiled_f32(out.ctypes.data_as(ctypes.c_void_p), out.ndim, ext, arr, n,
+                                          BORDER_CLAMP if clamped else BORDER_ZERO, tl, int(threads))
+    if rc:
+        raise RuntimeError(f"orc_apply_filter_tiled_f32 failed with {rc}")
     return out
 
 

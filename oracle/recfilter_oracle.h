@@ -62,6 +62,12 @@ int orc_apply_scan(void *data, int dtype, int ndim, const int64_t *extent,
 int orc_apply_filter(void *data, int dtype, int ndim, const int64_t *extent,
                      const orc_scan *scans, int n_scans, int border, int threads);
 
+/* Tiled CPU counterpart (recfilter_cpu_tiled.c; lib/recfilter.cpp:610-678 over the algorithm of lib/split.cpp): f32
+ * pixels, tile[d] = tile width along dimension d (divides the extent, <= 256; 0 = untiled).  Same result as
+ * orc_apply_filter up to f32 rounding. */
+int orc_apply_filter_tiled_f32(float *data, int ndim, const int64_t *extent, const orc_scan *scans, int n_scans,
+                               int border, const int *tile, int threads);
+
 /* Coefficient helpers (lib/iir_coeff.cpp). out must hold order+1 floats. */
 void orc_gaussian_weights(float sigma, int order, float *out);
 void orc_integral_image_coeff(int n, float *out);

@@ -140,3 +140,26 @@ def test_check_result_metric():
     out = np.array([1.0, 2.2, 4.0], dtype=np.float32)
     mx, mean = oracle.check_result(ref, out)
     assert abs(mx - 10.0) < 1e-3 and abs(mean - 10.0 / 3) < 1e-3
+
+
+# ---- the tiled CPU counterpart (oracle/recfilter_cpu_tiled.c: bench.py's second cpu_baseline entry) ----------------
+@pytest.mark.parametrize("name", sorted(n for n, c in rc.REFERENCE_TESTS.items() if c["dtype"] == np.float32))
+def test_tiled_cpu_counterpart_matches_the_untiled_oracle_on_the_reference_tests(name):
+    c = rc.REFERENCE_TESTS[name]
+    img = rc.random_image(c["shape"], np.float32, 5)
+    want = oracle.apply_filter(img.astype(np.float64), c["scans"], c["clamped"])
+    got = oracle.apply_filter_tiled(img, c["scans"], c["clamped"], tile=c["tile"], threads=2)
+    assert rc.rel_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("coeff,clamped,tile", [(rc.GAUSS2, True, 32), (rc.GAUSS3, True, 16), (rc.BICUBIC_COEFF, True, 8),
+                                                (rc.GAUSS2, False, 32)])
+def test_tiled_cpu_counterpart_clamped_and_mixed_tiles(coeff, clamped, tile):
+    img = rc.random_image((96, 160), np.float32, 7)
+    want = oracle.apply_filter(img.astype(np.float64), rc.xy_pm(coeff), clamped)
+    got = oracle.apply_filter_tiled(img, rc.xy_pm(coeff), clamped, tile=[tile, 0] if tile == 8 else tile, threads=3)
+    assert rc.rel_err(got, want) < 5e-5
+    # in place on the caller's array
+    work = img.copy()
+    oracle.apply_filter_tiled(work, rc.xy_pm(coeff), clamped, tile=tile, inplace=True)
+    assert rc.rel_err(work, want) < 5e-5
