@@ -96,7 +96,7 @@ __device__ __forceinline__ int slot_pos(int i, int c) { return c ^ (i & 15) ^ ((
 //       no reduction at all.
 // NGX / NGY: groups of four tails along x / y (compile time: they size the register arrays); K is a run-time value here
 template <int NGX, int NGY, int SLOTS, int AHEAD>
-__global__ void __launch_bounds__(kStreamThreads)
+__global__ void __launch_bounds__(kStreamThreads, 5)      // two workgroups of 9 waves per CU: at most 96 registers
 stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
                     const float *__restrict__ Hx,     // [vx][s][r][256]
                     const float *__restrict__ Hy,     // [vy][j][r][64]
