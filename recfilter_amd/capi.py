@@ -26,9 +26,10 @@ RF_F32, RF_F64, RF_I32, RF_I16 = range(4)
 RF_BORDER_ZERO, RF_BORDER_CLAMP = 0, 1
 RF_POINTWISE_PRE, RF_POINTWISE_POST = 1, 2
 RF_IN_PIXEL, RF_IN_U8 = 0, 1
-RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED = range(4)
+RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED, RF_PATH_TILED_OVERLAPPED = range(5)
 PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
-              RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused"}
+              RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused",
+              RF_PATH_TILED_OVERLAPPED: "tiled_overlapped"}
 
 # every symbol include/recfilter_amd.h declares
 EXPORTED_SYMBOLS = [

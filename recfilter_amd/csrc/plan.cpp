@@ -17,6 +17,8 @@ namespace rf {
 
 int build_fused_plan(rf_plan *plan, const rf_filter_desc *desc);  // plan_fused.cpp
 bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why);
+int build_overlap_plan(rf_plan *plan, const rf_filter_desc *desc);  // plan_overlap.cpp
+bool overlap_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why);
 
 namespace {
 
@@ -246,9 +248,19 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     int path = desc->path;
     std::string why;
     if (path == RF_PATH_AUTO) {
+        int filtered_dims = 0;
+        for (int d = 0; d < desc->ndim; d++) filtered_dims += plan->dims[d].scan_ids.empty() ? 0 : 1;
         if (fused_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_FUSED;
+        // a filter split() along two or more dimensions with small tiles: the fully overlapped tiling (two passes over
+        // the image instead of two per dimension)
+        else if (filtered_dims >= 2 && overlap_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_OVERLAPPED;
         else path = RF_PATH_TILED_GENERIC;
     }
+    if (path == RF_PATH_TILED_OVERLAPPED && !overlap_plan_applicable(plan.get(), desc, &why)) {
+        set_error("overlapped tiled path not applicable: %s", why.c_str());
+        return RF_ERR_UNSUPPORTED;
+    }
+    if (path < RF_PATH_UNTILED || path > RF_PATH_TILED_OVERLAPPED) { set_error("unknown path %d", path); return RF_ERR_INVALID_ARG; }
     if (path == RF_PATH_TILED_FUSED && !fused_plan_applicable(plan.get(), desc, &why)) {
         set_error("fused tiled path not applicable: %s", why.c_str());
         return RF_ERR_UNSUPPORTED;
@@ -257,6 +269,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     auto build = [&](int p) -> int {
         plan->path = p;
         if (p == RF_PATH_TILED_FUSED) return build_fused_plan(plan.get(), desc);
+        if (p == RF_PATH_TILED_OVERLAPPED) return build_overlap_plan(plan.get(), desc);
         switch (desc->dtype) {
             case RF_F32: return build_for_pixel<float>(plan.get(), desc, p);
             case RF_F64: return build_for_pixel<double>(plan.get(), desc, p);

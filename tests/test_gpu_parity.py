@@ -32,17 +32,18 @@ def _check(imgs, outs, scans, clamped):
             assert err < TOL, f"rel err {err}"
 
 
-@pytest.mark.parametrize("path", [1, 2], ids=["untiled", "tiled_generic"])
+@pytest.mark.parametrize("path", [1, 2, 4], ids=["untiled", "tiled_generic", "tiled_overlapped"])
 @pytest.mark.parametrize("name", sorted(rc.REFERENCE_TESTS))
 def test_reference_tests(name, path):
-    """Every configuration of /root/reference/tests/test_*.cpp, literal shapes and tile widths."""
+    """Every configuration of /root/reference/tests/test_*.cpp, literal shapes and tile widths.  tiled_overlapped is
+    the reference's own structure: all dimensions in one pass 1 / one pass 2, cross-dimension residuals in between."""
     case = rc.REFERENCE_TESTS[name]
     nd = len(case["shape"])
     tile = [case["tile"] if any(s[0] == d for s in case["scans"]) else 0 for d in range(nd)]
     imgs, outs, (got_path, tiles) = _run(case["shape"], case["scans"], case["dtype"], case["clamped"],
-                                         tile=tile if path == 2 else None, path=path)
+                                         tile=tile if path != 1 else None, path=path)
     assert got_path == path
-    if path == 2:
+    if path != 1:
         assert list(tiles) == tile
     _check(imgs, outs, case["scans"], case["clamped"])
 
@@ -71,6 +72,43 @@ def test_3d_and_1d_and_inplace(path):
     s1 = [(0, True, [1.0, 1.0])]
     imgs, outs, _ = _run((4096,), s1, path=path)        # BASELINE cfg1: 1-D prefix sum
     _check(imgs, outs, s1, False)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int16])
+@pytest.mark.parametrize("clamped", [False, True])
+def test_overlapped_3d_all_residual_pairs(dtype, clamped):
+    """RF_PATH_TILED_OVERLAPPED on a 3-D filter with different tiles / orders per dimension: x->y, x->z and y->z
+    residuals (lib/split.cpp:1814-1820), causal + anticausal scans in every dimension, every pixel type; also a filter
+    whose x dimension has no scans (y->z only) and the automatic path choice for split() filters."""
+    if np.issubdtype(dtype, np.integer):
+        scans = [(0, True, [1.0, 1.0]), (0, False, [1.0, 2.0, -1.0]), (1, False, [1.0, 1.0]), (1, True, [1.0, 3.0, -3.0, 1.0]),
+                 (2, True, [1.0, 1.0]), (2, False, [1.0, 1.0])]
+    else:
+        scans = [(0, True, [0.6, 0.3, -0.1]), (0, False, [0.7, 0.2]), (1, False, [0.5, 0.4, -0.1, 0.05]), (1, True, [0.8, 0.1]),
+                 (2, True, [0.9, 0.05]), (2, False, [0.5, 0.3, 0.1])]
+    shape, tile = (24, 20, 48), [16, 5, 4]
+    imgs, outs, (path, tiles) = _run(shape, scans, dtype, clamped, planes=2, tile=tile, path=4)
+    assert path == 4 and list(tiles) == tile
+    _check(imgs, outs, scans, clamped)
+    imgs, outs, (path, tiles) = _run(shape, scans, dtype, clamped, tile=tile, path=0)       # split() -> overlapped
+    assert path == 4
+    _check(imgs, outs, scans, clamped)
+    yz = [s for s in scans if s[0] != 0]
+    imgs, outs, (path, _) = _run(shape, yz, dtype, clamped, tile=[0, 5, 4], path=4, inplace=True)
+    assert path == 4
+    _check(imgs, outs, yz, clamped)
+
+
+def test_overlapped_2d_large_and_timed():
+    import torch
+    import recfilter_amd as rfa
+    scans = rc.xy_pm(rc.GAUSS3)
+    imgs, outs, (path, _) = _run((512, 768), scans, clamped=True, tile=[32, 32], path=4)
+    assert path == 4
+    _check(imgs, outs, scans, True)
+    with rfa.Plan((128, 128), scans, clamped=True, tile=[32, 32], path=4) as plan:
+        _, times = plan.execute_timed([torch.from_numpy(rc.random_image((128, 128))).cuda()])
+        assert [n for n, _ in times] == ["overlap_pass1", "carry_x", "overlap_residual_y", "carry_y", "overlap_pass2"]
 
 
 def test_high_order_and_ragged_extents():

@@ -300,3 +300,49 @@ def test_second_order_sections_reproduce_the_scan():
             y = oracle.apply_filter(y, [(0, True, s)], False)
         want = oracle.apply_filter(x, [(0, True, list(coeff))], False)
         assert rc.rel_err(y, want) < 1e-5
+
+
+# ---- the fully overlapped N-D tiling (RF_PATH_TILED_OVERLAPPED): residuals between every pair of dimensions --------
+import overlap_emulator as ovemu
+
+
+@pytest.mark.parametrize("name", ["test_trivial", "test_causal_xy", "test_causal_anticausal_xy", "test_generic_xy", "test_generic_xyz"])
+def test_overlapped_tables_reproduce_oracle_on_reference_tests(name):
+    case = rc.REFERENCE_TESTS[name]
+    shape = case["shape"]
+    tile = [case["tile"] if any(s[0] == d for s in case["scans"]) else 0 for d in range(len(shape))]
+    auto = _host_plan(shape, case["scans"], dtype=np.float64, clamped=case["clamped"], tile=tile)
+    assert auto.path == capi.RF_PATH_TILED_OVERLAPPED       # split() along >= 2 dimensions with small tiles
+    p = _host_plan(shape, case["scans"], dtype=np.float64, clamped=case["clamped"], tile=tile, path=capi.RF_PATH_TILED_OVERLAPPED)
+    assert p.path == capi.RF_PATH_TILED_OVERLAPPED and list(p.tiles) == tile
+    img = rc.random_image(shape).astype(np.float64)
+    want = oracle.apply_filter(img, case["scans"], case["clamped"])
+    got = ovemu.emulate_overlapped(img, case["scans"], tile, case["clamped"], p)
+    assert rc.rel_err(got, want) < 1e-11
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+def test_overlapped_3d_mixed_tiles_orders_and_borders(clamped):
+    # different tile widths and orders per dimension, causal + anticausal everywhere, a dimension without scans
+    scans = [(0, True, [0.6, 0.3, -0.1]), (0, False, [0.7, 0.2]), (1, False, [0.5, 0.4, -0.1, 0.05]), (1, True, [0.8, 0.1]),
+             (2, True, [0.9, 0.05]), (2, False, [0.5, 0.3, 0.1])]
+    shape = (12, 10, 16)
+    tile = [8, 5, 4]
+    p = _host_plan(shape, scans, dtype=np.float64, clamped=clamped, tile=tile, path=capi.RF_PATH_TILED_OVERLAPPED)
+    img = rc.random_image(shape, seed=3).astype(np.float64)
+    got = ovemu.emulate_overlapped(img, scans, tile, clamped, p)
+    assert rc.rel_err(got, oracle.apply_filter(img, scans, clamped)) < 1e-11
+    yz = [s for s in scans if s[0] != 0]                    # x unfiltered: y -> z is the only residual
+    p2 = _host_plan(shape, yz, dtype=np.float64, clamped=clamped, tile=[0, 5, 4], path=capi.RF_PATH_TILED_OVERLAPPED)
+    got2 = ovemu.emulate_overlapped(img, yz, [0, 5, 4], clamped, p2)
+    assert rc.rel_err(got2, oracle.apply_filter(img, yz, clamped)) < 1e-11
+
+
+def test_overlapped_path_preconditions():
+    scans = rc.REFERENCE_TESTS["test_generic_xyz"]["scans"]
+    with pytest.raises(rfa.RecFilterError):                  # needs an explicit tile for every filtered dimension
+        _host_plan((16, 16, 16), scans, tile=[4, 4, 0], path=capi.RF_PATH_TILED_OVERLAPPED)
+    with pytest.raises(rfa.RecFilterError):                  # tile volume above 4096 samples
+        _host_plan((64, 64, 64), scans, tile=[32, 16, 16], path=capi.RF_PATH_TILED_OVERLAPPED)
+    # without explicit tiles the automatic choice is unchanged
+    assert _host_plan((16, 16, 16), scans).path != capi.RF_PATH_TILED_OVERLAPPED
