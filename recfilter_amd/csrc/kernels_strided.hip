@@ -110,5 +110,6 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
 
 template int launch_strided_pass<float>(bool, int, int, const float *, float *, const StridedArgs<float> &, hipStream_t);
 template int launch_strided_pass<int32_t>(bool, int, int, const int32_t *, int32_t *, const StridedArgs<uint32_t> &, hipStream_t);
+template int launch_strided_pass<int16_t>(bool, int, int, const int16_t *, int16_t *, const StridedArgs<uint32_t> &, hipStream_t);
 
 }  // namespace rf

@@ -448,6 +448,8 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
 template int launch_fused_tails<float>(int, int, const void *, bool, const FusedArgs<float> &, const float *, const float *, hipStream_t);
 template int launch_fused_tails<int32_t>(int, int, const void *, bool, const FusedArgs<uint32_t> &, const uint32_t *,
                                          const uint32_t *, hipStream_t);
+template int launch_fused_tails<int16_t>(int, int, const void *, bool, const FusedArgs<uint32_t> &, const uint32_t *,
+                                         const uint32_t *, hipStream_t);
 template int launch_xscan_rows<float>(int, int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
 template int launch_xscan_rows<uint32_t>(int, int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);
 

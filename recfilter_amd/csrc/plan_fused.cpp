@@ -458,7 +458,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
 bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::string *why) {
     auto no = [&](const char *msg) { if (why) *why = msg; return false; };
-    if (plan->dtype != RF_F32 && plan->dtype != RF_I32) return no("pixel type must be f32 or i32");
+    if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return no("pixel type must be f32, i32 or i16");
     if (plan->ndim == 1) {
         // a long 1-D signal folded into chained rows (zero border only: the clamped prologue would differ per row)
         if (plan->clamped) return no("1-D: clamped border not supported on the fused path");
@@ -490,6 +490,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
 int build_fused_plan(rf_plan *plan, const rf_filter_desc *desc) {
     if (plan->dtype == RF_F32) return build_fused<float, double>(plan, desc);
     if (plan->dtype == RF_I32) return build_fused<int32_t, uint64_t>(plan, desc);
+    if (plan->dtype == RF_I16) return build_fused<int16_t, uint64_t>(plan, desc);
     set_error("fused path: unsupported pixel type");
     return RF_ERR_UNSUPPORTED;
 }

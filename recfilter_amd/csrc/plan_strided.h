@@ -14,7 +14,7 @@ namespace rf {
 inline int strided_tile(const rf_plan *plan, int d) {
     const DimInfo &di = plan->dims[d];
     if (di.scan_ids.empty() || di.k > kFusedMaxK || (int)di.scan_ids.size() > kFusedMaxScans) return 0;
-    if (plan->dtype != RF_F32 && plan->dtype != RF_I32) return 0;
+    if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return 0;
     if (di.N % 64 == 0) return 64;
     if (di.N % 32 == 0) return 32;
     return 0;

@@ -265,6 +265,11 @@ __device__ __forceinline__ typename Vec4<Acc>::type load_chunk(const char *p) {
     using A4 = typename Vec4<Acc>::type;
     if constexpr (sizeof(PI) == sizeof(Acc)) {
         return __builtin_nontemporal_load(reinterpret_cast<const A4 *>(p));
+    } else if constexpr (sizeof(PI) == 2) {
+        // int16 pixels (tests/test_type_invariance.cpp): one 8-byte load, sign-extended into the 32-bit ring
+        typedef short S4 __attribute__((ext_vector_type(4)));
+        const S4 w = __builtin_nontemporal_load(reinterpret_cast<const S4 *>(p));
+        return A4{(Acc)(int32_t)w.x, (Acc)(int32_t)w.y, (Acc)(int32_t)w.z, (Acc)(int32_t)w.w};
     } else {
         static_assert(sizeof(PI) == 1, "input planes are the pixel type or unsigned bytes");
         const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));

@@ -91,8 +91,8 @@ def test_overlapped_3d_all_residual_pairs(dtype, clamped):
     assert path == 4 and list(tiles) == tile
     _check(imgs, outs, scans, clamped)
     imgs, outs, (path, tiles) = _run(shape, scans, dtype, clamped, tile=tile, path=0)
-    # split() along several dimensions: the fused kernels where they apply (f32 / i32, orders <= 3), else overlapped
-    assert path == (3 if dtype in (np.float32, np.int32) else 4)
+    # split() along several dimensions: the fused kernels where they apply (f32 / i32 / i16, orders <= 3), else overlapped
+    assert path == (4 if dtype == np.float64 else 3)
     _check(imgs, outs, scans, clamped)
     yz = [s for s in scans if s[0] != 0]
     imgs, outs, (path, _) = _run(shape, yz, dtype, clamped, tile=[0, 5, 4], path=4, inplace=True)
@@ -417,6 +417,27 @@ def test_random_integer_filters_bit_exact(seed):
     imgs, outs, (path, _) = _run(shape, scans, dtype=np.int32, clamped=clamped, seed=seed)
     assert path == 3
     _check(imgs, outs, scans, clamped)          # wrap-around arithmetic, bit-exact
+    # int16 pixels (the reference's tests/test_type_invariance.cpp) ride the same fused kernels: 16-bit planes, 32-bit ring
+    imgs, outs, (path, _) = _run(shape, scans, dtype=np.int16, clamped=clamped, seed=seed, planes=2)
+    assert path == 3
+    _check(imgs, outs, scans, clamped)
+
+
+def test_int16_fused_partial_tiles_3d_and_reference_shape():
+    """int16 on the fused path beyond whole tiles: widths that are multiples of 4 only, partial tile rows, a volume
+    (fused x/y + strided z), in place, and the literal tests/test_type_invariance.cpp filter on a large image."""
+    s2 = rc.REFERENCE_TESTS["test_type_invariance"]["scans"]
+    for shape in [(70, 300), (33, 20), (135, 1000)]:
+        imgs, outs, (path, _) = _run(shape, s2, dtype=np.int16, seed=5)
+        assert path == 3
+        _check(imgs, outs, s2, False)
+    s3 = [(0, True, [1.0, 1.0]), (0, False, [1.0, 2.0, -1.0]), (1, False, [1.0, 1.0]), (2, True, [1.0, 1.0, -1.0]), (2, False, [1.0, 1.0])]
+    imgs, outs, (path, _) = _run((64, 96, 512), s3, dtype=np.int16, seed=6, inplace=True)
+    assert path == 3
+    _check(imgs, outs, s3, False)
+    imgs, outs, (path, _) = _run((2048, 2048), s2, dtype=np.int16, clamped=True, seed=7)
+    assert path == 3
+    _check(imgs, outs, s2, True)
 
 
 # ---- pointwise prologue / epilogue (rf_pointwise_desc; compute_at of a pointwise consumer) ----------------
