@@ -35,6 +35,7 @@ constexpr int kQRows = 16;                          // rows per ring slot: a qua
 constexpr int kSlotBytes = kQRows * kFusedTX * 4;   // 16 KiB
 constexpr int kStreamTY = 64;
 constexpr int kQPerTile = kStreamTY / kQRows;       // 4
+constexpr int kHyPitch = kStreamTY + 4;             // floats per row of the Hy table in LDS (padded: bank spread)
 constexpr int kStreamThreads = 576;                 // waves 0..3: x tails, waves 4..7: y tails, wave 8: loader
 
 
@@ -157,8 +158,10 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
         return;
     }
 
-    // Hy table -> LDS (all four border variants; ordered before its first use by B_0)
-    for (int i = tid; i < 4 * nyk * kStreamTY; i += 512) hy_lds[i] = Hy[i];
+    // Hy table -> LDS (all four border variants; ordered before its first use by B_0).  Rows are padded by four floats:
+    // the four tails of a group are read side by side (lanes 4b + j, 16 bytes each), 256-byte rows would put them on
+    // the same banks (4-way conflict on every read: profiles/r2/pmc_shader.json, 34 % of this kernel's LDS cycles).
+    for (int i = tid; i < 4 * nyk * kStreamTY; i += 512) hy_lds[(i / kStreamTY) * kHyPitch + i % kStreamTY] = Hy[i];
 
     const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
     const int w = wave & 3;                                          // column group 64w .. 64w+63
@@ -271,7 +274,7 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
             for (int gy = 0; gy < NGY; gy++) {
                 {
                     const int jr = 4 * gy + j4;
-                    const float *hp = hy_lds + (size_t)(vy * nyk + (jr < nyk ? jr : 0)) * kStreamTY + q * kQRows;
+                    const float *hp = hy_lds + (size_t)(vy * nyk + (jr < nyk ? jr : 0)) * kHyPitch + q * kQRows;
                     const float keep = jr < nyk ? 1.0f : 0.0f;
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
@@ -344,7 +347,7 @@ int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, cons
     static const int ring = getenv("RF_STREAM_RING") ? atoi(getenv("RF_STREAM_RING")) : 4;           // ring slots (tuning)
     const int nxk = a.nx * K;
     const size_t lds_rest = (size_t)2 * 4 * (nxk > 0 ? nxk : 1) * kStreamTY * sizeof(float) +
-                            (size_t)4 * (a.ny * K > 0 ? a.ny * K : 1) * kStreamTY * sizeof(float);
+                            (size_t)4 * (a.ny * K > 0 ? a.ny * K : 1) * kHyPitch * sizeof(float);
     const int ngx = nxk > 0 ? (nxk + 3) / 4 : 1, ngy = a.ny * K > 0 ? (a.ny * K + 3) / 4 : 1;
 #define RF_CASE(GX, GY, SLOTS, AHEAD)                                                                                    \
     if (ngx == GX && ngy == GY && ring == SLOTS) {                                                                       \
@@ -354,7 +357,7 @@ int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, cons
         RF_HIP_CHECK(hipGetDevice(&dev));                                                                                \
         if (!attr_set[dev & 63].load(std::memory_order_acquire)) {                                                       \
             RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                             (int)(SLOTS * kSlotBytes + (8 * 4 * GX + 4 * 4 * GY) * kStreamTY * sizeof(float)))); \
+                                             (int)(SLOTS * kSlotBytes + (8 * 4 * GX + 4 * 4 * GY) * kHyPitch * sizeof(float)))); \
             attr_set[dev & 63].store(true, std::memory_order_release);                                                   \
         }                                                                                                                \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kStreamThreads), (size_t)SLOTS * kSlotBytes + lds_rest, stream, src, a, Hx, \
