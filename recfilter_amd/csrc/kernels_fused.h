@@ -91,6 +91,17 @@ struct StridedArgs {
     const Acc *incoming;         // [s][r][line]
 };
 
+// Untiled scans with the x phase's parallelism inside the line (kernels_lines.hip): all scans of ONE dimension in one launch.
+template <typename Acc>
+struct LineScanArgs {
+    int64_t n, inner, lines;     // extent and stride of the filtered dimension, number of lines
+    int32_t n_scans, clamped;
+    FusedScan<Acc> scans[kFusedMaxScans];      // with the 16-sample segment tables R / P
+};
+template <typename P>
+int launch_line_scans(int K, bool strided, const P *src, P *dst, const LineScanArgs<typename PixelTraits<P>::Acc> &a,
+                      hipStream_t stream);
+
 template <typename P>
 int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
                         const StridedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream);

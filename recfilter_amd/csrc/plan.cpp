@@ -32,6 +32,50 @@ double cast_coeff(double c, int dtype) {
     return c;
 }
 
+// The untiled operator with the line-parallel kernels (kernels_lines.hip): pixel types of 2 / 4 bytes in the 32-bit
+// arithmetic, orders <= 3, <= 4 scans per dimension, extents that are multiples of 16 (a lane owns 16 samples; the
+// lines of a strided dimension are moved 16 at a time).
+bool line_scans_applicable(const rf_plan *plan) {
+    if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return false;
+    if (plan->shard_world > 1 || plan->scans.empty()) return false;
+    if (getenv("RF_NO_LINE_SCANS") != nullptr) return false;          // A/B runs against the one-thread-per-line kernel
+    bool strided = false;
+    for (int d = 0; d < plan->ndim; d++) {
+        const DimInfo &di = plan->dims[d];
+        if (di.scan_ids.empty()) continue;
+        if (di.k > kFusedMaxK || (int)di.scan_ids.size() > kFusedMaxScans || di.N % 16 != 0) return false;
+        if (d > 0) strided = true;
+    }
+    if (strided && plan->dims[0].N % 16 != 0) return false;
+    return true;
+}
+
+template <typename P, typename S>
+int build_line_scans(rf_plan *plan) {
+    using Acc = typename PixelTraits<P>::Acc;
+    bool first = true;
+    for (int d = 0; d < plan->ndim; d++) {
+        const DimInfo &di = plan->dims[d];
+        if (di.scan_ids.empty()) continue;
+        LineScanArgs<Acc> a{};
+        a.n = di.N; a.inner = di.stride; a.lines = di.lines;
+        a.n_scans = (int)di.scan_ids.size();
+        a.clamped = plan->clamped ? 1 : 0;
+        for (int i = 0; i < a.n_scans; i++) a.scans[i] = make_fused_scan<S, Acc>(plan->scans[di.scan_ids[i]], di.k, true);
+        const bool from_input = first, strided = d > 0;
+        const int K = di.k;
+        first = false;
+        Step st;
+        st.name = std::string("line_scans_") + "xyz"[d];
+        st.run = [plan, a, K, strided, from_input](int pl) {
+            const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
+            return launch_line_scans<P>(K, strided, src, (P *)plan->out[pl], a, plan->stream);
+        };
+        plan->begin_steps.push_back(st);
+    }
+    return RF_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 template <typename P>
 int build_untiled(rf_plan *plan) {
@@ -39,6 +83,10 @@ int build_untiled(rf_plan *plan) {
     if (plan->shard_world > 1) {
         set_error("the untiled path cannot be sharded across devices");
         return RF_ERR_UNSUPPORTED;
+    }
+    if constexpr (sizeof(P) <= 4 && !std::is_same<P, double>::value) {
+        using S = typename std::conditional<PixelTraits<P>::is_integer, uint64_t, double>::type;
+        if (line_scans_applicable(plan)) return build_line_scans<P, S>(plan);
     }
     bool first = true;
     for (size_t i = 0; i < plan->scans.size(); i++) {
@@ -250,7 +298,17 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     if (path == RF_PATH_AUTO) {
         int filtered_dims = 0;
         for (int d = 0; d < desc->ndim; d++) filtered_dims += plan->dims[d].scan_ids.empty() ? 0 : 1;
-        if (fused_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_FUSED;
+        // small images are launch-bound on the five-kernel tiled pipeline (30-35 us, most of it host enqueue time): the
+        // line-parallel untiled kernels need one launch per filtered dimension (kernels_lines.hip)
+        int64_t max_extent = 0;
+        for (int d = 0; d < desc->ndim; d++) max_extent = std::max<int64_t>(max_extent, plan->dims[d].N);
+        const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (0 = never; tuning / tests)
+        bool user_tiles = false;
+        for (int d = 0; d < desc->ndim; d++) user_tiles = user_tiles || desc->tile[d] > 0;
+        if (!user_tiles && world == 1 && max_extent <= small_limit && plan->total * plan->n_planes <= small_limit * small_limit * 4 &&
+            plan->pw.pre == false && plan->pw.post == false && line_scans_applicable(plan.get()))
+            path = RF_PATH_UNTILED;
+        else if (fused_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_FUSED;
         // a filter split() along two or more dimensions with small tiles: the fully overlapped tiling (two passes over
         // the image instead of two per dimension)
         else if (filtered_dims >= 2 && overlap_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_OVERLAPPED;

@@ -87,31 +87,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     };
     auto fused_scans = [&](const std::vector<int> &ids, bool with_segment_tables) {
         std::vector<FusedScan<Acc>> v;
-        for (int id : ids) {
-            FusedScan<Acc> f;
-            std::memset(&f, 0, sizeof(f));
-            ScanS<S> ts = make_table_scan<S>(plan->scans[id]);
-            f.causal = ts.causal ? 1 : 0;
-            f.b = table_to_acc<S, Acc>(ts.b);
-            for (int j = 0; j < K; j++) f.a[j] = table_to_acc<S, Acc>(ts.a[j]);
-            if (with_segment_tables) {
-                // segment-level tables in direction coordinates = tables of the causal twin at T = 16
-                ScanS<S> twin = ts;
-                twin.causal = true;
-                DimTables<S> seg = build_dim_tables<S>({twin}, K, kFusedSeg, false);
-                const std::vector<S> &R = seg.P(0, 0, 0);
-                for (int p = 0; p < kFusedSeg; p++)
-                    for (int j = 0; j < K; j++)     // direction position p -> memory position inside the segment
-                        f.R[j][ts.causal ? p : kFusedSeg - 1 - p] = table_to_acc<S, Acc>(R[(size_t)p * K + j]);
-                std::vector<S> Pw = seg.A[0];
-                for (int step = 0; step < 4; step++) {
-                    for (int r = 0; r < K; r++)
-                        for (int j = 0; j < K; j++) f.P[step][r][j] = table_to_acc<S, Acc>(Pw[r * K + j]);
-                    Pw = mat_mul<S>(Pw, Pw, K);
-                }
-            }
-            v.push_back(f);
-        }
+        for (int id : ids) v.push_back(make_fused_scan<S, Acc>(plan->scans[id], K, with_segment_tables));
         return v;
     };
     auto dev_scans = [&](const std::vector<int> &ids) {

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 #include "kernels_fused.h"
@@ -50,6 +51,35 @@ template <typename S>
 double table_to_double(S v) {
     if constexpr (std::is_same<S, uint64_t>::value) return (double)(int64_t)v;
     else return (double)v;
+}
+
+// One scan as the fused / line kernels read it: coefficients plus, with_segment_tables, the tables of the 16-sample
+// segment scan of the x phase (scan_device.h: R = effect of the entering state on the segment, in MEMORY order;
+// P = segment exit-state transfer over 1, 2, 4, 8 segments) -- the tables of the causal twin at T = 16.
+template <typename S, typename Acc>
+FusedScan<Acc> make_fused_scan(const Scan &scan, int K, bool with_segment_tables) {
+    FusedScan<Acc> f;
+    std::memset(&f, 0, sizeof(f));
+    ScanS<S> ts = make_table_scan<S>(scan);
+    f.causal = ts.causal ? 1 : 0;
+    f.b = table_to_acc<S, Acc>(ts.b);
+    for (int j = 0; j < K && j < kFusedMaxK; j++) f.a[j] = table_to_acc<S, Acc>(ts.a[j]);
+    if (with_segment_tables) {
+        ScanS<S> twin = ts;
+        twin.causal = true;
+        DimTables<S> seg = build_dim_tables<S>({twin}, K, kFusedSeg, false);
+        const std::vector<S> &R = seg.P(0, 0, 0);
+        for (int p = 0; p < kFusedSeg; p++)
+            for (int j = 0; j < K; j++)     // direction position p -> memory position inside the segment
+                f.R[j][ts.causal ? p : kFusedSeg - 1 - p] = table_to_acc<S, Acc>(R[(size_t)p * K + j]);
+        std::vector<S> Pw = seg.A[0];
+        for (int step = 0; step < 4; step++) {
+            for (int r = 0; r < K; r++)
+                for (int j = 0; j < K; j++) f.P[step][r][j] = table_to_acc<S, Acc>(Pw[r * K + j]);
+            Pw = mat_mul<S>(Pw, Pw, K);
+        }
+    }
+    return f;
 }
 
 // (A[s])^(i+1) for i = 0..M-1, flattened [s][i][r][j] in the kernels' arithmetic type (GenericDimArgs::Apow)

@@ -819,3 +819,44 @@ def test_steps_in_flight_keep_their_images_apart():
     for im, o in zip(imgs, outs):
         want = oracle.apply_filter(im.astype(np.float64), scans, True)
         assert rc.rel_err(o.cpu().numpy(), want) < 1e-4
+
+
+# ---- line-parallel untiled kernels (kernels_lines.hip): RF_PATH_UNTILED, and what RF_PATH_AUTO picks for small images ----
+@pytest.mark.parametrize("dtype", [np.float32, np.int32, np.int16])
+@pytest.mark.parametrize("shape,clamped", [((512, 512), True), ((64, 64), False), ((192, 320), True), ((1024, 768), False),
+                                            ((16, 4096), True), ((48, 32, 80), True), ((2048,), False)])
+def test_line_parallel_untiled_kernels(dtype, shape, clamped):
+    """Every scan walks the whole line (no tiling algebra at all): the x phase's 16-lane segment scan, tile after tile,
+    the state handed on in registers.  Widths / heights that are multiples of 16 only (partial last tiles), 1-D, 3-D."""
+    import torch
+    import recfilter_amd as rfa
+    nd = len(shape)
+    if np.issubdtype(dtype, np.integer):
+        scans = [(0, True, [1.0, 2.0, -1.0]), (0, False, [1.0, 1.0])] + ([(1, True, [1.0, 1.0]), (1, False, [2.0, 1.0, -1.0, 1.0])] if nd > 1 else []) \
+            + ([(2, False, [1.0, 1.0])] if nd > 2 else [])
+    else:
+        scans = [s for s in rc.xy_pm(rc.GAUSS3) if s[0] < nd] + ([(2, True, rc.GAUSS2), (2, False, [0.5, 0.5])] if nd > 2 else [])
+    imgs, outs, _ = _run(shape, scans, dtype, clamped, planes=2, path=1)
+    _check(imgs, outs, scans, clamped)
+    dev = torch.from_numpy(imgs[0]).cuda()
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, path=1) as plan:
+        _, times = plan.execute_timed([dev])
+        assert [n for n, _ in times] == ["line_scans_" + "xyz"[d] for d in range(nd)]      # one launch per dimension
+
+
+def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
+    import torch
+    import recfilter_amd as rfa
+    monkeypatch.delenv("RF_SMALL_LIMIT", raising=False)          # (tests/conftest.py switches the choice off for the suite)
+    scans = rc.xy_pm(rc.GAUSS2)
+    for n, want in ((256, 1), (1024, 1), (2048, 3)):
+        with rfa.Plan((n, n), scans, clamped=True) as plan:
+            assert plan.path == want, (n, plan.path_name)
+    imgs, outs, (path, _) = _run((512, 512), scans, clamped=True)
+    assert path == 1
+    _check(imgs, outs, scans, True)
+    # an explicit split() keeps the tiled kernels, and so do pointwise stages (fused into the tiled passes)
+    with rfa.Plan((512, 512), scans, clamped=True, tile=[32, 32]) as plan:
+        assert plan.path in (3, 4)
+    with rfa.Plan((512, 512), scans, clamped=True, prologue=(0.5, 0.0)) as plan:
+        assert plan.path == 3
