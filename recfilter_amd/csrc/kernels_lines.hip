@@ -31,7 +31,7 @@ constexpr int kLinesPerWG = 16;           // lines per workgroup (one per DPP ro
 
 template <typename P, typename Acc>
 __device__ __forceinline__ void load16(const P *p, Acc (&v)[1][kFusedSeg]) {
-    if constexpr (sizeof(P) == 4) {
+    if constexpr (sizeof(P) == sizeof(Acc)) {
         using A4 = typename Vec4<Acc>::type;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -46,7 +46,7 @@ __device__ __forceinline__ void load16(const P *p, Acc (&v)[1][kFusedSeg]) {
 
 template <typename P, typename Acc>
 __device__ __forceinline__ void store16(P *p, const Acc (&v)[1][kFusedSeg]) {
-    if constexpr (sizeof(P) == 4) {
+    if constexpr (sizeof(P) == sizeof(Acc)) {
         using A4 = typename Vec4<Acc>::type;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -63,7 +63,7 @@ __device__ __forceinline__ void store16(P *p, const Acc (&v)[1][kFusedSeg]) {
 // one sample of the workgroup's 16 consecutive lines (64 contiguous bytes for 4-byte pixels) <-> a padded LDS row
 template <typename P, typename Acc>
 __device__ __forceinline__ void load_lines16(const P *p, Acc *row, int nl) {
-    if constexpr (sizeof(P) == 4) {
+    if constexpr (sizeof(P) == sizeof(Acc)) {
         using A4 = typename Vec4<Acc>::type;
         if (nl == kLinesPerWG) {
 #pragma unroll
@@ -80,7 +80,7 @@ __device__ __forceinline__ void load_lines16(const P *p, Acc *row, int nl) {
 
 template <typename P, typename Acc>
 __device__ __forceinline__ void store_lines16(P *p, const Acc *row, int nl) {
-    if constexpr (sizeof(P) == 4) {
+    if constexpr (sizeof(P) == sizeof(Acc)) {
         using A4 = typename Vec4<Acc>::type;
         if (nl == kLinesPerWG) {
 #pragma unroll
@@ -309,7 +309,7 @@ int launch_line_scans(int K, bool strided, const P *src, P *dst, const LineScanA
         return RF_OK;                                                                                                 \
     }
     static const bool no_short = getenv("RF_LINES_NO_SHORT") != nullptr;          // A/B runs against the walking kernel
-    if (!no_short) {
+    if (!no_short && (sizeof(typename PixelTraits<P>::Acc) == 4 || mt <= 2)) {       // (f64: 32 registers per tile and lane)
         RF_SHORT(1, 1) RF_SHORT(2, 1) RF_SHORT(3, 1) RF_SHORT(1, 2) RF_SHORT(2, 2) RF_SHORT(3, 2) RF_SHORT(1, 4) RF_SHORT(2, 4) RF_SHORT(3, 4)
     }
 #undef RF_SHORT
@@ -327,6 +327,7 @@ int launch_line_scans(int K, bool strided, const P *src, P *dst, const LineScanA
 }
 
 template int launch_line_scans<float>(int, bool, const float *, float *, const LineScanArgs<float> &, hipStream_t);
+template int launch_line_scans<double>(int, bool, const double *, double *, const LineScanArgs<double> &, hipStream_t);
 template int launch_line_scans<int32_t>(int, bool, const int32_t *, int32_t *, const LineScanArgs<uint32_t> &, hipStream_t);
 template int launch_line_scans<int16_t>(int, bool, const int16_t *, int16_t *, const LineScanArgs<uint32_t> &, hipStream_t);
 

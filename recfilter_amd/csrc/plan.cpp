@@ -36,7 +36,6 @@ double cast_coeff(double c, int dtype) {
 // arithmetic, orders <= 3, <= 4 scans per dimension, extents that are multiples of 16 (a lane owns 16 samples; the
 // lines of a strided dimension are moved 16 at a time).
 bool line_scans_applicable(const rf_plan *plan) {
-    if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return false;
     if (plan->shard_world > 1 || plan->scans.empty()) return false;
     if (getenv("RF_NO_LINE_SCANS") != nullptr) return false;          // A/B runs against the one-thread-per-line kernel
     bool strided = false;
@@ -84,7 +83,7 @@ int build_untiled(rf_plan *plan) {
         set_error("the untiled path cannot be sharded across devices");
         return RF_ERR_UNSUPPORTED;
     }
-    if constexpr (sizeof(P) <= 4 && !std::is_same<P, double>::value) {
+    {
         using S = typename std::conditional<PixelTraits<P>::is_integer, uint64_t, double>::type;
         if (line_scans_applicable(plan)) return build_line_scans<P, S>(plan);
     }
@@ -302,7 +301,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         // line-parallel untiled kernels need one launch per filtered dimension (kernels_lines.hip)
         int64_t max_extent = 0;
         for (int d = 0; d < desc->ndim; d++) max_extent = std::max<int64_t>(max_extent, plan->dims[d].N);
-        const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (0 = never; tuning / tests)
+        const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (tuning / tests; 0 = the automatic path never picks the line kernels)
         bool user_tiles = false;
         for (int d = 0; d < desc->ndim; d++) user_tiles = user_tiles || desc->tile[d] > 0;
         if (!user_tiles && world == 1 && max_extent <= small_limit && plan->total * plan->n_planes <= small_limit * small_limit * 4 &&
@@ -312,6 +311,10 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         // a filter split() along two or more dimensions with small tiles: the fully overlapped tiling (two passes over
         // the image instead of two per dimension)
         else if (filtered_dims >= 2 && overlap_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_OVERLAPPED;
+        // what the fused kernels do not take (f64 pixels): the line-parallel untiled kernels beat the per-dimension tiled
+        // passes of the generic path at every size measured (profiles/r2/paths_4096.txt), unless the user tiled the filter
+        else if (!user_tiles && world == 1 && small_limit > 0 && line_scans_applicable(plan.get()))
+            path = RF_PATH_UNTILED;
         else path = RF_PATH_TILED_GENERIC;
     }
     if (path == RF_PATH_TILED_OVERLAPPED && !overlap_plan_applicable(plan.get(), desc, &why)) {

@@ -20,6 +20,13 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_move(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {          // two 32-bit moves (f64 pixels on the line kernels)
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
 // shift towards higher lanes (causal) = row_shr, towards lower lanes (anticausal) = row_shl;
 // lanes without a source inside their 16-lane row receive 0
 template <bool CAUSAL, int D, typename Acc>

@@ -822,7 +822,7 @@ def test_steps_in_flight_keep_their_images_apart():
 
 
 # ---- line-parallel untiled kernels (kernels_lines.hip): RF_PATH_UNTILED, and what RF_PATH_AUTO picks for small images ----
-@pytest.mark.parametrize("dtype", [np.float32, np.int32, np.int16])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int16])
 @pytest.mark.parametrize("shape,clamped", [((512, 512), True), ((64, 64), False), ((192, 320), True), ((1024, 768), False),
                                             ((16, 4096), True), ((48, 32, 80), True), ((2048,), False)])
 def test_line_parallel_untiled_kernels(dtype, shape, clamped):
@@ -853,6 +853,10 @@ def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
         with rfa.Plan((n, n), scans, clamped=True) as plan:
             assert plan.path == want, (n, plan.path_name)
     imgs, outs, (path, _) = _run((512, 512), scans, clamped=True)
+    assert path == 1
+    _check(imgs, outs, scans, True)
+    # f64 pixels (not on the fused kernels): the line kernels at every size, ahead of the per-dimension generic passes
+    imgs, outs, (path, _) = _run((2048, 1536), scans, np.float64, True)
     assert path == 1
     _check(imgs, outs, scans, True)
     # an explicit split() keeps the tiled kernels, and so do pointwise stages (fused into the tiled passes)
