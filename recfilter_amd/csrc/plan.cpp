@@ -304,10 +304,13 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (tuning / tests; 0 = the automatic path never picks the line kernels)
         bool user_tiles = false;
         for (int d = 0; d < desc->ndim; d++) user_tiles = user_tiles || desc->tile[d] > 0;
-        if (!user_tiles && world == 1 && max_extent <= small_limit && plan->total * plan->n_planes <= small_limit * small_limit * 4 &&
+        const bool fused_ok = fused_plan_applicable(plan.get(), desc, &why);
+        // (where the fused kernels apply, split() widths are hints -- the tile size never changes the result -- so a small
+        // split() filter takes the line kernels too: the reference's own sweep, scripts/profile_app.sh, tiles at 32)
+        if (fused_ok && world == 1 && max_extent <= small_limit && plan->total * plan->n_planes <= small_limit * small_limit * 4 &&
             plan->pw.pre == false && plan->pw.post == false && line_scans_applicable(plan.get()))
             path = RF_PATH_UNTILED;
-        else if (fused_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_FUSED;
+        else if (fused_ok) path = RF_PATH_TILED_FUSED;
         // a filter split() along two or more dimensions with small tiles: the fully overlapped tiling (two passes over
         // the image instead of two per dimension)
         else if (filtered_dims >= 2 && overlap_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_OVERLAPPED;
