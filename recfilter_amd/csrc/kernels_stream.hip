@@ -96,8 +96,11 @@ __device__ __forceinline__ int slot_pos(int i, int c) { return c ^ (i & 15) ^ ((
 //       accumulator D[b][i][j] = combined row jr at column 64w + 4b + i lives across the tile's four slots and needs
 //       no reduction at all.
 // NGX / NGY: groups of four tails along x / y (compile time: they size the register arrays); K is a run-time value here
+// Register budget: two 9-wave workgroups per CU need a SIMD with three free slots for the second one; at five waves per
+// SIMD (96 registers) it often finds none and the kernel runs with one workgroup per CU (a build of this kernel at 95
+// registers took 0.27 ms against 0.205 at 68).  Six waves per SIMD (80 registers) keep both resident.
 template <int NGX, int NGY, int SLOTS, int AHEAD>
-__global__ void __launch_bounds__(kStreamThreads, 5)      // two workgroups of 9 waves per CU: at most 96 registers
+__global__ void __launch_bounds__(kStreamThreads, 6)
 stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
                     const float *__restrict__ Hx,     // [vx][s][r][256]
                     const float *__restrict__ Hy,     // [vy][j][r][64]
