@@ -39,7 +39,7 @@ namespace {
 // EDGE: the image has partial tiles (width not a multiple of 256 or height not a multiple of TY); without it the
 // masks below are compile-time constants and the kernel stays lean.
 template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI>
-__global__ void __launch_bounds__(kFusedThreads, EPI ? 2 : 1)
+__global__ void __launch_bounds__(kFusedThreads, (EPI || PixelTraits<P>::is_integer) ? 2 : 1)
 fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
     using A4 = typename Vec4<Acc>::type;
