@@ -15,6 +15,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <functional>
 #include <algorithm>
 #include <cmath>
 #include <ostream>
@@ -176,10 +177,15 @@ class RecFilter {
         rf_plan *plan = nullptr;
         void *stream = nullptr;                  // HIP stream of enqueue() / realize() (set_stream); null = default stream
         std::vector<void *> out;                 // device buffers of the last realization
+        int shard_rank = 0, shard_world = 1;     // shard(): this object describes ONE rank's slab of a larger image
+        std::vector<int64_t> shard_extents;      // ... the slab extents of all ranks (empty: all equal)
+        std::vector<void *> xsend, xgathered;    // exchange buffers of realize_sharded(), one pair per exchange
         std::shared_ptr<std::vector<std::string>> schedule_log = std::make_shared<std::vector<std::string>>();
         ~Contents() {
             if (plan) rf_plan_destroy(plan);
             for (void *p : out) if (p) (void)hipFree(p);
+            for (void *p : xsend) if (p) (void)hipFree(p);
+            for (void *p : xgathered) if (p) (void)hipFree(p);
         }
     };
     std::shared_ptr<Contents> c;
@@ -403,7 +409,8 @@ public:
         d.border = c->clamped ? RF_BORDER_CLAMP : RF_BORDER_ZERO;
         d.n_scans = (int)sd.size(); d.scans = sd.data();
         d.path = c->tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
-        d.device = -1; d.shard_rank = 0; d.shard_world = 1;
+        d.device = -1; d.shard_rank = c->shard_rank; d.shard_world = c->shard_world;
+        d.shard_extents = c->shard_extents.empty() ? nullptr : c->shard_extents.data();
         if (!c->source && !c->inputs.empty() && c->inputs[0].bytes) d.pointwise.in_dtype = RF_IN_U8;
         if (!c->source && !c->inputs.empty() && (c->inputs[0].scale != 1.0f || c->inputs[0].bias != 0.0f)) {
             d.pointwise.flags |= RF_POINTWISE_PRE;
@@ -432,6 +439,73 @@ public:
             for (auto &p : c->out) if (hipMalloc(&p, bytes) != hipSuccess) fail("hipMalloc failed");
         }
         if (rf_plan_execute(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
+    }
+
+    /** Not in the reference (it has no multi-device path): this object filters ONE rank's slab of an image that is
+     *  partitioned along its outermost dimension over `world` GPUs, one process (or thread) per GPU.  The extents of the
+     *  RecFilterDims are the LOCAL slab's; `extents` lists every rank's extent along the outermost dimension when they
+     *  differ (whole tiles; the same list on every rank). */
+    void shard(int rank, int world, std::vector<int64_t> extents = {}) {
+        if (world < 1 || rank < 0 || rank >= world) fail("shard: rank out of range");
+        if (!extents.empty() && (int)extents.size() != world) fail("shard: one extent per rank");
+        c->shard_rank = rank; c->shard_world = world; c->shard_extents = std::move(extents);
+        c->compiled = false;
+    }
+
+    /** `all_gather(send, gathered, bytes_per_rank, stream)`: every rank contributes `bytes_per_rank` device bytes and
+     *  receives all ranks' contributions rank-major, ordered on `stream` (ncclAllGather(send, gathered, bytes, ncclChar,
+     *  comm, (hipStream_t)stream) is exactly that). */
+    using AllGather = std::function<void(const void *send, void *gathered, size_t bytes_per_rank, void *stream)>;
+
+    /** enqueue() for a sharded filter: pass 1 and the slab-local carries, then per exchange (ONE for all scans of the
+     *  sharded dimension up to order 3) the slab's exit carries, the caller's all-gather and the entering carries, then
+     *  the final pass -- rf_plan_begin / exchange_local / exchange_apply / finish (include/recfilter_amd.h).  No
+     *  synchronisation; the output planes are valid once the stream has drained. */
+    RecFilterRealization enqueue_sharded(const AllGather &all_gather) {
+        if (c->source) fail("a cascade cannot be sharded stage by stage: shard the merged filter");
+        if (!c->compiled) compile_jit();
+        std::vector<const void *> in;
+        for (auto &i : c->inputs) in.push_back(i.ptr);
+        const size_t bytes = plane_elems() * dtype_size(dtype());
+        if (c->out.size() != in.size()) {
+            for (void *p : c->out) (void)hipFree(p);
+            c->out.assign(in.size(), nullptr);
+            for (auto &p : c->out) if (hipMalloc(&p, bytes) != hipSuccess) fail("hipMalloc failed");
+        }
+        if (c->shard_world <= 1) {
+            if (rf_plan_execute(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
+        } else {
+            if (rf_plan_begin(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
+            const int nex = rf_plan_num_exchanges(c->plan);
+            if ((int)c->xsend.size() != nex) {
+                for (void *p : c->xsend) (void)hipFree(p);
+                for (void *p : c->xgathered) (void)hipFree(p);
+                c->xsend.assign((size_t)nex, nullptr); c->xgathered.assign((size_t)nex, nullptr);
+                for (int e = 0; e < nex; e++) {
+                    const size_t xb = rf_plan_exchange_bytes(c->plan, e);
+                    if (hipMalloc(&c->xsend[(size_t)e], xb) != hipSuccess ||
+                        hipMalloc(&c->xgathered[(size_t)e], xb * (size_t)c->shard_world) != hipSuccess)
+                        fail("hipMalloc failed");
+                }
+            }
+            for (int e = 0; e < nex; e++) {
+                if (rf_plan_exchange_local(c->plan, e, c->xsend[(size_t)e]) != RF_OK) fail(rf_last_error_string());
+                all_gather(c->xsend[(size_t)e], c->xgathered[(size_t)e], rf_plan_exchange_bytes(c->plan, e), c->stream);
+                if (rf_plan_exchange_apply(c->plan, e, c->xgathered[(size_t)e]) != RF_OK) fail(rf_last_error_string());
+            }
+            if (rf_plan_finish(c->plan) != RF_OK) fail(rf_last_error_string());
+        }
+        RecFilterRealization r;
+        r.planes = c->out; r.dtype = dtype(); r.bytes_per_plane = bytes;
+        for (auto &dm : c->dims) r.extent.push_back(dm.num_pixels());
+        return r;
+    }
+
+    /** realize() for a sharded filter: enqueue_sharded, then this rank's stream is drained */
+    RecFilterRealization realize_sharded(const AllGather &all_gather) {
+        RecFilterRealization r = enqueue_sharded(all_gather);
+        if (hipStreamSynchronize((hipStream_t)c->stream) != hipSuccess) fail("stream synchronisation failed");
+        return r;
     }
 
     /** Not in the reference (Halide owns its streams): the HIP stream this filter's kernels run on (a hipStream_t).  Every

@@ -118,6 +118,11 @@ typedef struct {
     int32_t  shard_rank;
     int32_t  shard_world;
     rf_pointwise_desc pointwise;      /* zeroed = none                                           */
+    /* slabs of different extents: shard_world extents along dimension ndim-1, one per rank, in rank order
+     * (shard_extents[shard_rank] == extent[ndim-1]); NULL = every slab has this rank's extent.  All ranks pass
+     * the same array: the tile width along the sharded dimension is chosen from their common divisor so that
+     * every rank tiles alike. */
+    const int64_t *shard_extents;
 } rf_filter_desc;
 
 typedef struct rf_plan rf_plan;
@@ -168,9 +173,9 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
  *                                                applied here, or by the final pass as it loads a carry (fused 2-D)
  *     rf_plan_finish(...)                        final correction pass
  * `send` and `gathered` are caller-owned device buffers.  With shard_world == 1 the apply step
- * is a no-op and may be skipped.  Every slab must have the same extent along the sharded dimension
- * (a slab's exit carry is propagated across the slabs between it and the receiver with tables built
- * from the local tile count). */
+ * is a no-op and may be skipped.  Slabs may have different extents along the sharded dimension
+ * (rf_filter_desc.shard_extents: a slab's exit carry is propagated across the slabs between it and the
+ * receiver with one transfer table per slab); the exchanged bytes per rank do not depend on them. */
 int rf_plan_num_exchanges(const rf_plan *plan);
 size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange);
 int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream);

@@ -59,7 +59,7 @@ class FilterDesc(ctypes.Structure):
                 ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDesc)),
                 ("tile", ctypes.c_int32 * RF_MAX_DIMS), ("path", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
-                ("pointwise", PointwiseDesc)]
+                ("pointwise", PointwiseDesc), ("shard_extents", ctypes.POINTER(ctypes.c_int64))]
 
 
 class RecFilterError(RuntimeError):

@@ -428,7 +428,7 @@ gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gat
         for (int j = 0; j < RF_MAX_ORDER; j++) nx[j] = Acc(0);
         for (int r = 0; r < k; r++) {
             Acc acc = gathered[h * rank_stride + plane_offset + (int64_t)r * a.g.lines + line];
-            for (int j = 0; j < k; j++) acc = acc + AM[r * k + j] * x[j];
+            for (int j = 0; j < k; j++) acc = acc + AM[(h * k + r) * k + j] * x[j];      // AM[h] = A^(tiles of slab h)
             nx[r] = acc;
         }
         for (int r = 0; r < k; r++) x[r] = nx[r];
@@ -439,7 +439,7 @@ gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gat
 // ---- merged exchange: one all-gather for all scans of the sharded dimension ---------------------------------
 // Every slab has completed its scans with zero entering carries and published the exit carry of each
 // (gathered[h][plane][s][r][line]).  The true exit of slab h for scan s is
-//     E_s[h] = E_s^local[h] + sum_{q <= s} X[type(h)][q][s] * in_q[h]
+//     E_s[h] = E_s^local[h] + sum_{q <= s} X[h][q][s] * in_q[h]
 // (X = the exit-tile rows of the cross-scan transfer Y, plan_generic.h), and in_s of the next slab in scan
 // direction is E_s[h].  One thread per line walks the slabs for every scan in order; the carries entering EVERY
 // slab are kept (the cross terms of later scans need them), n * world * k values in a private array.
@@ -461,12 +461,11 @@ merged_gather_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered, in
             const int h = causal ? i : world - 1 - i;
             for (int j = 0; j < k; j++) in[(s * world + h) * k + j] = prev[j];
             if (i == world - 1) break;        // nobody follows the last slab
-            const int type = (h == 0 ? 1 : 0) | (h == world - 1 ? 2 : 0);
             Acc e[RF_MAX_ORDER];
             for (int r = 0; r < k; r++) {
                 Acc acc = gathered[h * rank_stride + plane_offset + ((int64_t)s * k + r) * L + line];
                 for (int q = 0; q <= s; q++) {
-                    const Acc *Xm = X + (((int64_t)type * n + q) * n + s) * k * k;
+                    const Acc *Xm = X + (((int64_t)h * n + q) * n + s) * k * k;
                     for (int j = 0; j < k; j++) acc = acc + Xm[r * k + j] * in[(q * world + h) * k + j];
                 }
                 e[r] = acc;
@@ -515,14 +514,13 @@ merged_gather_reg_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered
                 if (h < world) {
 #pragma unroll
                     for (int j = 0; j < K; j++) in[s][h][j] = prev[j];
-                    const int type = (h == 0 ? 1 : 0) | (h == world - 1 ? 2 : 0);
                     Acc e[K];
 #pragma unroll
                     for (int r = 0; r < K; r++) {
                         Acc acc = ex[s][h][r];
 #pragma unroll
                         for (int q = 0; q <= s; q++) {
-                            const Acc *Xm = X + (((int64_t)type * NS + q) * NS + s) * K * K;
+                            const Acc *Xm = X + (((int64_t)h * NS + q) * NS + s) * K * K;
 #pragma unroll
                             for (int j = 0; j < K; j++) acc = acc + Xm[r * K + j] * in[q][h][j];
                         }

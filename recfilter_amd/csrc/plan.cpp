@@ -267,6 +267,24 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     if (plan->pw.pre) { plan->pw.pre_s = pwd.pre_scale; plan->pw.pre_b = pwd.pre_bias; }
     if (plan->pw.in_u8) plan->pw.pre = true;        // the conversion is a prologue (scale 1, bias 0 unless given)
     if (plan->pw.post) { plan->pw.post_f = pwd.post_filtered; plan->pw.post_i = pwd.post_input; plan->pw.post_b = pwd.post_bias; }
+    {
+        const int64_t own = desc->extent[desc->ndim - 1];
+        plan->shard_extents.assign((size_t)world, own);
+        if (desc->shard_extents != nullptr && world > 1) {
+            for (int h = 0; h < world; h++) {
+                if (desc->shard_extents[h] < 1) { set_error("shard_extents[%d] must be positive", h); return RF_ERR_INVALID_ARG; }
+                plan->shard_extents[(size_t)h] = desc->shard_extents[h];
+            }
+            if (desc->shard_extents[desc->shard_rank] != own) {
+                set_error("shard_extents[%d] = %lld is not this rank's extent %lld", desc->shard_rank,
+                          (long long)desc->shard_extents[desc->shard_rank], (long long)own);
+                return RF_ERR_INVALID_ARG;
+            }
+        }
+        int64_t g = 0;
+        for (int64_t e : plan->shard_extents) { int64_t a = e, b = g; while (b) { int64_t t = a % b; a = b; b = t; } g = a; }
+        plan->shard_common = g;
+    }
     plan->total = 1;
     for (int d = 0; d < desc->ndim; d++) {
         plan->dims[d].N = desc->extent[d];
@@ -350,6 +368,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         fresh->ndim = plan->ndim; fresh->dtype = plan->dtype; fresh->n_planes = plan->n_planes;
         fresh->clamped = plan->clamped; fresh->device = plan->device; fresh->host_only = plan->host_only;
         fresh->shard_rank = plan->shard_rank; fresh->shard_world = plan->shard_world;
+        fresh->shard_extents = plan->shard_extents; fresh->shard_common = plan->shard_common;
         fresh->scans = plan->scans; fresh->total = plan->total; fresh->pw = plan->pw;
         fresh->pw.pre_fused = fresh->pw.post_fused = false;
         for (int d = 0; d < RF_MAX_DIMS; d++) { fresh->dims[d] = plan->dims[d]; fresh->dims[d].T = 0; fresh->dims[d].M = 0; }

@@ -55,6 +55,12 @@ struct rf_plan {
     int device = 0;
     bool host_only = false;               // tables only, no device memory, cannot execute
     int shard_rank = 0, shard_world = 1;
+    std::vector<int64_t> shard_extents;   // extent of every rank's slab along the outermost dimension (size shard_world)
+    int64_t shard_common = 0;             // their greatest common divisor: what the tile width of that dimension must divide
+    // extent that decides the tile width of dimension d: the slabs' common divisor for the sharded one
+    int64_t tile_basis(int d) const { return (shard_world > 1 && d == ndim - 1) ? shard_common : dims[d].N; }
+    // tiles of slab h along the sharded dimension, given the tile width
+    int64_t slab_tiles(int h, int64_t T) const { return shard_extents[(size_t)h] / T; }
     rf::Pointwise pw;
     std::vector<rf::Scan> scans;          // grouped by dimension, otherwise in call order
     rf::DimInfo dims[RF_MAX_DIMS];

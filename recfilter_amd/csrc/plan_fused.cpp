@@ -53,10 +53,13 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const size_t first_begin_step = plan->begin_steps.size(), first_finish_step = plan->finish_steps.size();
     // tile height: 64 rows unless only 32 divides the height; any other height runs 64-row tiles (32 below 33 rows)
     // with a partial last tile row
-    int TY = (NY % 64 == 0) ? 64 : (NY % 32 == 0 || NY < 32) ? 32 : 64;
+    // (row shards: decided on the slabs' common divisor, so that every rank tiles alike)
+    const bool rows_sharded = plan->ndim == 2 && plan->shard_world > 1;
+    const int64_t NYB = rows_sharded ? plan->shard_common : NY;
+    int TY = (NYB % 64 == 0) ? 64 : (NYB % 32 == 0 || NYB < 32) ? 32 : 64;
     // a small image has too few 256 x 64 tiles to fill 256 CUs: half-height tiles double the workgroups
     // (2048^2: 43.5 -> 40.8 us, 1024^2: 38 -> 34.6 us; at 4096^2, 1024 tiles, the 64-row tiles win again)
-    if (TY == 64 && NY % 32 == 0 && ((NX + kFusedTX - 1) / kFusedTX) * (NY / 64) * NZ <= 384) TY = 32;
+    if (TY == 64 && NY % 32 == 0 && !rows_sharded && ((NX + kFusedTX - 1) / kFusedTX) * (NY / 64) * NZ <= 384) TY = 32;
     if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
         const int want = atoi(env);
         if (want == 32 || want == 64) TY = want;
@@ -189,15 +192,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             for (size_t e = 0; e < H.size(); e++) { hHy[e] = table_to_acc<S, Acc>(H[e]); dH[e] = table_to_double<S>(H[e]); }
             plan->tables["H_y"] = dH;
         }
-        hAMy.assign((size_t)ny * K * K, Acc(0));
+        if (y_sharded) hAMy = slab_powers<S, Acc>(plan, ty.A, TY, K);          // [j][slab][K x K], for the per-scan exchange
         hACy.assign((size_t)ny * K * K, Acc(0));
         for (int j = 0; j < ny; j++) {
-            std::vector<S> am = mat_pow<S>(ty.A[j], MY, K);
             std::vector<S> ac = mat_pow<S>(ty.A[j], Cy, K);
-            for (int e = 0; e < K * K; e++) {
-                hAMy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(am[e]);
-                hACy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(ac[e]);
-            }
+            for (int e = 0; e < K * K; e++) hACy[(size_t)j * K * K + e] = table_to_acc<S, Acc>(ac[e]);
         }
     }
 
@@ -362,7 +361,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         // one all-gather for all y scans (plan_generic.h, "merged exchange")
         // ... whose correction of the tails is left to pass 2 (FusedArgs::y_apply): no launch between gather and pass 2
         static const bool separate_apply = getenv("RF_SHARD_SEPARATE_APPLY") != nullptr;     // A/B runs
-        int rc = add_merged_exchange<S, Acc>(plan, ty, "y", MY, Ly, ymask, gyargs, yin, yin_pp, d_ACy, Cy, "carry_y",
+        int rc = add_merged_exchange<S, Acc>(plan, ty, "y", MY, TY, Ly, ymask, gyargs, yin, yin_pp, d_ACy, Cy, "carry_y",
                                              separate_apply ? nullptr : &d_Yapply);
         if (rc != RF_OK) return rc;
     } else {
@@ -374,7 +373,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             ex.scratch = plan->alloc(ex.bytes, true, &status);
             if (status != RF_OK) return status;
             ex.send = ex.scratch;
-            const Acc *AMj = d_AMy + (size_t)j * K * K;
+            const Acc *AMj = d_AMy + (size_t)j * plan->shard_world * K * K;
             const int64_t rank_stride = (int64_t)np * K * Ly;
             ex.form_incoming = [plan, gyargs, j, rank_stride, plane_stride, AMj](const void *gathered) {
                 for (int pl = 0; pl < plan->n_planes; pl++) {
@@ -447,7 +446,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
     if (plan->dims[0].N % 4 != 0) return no("width must be a multiple of 4 (16-byte rows)");
-    if (plan->ndim == 2 && plan->shard_world > 1 && plan->dims[1].N % 32 != 0)
+    if (plan->ndim == 2 && plan->shard_world > 1 && plan->shard_common % 32 != 0)
         return no("row-sharded slabs must be whole tiles (height a multiple of 32)");
     const int K = fused_order(plan);
     if (K > kFusedMaxK) return no("feedback order above 3");

@@ -153,6 +153,20 @@ std::vector<S> cross_scan_transfer(const DimTables<S> &tab, int64_t M, bool firs
     return Y;
 }
 
+// A_s^(tiles of slab h) for every scan and every slab of the sharded dimension, [s][h][k x k]: what carries the state
+// entering slab h to its exit (per-scan exchange; slabs may have different extents).
+template <typename S, typename Acc>
+std::vector<Acc> slab_powers(const rf_plan *plan, const std::vector<std::vector<S>> &A, int64_t T, int k) {
+    const int n = (int)A.size(), world = plan->shard_world;
+    std::vector<Acc> out((size_t)n * world * k * k, Acc(0));
+    for (int s = 0; s < n; s++)
+        for (int h = 0; h < world; h++) {
+            std::vector<S> am = mat_pow<S>(A[s], plan->slab_tiles(h, T), k);
+            for (int e = 0; e < k * k; e++) out[((size_t)s * world + h) * k * k + e] = table_to_acc<S, Acc>(am[e]);
+        }
+    return out;
+}
+
 inline bool merged_exchange_applies(int n_scans, int k, int world) {
     return world > 1 && n_scans >= 1 && n_scans <= 4 && k >= 1 && k <= 3 && n_scans * world * k <= 128;
 }
@@ -160,29 +174,30 @@ inline bool merged_exchange_applies(int n_scans, int k, int world) {
 // Exchange structure of a sharded dimension with ONE all-gather: the local step completes every scan with zero
 // entering carries and publishes all exit carries ([plane][s][r][line]); the apply step derives every scan's true
 // entering carry from the gathered exits and corrects all tails in one pass.
-// (The slabs must have the same number of tiles: the exit transfers of the other slabs are computed from M.)
+// (T: the tile width, the same on every rank; slab h has plan->slab_tiles(h, T) tiles.)
 template <typename S, typename Acc, typename ArgsFn>
-int add_merged_exchange(rf_plan *plan, const DimTables<S> &tab, const std::string &dn, int64_t M, int64_t lines,
+int add_merged_exchange(rf_plan *plan, const DimTables<S> &tab, const std::string &dn, int64_t M, int64_t T, int64_t lines,
                         uint32_t causal_mask, ArgsFn gargs, Acc *incoming, size_t inc_pp, const Acc *d_AC, int C,
                         const std::string &carry_name, const Acc **apply_in_final_pass = nullptr) {
     int status = RF_OK;
     const int n = tab.n, K = tab.k, kk = K * K, np = plan->n_planes;
     const int world = plan->shard_world, rank = plan->shard_rank;
-    const int own_type = (rank == 0 ? 1 : 0) | (rank == world - 1 ? 2 : 0);
-    std::vector<Acc> hY, hX((size_t)4 * n * n * kk, Acc(0));
+    // X[h]: the exit-tile rows of slab h's transfer (its own tile count and border type); Y: this slab's, every tile
+    std::vector<Acc> hY, hX((size_t)world * n * n * kk, Acc(0));
     std::vector<double> dY, dX(hX.size(), 0.0);
-    for (int type = 0; type < 4; type++) {
-        std::vector<S> Y = cross_scan_transfer<S>(tab, M, (type & 1) != 0, (type & 2) != 0);
+    for (int h = 0; h < world; h++) {
+        const int64_t Mh = plan->slab_tiles(h, T);
+        std::vector<S> Y = cross_scan_transfer<S>(tab, Mh, h == 0, h == world - 1);
         for (int q = 0; q < n; q++)
             for (int s = q; s < n; s++) {
-                const int64_t t_exit = tab.scans[s].causal ? M - 1 : 0;
+                const int64_t t_exit = tab.scans[s].causal ? Mh - 1 : 0;
                 for (int e = 0; e < kk; e++) {
-                    const S v = Y[(((size_t)q * n + s) * M + t_exit) * kk + e];
-                    hX[(((size_t)type * n + q) * n + s) * kk + e] = table_to_acc<S, Acc>(v);
-                    dX[(((size_t)type * n + q) * n + s) * kk + e] = table_to_double<S>(v);
+                    const S v = Y[(((size_t)q * n + s) * Mh + t_exit) * kk + e];
+                    hX[(((size_t)h * n + q) * n + s) * kk + e] = table_to_acc<S, Acc>(v);
+                    dX[(((size_t)h * n + q) * n + s) * kk + e] = table_to_double<S>(v);
                 }
             }
-        if (type == own_type) {
+        if (h == rank) {
             hY.resize(Y.size());
             dY.resize(Y.size());
             for (size_t e = 0; e < Y.size(); e++) { hY[e] = table_to_acc<S, Acc>(Y[e]); dY[e] = table_to_double<S>(Y[e]); }
@@ -256,7 +271,7 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
     const bool first_dim = from_input_flag;
     {
         DimInfo &di = plan->dims[d];
-        int T = pick_generic_tile(di.N, di.k, tile_hint);
+        int T = pick_generic_tile(plan->tile_basis(d), di.k, tile_hint);       // (sharded: every slab must tile alike)
         if (T == 0) {
             set_error("no tile width <= %d divides extent %lld of dimension %d", kGenericMaxTile, (long long)di.N, d);
             return RF_ERR_UNSUPPORTED;
@@ -307,12 +322,11 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
 
         // A^M for the exchange (sharded outermost dimension), A^C for the blocked carry scan
         const int C = carry_chunk_length(di.M, di.lines, k);
-        std::vector<Acc> hAM((size_t)n * k * k, Acc(0)), hAC((size_t)n * k * k, Acc(0));
+        std::vector<Acc> hAM = slab_powers<S, Acc>(plan, tab.A, T, k), hAC((size_t)n * k * k, Acc(0));
         uint32_t causal_mask = 0;
         for (int s = 0; s < n; s++) {
-            std::vector<S> am = mat_pow<S>(tab.A[s], di.M, k), ac = mat_pow<S>(tab.A[s], C, k);
+            std::vector<S> ac = mat_pow<S>(tab.A[s], C, k);
             for (int e = 0; e < k * k; e++) {
-                hAM[(size_t)s * k * k + e] = table_to_acc<S, Acc>(am[e]);
                 hAC[(size_t)s * k * k + e] = table_to_acc<S, Acc>(ac[e]);
             }
             if (ts[s].causal) causal_mask |= 1u << s;
@@ -362,7 +376,7 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
 
         const bool merged = is_exchange_dim && merged_exchange_applies(n, k, plan->shard_world);
         if (merged) {
-            int rc = add_merged_exchange<S, Acc>(plan, tab, dn, di.M, di.lines, causal_mask, args_for, incoming, inc_per_plane,
+            int rc = add_merged_exchange<S, Acc>(plan, tab, dn, di.M, T, di.lines, causal_mask, args_for, incoming, inc_per_plane,
                                                  dACp, C, "generic_carry_" + dn);
             if (rc != RF_OK) return rc;
         }
@@ -375,7 +389,7 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
                 ex.scratch = plan->alloc(ex.bytes, true, &status);
                 if (status != RF_OK) return status;
                 ex.send = ex.scratch;
-                const Acc *AMs = dAMp + (size_t)s * k * k;
+                const Acc *AMs = dAMp + (size_t)s * plan->shard_world * k * k;      // [slab][k x k]
                 int64_t rank_stride = (int64_t)plan->n_planes * k * di.lines;
                 int64_t plane_stride = (int64_t)k * di.lines;
                 ex.form_incoming = [plan, args_for, s, rank_stride, plane_stride, AMs](const void *gathered) {

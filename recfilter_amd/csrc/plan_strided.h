@@ -15,8 +15,9 @@ inline int strided_tile(const rf_plan *plan, int d) {
     const DimInfo &di = plan->dims[d];
     if (di.scan_ids.empty() || di.k > kFusedMaxK || (int)di.scan_ids.size() > kFusedMaxScans) return 0;
     if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return 0;
-    if (di.N % 64 == 0) return 64;
-    if (di.N % 32 == 0) return 32;
+    const int64_t basis = plan->tile_basis(d);       // sharded dimension: every rank's slab must tile alike
+    if (basis % 64 == 0) return 64;
+    if (basis % 32 == 0) return 32;
     return 0;
 }
 
@@ -65,12 +66,11 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
                     dW[idx] = table_to_double<S>(tab.Wm(v, q, s)[e]);
                 }
     for (int s = 0; s < n; s++) {
-        std::vector<S> ac = mat_pow<S>(tab.A[s], C, K), am = mat_pow<S>(tab.A[s], M, K);
+        std::vector<S> ac = mat_pow<S>(tab.A[s], C, K);
         for (int e = 0; e < K * K; e++) {
             hA[(size_t)s * K * K + e] = table_to_acc<S, Acc>(tab.A[s][e]);
             dA[(size_t)s * K * K + e] = table_to_double<S>(tab.A[s][e]);
             hAC[(size_t)s * K * K + e] = table_to_acc<S, Acc>(ac[e]);
-            hAM[(size_t)s * K * K + e] = table_to_acc<S, Acc>(am[e]);
         }
     }
     plan->tables["W_" + dn] = dW;
@@ -80,6 +80,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     const Acc *d_W = (const Acc *)plan->upload(hW.data(), hW.size() * sizeof(Acc), &status);
     const Acc *d_A = (const Acc *)plan->upload(hA.data(), hA.size() * sizeof(Acc), &status);
     const Acc *d_AC = (const Acc *)plan->upload(hAC.data(), hAC.size() * sizeof(Acc), &status);
+    hAM = slab_powers<S, Acc>(plan, tab.A, TZ, K);                 // [s][slab][K x K]
     const Acc *d_AM = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
     const Acc *d_Apow = nullptr;
     if (sharded) {
@@ -129,7 +130,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
         };
         plan->begin_steps.push_back(cs);
     } else if (merged_exchange_applies(n, K, plan->shard_world)) {
-        int rc = add_merged_exchange<S, Acc>(plan, tab, dn, M, di.lines, mask, gargs, incoming, inc_pp, d_AC, C, "carry_" + dn);
+        int rc = add_merged_exchange<S, Acc>(plan, tab, dn, M, TZ, di.lines, mask, gargs, incoming, inc_pp, d_AC, C, "carry_" + dn);
         if (rc != RF_OK) return rc;
     } else {
         for (int s = 0; s < n; s++) {
@@ -140,7 +141,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
             ex.scratch = plan->alloc(ex.bytes, true, &status);
             if (status != RF_OK) return status;
             ex.send = ex.scratch;
-            const Acc *AMs = d_AM + (size_t)s * K * K;
+            const Acc *AMs = d_AM + (size_t)s * plan->shard_world * K * K;
             ex.form_incoming = [plan, gargs, s, rank_stride, plane_stride, AMs](const void *gathered) {
                 for (int pl = 0; pl < plan->n_planes; pl++) {
                     int rc = launch_gather_incoming<Acc>(gargs(pl), s, (const Acc *)gathered, rank_stride, pl * plane_stride,

@@ -6,9 +6,10 @@ along the sharded dimension the only cross-GPU dependency is the k-row carry at 
 boundary; because the carry recurrence is linear with known k x k matrices per slab, each rank
 publishes the exit carries of its slab computed with zero incoming carries and ONE all-gather
 (for all scans of the dimension together; one per scan for orders > 3 or more than 4 scans) lets
-every rank form its true incoming carries locally.  Slabs must have
-equal extents.  The reference has no multi-device path; this is the MI355X-native addition
-BASELINE.json asks for.
+every rank form its true incoming carries locally.  Slabs may have
+different extents (`slab_extents`, the same list on every rank; `split_extent` makes one of whole
+tiles): the bytes a rank exchanges do not depend on them.  The reference has no multi-device path;
+this is the MI355X-native addition BASELINE.json asks for.
 
 The driver is backend-agnostic: `engine` is anything with the stepping API of
 recfilter_amd.Plan (begin / num_exchanges / exchange_bytes / exchange_local / exchange_apply /
@@ -25,6 +26,16 @@ from . import capi
 from .plan import Plan
 
 
+def split_extent(extent: int, world: int, granule: int = 64) -> list:
+    """Slab extents for `world` ranks along a sharded dimension of `extent` samples: whole granules (tiles), as even
+    as they come -- the first extent/granule % world ranks get one granule more.  `extent` must be a multiple of
+    `granule` and hold at least one granule per rank."""
+    if extent % granule or extent // granule < world:
+        raise ValueError(f"cannot split {extent} into {world} slabs of whole {granule}-sample tiles")
+    g, extra = divmod(extent // granule, world)
+    return [(g + (1 if r < extra else 0)) * granule for r in range(world)]
+
+
 class ShardedFilter:
     """`inflight` > 1 keeps that many executions in flight, each on its own HIP stream with its own plan (workspace)
     and exchange buffers: the latency-bound carry kernels and the all-gather of one execution then run beside the
@@ -33,7 +44,7 @@ class ShardedFilter:
 
     def __init__(self, local_shape: Sequence[int], scans, clamped: bool = False, planes: int = 1,
                  rank: int = 0, world: int = 1, path: int = capi.RF_PATH_AUTO, dtype=np.float32,
-                 tile=None, group=None, engine=None, inflight: int = 1):
+                 tile=None, group=None, engine=None, inflight: int = 1, slab_extents: Optional[Sequence[int]] = None):
         self.rank, self.world, self.group = int(rank), int(world), group
         self.inflight = max(1, int(inflight))
         if engine is not None and self.inflight > 1:
@@ -41,7 +52,7 @@ class ShardedFilter:
 
         def make():
             return Plan(local_shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path,
-                        shard_rank=rank, shard_world=world)
+                        shard_rank=rank, shard_world=world, shard_extents=slab_extents)
         self.plans = [engine if engine is not None else make()]
         self.plans += [make() for _ in range(self.inflight - 1)]
         self.plan = self.plans[0]

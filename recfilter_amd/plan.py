@@ -40,7 +40,7 @@ class Plan:
 
     def __init__(self, shape: Sequence[int], scans: Sequence[Scan], dtype=np.float32, clamped: bool = False,
                  planes: int = 1, tile: Optional[Sequence[int]] = None, path: int = capi.RF_PATH_AUTO,
-                 device: int = -1, shard_rank: int = 0, shard_world: int = 1,
+                 device: int = -1, shard_rank: int = 0, shard_world: int = 1, shard_extents: Optional[Sequence[int]] = None,
                  prologue: Optional[Tuple[float, float]] = None,
                  epilogue: Optional[Tuple[float, float, float]] = None, input_dtype=None):
         """prologue = (scale, bias): x' = scale*in + bias before the first scan;
@@ -82,6 +82,12 @@ class Plan:
         d.path = int(path)
         d.device = int(device)
         d.shard_rank, d.shard_world = int(shard_rank), int(shard_world)
+        if shard_extents is not None:
+            # rf_filter_desc.shard_extents: the extent of every rank's slab along the outermost dimension
+            if len(shard_extents) != int(shard_world):
+                raise ValueError("shard_extents needs one extent per rank")
+            self._shard_extents = (ctypes.c_int64 * int(shard_world))(*[int(e) for e in shard_extents])
+            d.shard_extents = ctypes.cast(self._shard_extents, ctypes.POINTER(ctypes.c_int64))
         if prologue is not None:
             d.pointwise.flags |= capi.RF_POINTWISE_PRE
             d.pointwise.pre_scale, d.pointwise.pre_bias = float(prologue[0]), float(prologue[1])

@@ -7,7 +7,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "recfilter.hpp"
@@ -312,6 +315,77 @@ int main() {
         }
         filters.clear();
         for (int i = 0; i < 2; i++) (void)hipStreamDestroy(st[i]);
+    }
+    {   // sharded realization from C++ (no counterpart in the reference): three ranks as three threads on this one device,
+        // row slabs of different heights, the all-gather emulated with device copies between two thread barriers.  With
+        // RCCL the callback is ncclAllGather(send, gathered, bytes, ncclChar, comm, (hipStream_t)stream).
+        const int width = 512, world = 3;
+        const std::vector<int64_t> extents = {128, 64, 192};
+        const int height = 128 + 64 + 192;
+        std::vector<float> image = random_image((size_t)width * height, 11);
+        const std::vector<float> W = {0.30f, 0.90f, -0.25f};
+        struct Barrier {
+            std::mutex m; std::condition_variable cv; int count = 0, generation = 0, n;
+            explicit Barrier(int n_) : n(n_) {}
+            void wait() {
+                std::unique_lock<std::mutex> lk(m);
+                const int g = generation;
+                if (++count == n) { count = 0; generation++; cv.notify_all(); }
+                else cv.wait(lk, [&] { return g != generation; });
+            }
+        } barrier(world);
+        std::vector<const void *> sends(world, nullptr);
+        std::vector<std::vector<float>> outs(world);
+        std::vector<std::string> errors(world);
+        std::vector<int> exchanges(world, -1);
+        auto rank_main = [&](int rank) {
+            try {
+                hipStream_t st;
+                if (hipStreamCreate(&st) != hipSuccess) throw RecFilterError("hipStreamCreate failed");
+                int64_t lo = 0;
+                for (int r = 0; r < rank; r++) lo += extents[r];
+                std::vector<float> slab(image.begin() + lo * width, image.begin() + (lo + extents[rank]) * width);
+                float *d = upload(slab);
+                RecFilterDim x("x", width), y("y", (int)extents[rank]);
+                RecFilter F;
+                F(x, y) = RecFilterImage(d);
+                F.add_filter(+x, W); F.add_filter(-x, W); F.add_filter(+y, W); F.add_filter(-y, W);
+                F.split_all_dimensions(32);
+                F.shard(rank, world, extents);
+                F.set_stream(st);
+                int n_calls = 0;
+                RecFilter::AllGather gather = [&](const void *send, void *gathered, size_t bytes, void *stream) {
+                    n_calls++;
+                    sends[rank] = send;
+                    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) throw RecFilterError("sync failed");
+                    barrier.wait();                         // every rank's exit carries are written
+                    for (int r = 0; r < world; r++)
+                        if (hipMemcpyAsync((char *)gathered + (size_t)r * bytes, sends[r], bytes, hipMemcpyDeviceToDevice,
+                                           (hipStream_t)stream) != hipSuccess) throw RecFilterError("copy failed");
+                    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) throw RecFilterError("sync failed");
+                    barrier.wait();                         // ... and read by everybody
+                };
+                outs[rank] = F.realize_sharded(gather).to_host<float>();
+                exchanges[rank] = n_calls;
+                (void)hipFree(d);
+                (void)hipStreamDestroy(st);
+            } catch (const std::exception &e) { errors[rank] = e.what(); }
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < world; r++) threads.emplace_back(rank_main, r);
+        for (auto &t : threads) t.join();
+        bool ok = true;
+        for (int r = 0; r < world; r++)
+            if (!errors[r].empty()) { std::fprintf(stderr, "rank %d: %s\n", r, errors[r].c_str()); ok = false; }
+        if (!ok) { failures++; std::printf("%-34s FAILED (exception)\n", "sharded realization, 3 ranks"); }
+        else {
+            std::vector<float> ref = image, got;
+            loop_scan(ref, width, height, 1, 0, true, W); loop_scan(ref, width, height, 1, 0, false, W);
+            loop_scan(ref, width, height, 1, 1, true, W); loop_scan(ref, width, height, 1, 1, false, W);
+            for (int r = 0; r < world; r++) got.insert(got.end(), outs[r].begin(), outs[r].end());
+            report("sharded realization, 3 ranks", rel_err(ref, got));
+            if (exchanges[0] != 1) { failures++; std::printf("expected ONE all-gather per execution, saw %d\n", exchanges[0]); }
+        }
     }
     std::printf("%s\n", failures ? "SOME TESTS FAILED" : "all front-end tests passed");
     return failures ? 1 : 0;

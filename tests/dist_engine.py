@@ -25,7 +25,7 @@ def _view(ptr: int, n: int) -> np.ndarray:
 
 
 class NumpySlabEngine:
-    def __init__(self, local_shape, scans, clamped, planes, rank, world, tile=None):
+    def __init__(self, local_shape, scans, clamped, planes, rank, world, tile=None, slab_extents=None):
         self.shape, self.scans, self.clamped = tuple(local_shape), list(scans), clamped
         self.planes, self.rank, self.world = planes, rank, world
         nd = len(self.shape)
@@ -33,7 +33,8 @@ class NumpySlabEngine:
             tile = [0] * nd
         self.plan = rfa.Plan(self.shape, scans, dtype=np.float64, clamped=clamped, planes=planes, tile=tile,
                              path=capi.RF_PATH_TILED_GENERIC, device=capi.RF_DEVICE_HOST_ONLY,
-                             shard_rank=rank, shard_world=world)
+                             shard_rank=rank, shard_world=world, shard_extents=slab_extents)
+        self.slab_extents = list(slab_extents) if slab_extents is not None else [self.shape[0]] * world
         self.tiles = self.plan.tiles
         self.outer = nd - 1
         self.outer_scans = [(bool(c), [float(np.float32(v)) for v in co]) for d, c, co in scans if d == self.outer]
@@ -53,7 +54,7 @@ class NumpySlabEngine:
             try:
                 name = "xyz"[self.outer]
                 self.Y = self.plan.table("Y_" + name).reshape(self.n, self.n, self.M, self.k, self.k)
-                self.X = self.plan.table("X_" + name).reshape(4, self.n, self.n, self.k, self.k)
+                self.X = self.plan.table("X_" + name).reshape(world, self.n, self.n, self.k, self.k)      # one per slab
                 self.merged = True
             except Exception:
                 self.merged = False
@@ -175,10 +176,9 @@ class NumpySlabEngine:
                     ins[s, h] = prev
                     if i == W - 1:
                         break
-                    typ = (1 if h == 0 else 0) | (2 if h == W - 1 else 0)
                     e = gathered[h, pl, s].copy()
                     for q in range(s + 1):
-                        e += self.X[typ, q, s] @ ins[q, h]
+                        e += self.X[h, q, s] @ ins[q, h]
                     prev = e
                 for j in range(k):
                     self.incoming[pl][s][j] = ins[s, self.rank, j].copy()
@@ -194,13 +194,13 @@ class NumpySlabEngine:
         gathered = _view(gathered_ptr, self.world * self.planes * k * self.lines).reshape(
             self.world, self.planes, k, self.lines).astype(np.float64)
         causal = self.outer_scans[s][0]
-        AM = np.linalg.matrix_power(self.A[s], M)
+        AM = [np.linalg.matrix_power(self.A[s], e // self.T) for e in self.slab_extents]      # per slab
         for pl in range(self.planes):
             x = np.zeros((k, self.lines))
             count = self.rank if causal else self.world - 1 - self.rank
             for i in range(count):
                 h = i if causal else self.world - 1 - i
-                x = gathered[h, pl] + AM @ x
+                x = gathered[h, pl] + AM[h] @ x
             for j in range(k):
                 self.incoming[pl][s][j] = x[j].copy()
             for i in range(M):

@@ -36,21 +36,28 @@ def _worker(rank, world, port, case, result_dir):
     try:
         shape, scans, clamped, planes, tile = case["shape"], case["scans"], case["clamped"], case["planes"], case["tile"]
         full = [rc.random_image(shape, np.float32, 77 + p) for p in range(planes)]
-        n = shape[0] // world
+        extents = case.get("extents")              # slabs of different extents (rf_filter_desc.shard_extents)
+        if extents is None:
+            extents = [shape[0] // world] * world
+        lo = sum(extents[:rank])
+        n = extents[rank]
         local_shape = (n,) + tuple(shape[1:])
-        inputs = [torch.from_numpy(np.ascontiguousarray(f[rank * n:(rank + 1) * n])) for f in full]
+        inputs = [torch.from_numpy(np.ascontiguousarray(f[lo:lo + n])) for f in full]
         outputs = [torch.empty_like(t) for t in inputs]
-        engine = NumpySlabEngine(local_shape, scans, clamped, planes, rank, world, tile=tile)
+        engine = NumpySlabEngine(local_shape, scans, clamped, planes, rank, world, tile=tile,
+                                 slab_extents=extents if case.get("extents") else None)
         filt = ShardedFilter(local_shape, scans, clamped=clamped, planes=planes, rank=rank, world=world, engine=engine)
         filt.execute(inputs, outputs)
         filt.execute(inputs, outputs)          # a second execute reuses the exchange buffers
         for p in range(planes):
-            want = oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[rank * n:(rank + 1) * n]
+            want = oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[lo:lo + n]
             err = rc.rel_err(outputs[p].numpy(), want)
             assert err < 1e-5, f"rank {rank} plane {p}: rel err {err}"
         n_outer = sum(1 for s in scans if s[0] == len(shape) - 1)
         assert engine.num_exchanges == (1 if engine.merged else n_outer)
         assert engine.merged == (world > 1 and 1 <= n_outer <= 4)       # every case here has order <= 3
+        if case.get("extents"):
+            assert engine.tiles[len(shape) - 1] == case["tile"][len(shape) - 1]     # every rank tiles alike
         open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -86,6 +93,43 @@ def test_sharded_filter_over_gloo(name, world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+UNEQUAL = {       # name -> (base case, {world: slab extents}): whole tiles, different counts per rank
+    "gauss2_xy_clamped": {2: [32, 16], 3: [24, 8, 16], 4: [8, 16, 8, 16]},
+    "generic_xyz": {2: [16, 8], 3: [4, 12, 8], 4: [4, 8, 4, 8]},
+    "y_only_mixed": {2: [24, 12], 3: [6, 18, 12], 4: [6, 12, 6, 12]},
+    "y_five_scans": {2: [24, 12], 3: [6, 18, 12]},          # more than four scans: one exchange per scan, A^(tiles of a slab)
+}
+
+
+@pytest.mark.parametrize("name,world", [(n, w) for n in sorted(UNEQUAL) for w in sorted(UNEQUAL[n])])
+def test_sharded_filter_unequal_slabs_over_gloo(name, world, tmp_path):
+    """Slabs of different extents (rf_filter_desc.shard_extents): the tile width comes from their common divisor, the
+    exit transfer of every slab from its own tile count."""
+    import torch.multiprocessing as mp
+    if name == "y_five_scans":
+        case = dict(shape=(36, 16), planes=1, clamped=True, tile=[0, 6])
+        case["scans"] = [(1, bool(i % 2), [0.5, 0.4 - 0.05 * i]) for i in range(5)]
+    else:
+        case = dict(CASES[name])
+        case["scans"] = _scans(name)
+    case["extents"] = UNEQUAL[name][world]
+    assert sum(case["extents"]) == case["shape"][0]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_split_extent_whole_tiles():
+    from recfilter_amd.dist import split_extent
+    assert split_extent(16384, 8) == [2048] * 8
+    assert split_extent(64 * 11, 4) == [192, 192, 192, 128]
+    assert split_extent(96, 3, granule=32) == [32, 32, 32]
+    with pytest.raises(ValueError):
+        split_extent(100, 2)
+    with pytest.raises(ValueError):
+        split_extent(64, 2)
 
 
 def test_single_rank_driver_is_plain_execute(tmp_path):

@@ -291,18 +291,20 @@ def test_fused_matches_untiled_gpu_at_full_size_properties():
 
 
 # ---- sharded execution (stepping API of the C ABI), all "ranks" emulated on the one GPU of the test box ----
-def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32):
+def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32, extents=None, tile=None):
     import torch
     import recfilter_amd as rfa
     if np.issubdtype(dtype, np.integer):
         full = [np.random.default_rng(31 + p).integers(0, 4, size=shape).astype(dtype) for p in range(planes)]
     else:
         full = [rc.random_image(shape, np.float32, 31 + p) for p in range(planes)]
-    n = shape[0] // world
-    local = (n,) + tuple(shape[1:])
-    plans = [rfa.Plan(local, scans, dtype=dtype, clamped=clamped, planes=planes, path=path, shard_rank=r, shard_world=world)
+    ext = list(extents) if extents is not None else [shape[0] // world] * world      # slab extents along the sharded dimension
+    assert sum(ext) == shape[0] and len(ext) == world
+    lo = [sum(ext[:r]) for r in range(world)]
+    plans = [rfa.Plan((ext[r],) + tuple(shape[1:]), scans, dtype=dtype, clamped=clamped, planes=planes, path=path, tile=tile,
+                      shard_rank=r, shard_world=world, shard_extents=extents)
              for r in range(world)]
-    ins = [[torch.from_numpy(np.ascontiguousarray(f[r * n:(r + 1) * n])).cuda() for f in full] for r in range(world)]
+    ins = [[torch.from_numpy(np.ascontiguousarray(f[lo[r]:lo[r] + ext[r]])).cuda() for f in full] for r in range(world)]
     outs = [[torch.empty_like(t) for t in ins[r]] for r in range(world)]
     for r in range(world):
         plans[r].begin(ins[r], outs[r])
@@ -331,6 +333,47 @@ def test_sharded_fused_2d_rows(world):
     full, got, (path, nex) = _run_sharded((64 * 2 * world, 512), scans, True, world, path=0, planes=2)
     assert path == 3 and nex == 1
     _check(full, got, scans, True)
+
+
+@pytest.mark.parametrize("extents", [[128, 64], [64, 192, 128], [64, 128, 64, 192, 64], [96, 32, 64]])
+def test_sharded_fused_2d_rows_unequal_slabs(extents):
+    """Row slabs of different heights (rf_filter_desc.shard_extents): the tile height comes from the slabs' common divisor
+    (32 rows for the last case), every slab's exit transfer from its own tile count; still ONE exchange, applied by pass 2."""
+    scans = rc.xy_pm(rc.GAUSS2)
+    ints = [(0, True, [1.0, 2.0, -1.0]), (1, True, [1.0, 2.0, -1.0]), (1, False, [1.0, 1.0])]      # bit-exact in the int32 ring
+    for dtype, sc, clamped in ((np.float32, scans, True), (np.int32, ints, False)):
+        full, got, (path, nex) = _run_sharded((sum(extents), 512), sc, clamped, len(extents), path=0, planes=2, dtype=dtype,
+                                              extents=extents)
+        assert path == 3 and nex == 1
+        _check(full, got, sc, clamped)
+
+
+def test_sharded_unequal_slabs_other_paths():
+    """Unequal slabs on the strided z stage (merged exchange + merged_apply), on the generic path with one exchange per
+    scan (five scans along y: A^(tiles of a slab) per slab) and with the merged exchange of the generic path."""
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    full, got, (path, nex) = _run_sharded((64 + 128 + 64, 32, 256), scans, False, 3, path=0, extents=[64, 128, 64])
+    assert path == 3 and nex == 1
+    _check(full, got, scans, False)
+    five = [(1, bool(i % 2), [0.5, 0.4 - 0.05 * i]) for i in range(5)] + [(0, True, [0.7, 0.3])]
+    full, got, (path, nex) = _run_sharded((24 + 8 + 16, 40), five, True, 3, path=2, extents=[24, 8, 16], tile=[8, 8])
+    assert path == 2 and nex == 5
+    _check(full, got, five, True)
+    three = rc.xy_pm(rc.GAUSS2)
+    full, got, (path, nex) = _run_sharded((24 + 8 + 16, 40), three, True, 3, path=2, extents=[24, 8, 16], tile=[8, 8])
+    assert path == 2 and nex == 1
+    _check(full, got, three, True)
+
+
+def test_shard_extents_are_validated():
+    import recfilter_amd as rfa
+    scans = rc.xy_pm(rc.GAUSS2)
+    with pytest.raises(rfa.RecFilterError):          # this rank's entry is not its extent
+        rfa.Plan((128, 512), scans, clamped=True, shard_rank=0, shard_world=2, shard_extents=[64, 128])
+    with pytest.raises(rfa.RecFilterError):
+        rfa.Plan((128, 512), scans, clamped=True, shard_rank=0, shard_world=2, shard_extents=[128, 0])
+    with pytest.raises(ValueError):
+        rfa.Plan((128, 512), scans, clamped=True, shard_rank=0, shard_world=2, shard_extents=[128])
 
 
 @pytest.mark.parametrize("world", [2, 4])
