@@ -320,12 +320,17 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         int64_t max_extent = 0;
         for (int d = 0; d < desc->ndim; d++) max_extent = std::max<int64_t>(max_extent, plan->dims[d].N);
         const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (tuning / tests; 0 = the automatic path never picks the line kernels)
+        // ... up to 1792 for order-3 filters with four or more scans, whose five tiled launches are the heaviest (C++ caller,
+        // gaussian_3xy: 1152^2 47 -> 33 us, 1536^2 50 -> 45 us, even at 2048^2; order 1 and 2 cross over at 1024..1152)
+        int max_order = 0;
+        for (const Scan &sc : plan->scans) max_order = std::max(max_order, sc.order);
+        const int64_t long_limit = (small_limit == 1024 && max_order >= 3 && plan->scans.size() >= 4) ? 1792 : small_limit;
         bool user_tiles = false;
         for (int d = 0; d < desc->ndim; d++) user_tiles = user_tiles || desc->tile[d] > 0;
         const bool fused_ok = fused_plan_applicable(plan.get(), desc, &why);
         // (where the fused kernels apply, split() widths are hints -- the tile size never changes the result -- so a small
         // split() filter takes the line kernels too: the reference's own sweep, scripts/profile_app.sh, tiles at 32)
-        if (fused_ok && world == 1 && max_extent <= small_limit && plan->total * plan->n_planes <= small_limit * small_limit * 4 &&
+        if (fused_ok && world == 1 && max_extent <= long_limit && plan->total * plan->n_planes <= long_limit * long_limit * 4 &&
             plan->pw.pre == false && plan->pw.post == false && line_scans_applicable(plan.get()))
             path = RF_PATH_UNTILED;
         else if (fused_ok) path = RF_PATH_TILED_FUSED;

@@ -867,7 +867,8 @@ def test_steps_in_flight_keep_their_images_apart():
 # ---- line-parallel untiled kernels (kernels_lines.hip): RF_PATH_UNTILED, and what RF_PATH_AUTO picks for small images ----
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int16])
 @pytest.mark.parametrize("shape,clamped", [((512, 512), True), ((64, 64), False), ((192, 320), True), ((1024, 768), False),
-                                            ((16, 4096), True), ((48, 32, 80), True), ((2048,), False)])
+                                            ((16, 4096), True), ((48, 32, 80), True), ((2048,), False),
+                                            ((1296, 1808), True), ((2048, 1040), False)])      # lines of 1025..2048 samples: eight tiles in registers
 def test_line_parallel_untiled_kernels(dtype, shape, clamped):
     """Every scan walks the whole line (no tiling algebra at all): the x phase's 16-lane segment scan, tile after tile,
     the state handed on in registers.  Widths / heights that are multiples of 16 only (partial last tiles), 1-D, 3-D."""
@@ -892,8 +893,11 @@ def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
     import recfilter_amd as rfa
     monkeypatch.delenv("RF_SMALL_LIMIT", raising=False)          # (tests/conftest.py switches the choice off for the suite)
     scans = rc.xy_pm(rc.GAUSS2)
-    for n, want in ((256, 1), (1024, 1), (2048, 3)):
+    for n, want in ((256, 1), (1024, 1), (1536, 3), (2048, 3)):
         with rfa.Plan((n, n), scans, clamped=True) as plan:
+            assert plan.path == want, (n, plan.path_name)
+    for n, want in ((1024, 1), (1536, 1), (1792, 1), (2048, 3)):        # order 3, four scans: the line kernels up to 1792
+        with rfa.Plan((n, n), rc.xy_pm(rc.GAUSS3), clamped=True) as plan:
             assert plan.path == want, (n, plan.path_name)
     imgs, outs, (path, _) = _run((512, 512), scans, clamped=True)
     assert path == 1
