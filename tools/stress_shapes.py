@@ -11,7 +11,7 @@ import ref_cases as rc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] == "overlap" else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), 4 * int(rng.integers(1, 2400)))
@@ -43,3 +43,39 @@ for case in range(n_cases):
         print(f"{case:3d} {pf.path_name:13s} {str(shape):22s} scans={len(scans)} clamped={int(clamped)} {str(dtype)[6:]:8s} err={err:.3e}",
               "" if err < (1 if dtype == torch.int32 else 2e-4) else "  <-- CHECK", flush=True)
 print("worst", worst)
+
+# ---- the fully overlapped tiling (path 4) on random small shapes / tiles / pixel types against the untiled path ----
+if len(sys.argv) > 3 and sys.argv[3] == "overlap":
+    worst = 0.0
+    for case in range(n_cases):
+        ndim = 2 if case % 3 else 3
+        tiles = [int(rng.choice([4, 8, 16, 32])) for _ in range(ndim)]
+        while np.prod(tiles) > 4096:
+            tiles[int(rng.integers(0, ndim))] //= 2
+        shape = tuple(int(t * rng.integers(1, 9)) for t in reversed(tiles))          # numpy order: outermost first
+        scans = []
+        for d in range(ndim):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(1, min(5, tiles[d]) + 1))
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        npdt = [np.float32, np.float64, np.int32][case % 3]
+        if npdt == np.int32:
+            scans = [(d, c, [float(int(rng.integers(1, 3)))] + [float(int(rng.integers(-2, 3))) for _ in co[1:]]) for d, c, co in scans]
+            img = torch.randint(0, 16, shape, dtype=torch.int32, device="cuda")
+        else:
+            img = torch.rand(shape, device="cuda", dtype=torch.float64 if npdt == np.float64 else torch.float32)
+        with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=4, tile=tiles) as po, \
+                rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1) as pu:
+            oo, ou = po.execute([img])[0], pu.execute([img])[0]
+            torch.cuda.synchronize()
+            if npdt == np.int32:
+                err = float((oo != ou).sum().item())
+            else:
+                peak = float(ou.abs().max().item())
+                err = float(((oo - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
+            worst = max(worst, err)
+            print(f"{case:3d} {po.path_name:16s} {str(shape):18s} tiles={tiles} scans={len(scans)} clamped={int(clamped)} {np.dtype(npdt).name:8s} err={err:.3e}",
+                  "" if err < (1 if npdt == np.int32 else 2e-4) else "  <-- CHECK", flush=True)
+    print("worst (overlapped)", worst)
