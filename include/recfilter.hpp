@@ -606,3 +606,18 @@ inline int gaussian_box_filter(int k, float sigma) {
     if (rf_gaussian_box_filter(k, sigma, &w) != RF_OK) throw RecFilterError(rf_last_error_string());
     return w;
 }
+
+/** The pointwise-with-offsets Funcs the reference's apps define on top of a filter's result (Halide expressions there):
+ *  box_difference -- apps/box/box_filter.h:36-39, 128-139; tap_filter -- any clamped tap combination, e.g. diff_op_x /
+ *  diff_op_y / diff_op_xy of apps/DoG/diff_gauss.cpp:176-197.  Device planes in, device plane out, on `stream`. */
+inline void box_difference(const RecFilterRealization &table, int plane, void *out, int radius, std::vector<int32_t> order,
+                           void *stream = nullptr) {
+    order.resize(table.extent.size(), 0);
+    if (rf_box_difference(table.planes.at((size_t)plane), out, (int)table.extent.size(), table.extent.data(), table.dtype, radius,
+                          order.data(), stream) != RF_OK) throw RecFilterError(rf_last_error_string());
+}
+inline void tap_filter(const std::vector<const void *> &in_planes, void *out, const std::vector<int64_t> &extent, int dtype,
+                       const std::vector<rf_tap> &taps, void *stream = nullptr) {
+    if (rf_tap_filter(in_planes.data(), (int)in_planes.size(), out, (int)extent.size(), extent.data(), dtype, taps.data(),
+                      (int)taps.size(), stream) != RF_OK) throw RecFilterError(rf_last_error_string());
+}

@@ -208,6 +208,21 @@ int rf_gaussian_box_filter(int k, float sigma, int *width_out);
 int rf_box_difference(const void *in, void *out, int ndim, const int64_t *extent, int dtype, int radius,
                       const int32_t *order, void *stream);
 
+/* ---- clamped tap combinations (the other pointwise-with-offsets Funcs of the reference's apps) -------- */
+/* out(p) = sum_t weight_t * in_planes[plane_t]( clamp(p + offset_t) ),  clamp per dimension to [0, extent-1].
+ * Covers every difference operator the apps put behind a summed-area table that rf_box_difference does not:
+ * apps/DoG/diff_gauss.cpp:176-197 (diff_op_x / diff_op_y: taps +B, -1 (twice), -2B-2, one division; diff_op_xy with two
+ * radii on one table; the final difference of two planes).  At most RF_MAX_TAPS taps over at most RF_MAX_PLANES input
+ * planes; dense x-fastest device planes of one floating-point type; `out` must not alias an input.  One gather kernel. */
+#define RF_MAX_TAPS 16
+typedef struct {
+    int32_t plane;                    /* index into in_planes                                      */
+    int32_t offset[RF_MAX_DIMS];      /* per dimension, x first                                    */
+    float   weight;
+} rf_tap;
+int rf_tap_filter(const void *const *in_planes, int n_in, void *out, int ndim, const int64_t *extent, int dtype,
+                  const rf_tap *taps, int n_taps, void *stream);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 const char *rf_last_error_string(void);
 const char *rf_version(void);

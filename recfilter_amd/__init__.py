@@ -9,11 +9,11 @@ from . import capi
 from .capi import RecFilterError, build_library
 from .filter import (Pointwise, RecFilter, RecFilterDim, RecFilterDimAndCausality, RecFilterSchedule,
                      RecFilterUsageError)
-from .plan import (Plan, box_difference, gaussian_box_filter, second_order_sections, gaussian_weights, integral_image_coeff,
+from .plan import (Plan, box_difference, tap_filter, gaussian_box_filter, second_order_sections, gaussian_weights, integral_image_coeff,
                    overlap_feedback_coeff)
 
 __all__ = [
     "capi", "RecFilterError", "build_library", "Pointwise", "RecFilter", "RecFilterDim", "RecFilterDimAndCausality",
-    "RecFilterSchedule", "RecFilterUsageError", "Plan", "box_difference", "second_order_sections", "gaussian_box_filter", "gaussian_weights",
+    "RecFilterSchedule", "RecFilterUsageError", "Plan", "box_difference", "tap_filter", "second_order_sections", "gaussian_box_filter", "gaussian_weights",
     "integral_image_coeff", "overlap_feedback_coeff",
 ]

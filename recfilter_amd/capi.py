@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "rf_plan_exchange_bytes",
     "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_finish",
     "rf_plan_table", "rf_plan_debug_buffer", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
-    "rf_gaussian_box_filter", "rf_box_difference", "rf_last_error_string", "rf_version", "rf_device_count",
+    "rf_gaussian_box_filter", "rf_box_difference", "rf_tap_filter", "rf_last_error_string", "rf_version", "rf_device_count",
 ]
 
 
@@ -60,6 +60,10 @@ class FilterDesc(ctypes.Structure):
                 ("tile", ctypes.c_int32 * RF_MAX_DIMS), ("path", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
                 ("pointwise", PointwiseDesc), ("shard_extents", ctypes.POINTER(ctypes.c_int64))]
+
+
+class Tap(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_int32), ("offset", ctypes.c_int32 * RF_MAX_DIMS), ("weight", ctypes.c_float)]
 
 
 class RecFilterError(RuntimeError):
@@ -122,6 +126,8 @@ def lib() -> ctypes.CDLL:
     L.rf_gaussian_box_filter.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
     L.rf_box_difference.argtypes = [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_int32), vp]
+    L.rf_tap_filter.argtypes = [vpp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
+                                ctypes.POINTER(Tap), ctypes.c_int, vp]
     L.rf_last_error_string.restype = ctypes.c_char_p
     L.rf_version.restype = ctypes.c_char_p
     _lib = L

@@ -308,6 +308,40 @@ int rf_box_difference(const void *in, void *out, int ndim, const int64_t *extent
     return RF_ERR_UNSUPPORTED;
 }
 
+int rf_tap_filter(const void *const *in_planes, int n_in, void *out, int ndim, const int64_t *extent, int dtype,
+                  const rf_tap *taps, int n_taps, void *stream) {
+    if (!in_planes || !out || !extent || !taps) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    if (ndim < 1 || ndim > RF_MAX_DIMS) { set_error("ndim must be 1..%d", RF_MAX_DIMS); return RF_ERR_INVALID_ARG; }
+    if (n_in < 1 || n_in > RF_MAX_PLANES) { set_error("1..%d input planes", RF_MAX_PLANES); return RF_ERR_INVALID_ARG; }
+    if (n_taps < 1 || n_taps > RF_MAX_TAPS) { set_error("1..%d taps", RF_MAX_TAPS); return RF_ERR_INVALID_ARG; }
+    TapArgs a{};
+    for (int d = 0; d < RF_MAX_DIMS; d++) {
+        a.n[d] = d < ndim ? extent[d] : 1;
+        if (a.n[d] < 1) { set_error("extent[%d] must be positive", d); return RF_ERR_INVALID_ARG; }
+    }
+    for (int p = 0; p < n_in; p++) {
+        if (!in_planes[p]) { set_error("input plane %d is null", p); return RF_ERR_INVALID_ARG; }
+        if (in_planes[p] == out) { set_error("tap_filter gathers: out must differ from every input"); return RF_ERR_INVALID_ARG; }
+        a.in[p] = in_planes[p];
+    }
+    a.n_taps = n_taps;
+    for (int t = 0; t < n_taps; t++) {
+        if (taps[t].plane < 0 || taps[t].plane >= n_in) { set_error("tap %d: plane %d out of range", t, taps[t].plane); return RF_ERR_INVALID_ARG; }
+        a.plane[t] = taps[t].plane;
+        a.weight[t] = taps[t].weight;
+        for (int d = 0; d < RF_MAX_DIMS; d++) {
+            a.off[t][d] = d < ndim ? taps[t].offset[d] : 0;
+            if (d >= ndim && taps[t].offset[d] != 0) { set_error("tap %d: offset along a missing dimension", t); return RF_ERR_INVALID_ARG; }
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (this library has no CPU fallback)"); return RF_ERR_HIP; }
+    if (dtype == RF_F32) return launch_tap_filter<float>((float *)out, a, (hipStream_t)stream);
+    if (dtype == RF_F64) return launch_tap_filter<double>((double *)out, a, (hipStream_t)stream);
+    set_error("tap_filter needs a floating-point pixel type");
+    return RF_ERR_UNSUPPORTED;
+}
+
 const char *rf_last_error_string(void) { return g_last_error.c_str(); }
 const char *rf_version(void) { return "recfilter_amd 0.1 (gfx950)"; }
 

@@ -48,6 +48,18 @@ struct BoxDiffArgs {
 template <typename P>
 int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t stream);
 
+// ---- clamped tap combinations (rf_tap_filter) ----
+struct TapArgs {
+    int64_t n[RF_MAX_DIMS];                  // extents, x first (1 for missing dimensions)
+    int32_t n_taps;
+    int32_t plane[RF_MAX_TAPS];
+    int32_t off[RF_MAX_TAPS][RF_MAX_DIMS];
+    float weight[RF_MAX_TAPS];
+    const void *in[RF_MAX_PLANES];
+};
+template <typename P>
+int launch_tap_filter(P *out, const TapArgs &a, hipStream_t stream);
+
 // ---- generic tiled path, any tile width T <= kGenericMaxTile dividing n -------------------
 constexpr int kGenericMaxTile = 128;
 

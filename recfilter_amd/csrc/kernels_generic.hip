@@ -741,6 +741,49 @@ int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
+// rf_tap_filter: out(p) = sum_t w_t * in[plane_t](clamp(p + off_t)).  One thread per four consecutive x samples; every
+// tap of a row is a (shifted, clamped) run of the same row or of a row a few lines away -- L2 serves the re-reads.
+template <typename P>
+__global__ void __launch_bounds__(kBlock)
+tap_filter_kernel(P *__restrict__ out, TapArgs a) {
+    const int64_t nx = a.n[0], ny = a.n[1], nz = a.n[2];
+    const int64_t xg = (nx + 3) / 4;
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= xg * ny * nz) return;
+    const int64_t x0 = (idx % xg) * 4, y = (idx / xg) % ny, z = idx / (xg * ny);
+    P acc[4] = {P(0), P(0), P(0), P(0)};
+    for (int t = 0; t < a.n_taps; t++) {
+        const P *src = reinterpret_cast<const P *>(a.in[a.plane[t]]);
+        int64_t yy = y + a.off[t][1], zz = z + a.off[t][2];
+        yy = yy < 0 ? 0 : (yy > ny - 1 ? ny - 1 : yy);
+        zz = zz < 0 ? 0 : (zz > nz - 1 ? nz - 1 : zz);
+        const P *row = src + (zz * ny + yy) * nx;
+        const P w = (P)a.weight[t];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int64_t xx = x0 + i + a.off[t][0];
+            xx = xx < 0 ? 0 : (xx > nx - 1 ? nx - 1 : xx);
+            acc[i] = acc[i] + w * row[xx];
+        }
+    }
+    P *dst = out + (z * ny + y) * nx + x0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (x0 + i < nx) dst[i] = acc[i];
+}
+
+template <typename P>
+int launch_tap_filter(P *out, const TapArgs &a, hipStream_t stream) {
+    const int64_t threads = ((a.n[0] + 3) / 4) * a.n[1] * a.n[2];
+    const int64_t blocks = (threads + kBlock - 1) / kBlock;
+    if (blocks >= (1ll << 31)) { set_error("tap_filter: extents too large"); return RF_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL((tap_filter_kernel<P>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, a);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+template int launch_tap_filter<float>(float *, const TapArgs &, hipStream_t);
+template int launch_tap_filter<double>(double *, const TapArgs &, hipStream_t);
+
 template int launch_box_difference<float>(const float *, float *, const BoxDiffArgs &, hipStream_t);
 template int launch_box_difference<double>(const double *, double *, const BoxDiffArgs &, hipStream_t);
 

@@ -279,6 +279,32 @@ def box_difference(table, radius: int, order: Sequence[int], out=None, stream=No
     return out
 
 
+def tap_filter(inputs, taps, out=None, stream=None):
+    """rf_tap_filter: out(p) = sum_t weight_t * inputs[plane_t](clamp(p + offset_t)) -- the clamped difference operators
+    the reference's apps put behind a summed-area table (apps/DoG/diff_gauss.cpp:176-197).  `inputs` are device tensors
+    of one shape and floating-point type; `taps` is a list of (plane, offset, weight) with offset in (x, y, z) order."""
+    import torch
+    inputs = list(inputs)
+    if out is None:
+        out = torch.empty_like(inputs[0])
+    shape = tuple(inputs[0].shape)
+    for t in inputs + [out]:
+        if not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != shape or t.dtype != inputs[0].dtype:
+            raise ValueError("tap_filter needs contiguous device tensors of one shape and type")
+    nd = len(shape)
+    ext = (ctypes.c_int64 * nd)(*reversed(shape))
+    arr = (capi.Tap * len(taps))()
+    for i, (plane, offset, weight) in enumerate(taps):
+        arr[i].plane, arr[i].weight = int(plane), float(weight)
+        offset = list(offset) + [0] * (capi.RF_MAX_DIMS - len(offset))
+        for d in range(capi.RF_MAX_DIMS):
+            arr[i].offset[d] = int(offset[d])
+    ptrs = (ctypes.c_void_p * len(inputs))(*[t.data_ptr() for t in inputs])
+    capi.check(capi.lib().rf_tap_filter(ptrs, len(inputs), ctypes.c_void_p(out.data_ptr()), nd, ext, _dtype_code(inputs[0].dtype),
+                                        arr, len(taps), Plan._stream(stream)))
+    return out
+
+
 def second_order_sections(coeff: Sequence[float]) -> List[List[float]]:
     """Factors one scan {b, a1..ak} (y[i] = b x[i] + sum_j a_j y[i-j-1]) into first/second-order scans with the same
     transfer function: the poles (roots of z^k - a1 z^(k-1) - ... - ak) are paired into conjugate pairs / pairs of real

@@ -104,3 +104,46 @@ def box_difference(table, radius, order):
         for _ in range(o):
             out = (np.take(out, hi, axis=axis) - np.take(out, lo, axis=axis)) / (2 * radius + 1)
     return out
+
+
+def tap_filter(planes, taps):
+    """rf_tap_filter restated: out(p) = sum_t w_t * planes[plane_t](clamp(p + off_t)), offsets in (x, y, z) order."""
+    planes = [np.asarray(p, dtype=np.float64) for p in planes]
+    shape = planes[0].shape
+    nd = len(shape)
+    out = np.zeros(shape)
+    grids = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    for plane, off, w in taps:
+        off = list(off) + [0] * (nd - len(off))
+        idx = tuple(np.clip(grids[ax] + off[nd - 1 - ax], 0, shape[ax] - 1) for ax in range(nd))
+        out += w * planes[plane][idx]
+    return out
+
+
+def dog_taps(B1, B2):
+    """The difference operators of apps/DoG/diff_gauss.cpp as tap lists (plane, (dx, dy), weight):
+    diff_op_xy (:187-193) for two radii on one table, diff_op_x / diff_op_y (:176-184) per plane, and the final
+    difference of the two planes (:103)."""
+    def xy(B):
+        s = 1.0 / (2 * B + 1) ** 2
+        return [(0, (B, B), s), (0, (B, -B - 1), -s), (0, (-B - 1, -B - 1), s), (0, (-B - 1, B), -s)]
+
+    def x2(B, plane=0, sign=1.0):
+        s = sign / (2 * B + 1)
+        return [(plane, (B, 0), s), (plane, (-1, 0), -2.0 * s), (plane, (-2 * B - 2, 0), s)]
+
+    def y2(B, plane=0, sign=1.0):
+        s = sign / (2 * B + 1)
+        return [(plane, (0, B), s), (plane, (0, -1), -2.0 * s), (plane, (0, -2 * B - 2), s)]
+    return dict(box1=[xy(B1), xy(B2)], box2x=[x2(B1), x2(B2)], dog=y2(B1, 0, 1.0) + y2(B2, 1, -1.0))
+
+
+def dog_pipeline(image, B1, B2, scan):
+    """apps/DoG/diff_gauss.cpp:66-103 with `scan(img, scans)` as the recursive-filter step (zero border)."""
+    taps = dog_taps(B1, B2)
+    sat = scan(image, [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])])
+    box1 = [tap_filter([sat], t) for t in taps["box1"]]
+    sat2x = [scan(b, [(0, True, [1.0, 2.0, -1.0])]) for b in box1]
+    box2x = [tap_filter([s2], t) for s2, t in zip(sat2x, taps["box2x"])]
+    sat2y = [scan(b, [(1, True, [1.0, 2.0, -1.0])]) for b in box2x]
+    return tap_filter(sat2y, taps["dog"])

@@ -914,3 +914,29 @@ def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
         assert plan.path == 3
     with rfa.Plan((512, 512), scans, dtype=np.float64, clamped=True, tile=[32, 32]) as plan:
         assert plan.path == 4
+
+
+def test_tap_filter_against_numpy():
+    """rf_tap_filter (the clamped difference Funcs of apps/DoG/diff_gauss.cpp:176-197) against its numpy restatement:
+    2-D with two input planes, 3-D, 1-D, f32 and f64, widths that are not multiples of 4; misuse is rejected."""
+    import torch
+    import recfilter_amd as rfa
+    import ref_loops
+    rng = np.random.default_rng(5)
+    for shape, dt in (((37, 50), np.float32), ((64, 131), np.float64), ((5, 9, 22), np.float32), ((301,), np.float32)):
+        nd = len(shape)
+        planes = [rng.random(shape).astype(dt) for _ in range(2)]
+        taps = [(int(rng.integers(0, 2)), [int(v) for v in rng.integers(-9, 10, size=nd)], float(np.float32(rng.uniform(-1, 1)))) for _ in range(7)]      # (weights travel as f32)
+        got = rfa.tap_filter([torch.from_numpy(p).cuda() for p in planes], taps).cpu().numpy()
+        want = ref_loops.tap_filter(planes, taps)
+        assert np.abs(got - want).max() < (1e-5 if dt == np.float32 else 1e-12)
+    B1, B2 = 3, 5
+    t = ref_loops.dog_taps(B1, B2)
+    assert len(t["dog"]) == 6 and len(t["box1"][0]) == 4
+    a = torch.rand((16, 16), device="cuda")
+    with pytest.raises(rfa.RecFilterError):
+        rfa.tap_filter([a], [(1, (0, 0), 1.0)])                    # plane out of range
+    with pytest.raises(rfa.RecFilterError):
+        rfa.tap_filter([a], [(0, (0, 0), 1.0)], out=a)             # the operator gathers
+    with pytest.raises(rfa.RecFilterError):
+        rfa.tap_filter([a], [(0, (0, 0), 1.0)] * 17)               # more than RF_MAX_TAPS

@@ -215,6 +215,58 @@ def _box(stages):
     return build
 
 
+def app_dog(rfa, w, t):
+    """apps/DoG/diff_gauss.cpp: difference of two Gaussians (sigma 1 and 2), each approximated by three box filters:
+    summed-area table -> xy differences for both radii (a Tuple from here on) -> second-order integral along x -> x
+    differences -> the same along y -> difference of the two planes.  The recursive filters are RecFilters (the Tuple
+    stages filter both planes in one launch per step), the difference Funcs rf_tap_filter."""
+    import torch
+    import ref_loops
+    # three box iterations for sigma 1 and 2, what the app's comment says (diff_gauss.cpp:48-52).  Its call
+    # gaussian_box_filter(sigma1, 3) binds as (iterations, sigma) = (1, 3.0) / (2, 3.0) under lib/iir_coeff.h:70 and gives
+    # the SAME radius 8 twice, i.e. an output that is zero up to rounding -- nothing a check could hold on to.
+    B1, B2 = rfa.gaussian_box_filter(3, 1.0), rfa.gaussian_box_filter(3, 2.0)
+    img = _image((w, w))
+    pad = max(3 * B1 + 3, 3 * B2 + 3)
+    img[:pad], img[-pad:], img[:, :pad], img[:, -pad:] = 0, 0, 0, 0
+    x, y = rfa.RecFilterDim("x", w), rfa.RecFilterDim("y", w)
+    taps = ref_loops.dog_taps(B1, B2)
+    box1 = [torch.empty_like(img) for _ in range(2)]
+    box2x = [torch.empty_like(img) for _ in range(2)]
+    out = torch.empty_like(img)
+    SAT = rfa.RecFilter("SAT"); SAT[x, y] = img
+    SAT.add_filter(+x, [1.0, 1.0]); SAT.add_filter(+y, [1.0, 1.0]); SAT.split_all_dimensions(t)
+    SAT2x = rfa.RecFilter("SAT2x"); SAT2x[x, y] = box1
+    SAT2x.add_filter(+x, [1.0, 2.0, -1.0]); SAT2x.split_all_dimensions(t)
+    SAT2y = rfa.RecFilter("SAT2y"); SAT2y[x, y] = box2x
+    SAT2y.add_filter(+y, [1.0, 2.0, -1.0]); SAT2y.split_all_dimensions(t)
+
+    class Chain:
+        def realize(self):
+            sat = SAT.realize()[0]
+            for p in range(2):
+                rfa.tap_filter([sat], taps["box1"][p], out=box1[p])
+            s2x = SAT2x.realize()
+            for p in range(2):
+                rfa.tap_filter([s2x[p]], taps["box2x"][p], out=box2x[p])
+            rfa.tap_filter(SAT2y.realize(), taps["dog"], out=out)
+            return [out]
+
+        def profile(self, iterations):
+            import time
+            self.realize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iterations):
+                self.realize()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1000.0 / iterations
+
+    def expect_fn(_unused, im):
+        import oracle
+        return ref_loops.dog_pipeline(im, B1, B2, lambda a, sc: oracle.apply_filter(a, sc, False))
+    return Chain(), img, [], False, expect_fn
+
+
 def _audio(kind):
     def build(rfa, w, t, param):                  # apps/audio/audio_filter_{high_order,biquads}.cpp
         img = _image((w,))
@@ -256,6 +308,7 @@ APPS = {
     "biquintic_cascaded": _bspline(BIQUINTIC, True),
     "usm_naive": _usm(False), "usm_optimized": _usm(True),
     "box_filter_1": _box([1]), "box_filter_3": _box([1, 2]), "box_filter_6": _box([2, 2, 2]),
+    "diff_gauss": app_dog,
 }
 SWEEP_APPS = {      # the 1-D apps sweep a filter parameter at one width instead (apps/audio/*.cpp)
     # the app sweeps orders 1..29 step 2; orders above 3 run here as f32 first/second-order sections, and that cascade
