@@ -125,6 +125,11 @@ int carry_chunk_count(int64_t M, int64_t lines, int C, int K = 1);
 template <typename P>
 int launch_fused_pass2(int K, int TY, const void *src, bool src_u8, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                        hipStream_t stream);
+// the same pass on 256 x 128 tiles: two 64-row halves through the LDS, the 128-sample column in registers
+// (kernels_fused_tall.hip); halves the y tails and every kernel that walks them
+template <typename P>
+int launch_fused_pass2_tall(int K, const void *src, bool src_u8, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
+                            hipStream_t stream);
 // pass 1 as a contraction with precomputed impulse responses (kernels_tails.hip)
 template <typename P>
 int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedArgs<typename PixelTraits<P>::Acc> &a,

@@ -38,7 +38,10 @@ namespace {
 // persistent, register-prefetching variant of this kernel were measured slower in round 1 and removed.)
 // EDGE: the image has partial tiles (width not a multiple of 256 or height not a multiple of TY); without it the
 // masks below are compile-time constants and the kernel stays lean.
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI>
+// YPAT: the directions of the y scans when they are the usual ones -- 1: one causal scan, 2: causal then anticausal; 0: any.
+// With a run-time direction inside the loop over the scans every sample of the column is a phi of two register
+// assignments: ~TY register copies per scan (and spills on the 128-row tiles of kernels_fused_tall.hip).
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0>
 __global__ void __launch_bounds__(kFusedThreads, (EPI || PixelTraits<P>::is_integer) ? 2 : 1)
 fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -242,22 +245,34 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         Acc col[TY];
 #pragma unroll
         for (int i = 0; i < TY; i++) col[i] = tile[i * kFusedTX + e];
-#pragma unroll 1
-        for (int j = 0; j < a.ny; j++) {
-            const FusedScanY<Acc> &sc = a.ys[j];
-            const bool causal = sc.causal != 0;
-            const bool border = causal ? (ty == 0 && a.y_first_border) : (ty == a.MY - 1 && a.y_last_border);
-            const bool clamp_first = a.clamped && border;
-            Acc c[K];
-#pragma unroll
-            for (int r = 0; r < K; r++) {
-                c[r] = CY[0][r];
-#pragma unroll
-                for (int q = 1; q < kFusedMaxScans; q++) c[r] = (j == q) ? CY[q][r] : c[r];
+        if constexpr (YPAT == 1 || YPAT == 2) {
+            static_assert(!EDGE || YPAT == 0, "the fixed patterns are instantiated for whole tiles");
+            {
+                const bool clamp_first = a.clamped && ty == 0 && a.y_first_border;
+                scan_col<Acc, true, K, TY>(col, a.ys[0], clamp_first, CY[0]);
             }
-            if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
-            else if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
-            else scan_col_partial_up<Acc, K, TY>(col, sc, clamp_first, rows_here);     // partial last tile row
+            if constexpr (YPAT == 2) {
+                const bool clamp_first = a.clamped && ty == a.MY - 1 && a.y_last_border;
+                scan_col<Acc, false, K, TY>(col, a.ys[1], clamp_first, CY[1]);
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < a.ny; j++) {
+                const FusedScanY<Acc> &sc = a.ys[j];
+                const bool causal = sc.causal != 0;
+                const bool border = causal ? (ty == 0 && a.y_first_border) : (ty == a.MY - 1 && a.y_last_border);
+                const bool clamp_first = a.clamped && border;
+                Acc c[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) {
+                    c[r] = CY[0][r];
+#pragma unroll
+                    for (int q = 1; q < kFusedMaxScans; q++) c[r] = (j == q) ? CY[q][r] : c[r];
+                }
+                if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
+                else if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
+                else scan_col_partial_up<Acc, K, TY>(col, sc, clamp_first, rows_here);     // partial last tile row
+            }
         }
         if constexpr (!PixelTraits<P>::is_integer) {
             // fused epilogue (compute_at of a pointwise consumer, lib/recfilter.cpp:473-573); x' was applied at the load
@@ -306,7 +321,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     }
 }
 
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI>
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0>
 int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
@@ -318,12 +333,12 @@ int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename Pixe
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::atomic<bool> &done = attr_set[dev & 63];
     if (!done.load(std::memory_order_acquire)) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -337,6 +352,7 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
     bool epi = false;
     const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
+    const int ypat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
 #define RF_CASE(KK, TT)                                                                                         \
     if (K == KK && TY == TT) {                                                                                  \
         if constexpr (!PixelTraits<P>::is_integer) {                                                            \
@@ -344,6 +360,10 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
             if (epi) return launch_fused_pass2_impl<P, KK, TT, true, false, PI>(src, dst, a, stream);           \
         }                                                                                                       \
         if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true, PI>(src, dst, a, stream);              \
+        if constexpr (TT == 64 && std::is_same<P, PI>::value) {        /* the usual y scans, directions fixed at compile time */ \
+            if (ypat == 1) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 1>(src, dst, a, stream); \
+            if (ypat == 2) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 2>(src, dst, a, stream); \
+        }                                                                                                       \
         return launch_fused_pass2_impl<P, KK, TT, false, false, PI>(src, dst, a, stream);                       \
     }
     RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)

@@ -236,7 +236,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // touches every tail sample anyway; the y carry scan then needs no knowledge of x.  The G table of the
 // interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
 // border tiles read their variant from memory.
-template <typename Acc, int K, bool EDGE>
+template <typename Acc, int K, bool EDGE, bool TALL>
 __global__ void __launch_bounds__(256, 6)
 xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
@@ -286,23 +286,27 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
         if (row_ok) {
             const int r = jr % K, j = jr / K;
             const int vy = ((ty == 0 && a.y_first_border) ? 1 : 0) | ((ty == a.MY - 1 && a.y_last_border) ? 2 : 0);
-            const bool lane_in = 4 * l < TY;
-            A4 hy = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
-            if (lane_in) hy = *reinterpret_cast<const A4 *>(Hy + ((size_t)(vy * a.ny + j) * K + r) * TY + 4 * l);
             const int64_t Lx = a.NYP * a.NZ;
-            const int64_t y0 = (int64_t)ty * TY + a.NYP * z + 4 * l;
+            // the row's 16 lanes split the TY-term sums: four consecutive rows per lane and 64-row block (TY <= 128)
 #pragma unroll
-            for (int q = 0; q < kFusedMaxScans; q++) {
-                if (q < a.nx) {
-                    const bool qc = a.xs[q].causal != 0;
-                    const bool q_first = qc ? (tx == 0) : (tx == a.MX - 1);
-                    const int tp = qc ? tx - 1 : tx + 1;
+            for (int blk = 0; blk < (TALL ? 128 : 64); blk += 64) {
+                const bool lane_in = blk + 4 * l < TY;
+                A4 hy = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+                if (lane_in) hy = *reinterpret_cast<const A4 *>(Hy + ((size_t)(vy * a.ny + j) * K + r) * TY + blk + 4 * l);
+                const int64_t y0 = (int64_t)ty * TY + a.NYP * z + blk + 4 * l;
 #pragma unroll
-                    for (int o = 0; o < K; o++) {
-                        A4 c = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
-                        if (!q_first && lane_in)
-                            c = *reinterpret_cast<const A4 *>(a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + y0);
-                        tv[q * K + o] = hy.x * c.x + hy.y * c.y + hy.z * c.z + hy.w * c.w;
+                for (int q = 0; q < kFusedMaxScans; q++) {
+                    if (q < a.nx) {
+                        const bool qc = a.xs[q].causal != 0;
+                        const bool q_first = qc ? (tx == 0) : (tx == a.MX - 1);
+                        const int tp = qc ? tx - 1 : tx + 1;
+#pragma unroll
+                        for (int o = 0; o < K; o++) {
+                            A4 c = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+                            if (!q_first && lane_in)
+                                c = *reinterpret_cast<const A4 *>(a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + y0);
+                            tv[q * K + o] = tv[q * K + o] + (hy.x * c.x + hy.y * c.y + hy.z * c.z + hy.w * c.w);
+                        }
                     }
                 }
             }
@@ -412,6 +416,7 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     }
     RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
     RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
+    RF_CASE(1, 128) RF_CASE(2, 128) RF_CASE(3, 128)
 #undef RF_CASE
     set_error("fused tails: unsupported order %d / tile height %d", K, TY);
     return RF_ERR_UNSUPPORTED;
@@ -434,8 +439,13 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
     const size_t g_bytes = (size_t)a.nx * K * kFusedTX * sizeof(Acc);
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \
-        if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
-        else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
+        if (TY > 64) {      /* 128-row tiles: two 64-row blocks of the carry strips per lane */                            \
+            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, true>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
+            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, true>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
+        } else {                                                                                                           \
+            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, false>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
+            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, false>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
+        }                                                                                                                  \
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }

@@ -60,9 +60,18 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // a small image has too few 256 x 64 tiles to fill 256 CUs: half-height tiles double the workgroups
     // (2048^2: 43.5 -> 40.8 us, 1024^2: 38 -> 34.6 us; at 4096^2, 1024 tiles, the 64-row tiles win again)
     if (TY == 64 && NY % 32 == 0 && !rows_sharded && ((NX + kFusedTX - 1) / kFusedTX) * (NY / 64) * NZ <= 384) TY = 32;
+    // Large images: 128-row tiles halve the y tails and the kernels that walk them between the passes; the final pass
+    // takes such a tile through the LDS in two halves and keeps its columns in registers (kernels_fused_tall.hip).
+    // Needs whole 128-row tiles in y... and enough of them to fill the chip several times over.
+    const int nx_early = (int)dx.scan_ids.size(), ny_early = (int)dy.scan_ids.size();
+    // Order 1 keeps 64 rows: its tails are small and the taller final pass costs more than they save (cfg4a: 1.63 -> 1.68 ms;
+    // order 2, cfg3: 0.624 -> 0.621; order 3, cfg4b: 2.25 -> 1.97 ms).
+    if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && K >= 2 && NYB % 128 == 0 && getenv("RF_NO_TALL_TILES") == nullptr &&
+        ((NX + kFusedTX - 1) / kFusedTX) * (NY / 128) * NZ >= 4096)
+        TY = 128;
     if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
         const int want = atoi(env);
-        if (want == 32 || want == 64) TY = want;
+        if (want == 32 || want == 64 || (want == 128 && !chained && (!rows_sharded || NYB % 128 == 0))) TY = want;
     }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
     // The width only has to be a multiple of 4 (rows stay 16-byte aligned): the last tile of a row may be partial.  Its
@@ -404,6 +413,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     p2.run = [plan, fargs, K, TY, d_Yapply](int pl) {
         FusedArgs<Acc> a = fargs(pl);
         a.y_apply = d_Yapply;
+        if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
         return launch_fused_pass2<P>(K, TY, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);

@@ -940,3 +940,67 @@ def test_tap_filter_against_numpy():
         rfa.tap_filter([a], [(0, (0, 0), 1.0)], out=a)             # the operator gathers
     with pytest.raises(rfa.RecFilterError):
         rfa.tap_filter([a], [(0, (0, 0), 1.0)] * 17)               # more than RF_MAX_TAPS
+
+
+# ---- 256 x 128 tiles (kernels_fused_tall.hip): what RF_PATH_AUTO picks for large images of order >= 2, forced here on small ones ----
+@pytest.mark.parametrize("seed", range(10))
+def test_tall_tiles_random_filters_and_shapes(seed, monkeypatch):
+    """The 128-row final pass (two 64-row halves through the LDS, the column in registers), the 128-row tail extraction and
+    the two-block residual: random filters (every y scan pattern, orders 1..3), heights and widths with partial last tiles
+    (a last tile row of fewer than 64 rows leaves the second half empty), float against the oracle, integers bit-exact."""
+    monkeypatch.setenv("RF_FUSED_TY", "128")
+    rng = np.random.default_rng(5100 + seed)
+    shape = (int(rng.integers(1, 420)), 4 * int(rng.integers(1, 200)))
+    clamped = bool(rng.integers(0, 2))
+    if seed % 3 == 2:
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(1, 4))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.integers(1, 3))] + [float(rng.integers(-2, 3)) for _ in range(k)]))
+        imgs, outs, (path, tiles) = _run(shape, scans, dtype=np.int32, clamped=clamped, seed=seed, planes=2)
+    else:
+        scans = _random_filter(rng, 2)
+        if seed % 3 == 0:
+            scans = rc.xy_pm(rc.GAUSS3 if seed % 2 else rc.GAUSS2)            # the fixed causal / anticausal pattern
+        imgs, outs, (path, tiles) = _run(shape, scans, clamped=clamped, seed=seed)
+    assert path == 3 and (list(tiles)[:2] == [256, 128] or not any(s[0] == 1 for s in scans) or not any(s[0] == 0 for s in scans)), (shape, tiles)
+    _check(imgs, outs, scans, clamped)
+
+
+def test_tall_tiles_other_features(monkeypatch):
+    """128-row tiles with the rest of the fused path: row shards (the entering carries applied by the final pass, slabs of
+    different heights), a 3-D volume with a z stage behind, batched Tuple planes, uint8 input and a pointwise epilogue,
+    int16 pixels; and what the automatic choice is."""
+    import torch
+    import recfilter_amd as rfa
+    monkeypatch.setenv("RF_FUSED_TY", "128")
+    scans = rc.xy_pm(rc.GAUSS2)
+    full, got, (path, nex) = _run_sharded((128 + 384 + 256, 512), scans, True, 3, path=0, planes=2, extents=[128, 384, 256])
+    assert path == 3 and nex == 1
+    _check(full, got, scans, True)
+    s3 = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    imgs, outs, (path, tiles) = _run((64, 256, 512), s3, clamped=False)
+    assert path == 3 and list(tiles)[:2] == [256, 128]
+    _check(imgs, outs, s3, False)
+    imgs, outs, (path, tiles) = _run((384, 512), rc.xy_pm(rc.GAUSS3), clamped=True, planes=3)
+    assert path == 3 and list(tiles)[:2] == [256, 128]
+    _check(imgs, outs, rc.xy_pm(rc.GAUSS3), True)
+    ints = [(0, True, [1.0, 2.0, -1.0]), (0, False, [1.0, 1.0]), (1, True, [1.0, 2.0, -1.0]), (1, False, [1.0, 1.0])]
+    imgs, outs, (path, tiles) = _run((200, 520), ints, dtype=np.int16, clamped=False)
+    assert path == 3 and list(tiles)[:2] == [256, 128]
+    _check(imgs, outs, ints, False)
+    # uint8 input, prologue and unsharp-mask epilogue
+    img8 = torch.randint(0, 256, (300, 768), dtype=torch.uint8, device="cuda")
+    w = 0.7
+    with rfa.Plan((300, 768), scans, clamped=True, prologue=(1.0 / 255.0, 0.0), epilogue=(-w, 1.0 + w, 0.0), input_dtype=np.uint8) as plan:
+        assert list(plan.tiles)[:2] == [256, 128]
+        out = plan.execute([img8])[0].cpu().numpy()
+    x = img8.cpu().numpy().astype(np.float64) / 255.0
+    want = (1.0 + w) * x - w * oracle.apply_filter(x, scans, True)
+    assert np.abs(out - want).max() < 2e-5
+    monkeypatch.delenv("RF_FUSED_TY")
+    for shape, sc, want_ty in (((16384, 8192), scans, 128), ((16384, 8192), rc.xy_pm([1.3, -0.3]), 64), ((2048, 2048), scans, 32),
+                               ((8192, 8192), scans, 64), ((16384 + 64, 8192), scans, 64)):
+        with rfa.Plan(shape, sc, clamped=True) as plan:
+            assert list(plan.tiles)[:2] == [256, want_ty], (shape, plan.tiles)
