@@ -66,7 +66,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const int nx_early = (int)dx.scan_ids.size(), ny_early = (int)dy.scan_ids.size();
     // Order 1 keeps 64 rows: its tails are small and the taller final pass costs more than they save (cfg4a: 1.63 -> 1.68 ms;
     // order 2, cfg3: 0.624 -> 0.621; order 3, cfg4b: 2.25 -> 1.97 ms).
-    if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && K >= 2 && NYB % 128 == 0 && getenv("RF_NO_TALL_TILES") == nullptr &&
+    // (integer pixels keep 64 rows as well: their final pass needs more registers than the 128-sample column leaves)
+    if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && K >= 2 && !PixelTraits<P>::is_integer && NYB % 128 == 0 &&
+        getenv("RF_NO_TALL_TILES") == nullptr &&
         ((NX + kFusedTX - 1) / kFusedTX) * (NY / 128) * NZ >= 4096)
         TY = 128;
     if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
