@@ -8,6 +8,8 @@
 // carries (lib/split.cpp:1008-1130) and stores the tile; the carry stage in between is
 // carry_block_kernel (kernels_carry.hip).  This is the y phase of the fused kernel fed straight from
 // HBM; it is what the 3-D configs run for z after the fused x/y stage.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "kernels_fused.h"
 
@@ -41,21 +43,31 @@ __device__ __forceinline__ void scan_regs(Acc (&col)[TZ], const FusedScanY<Acc> 
     }
 }
 
-template <typename P, int K, int TZ, bool FINAL>
+// UNI: a.inner is a multiple of 256, so the 256 lines of a workgroup sit in one run of the inner dimensions: every access
+// is (a scalar base advanced per sample) + (one 32-bit lane offset) instead of an address of its own per sample -- that was
+// one register per sample on top of the column (133 registers at 64 samples: three waves per SIMD).
+// PAT: the directions of the scans when they are the usual ones -- 1: one causal scan, 2: causal then anticausal; 0: any
+// (a run-time direction inside the loop over the scans costs a register copy per sample and scan, kernels_fused.hip).
+template <typename P, int K, int TZ, bool FINAL, bool UNI, int PAT>
 __global__ void __launch_bounds__(256)
 strided_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, StridedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
     const int64_t line = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (line >= a.lines) return;
     const int t = blockIdx.y;
-    const int64_t base = (line / a.inner) * a.n * a.inner + (line % a.inner) + (int64_t)t * TZ * a.inner;
+    const int64_t l0 = (int64_t)blockIdx.x * 256;                    // wave-uniform
+    const int64_t ubase = (l0 / a.inner) * a.n * a.inner + (l0 % a.inner) + (int64_t)t * TZ * a.inner;
+    const int64_t base = UNI ? ubase + threadIdx.x : (line / a.inner) * a.n * a.inner + (line % a.inner) + (int64_t)t * TZ * a.inner;
+    const uint32_t lane = threadIdx.x;
     Acc col[TZ];
 #pragma unroll
-    for (int i = 0; i < TZ; i++) col[i] = PixelTraits<P>::load(__builtin_nontemporal_load(src + base + (int64_t)i * a.inner));
-#pragma unroll 1
-    for (int s = 0; s < a.n_scans; s++) {
+    for (int i = 0; i < TZ; i++) {
+        if constexpr (UNI) col[i] = PixelTraits<P>::load(__builtin_nontemporal_load(src + (ubase + (int64_t)i * a.inner) + lane));
+        else col[i] = PixelTraits<P>::load(__builtin_nontemporal_load(src + base + (int64_t)i * a.inner));
+    }
+    auto one_scan = [&](int s, auto causal_tag) __attribute__((always_inline)) {
+        constexpr bool causal = decltype(causal_tag)::value;
         const FusedScanY<Acc> &sc = a.scans[s];
-        const bool causal = sc.causal != 0;
         const bool tile_first = causal ? (t == 0) : (t == a.M - 1);
         const bool border = causal ? (t == 0 && a.first_is_border) : (t == a.M - 1 && a.last_is_border);
         Acc carry[K];
@@ -72,17 +84,31 @@ strided_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, StridedArgs<
             }
         }
         const bool clamp_first = a.clamped && border;
-        if (causal) scan_regs<Acc, true, K, TZ>(col, sc, clamp_first, carry);
-        else        scan_regs<Acc, false, K, TZ>(col, sc, clamp_first, carry);
+        scan_regs<Acc, causal, K, TZ>(col, sc, clamp_first, carry);
         if (!FINAL) {
 #pragma unroll
             for (int r = 0; r < K; r++)
                 a.tails[(((int64_t)s * a.M + t) * K + r) * a.lines + line] = causal ? col[TZ - 1 - r] : col[r];
         }
+    };
+    if constexpr (PAT == 1) {
+        one_scan(0, std::true_type{});
+    } else if constexpr (PAT == 2) {
+        one_scan(0, std::true_type{});
+        one_scan(1, std::false_type{});
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < a.n_scans; s++) {
+            if (a.scans[s].causal != 0) one_scan(s, std::true_type{});
+            else one_scan(s, std::false_type{});
+        }
     }
     if (FINAL) {
 #pragma unroll
-        for (int i = 0; i < TZ; i++) __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), dst + base + (int64_t)i * a.inner);
+        for (int i = 0; i < TZ; i++) {
+            if constexpr (UNI) __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), dst + (ubase + (int64_t)i * a.inner) + lane);
+            else __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), dst + base + (int64_t)i * a.inner);
+        }
     }
 }
 
@@ -94,16 +120,30 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
     if (a.lines <= 0 || a.M <= 0) return RF_OK;
     if (a.M > 65535) { set_error("strided path: too many tiles"); return RF_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)((a.lines + 255) / 256), (unsigned)a.M);
+    // the fast variants: whole runs of 256 lines per workgroup, the usual scan patterns (else the general one)
+    const bool uni = a.inner % 256 == 0 && a.lines % 256 == 0;
+    const int pat = (a.n_scans == 1 && a.scans[0].causal != 0) ? 1
+                  : (a.n_scans == 2 && a.scans[0].causal != 0 && a.scans[1].causal == 0) ? 2 : 0;
+    // Workgroups per CU: these kernels stream 64 or 128 rows per wave that lie a whole plane apart; beyond three waves
+    // per SIMD more rows in flight make the memory system slower, not faster (2048^3, 64 samples per thread: 5.7 ms at
+    // three waves per SIMD, 6.9 ms at six).  An unused LDS allocation bounds the residency.
+    static const int wgs_per_cu = getenv("RF_STRIDED_WGS") ? atoi(getenv("RF_STRIDED_WGS")) : 3;
+    const size_t pad_lds = wgs_per_cu >= 1 && wgs_per_cu <= 8 ? (size_t)(160 * 1024 / wgs_per_cu) & ~(size_t)1023 : 0;
+    const size_t lds_bytes = pad_lds > 64 * 1024 ? 64 * 1024 : pad_lds;      // (more than 64 KiB would need an opt-in per kernel)
+#define RF_LAUNCH(KK, TT, FF, UU, PP)                                                                                \
+    { hipLaunchKernelGGL((strided_pass_kernel<P, KK, TT, FF, UU, PP>), grid, dim3(256), UU ? lds_bytes : 0, stream, src, dst, a); \
+      RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
 #define RF_CASE(KK, TT)                                                                                              \
     if (K == KK && TZ == TT) {                                                                                        \
-        if (final_pass) hipLaunchKernelGGL((strided_pass_kernel<P, KK, TT, true>), grid, dim3(256), 0, stream, src, dst, a); \
-        else hipLaunchKernelGGL((strided_pass_kernel<P, KK, TT, false>), grid, dim3(256), 0, stream, src, dst, a);    \
-        RF_HIP_CHECK(hipGetLastError());                                                                              \
-        return RF_OK;                                                                                                 \
+        if (uni && pat == 2) { if (final_pass) RF_LAUNCH(KK, TT, true, true, 2) else RF_LAUNCH(KK, TT, false, true, 2) } \
+        if (uni && pat == 1) { if (final_pass) RF_LAUNCH(KK, TT, true, true, 1) else RF_LAUNCH(KK, TT, false, true, 1) } \
+        if (final_pass) RF_LAUNCH(KK, TT, true, false, 0) else RF_LAUNCH(KK, TT, false, false, 0)                     \
     }
     RF_CASE(1, 64) RF_CASE(2, 64) RF_CASE(3, 64)
     RF_CASE(1, 32) RF_CASE(2, 32) RF_CASE(3, 32)
+    RF_CASE(1, 128) RF_CASE(2, 128) RF_CASE(3, 128)
 #undef RF_CASE
+#undef RF_LAUNCH
     set_error("strided path: unsupported order %d / tile %d", K, TZ);
     return RF_ERR_UNSUPPORTED;
 }
