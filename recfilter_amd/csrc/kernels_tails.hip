@@ -18,6 +18,7 @@
 //
 // fused_tails_kernel stages HALF tiles (256 x 32, 32 KiB of LDS) so that four to five workgroups fit a
 // CU; the second half's pixels are already in flight while the first half is contracted.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -398,7 +399,8 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
     if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    const size_t hx_bytes = (size_t)(a.nx > 0 ? a.nx : 1) * K * kFusedTX * sizeof(typename PixelTraits<P>::Acc);
+    static const size_t pad_bytes = getenv("RF_TAILS_PAD_LDS") ? (size_t)atoi(getenv("RF_TAILS_PAD_LDS")) : 0;     // A/B: bounds the residency
+    const size_t hx_bytes = (size_t)(a.nx > 0 ? a.nx : 1) * K * kFusedTX * sizeof(typename PixelTraits<P>::Acc) + pad_bytes;
 #define RF_CASE(KK, TT)                                                                                             \
     if (K == KK && TY == TT) {                                                                                       \
         if constexpr (std::is_same<P, float>::value) {                                                               \

@@ -11,7 +11,7 @@ import ref_cases as rc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(0 if len(sys.argv) > 3 and sys.argv[3] == "overlap" else n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), 4 * int(rng.integers(1, 2400)))
@@ -79,3 +79,27 @@ if len(sys.argv) > 3 and sys.argv[3] == "overlap":
             print(f"{case:3d} {po.path_name:16s} {str(shape):18s} tiles={tiles} scans={len(scans)} clamped={int(clamped)} {np.dtype(npdt).name:8s} err={err:.3e}",
                   "" if err < (1 if npdt == np.int32 else 2e-4) else "  <-- CHECK", flush=True)
     print("worst (overlapped)", worst)
+
+# ---- large images: what RF_PATH_AUTO picks there (256 x 128 tiles for order >= 2) against the untiled path ----
+if len(sys.argv) > 3 and sys.argv[3] == "big":
+    worst = 0.0
+    for case in range(n_cases):
+        rows = 128 * int(rng.integers(48, 129)) if case % 3 else int(rng.integers(6200, 16000))
+        cols = 4 * int(rng.integers(2100, 4097))
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(2, 4)) if d == 0 or not scans else int(rng.integers(1, 4))
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        img = torch.rand((rows, cols), device="cuda")
+        with rfa.Plan((rows, cols), scans, clamped=clamped) as pf, rfa.Plan((rows, cols), scans, clamped=clamped, path=1) as pu:
+            of, ou = pf.execute([img])[0], pu.execute([img])[0]
+            torch.cuda.synchronize()
+            peak = float(ou.abs().max().item())
+            err = float(((of - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
+            worst = max(worst, err)
+            print(f"{case:3d} {pf.path_name:13s} tiles={list(pf.tiles)} {str((rows, cols)):16s} scans={len(scans)} clamped={int(clamped)} err={err:.3e}",
+                  "" if err < 2e-4 else "  <-- CHECK", flush=True)
+    print("worst (big)", worst)
