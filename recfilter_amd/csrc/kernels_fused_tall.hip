@@ -102,6 +102,73 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
         }
     }
 
+    const char *spb = reinterpret_cast<const char *>(src + tile_off);
+    const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
+    const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
+    const bool chunk_in = 4 * cc < last_cols;
+    const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+
+    Acc col[TY];              // this thread's column, all 128 rows
+    A4 tmp[2][TL / 4];       // both halves are requested up front
+    // The x carries entering the rows of both halves: requested before the pixels, parked in LDS behind the tile once they
+    // have arrived ([half][s][n][j][row slot]; read by every lane of a row, used by its entry lane) -- a 128-sample column,
+    // a prefetched half tile and the x phase leave no registers for them.
+    Acc *cx_lds = tile + TL * kFusedTX;
+    Acc CX[2][kFusedMaxScans][NR][K];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int64_t line0 = (int64_t)ty * TY + TL * h + slot + a.NYP * z;
+#pragma unroll
+        for (int s = 0; s < kFusedMaxScans; s++) {
+#pragma unroll
+            for (int n = 0; n < NR; n++)
+#pragma unroll
+                for (int j = 0; j < K; j++) CX[h][s][n][j] = Acc(0);
+            if (s < a.nx) {
+                const bool causal = a.xs[s].causal != 0;
+                const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
+                const bool first_lane = causal ? (l == 0) : (l == last_lane);
+                if (first_lane) {
+                    const int tp = causal ? tx - 1 : tx + 1;
+                    const Acc *cp = tile_first ? a.x_incoming + (int64_t)s * K * Lx : a.xt + ((int64_t)s * a.MX + tp) * K * Lx;
+#pragma unroll
+                    for (int n = 0; n < NR; n++)
+#pragma unroll
+                        for (int j = 0; j < K; j++) CX[h][s][n][j] = cp[j * Lx + line0 + 16 * n];
+                }
+            }
+        }
+    }
+    auto park_carries = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int s = 0; s < kFusedMaxScans; s++) {
+                if (s < a.nx) {
+                    const bool causal = a.xs[s].causal != 0;
+                    const bool first_lane = causal ? (l == 0) : (l == last_lane);
+                    if (first_lane) {
+#pragma unroll
+                        for (int n = 0; n < NR; n++)
+#pragma unroll
+                            for (int j = 0; j < K; j++) cx_lds[(((h * kFusedMaxScans + s) * NR + n) * K + j) * 16 + slot] = CX[h][s][n][j];
+                    }
+                }
+            }
+    };
+    auto request_pixels = [&](int h) {
+        // wave w streams rows w, w+4, ... of the half
+#pragma unroll
+        for (int i = 0; i < TL / 4; i++) {
+            const int row = TL * h + rg + 4 * i;
+            const bool in = chunk_in && (!EDGE || row < rows_here);
+            tmp[h][i] = in ? load_chunk<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes)) : zero4;
+        }
+    };
+
+    request_pixels(0);
+    request_pixels(1);
+    park_carries();
     // ... and wait in LDS meanwhile, [j][r][column] behind the x carries (registers are the scarce resource here)
     Acc *cy_lds = tile + kHalfRows * kFusedTX + 2 * kFusedMaxScans * (kHalfRows / 16) * K * 16;
 #pragma unroll
@@ -111,54 +178,6 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
             for (int r = 0; r < K; r++) cy_lds[(j * K + r) * kFusedTX + t] = CY[j][r];
         }
 
-    const char *spb = reinterpret_cast<const char *>(src + tile_off);
-    const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
-    const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
-    const bool chunk_in = 4 * cc < last_cols;
-    const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
-
-    Acc col[TY];              // this thread's column, all 128 rows
-    A4 tmp[TL / 4];
-    // The x carries entering a half's rows wait in LDS behind the tile ([s][n][j][row slot]; read by every lane of a row,
-    // used by its entry lane): a 128-sample column, a prefetched half tile and the x phase leave no registers for them.
-    Acc *cx_lds = tile + TL * kFusedTX;
-    auto park_carries = [&](int h) {
-        const int64_t line0 = (int64_t)ty * TY + TL * h + slot + a.NYP * z;
-#pragma unroll
-        for (int s = 0; s < kFusedMaxScans; s++) {
-            if (s < a.nx) {
-                const bool causal = a.xs[s].causal != 0;
-                const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-                const bool first_lane = causal ? (l == 0) : (l == last_lane);
-                if (first_lane) {
-                    const int tp = causal ? tx - 1 : tx + 1;
-                    const Acc *cp = tile_first ? a.x_incoming + (int64_t)s * K * Lx : a.xt + ((int64_t)s * a.MX + tp) * K * Lx;
-                    Acc c[NR][K];
-#pragma unroll
-                    for (int n = 0; n < NR; n++)
-#pragma unroll
-                        for (int j = 0; j < K; j++) c[n][j] = cp[j * Lx + line0 + 16 * n];
-#pragma unroll
-                    for (int n = 0; n < NR; n++)
-#pragma unroll
-                        for (int j = 0; j < K; j++) cx_lds[(((h * kFusedMaxScans + s) * NR + n) * K + j) * 16 + slot] = c[n][j];
-                }
-            }
-        }
-    };
-    auto request_pixels = [&](int h) {
-        // wave w streams rows w, w+4, ... of the half
-#pragma unroll
-        for (int i = 0; i < TL / 4; i++) {
-            const int row = TL * h + rg + 4 * i;
-            const bool in = chunk_in && (!EDGE || row < rows_here);
-            tmp[i] = in ? load_chunk<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes)) : zero4;
-        }
-    };
-
-    request_pixels(0);
-    park_carries(0);
-    park_carries(1);
 #pragma unroll
     for (int h = 0; h < TY / TL; h++) {
         if constexpr (!PixelTraits<P>::is_integer) {
@@ -167,17 +186,15 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                 for (int i = 0; i < TL / 4; i++) {
                     const bool in = chunk_in && TL * h + rg + 4 * i < rows_here;      // samples beyond the image stay zero
                     const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
-                    tmp[i].x = s * tmp[i].x + b; tmp[i].y = s * tmp[i].y + b;
-                    tmp[i].z = s * tmp[i].z + b; tmp[i].w = s * tmp[i].w + b;
+                    tmp[h][i].x = s * tmp[h][i].x + b; tmp[h][i].y = s * tmp[h][i].y + b;
+                    tmp[h][i].z = s * tmp[h][i].z + b; tmp[h][i].w = s * tmp[h][i].w + b;
                 }
             }
         }
         if (h > 0) __syncthreads();                             // the previous half's columns are out of LDS
 #pragma unroll
-        for (int i = 0; i < TL / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[i];
+        for (int i = 0; i < TL / 4; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = tmp[h][i];
         __syncthreads();
-        // the second half's pixels travel during this half's x phase (tmp is free again)
-        if (h + 1 < TY / TL) request_pixels(h + 1);
         // ---- x phase of this half ----
         if (a.nx > 0) {
             Acc v[NR][kFusedSeg];
