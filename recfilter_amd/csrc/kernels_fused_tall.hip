@@ -25,7 +25,8 @@ constexpr int kHalfRows = 64;
 // YPAT: the directions of the y scans when they are the usual ones -- 1: one causal scan, 2: causal then anticausal; 0: any
 // (a run-time direction inside the loop over the scans makes every sample of the column a phi of two register
 // assignments: a hundred and more register copies per scan and, on a 128-sample column, spills).
-template <typename P, int K, bool EDGE, typename PI, int YPAT>
+// EARLY (whole tiles, one of the fixed patterns, no epilogue): the rows are stored from inside the last scan.
+template <typename P, int K, bool EDGE, typename PI, int YPAT, bool EARLY>
 __global__ void __launch_bounds__(kFusedThreads, 2)
 fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -251,11 +252,27 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
             else scan_col_partial_up<Acc, K, TY>(col, sc, clamp_first, rows_here);
         }
     };
-    if constexpr (YPAT == 1) {
-        y_scan(0, std::true_type{});
-    } else if constexpr (YPAT == 2) {
-        y_scan(0, std::true_type{});
-        y_scan(1, std::false_type{});
+    // whole tiles without an epilogue: the rows are stored from inside the last scan, each as soon as it is final
+    char *dpb_early = reinterpret_cast<char *>(dst + tile_off);
+    static_assert(!EARLY || (!EDGE && YPAT > 0), "early stores: whole tiles, fixed scan pattern");
+    auto row_out = [&](int m, Acc v) __attribute__((always_inline)) {
+        __builtin_nontemporal_store(PixelTraits<P>::store(v),
+                                    reinterpret_cast<P *>(dpb_early + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)m * a.row_bytes)));
+    };
+    if constexpr (YPAT == 1 || YPAT == 2) {
+        if (YPAT == 2) y_scan(0, std::true_type{});
+        if constexpr (EARLY) {
+            constexpr int jl = YPAT - 1;
+            const bool clamp_first = a.clamped && (YPAT == 1 ? (ty == 0 && a.y_first_border) : (ty == a.MY - 1 && a.y_last_border));
+            Acc c[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) c[r] = cy_lds[(jl * K + r) * kFusedTX + t];
+            scan_col<Acc, YPAT == 1, K, TY>(col, a.ys[jl], clamp_first, c, row_out);
+            return;
+        } else {
+            if (YPAT == 1) y_scan(0, std::true_type{});
+            else y_scan(1, std::false_type{});
+        }
     } else {
 #pragma unroll 1
         for (int j = 0; j < a.ny; j++) {
@@ -295,7 +312,7 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     }
 }
 
-template <typename P, int K, bool EDGE, typename PI, int YPAT>
+template <typename P, int K, bool EDGE, typename PI, int YPAT, bool EARLY>
 int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     // the half tile + the x carries of both halves ([2][4 scans][4 rows][K][16 slots])
@@ -307,21 +324,28 @@ int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::atomic<bool> &done = attr_set[dev & 63];
     if (!done.load(std::memory_order_acquire)) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
 
 template <typename P, int K, bool EDGE, typename PI>
 int launch_tall_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
-    if (a.ny == 1 && a.ys[0].causal != 0) return launch_tall_pat<P, K, EDGE, PI, 1>(src, dst, a, stream);
-    if (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) return launch_tall_pat<P, K, EDGE, PI, 2>(src, dst, a, stream);
-    return launch_tall_pat<P, K, EDGE, PI, 0>(src, dst, a, stream);
+    const int pat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
+    bool early = !EDGE && pat > 0;
+    if constexpr (!PixelTraits<P>::is_integer) early = early && (a.pw_flags & 2) == 0;
+    if constexpr (!EDGE) {
+        if (early && pat == 1) return launch_tall_pat<P, K, EDGE, PI, 1, true>(src, dst, a, stream);
+        if (early && pat == 2) return launch_tall_pat<P, K, EDGE, PI, 2, true>(src, dst, a, stream);
+    }
+    if (pat == 1) return launch_tall_pat<P, K, EDGE, PI, 1, false>(src, dst, a, stream);
+    if (pat == 2) return launch_tall_pat<P, K, EDGE, PI, 2, false>(src, dst, a, stream);
+    return launch_tall_pat<P, K, EDGE, PI, 0, false>(src, dst, a, stream);
 }
 
 }  // namespace

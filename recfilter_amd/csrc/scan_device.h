@@ -184,9 +184,13 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
 }
 
 // ---- y phase: one scan up or down a register column -----------------------------------------
-template <typename Acc, bool CAUSAL, int K, int TY, typename SC>
+// `done(m, value)` is called for every row as soon as it is final (the last scan of a pass stores from there: the
+// rows leave while the recurrence still runs, instead of TY stores in one burst behind it)
+struct NoRowSink { __device__ __forceinline__ void operator()(int, float) const {} __device__ __forceinline__ void operator()(int, double) const {}
+                   __device__ __forceinline__ void operator()(int, uint32_t) const {} };
+template <typename Acc, bool CAUSAL, int K, int TY, typename SC, typename Sink = NoRowSink>
 __device__ __forceinline__ void scan_col(Acc (&col)[TY], const SC &sc, bool clamp_first,
-                                         const Acc (&carry)[K]) {
+                                         const Acc (&carry)[K], const Sink &done = Sink()) {
     Acc h[K];
 #pragma unroll
     for (int j = 0; j < K; j++) h[j] = carry[j];
@@ -223,6 +227,7 @@ __device__ __forceinline__ void scan_col(Acc (&col)[TY], const SC &sc, bool clam
         h[0] = acc;
         if (p == 0) y0 = acc;
         col[m] = acc;
+        done(m, acc);
     }
 }
 
