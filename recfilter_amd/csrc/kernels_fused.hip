@@ -245,15 +245,26 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         Acc col[TY];
 #pragma unroll
         for (int i = 0; i < TY; i++) col[i] = tile[i * kFusedTX + e];
-        if constexpr (YPAT == 1 || YPAT == 2) {
+        if constexpr (YPAT >= 1) {
+            // YPAT 3 / 4: pattern 1 / 2 without an epilogue -- the rows are stored from inside the last scan, each as soon
+            // as it is final, instead of TY stores in one burst behind the recurrence
             static_assert(!EDGE || YPAT == 0, "the fixed patterns are instantiated for whole tiles");
+            constexpr int PAT = YPAT > 2 ? YPAT - 2 : YPAT;
+            constexpr bool EARLY = YPAT > 2;
+            char *dpb_early = reinterpret_cast<char *>(dst + tile_off);
+            auto row_out = [&](int m, Acc v) __attribute__((always_inline)) {
+                __builtin_nontemporal_store(PixelTraits<P>::store(v),
+                                            reinterpret_cast<P *>(dpb_early + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)m * a.row_bytes)));
+            };
             {
                 const bool clamp_first = a.clamped && ty == 0 && a.y_first_border;
-                scan_col<Acc, true, K, TY>(col, a.ys[0], clamp_first, CY[0]);
+                if constexpr (EARLY && PAT == 1) { scan_col<Acc, true, K, TY>(col, a.ys[0], clamp_first, CY[0], row_out); return; }
+                else scan_col<Acc, true, K, TY>(col, a.ys[0], clamp_first, CY[0]);
             }
-            if constexpr (YPAT == 2) {
+            if constexpr (PAT == 2) {
                 const bool clamp_first = a.clamped && ty == a.MY - 1 && a.y_last_border;
-                scan_col<Acc, false, K, TY>(col, a.ys[1], clamp_first, CY[1]);
+                if constexpr (EARLY) { scan_col<Acc, false, K, TY>(col, a.ys[1], clamp_first, CY[1], row_out); return; }
+                else scan_col<Acc, false, K, TY>(col, a.ys[1], clamp_first, CY[1]);
             }
         } else {
 #pragma unroll 1
@@ -353,6 +364,8 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
     const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
     const int ypat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
+    bool early = true;        // no epilogue: rows can leave from inside the last scan
+    if constexpr (!PixelTraits<P>::is_integer) early = (a.pw_flags & 2) == 0;
 #define RF_CASE(KK, TT)                                                                                         \
     if (K == KK && TY == TT) {                                                                                  \
         if constexpr (!PixelTraits<P>::is_integer) {                                                            \
@@ -361,6 +374,8 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
         }                                                                                                       \
         if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true, PI>(src, dst, a, stream);              \
         if constexpr (TT == 64 && std::is_same<P, PI>::value) {        /* the usual y scans, directions fixed at compile time */ \
+            if (ypat == 1 && early) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 3>(src, dst, a, stream); \
+            if (ypat == 2 && early) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 4>(src, dst, a, stream); \
             if (ypat == 1) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 1>(src, dst, a, stream); \
             if (ypat == 2) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 2>(src, dst, a, stream); \
         }                                                                                                       \
