@@ -30,6 +30,7 @@ constexpr int kCarryLines = 64;    // lines per workgroup = one wave: 256-byte c
 constexpr int kCarryChunks = 16;   // chunks per line per block of tiles = waves per workgroup
 constexpr int kCarryMaxC = 16;     // tiles per chunk (orders <= 3; higher orders keep 4 tiles of k-vectors in registers)
 constexpr int kCarryMaxCHigh = 4;
+constexpr int kCarryPair3MaxC = 8;  // order-3 pair kernel: 8 tiles per thread
 constexpr int kCarryChunksHigh = 8; // and at most 8 chunk-waves, which bounds the LDS combine buffer (k = 8 in f64: 32 KiB)
 
 template <typename Acc, int K>
@@ -197,8 +198,8 @@ __device__ __forceinline__ void pair_matvec(const Acc *__restrict__ m, const Acc
         for (int j = 0; j < K; j++) y[r] = y[r] + m[r * K + j] * x[j];
 }
 
-template <typename Acc, int K, int KP, bool CAUSAL>
-__device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, const CarryGeom &g, Acc *__restrict__ tails,
+template <typename Acc, int K, int KP, bool CAUSAL, int MAXC>
+__device__ __forceinline__ void pair_run_scan(Acc (&t)[MAXC][KP], int s, const CarryGeom &g, Acc *__restrict__ tails,
                                           const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
                                           Acc (*exits)[kCarryLines][K], int ln, int ch, int n_chunks, int t0, int nvalid,
                                           uint32_t line, bool line_ok, Acc *__restrict__ send) {
@@ -213,8 +214,8 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, c
     for (int r = 0; r < K; r++) x[r] = Acc(0);
     // chunk-local recurrence in scan direction, zero entering state
 #pragma unroll
-    for (int p = 0; p < kCarryMaxC; p++) {
-        const int ii = causal ? p : kCarryMaxC - 1 - p;
+    for (int p = 0; p < MAXC; p++) {
+        const int ii = causal ? p : MAXC - 1 - p;
         if (ii < nvalid) {
             pair_matvec<Acc, K, KP>(Am, x, t[ii]);
 #pragma unroll
@@ -256,8 +257,8 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, c
     // propagate through the chunk and store
     const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
 #pragma unroll
-    for (int p = 0; p < kCarryMaxC; p++) {
-        const int ii = causal ? p : kCarryMaxC - 1 - p;
+    for (int p = 0; p < MAXC; p++) {
+        const int ii = causal ? p : MAXC - 1 - p;
         if (ii < nvalid) {
             Acc y[K];
 #pragma unroll
@@ -282,7 +283,9 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[kCarryMaxC][KP], int s, c
 // terms of the second scan (create_tail_residual_term, lib/split.cpp:912-1004) from its own registers plus one
 // halo tile from each neighbouring chunk (through LDS).  The general kernel above re-reads the first scan's
 // completed tails from memory behind a barrier instead.
-template <typename Acc, int K>
+// MAXC: tiles a thread owns (16; 8 for order 3, whose two register-resident scans of 16 tiles do not fit the 128 registers
+// of a 16-wave workgroup -- lines of at most 128 tiles, i.e. every image on 128-row tiles, take it)
+template <typename Acc, int K, int MAXC>
 __global__ void __launch_bounds__(kCarryLines * kCarryChunks)
 carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
                   const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
@@ -304,11 +307,11 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);     // wave-uniform
 
     constexpr int KP = K < 2 ? 2 : K;
-    Acc ta[kCarryMaxC][KP], tb[kCarryMaxC][KP];              // owned tiles of scan s0 / s0+1
-    auto load_scan = [&](Acc (&t)[kCarryMaxC][KP], int s) {
+    Acc ta[MAXC][KP], tb[MAXC][KP];              // owned tiles of scan s0 / s0+1
+    auto load_scan = [&](Acc (&t)[MAXC][KP], int s) {
         const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
 #pragma unroll
-        for (int ii = 0; ii < kCarryMaxC; ii++) {
+        for (int ii = 0; ii < MAXC; ii++) {
 #pragma unroll
             for (int r = 0; r < KP; r++) t[ii][r] = Acc(0);
             if (ii < nvalid) {
@@ -320,8 +323,8 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     load_scan(ta, s0);
     load_scan(tb, s0 + 1);
 
-    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, KP, true>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send);
-    else                            pair_run_scan<Acc, K, KP, false>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send);
+    if ((g.causal_mask >> s0) & 1u) pair_run_scan<Acc, K, KP, true, MAXC>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send);
+    else                            pair_run_scan<Acc, K, KP, false, MAXC>(ta, s0, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send);
 
     // ---- chaining of scan s0+1 on the completed scan s0 ----
     {
@@ -332,12 +335,12 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
             edge[ch][0][ln][r] = ta[0][r];
             Acc last = ta[0][r];
 #pragma unroll
-            for (int ii = 1; ii < kCarryMaxC; ii++) last = (ii < nvalid) ? ta[ii][r] : last;
+            for (int ii = 1; ii < MAXC; ii++) last = (ii < nvalid) ? ta[ii][r] : last;
             edge[ch][1][ln][r] = last;
         }
         __syncthreads();
 #pragma unroll
-        for (int ii = 0; ii < kCarryMaxC; ii++) {
+        for (int ii = 0; ii < MAXC; ii++) {
             if (ii < nvalid) {
                 const int tt = t0 + ii;
                 const int v = ((tt == 0 && g.first_is_border) ? 1 : 0) | ((tt == M - 1 && g.last_is_border) ? 2 : 0);
@@ -352,7 +355,7 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
                 } else {                   // ... of an anticausal scan from the tile after
 #pragma unroll
                     for (int o = 0; o < K; o++)
-                        c[o] = (ii + 1 < nvalid) ? ta[ii + 1 < kCarryMaxC ? ii + 1 : 0][o] : edge[ch + 1][0][ln][o];
+                        c[o] = (ii + 1 < nvalid) ? ta[ii + 1 < MAXC ? ii + 1 : 0][o] : edge[ch + 1][0][ln][o];
                 }
                 const Acc *Wm = Wtab + (((v * g.n_scans + q) * g.n_scans + s) * K) * K;
                 pair_matvec<Acc, K, KP>(Wm, c, tb[ii]);
@@ -361,8 +364,8 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     }
     __syncthreads();          // exits[] is reused by the second scan
     Acc *send2 = send != nullptr ? send + (uint32_t)K * L : nullptr;
-    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, KP, true>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send2);
-    else                                  pair_run_scan<Acc, K, KP, false>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send2);
+    if ((g.causal_mask >> (s0 + 1)) & 1u) pair_run_scan<Acc, K, KP, true, MAXC>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send2);
+    else                                  pair_run_scan<Acc, K, KP, false, MAXC>(tb, s0 + 1, g, tails, Atab, AC, C, exits, ln, ch, n_chunks, t0, nvalid, line, line_ok, send2);
 }
 
 // Row chaining for a long 1-D signal folded into NY rows of MX tiles (plan_fused.cpp, "chained rows"): the
@@ -436,6 +439,7 @@ template int launch_row_chain<uint32_t>(int, const uint32_t *, uint32_t *, int, 
                                         hipStream_t);
 
 int carry_chunk_count(int64_t M, int64_t lines, int C, int K) {
+    if (K == 3 && M > 64 && C <= kCarryPair3MaxC && (int64_t)kCarryChunks * C >= M) return (int)((M + C - 1) / C);      // the pair kernel's chunking
     const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
     int64_t want = (4096 + line_groups - 1) / line_groups;
@@ -469,10 +473,17 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     if constexpr (sizeof(Acc) == 4) {
         static const bool pair_off = getenv("RF_CARRY_NO_PAIR") != nullptr;     // tuning knob: always the general kernel
         if (s_end - s_begin == 2 && K <= 2 && (int64_t)n_chunks * C >= a.M && !pair_off) {
-            if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+            if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1, kCarryMaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
                                            (const Acc *)a.incoming, a.W, a.A, AC, C, send);
-            else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+            else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2, kCarryMaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
                                            (const Acc *)a.incoming, a.W, a.A, AC, C, send);
+            RF_HIP_CHECK(hipGetLastError());
+            return RF_OK;
+        }
+        static const bool pair3_off = getenv("RF_CARRY_NO_PAIR3") != nullptr;
+        if (s_end - s_begin == 2 && K == 3 && a.M > 64 && C <= kCarryPair3MaxC && (int64_t)n_chunks * C >= a.M && !pair_off && !pair3_off) {
+            hipLaunchKernelGGL((carry_pair_kernel<Acc, 3, kCarryPair3MaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+                               (const Acc *)a.incoming, a.W, a.A, AC, C, send);
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
         }
@@ -487,6 +498,12 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
 }
 
 int carry_chunk_length(int64_t M, int64_t lines, int K) {
+    // order 3: chunks of at most 8 tiles whenever 16 of them cover the line, so that two scans of a dimension fit the
+    // register-chained pair kernel
+    // (long lines only: at 64 tiles per line the general kernel is as fast)
+    if (K == 3 && M > 64 && M <= (int64_t)kCarryChunks * kCarryPair3MaxC && getenv("RF_CARRY_NO_PAIR3") == nullptr &&
+        getenv("RF_CARRY_NO_PAIR") == nullptr)
+        return (int)((M + kCarryChunks - 1) / kCarryChunks);
     const int max_c = K <= 3 ? kCarryMaxC : kCarryMaxCHigh;
     const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     // Chunks (waves) per line: enough to put ~4096 waves on the chip, no more -- with many lines a single

@@ -152,7 +152,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     std::vector<DevScan<Acc>> hxd = dev_scans(dx.scan_ids), hyd = dev_scans(dy.scan_ids);
     std::vector<Acc> hWx, hAx, hWy, hAy, hG, hAMy, hACx, hACy, hHx, hHy, hAMx, hAMSx, hApowX, hApowY;
     const int chain_S = (int)((NY + 63) / 64);     // rows per lane of the row-chain kernel
-    const int Cx = carry_chunk_length(MX, Lx), Cy = carry_chunk_length(MY, Ly);
+    const int Cx = carry_chunk_length(MX, Lx, K), Cy = carry_chunk_length(MY, Ly, K);
     if (nx > 0) {
         DimTables<S> tx = build_dim_tables<S>(table_scans(dx.scan_ids), K, kFusedTX, plan->clamped, TVx);
         flatten_W(tx, nx, hWx, hAx, "x");

@@ -61,7 +61,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
         if (t.causal) mask |= 1u << i;
     }
     DimTables<S> tab = build_dim_tables<S>(ts, K, TZ, plan->clamped);
-    const int C = carry_chunk_length(M, di.lines);
+    const int C = carry_chunk_length(M, di.lines, K);
     std::vector<Acc> hW((size_t)4 * n * n * K * K, Acc(0)), hA((size_t)n * K * K), hAC(hA.size()), hAM(hA.size());
     std::vector<double> dW(hW.size(), 0.0), dA(hA.size(), 0.0);
     for (int v = 0; v < 4; v++)
