@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, scans, clamped, planes, result_dir):
+def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extents=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch
@@ -36,21 +36,22 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         full = [rc.random_image(shape, np.float32, 91 + p) for p in range(planes)]
-        n = shape[0] // world
+        ext = list(extents) if extents else [shape[0] // world] * world        # slabs may differ (shard_extents)
+        lo, n = sum(ext[:rank]), ext[rank]
         local = (n,) + tuple(shape[1:])
-        inputs = [torch.from_numpy(np.ascontiguousarray(f[rank * n:(rank + 1) * n])).cuda() for f in full]
+        inputs = [torch.from_numpy(np.ascontiguousarray(f[lo:lo + n])).cuda() for f in full]
         outputs = [torch.empty_like(t) for t in inputs]
-        filt = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world)
+        filt = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, slab_extents=extents)
         assert filt.plan.path_name == "tiled_fused"
         for _ in range(2):                     # the second execute reuses the exchange buffers
             filt.execute(inputs, outputs)
         torch.cuda.synchronize()
-        wants = [oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[rank * n:(rank + 1) * n] for p in range(planes)]
+        wants = [oracle.apply_filter(full[p].astype(np.float64), scans, clamped)[lo:lo + n] for p in range(planes)]
         for p in range(planes):
             err = rc.rel_err(outputs[p].cpu().numpy(), wants[p])
             assert err < 1e-4, f"rank {rank} plane {p}: rel err {err}"
         # steps in flight: two slots (own stream, plan, exchange buffers, output planes), five submits, one drain
-        piped = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, inflight=2)
+        piped = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, inflight=2, slab_extents=extents)
         sets = [[torch.zeros_like(t) for t in inputs] for _ in range(2)]
         for i in range(5):
             piped.submit(inputs, sets[i % 2])
@@ -65,17 +66,20 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d"])
+@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d", "rows_2d_unequal"])
 def test_two_processes_one_gpu(case, tmp_path):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     import ref_cases as rc
+    extents = None
     if case == "rows_2d":
         shape, scans, clamped, planes = (256, 768), rc.xy_pm(rc.GAUSS2), True, 2
+    elif case == "rows_2d_unequal":
+        shape, scans, clamped, planes, extents = (320, 768), rc.xy_pm(rc.GAUSS2), True, 2, [192, 128]
     else:
         shape, scans, clamped, planes = (32, 96, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path), extents), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
