@@ -6,6 +6,7 @@
 //     coefficient permutation the reference forgets)
 //   * split() preconditions (tile divides extent)   lib/recfilter.h:311, lib/split.cpp:1879-1931
 #include "plan.h"
+#include "sections.h"
 #include "plan_generic.h"
 
 #include <algorithm>
@@ -307,6 +308,45 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
             plan->dims[d].k = std::max(plan->dims[d].k, r.order);
             plan->dims[d].scan_ids.push_back((int)plan->scans.size());
             plan->scans.push_back(s);
+        }
+    }
+
+    // Orders above 3 (lib/split.cpp:575-578 pads any order; the fused kernels stop at 3): with a zero border and float
+    // pixels a scan of order 4..RF_MAX_ORDER is the same filter as its first/second/third-order sections applied one after
+    // the other (sections.h), and those the fused kernels take -- as long as no dimension ends up with more than four scans.
+    // The rewrite is kept only if it makes the fused path applicable; every other path runs the scans as given.
+    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && !plan->clamped &&
+        (plan->dtype == RF_F32 || plan->dtype == RF_F64) && getenv("RF_NO_SECTIONS") == nullptr) {
+        bool high = false;
+        for (const Scan &sc : plan->scans) high = high || sc.order > kFusedMaxK;
+        if (high) {
+            std::vector<Scan> rewritten;
+            bool ok = true;
+            const int dtype = plan->dtype;
+            for (const Scan &sc : plan->scans) {
+                if (sc.order <= kFusedMaxK) { rewritten.push_back(sc); continue; }
+                std::vector<Scan> sec;
+                ok = ok && split_into_sections(sc, kFusedMaxK, [dtype](double v) { return cast_coeff(v, dtype); }, sec);
+                if (!ok) break;
+                rewritten.insert(rewritten.end(), sec.begin(), sec.end());
+            }
+            if (ok) {
+                std::vector<Scan> original = plan->scans;
+                DimInfo saved[RF_MAX_DIMS];
+                for (int d = 0; d < RF_MAX_DIMS; d++) saved[d] = plan->dims[d];
+                plan->scans = rewritten;
+                for (int d = 0; d < desc->ndim; d++) { plan->dims[d].scan_ids.clear(); plan->dims[d].k = 0; }
+                for (size_t i = 0; i < plan->scans.size(); i++) {
+                    DimInfo &di = plan->dims[plan->scans[i].dim];
+                    di.scan_ids.push_back((int)i);
+                    di.k = std::max(di.k, plan->scans[i].order);
+                }
+                std::string unused;
+                if (!fused_plan_applicable(plan.get(), desc, &unused)) {
+                    plan->scans = original;
+                    for (int d = 0; d < RF_MAX_DIMS; d++) plan->dims[d] = saved[d];
+                }
+            }
         }
     }
 

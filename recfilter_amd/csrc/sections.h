@@ -1,0 +1,123 @@
+// sections.h -- a recursive scan of order 4..RF_MAX_ORDER as first/second/third-order scans with the same transfer
+// function (host side; the plan rewrite that keeps such filters on the fused kernels).
+//
+// y[i] = b x[i] + sum_j a_j y[i-1-j] has the poles of z^k - a_0 z^(k-1) - ... - a_(k-1).  Conjugate pairs become second-order
+// sections (2 Re p, -|p|^2); a pair takes a real pole along (third order) while there are any, the remaining real poles go
+// three, two or one to a section -- as few scans as real coefficients allow.  Applied one after the other in the same direction with a ZERO
+// border the sections reproduce the original scan up to rounding (the inverse of overlap_feedback_coeff,
+// lib/iir_coeff.cpp:236-263).  The caller keeps the original when the recomposed denominator differs from it by more than
+// rounding (clustered poles) or when the border is clamped (the clamped prologue of a high-order scan is not the
+// composition of the sections' prologues).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "rf_internal.h"
+
+namespace rf {
+
+// roots of the monic polynomial z^k + c[0] z^(k-1) + ... + c[k-1] (Durand-Kerner); false when it does not converge
+inline bool monic_roots(const std::vector<double> &c, std::vector<std::complex<double>> &roots) {
+    const int k = (int)c.size();
+    double bound = 0.0;
+    for (double v : c) bound = std::max(bound, std::fabs(v));
+    bound = 1.0 + bound;                                          // Cauchy bound
+    roots.resize(k);
+    const std::complex<double> seed(0.4, 0.9);
+    std::complex<double> p(1.0, 0.0);
+    for (int i = 0; i < k; i++) { roots[i] = p * (0.5 * bound); p *= seed; }
+    auto eval = [&](std::complex<double> z) {
+        std::complex<double> v(1.0, 0.0);
+        for (int i = 0; i < k; i++) v = v * z + c[i];
+        return v;
+    };
+    for (int it = 0; it < 500; it++) {
+        double step = 0.0;
+        for (int i = 0; i < k; i++) {
+            std::complex<double> den(1.0, 0.0);
+            for (int j = 0; j < k; j++) if (j != i) den *= roots[i] - roots[j];
+            if (std::abs(den) < 1e-300) return false;
+            const std::complex<double> d = eval(roots[i]) / den;
+            roots[i] -= d;
+            step = std::max(step, std::abs(d));
+        }
+        if (step < 1e-15 * bound) return true;
+    }
+    return false;
+}
+
+// denominators are stored as feedback taps a[] (1 - a_0 z^-1 - a_1 z^-2 - ...); product of two of them
+inline std::vector<double> multiply_feedback(const std::vector<double> &a, const std::vector<double> &b) {
+    std::vector<double> pa(a.size() + 1, 1.0), pb(b.size() + 1, 1.0);
+    for (size_t i = 0; i < a.size(); i++) pa[i + 1] = -a[i];
+    for (size_t i = 0; i < b.size(); i++) pb[i + 1] = -b[i];
+    std::vector<double> pc(pa.size() + pb.size() - 1, 0.0);
+    for (size_t i = 0; i < pa.size(); i++)
+        for (size_t j = 0; j < pb.size(); j++) pc[i + j] += pa[i] * pb[j];
+    std::vector<double> out(pc.size() - 1);
+    for (size_t i = 0; i + 1 < pc.size(); i++) out[i] = -pc[i + 1];
+    return out;
+}
+
+// `cast`: rounding of a coefficient through the pixel type.  Sections of order <= max_order, first one carries b.
+template <typename Cast>
+bool split_into_sections(const Scan &s, int max_order, Cast cast, std::vector<Scan> &out) {
+    const int k = s.order;
+    std::vector<double> c(k);
+    for (int i = 0; i < k; i++) c[i] = -s.a[i];
+    std::vector<std::complex<double>> roots;
+    if (!monic_roots(c, roots)) return false;
+    std::vector<std::vector<double>> quad;
+    std::vector<bool> used(k, false);
+    std::vector<double> reals;
+    for (int i = 0; i < k; i++) {
+        if (used[i]) continue;
+        const double tol = 1e-9 * std::max(1.0, std::abs(roots[i]));
+        if (std::fabs(roots[i].imag()) <= tol) { reals.push_back(roots[i].real()); used[i] = true; continue; }
+        int best = -1;                                            // its conjugate
+        for (int j = 0; j < k; j++)
+            if (!used[j] && j != i && (best < 0 || std::abs(roots[j] - std::conj(roots[i])) < std::abs(roots[best] - std::conj(roots[i])))) best = j;
+        if (best < 0 || std::abs(roots[best] - std::conj(roots[i])) > 1e-6 * std::max(1.0, std::abs(roots[i]))) return false;
+        const std::complex<double> p = 0.5 * (roots[i] + std::conj(roots[best]));
+        quad.push_back({2.0 * p.real(), -std::norm(p)});
+        used[i] = used[best] = true;
+    }
+    // pack into as few sections of order <= max_order as real coefficients allow: a conjugate pair takes a real pole along
+    // (third order) while there are any; the real poles left over go three, two or one to a section
+    std::sort(reals.begin(), reals.end(), [](double x, double y) { return std::fabs(x) > std::fabs(y); });
+    std::vector<std::vector<double>> sections;
+    size_t r = 0;
+    for (auto &q : quad) {
+        if (max_order >= 3 && r < reals.size()) sections.push_back(multiply_feedback(q, {reals[r++]}));
+        else sections.push_back(q);
+    }
+    while (r < reals.size()) {
+        const size_t take = std::min<size_t>(reals.size() - r, (size_t)std::min(max_order, 3));
+        std::vector<double> sec = {reals[r]};
+        for (size_t i = 1; i < take; i++) sec = multiply_feedback(sec, {reals[r + i]});
+        sections.push_back(sec);
+        r += take;
+    }
+    // fewer, larger sections while they fit: 2 + 2 + 2 stays, but nothing larger than max_order is built
+    std::vector<double> recomposed;
+    out.clear();
+    for (size_t i = 0; i < sections.size(); i++) {
+        if ((int)sections[i].size() > max_order) return false;
+        Scan t = s;
+        t.order = (int)sections[i].size();
+        t.b = i == 0 ? s.b : cast(1.0);
+        for (int j = 0; j < RF_MAX_ORDER; j++) t.a[j] = j < t.order ? cast(sections[i][j]) : 0.0;
+        out.push_back(t);
+        std::vector<double> rounded(t.a, t.a + t.order);
+        recomposed = recomposed.empty() ? rounded : multiply_feedback(recomposed, rounded);
+    }
+    if ((int)recomposed.size() != k) return false;
+    double scale = 1.0, err = 0.0;
+    for (int i = 0; i < k; i++) { scale = std::max(scale, std::fabs(s.a[i])); err = std::max(err, std::fabs(recomposed[i] - s.a[i])); }
+    return err <= 2e-6 * scale;                                   // sections rounded to the pixel type still give this filter
+}
+
+}  // namespace rf

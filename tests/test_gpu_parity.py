@@ -1004,3 +1004,54 @@ def test_tall_tiles_other_features(monkeypatch):
                                ((8192, 8192), scans, 64), ((16384 + 64, 8192), scans, 64)):
         with rfa.Plan(shape, sc, clamped=True) as plan:
             assert list(plan.tiles)[:2] == [256, want_ty], (shape, plan.tiles)
+
+
+# ---- orders above 3: the plan splits a scan into first/second/third-order sections (sections.h) and stays on the fused kernels ----
+def _from_poles(poles, b=0.3):
+    p = np.poly(poles).real
+    return [b] + [float(-v) for v in p[1:]]
+
+
+@pytest.mark.parametrize("name,poles", [
+    ("order4", [0.7, 0.6, 0.3 + 0.5j, 0.3 - 0.5j]),
+    ("order5", [0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j]),
+    ("order6", [0.85, 0.1, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j]),
+])
+def test_high_order_scans_run_as_sections_on_the_fused_path(name, poles):
+    """lib/split.cpp:575-578 takes any order; here a zero-border float filter of order 4..6 is rewritten into sections of
+    order <= 3 with the same transfer function and runs on the fused kernels.  Checked against the
+    oracle run on the ORIGINAL high-order coefficients."""
+    import recfilter_amd as rfa
+    co = _from_poles(poles)
+    scans = [(0, True, co), (0, False, co), (1, True, co), (1, False, co)]
+    imgs, outs, (path, tiles) = _run((328, 1024), scans, clamped=False)
+    assert path == 3, (name, path)
+    _check(imgs, outs, scans, False)
+    # a clamped border keeps the scans as given (the prologue of a high-order scan is not its sections' prologues)
+    imgs, outs, (path, _) = _run((128, 256), scans, clamped=True)
+    assert path != 3
+    _check(imgs, outs, scans, True)
+
+
+def test_high_order_sections_other_cases():
+    """One causal scan of order 8 per dimension (three sections each), a 1-D signal of order 9 on the chained-rows path,
+    and filters the rewrite must leave alone: three conjugate pairs twice per dimension (six sections > four scans),
+    integer pixels."""
+    import recfilter_amd as rfa
+    o8 = _from_poles([0.8, -0.7, 0.5, -0.3, 0.3 + 0.6j, 0.3 - 0.6j, -0.1 + 0.7j, -0.1 - 0.7j], b=0.2)
+    scans = [(0, True, o8), (1, True, o8)]
+    imgs, outs, (path, _) = _run((256, 512), scans, clamped=False)
+    assert path == 3
+    _check(imgs, outs, scans, False)
+    sig, out1, (path, _) = _run((8192 * 4,), [(0, True, o8)], clamped=False)       # (RF_MAX_ORDER is 8)
+    assert path == 3
+    _check(sig, out1, [(0, True, o8)], False)
+    o6c = _from_poles([0.6 + 0.2j, 0.6 - 0.2j, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j])
+    scans = [(0, True, o6c), (0, False, o6c), (1, True, o6c)]
+    imgs, outs, (path, _) = _run((128, 256), scans, clamped=False)
+    assert path != 3
+    _check(imgs, outs, scans, False)
+    ints = [(0, True, [1.0, 1.0, 0.0, 0.0, 1.0]), (1, True, [1.0, 1.0])]
+    imgs, outs, (path, _) = _run((64, 256), ints, dtype=np.int32, clamped=False)
+    assert path != 3
+    _check(imgs, outs, ints, False)

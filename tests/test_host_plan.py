@@ -346,3 +346,29 @@ def test_overlapped_path_preconditions():
         _host_plan((64, 64, 64), scans, tile=[32, 16, 16], path=capi.RF_PATH_TILED_OVERLAPPED)
     # without explicit tiles the automatic choice is unchanged
     assert _host_plan((16, 16, 16), scans).path != capi.RF_PATH_TILED_OVERLAPPED
+
+
+def test_high_order_scans_are_split_into_sections_for_the_fused_path(monkeypatch):
+    """Plan rewrite of sections.h, decided on the host: zero border + float pixels + at most four scans per dimension after
+    the split -> fused; otherwise the scans run as given on another path."""
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    monkeypatch.setenv("RF_SMALL_LIMIT", "0")
+
+    def from_poles(poles, b=0.3):
+        p = np.poly(poles).real
+        return [b] + [float(-v) for v in p[1:]]
+    o5 = from_poles([0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j])
+    o6c = from_poles([0.6 + 0.2j, 0.6 - 0.2j, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j])
+    xy = lambda co: [(0, True, co), (0, False, co), (1, True, co), (1, False, co)]
+
+    def path_of(scans, **kw):
+        with rfa.Plan((512, 512), scans, device=capi.RF_DEVICE_HOST_ONLY, **kw) as plan:
+            return plan.path_name
+    assert path_of(xy(o5), clamped=False) == "tiled_fused"                 # 5 = 3 + 2: four scans per dimension
+    assert path_of(xy(o5), clamped=True) != "tiled_fused"                  # clamped border: not the same filter
+    assert path_of(xy(o5), clamped=False, dtype=np.float64) != "tiled_fused"     # (f64 is not on the fused kernels)
+    assert path_of(xy(o6c), clamped=False) != "tiled_fused"                # three conjugate pairs, twice: six scans per dimension
+    assert path_of([(0, True, o6c), (1, True, o6c)], clamped=False) == "tiled_fused"
+    monkeypatch.setenv("RF_NO_SECTIONS", "1")
+    assert path_of(xy(o5), clamped=False) != "tiled_fused"
