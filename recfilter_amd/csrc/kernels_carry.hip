@@ -437,6 +437,7 @@ int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool 
 template int launch_row_chain<float>(int, const float *, float *, int, bool, const float *, const float *, int, hipStream_t);
 template int launch_row_chain<uint32_t>(int, const uint32_t *, uint32_t *, int, bool, const uint32_t *, const uint32_t *, int,
                                         hipStream_t);
+template int launch_row_chain<double>(int, const double *, double *, int, bool, const double *, const double *, int, hipStream_t);
 
 int carry_chunk_count(int64_t M, int64_t lines, int C, int K) {
     if (K == 3 && M > 64 && C <= kCarryPair3MaxC && (int64_t)kCarryChunks * C >= M) return (int)((M + C - 1) / C);      // the pair kernel's chunking

@@ -402,5 +402,6 @@ int launch_fused_pass2(int K, int TY, const void *src, bool src_u8, P *dst, cons
 template int launch_fused_pass2<float>(int, int, const void *, bool, float *, const FusedArgs<float> &, hipStream_t);
 template int launch_fused_pass2<int32_t>(int, int, const void *, bool, int32_t *, const FusedArgs<uint32_t> &, hipStream_t);
 template int launch_fused_pass2<int16_t>(int, int, const void *, bool, int16_t *, const FusedArgs<uint32_t> &, hipStream_t);
+template int launch_fused_pass2<double>(int, int, const void *, bool, double *, const FusedArgs<double> &, hipStream_t);
 
 }  // namespace rf

@@ -29,7 +29,6 @@ namespace rf {
 
 namespace {
 
-constexpr int kTailRows = 32;     // rows staged per step
 
 typedef float F2 __attribute__((ext_vector_type(2)));     // operands of the packed f32 instructions
 
@@ -40,6 +39,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
                    const typename PixelTraits<P>::Acc *__restrict__ Hy) {   // [vy][j][r][TY]
     using Acc = typename PixelTraits<P>::Acc;
     using A4 = typename Vec4<Acc>::type;
+    constexpr int kTailRows = sizeof(Acc) == 8 ? 16 : 32;          // rows staged per step: 32 KiB of LDS
     __shared__ __attribute__((aligned(16))) Acc tile[kTailRows * kFusedTX];
     // Hx of this tile's variant: nx * K rows of 256, dynamic so that a filter with two x scans of order 3 (6 KiB instead
     // of 12) still fits four workgroups per CU
@@ -238,7 +238,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
 // border tiles read their variant from memory.
 template <typename Acc, int K, bool EDGE, bool TALL>
-__global__ void __launch_bounds__(256, 6)
+__global__ void __launch_bounds__(256, sizeof(Acc) == 8 ? 3 : 6)
 xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
@@ -462,7 +462,9 @@ template int launch_fused_tails<int32_t>(int, int, const void *, bool, const Fus
                                          const uint32_t *, hipStream_t);
 template int launch_fused_tails<int16_t>(int, int, const void *, bool, const FusedArgs<uint32_t> &, const uint32_t *,
                                          const uint32_t *, hipStream_t);
+template int launch_fused_tails<double>(int, int, const void *, bool, const FusedArgs<double> &, const double *, const double *, hipStream_t);
 template int launch_xscan_rows<float>(int, int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
 template int launch_xscan_rows<uint32_t>(int, int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);
+template int launch_xscan_rows<double>(int, int, const FusedArgs<double> &, const double *, const double *, hipStream_t);
 
 }  // namespace rf

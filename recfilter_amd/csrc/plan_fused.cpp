@@ -75,6 +75,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         const int want = atoi(env);
         if (want == 32 || want == 64 || (want == 128 && !chained && (!rows_sharded || NYB % 128 == 0))) TY = want;
     }
+    // f64 pixels: a 256 x 32 tile is the 64 KiB of LDS a 256 x 64 tile of f32 takes (any height: partial last tile row)
+    if (sizeof(Acc) == 8) {
+        if (rows_sharded && NYB % 32 != 0) { set_error("row-sharded f64 slabs must be multiples of 32 rows"); return RF_ERR_UNSUPPORTED; }
+        TY = 32;
+    }
     const int nx = (int)dx.scan_ids.size(), ny = (int)dy.scan_ids.size();
     // The width only has to be a multiple of 4 (rows stay 16-byte aligned): the last tile of a row may be partial.  Its
     // missing samples are loaded as zeros and never stored; the tables of the "last tile" variants are built for the
@@ -415,7 +420,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     p2.run = [plan, fargs, K, TY, d_Yapply](int pl) {
         FusedArgs<Acc> a = fargs(pl);
         a.y_apply = d_Yapply;
-        if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
+        if constexpr (sizeof(Acc) == 4) {
+            if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
+        }
         return launch_fused_pass2<P>(K, TY, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
@@ -423,8 +430,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     // ---- z (3-D): filtered after the fused x/y stage, reading and writing the output planes ----
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
-        int rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false)
+        int rc;
+        if constexpr (sizeof(Acc) == 4)
+            rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false)
                                            : add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
+        else rc = add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);      // (f64: no strided kernels)
         if (rc != RF_OK) return rc;
     }
     if (batch) {
@@ -445,7 +455,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
 bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::string *why) {
     auto no = [&](const char *msg) { if (why) *why = msg; return false; };
-    if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return no("pixel type must be f32, i32 or i16");
+    if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16 && plan->dtype != RF_F64)
+        return no("pixel type must be f32, f64, i32 or i16");
+    if (plan->dtype == RF_F64 && (plan->ndim < 2 || plan->pw.in_u8)) return no("f64 pixels: 2-D / 3-D images of f64 samples");
     if (plan->ndim == 1) {
         // a long 1-D signal folded into chained rows (zero border only: the clamped prologue would differ per row)
         if (plan->clamped) return no("1-D: clamped border not supported on the fused path");
@@ -478,6 +490,7 @@ int build_fused_plan(rf_plan *plan, const rf_filter_desc *desc) {
     if (plan->dtype == RF_F32) return build_fused<float, double>(plan, desc);
     if (plan->dtype == RF_I32) return build_fused<int32_t, uint64_t>(plan, desc);
     if (plan->dtype == RF_I16) return build_fused<int16_t, uint64_t>(plan, desc);
+    if (plan->dtype == RF_F64) return build_fused<double, double>(plan, desc);
     set_error("fused path: unsupported pixel type");
     return RF_ERR_UNSUPPORTED;
 }

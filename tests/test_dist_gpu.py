@@ -106,7 +106,7 @@ def test_bench_two_ranks_over_gloo(launcher):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["path"] == "tiled_fused"
     assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0
-    assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] == "fused_pass2"
+    assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] in ("fused_pass2", "fused_tails")     # (the dominant one; a toss-up at this size)
 
 
 def test_bench_refuses_more_ranks_than_devices():

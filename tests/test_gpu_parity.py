@@ -91,8 +91,8 @@ def test_overlapped_3d_all_residual_pairs(dtype, clamped):
     assert path == 4 and list(tiles) == tile
     _check(imgs, outs, scans, clamped)
     imgs, outs, (path, tiles) = _run(shape, scans, dtype, clamped, tile=tile, path=0)
-    # split() along several dimensions: the fused kernels where they apply (f32 / i32 / i16, orders <= 3), else overlapped
-    assert path == (4 if dtype == np.float64 else 3)
+    # split() along several dimensions: the fused kernels where they apply (f32 / f64 / i32 / i16, orders <= 3), else overlapped
+    assert path == 3
     _check(imgs, outs, scans, clamped)
     yz = [s for s in scans if s[0] != 0]
     imgs, outs, (path, _) = _run(shape, yz, dtype, clamped, tile=[0, 5, 4], path=4, inplace=True)
@@ -297,7 +297,7 @@ def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32,
     if np.issubdtype(dtype, np.integer):
         full = [np.random.default_rng(31 + p).integers(0, 4, size=shape).astype(dtype) for p in range(planes)]
     else:
-        full = [rc.random_image(shape, np.float32, 31 + p) for p in range(planes)]
+        full = [rc.random_image(shape, dtype, 31 + p) for p in range(planes)]
     ext = list(extents) if extents is not None else [shape[0] // world] * world      # slab extents along the sharded dimension
     assert sum(ext) == shape[0] and len(ext) == world
     lo = [sum(ext[:r]) for r in range(world)]
@@ -902,18 +902,21 @@ def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
     imgs, outs, (path, _) = _run((512, 512), scans, clamped=True)
     assert path == 1
     _check(imgs, outs, scans, True)
-    # f64 pixels (not on the fused kernels): the line kernels at every size, ahead of the per-dimension generic passes
+    # f64 pixels: the fused kernels (256 x 32 tiles) above the small-image limit, the line kernels below
     imgs, outs, (path, _) = _run((2048, 1536), scans, np.float64, True)
+    assert path == 3
+    _check(imgs, outs, scans, True)
+    imgs, outs, (path, _) = _run((512, 384), scans, np.float64, True)
     assert path == 1
     _check(imgs, outs, scans, True)
     # split() widths are hints where the fused kernels apply (the tile size never changes the result): still the line
-    # kernels; pointwise stages stay on the tiled passes they are fused into; f64 split() filters keep their tiles
+    # kernels; pointwise stages stay on the tiled passes they are fused into
     with rfa.Plan((512, 512), scans, clamped=True, tile=[32, 32]) as plan:
         assert plan.path == 1
     with rfa.Plan((512, 512), scans, clamped=True, prologue=(0.5, 0.0)) as plan:
         assert plan.path == 3
     with rfa.Plan((512, 512), scans, dtype=np.float64, clamped=True, tile=[32, 32]) as plan:
-        assert plan.path == 4
+        assert plan.path == 1
 
 
 def test_tap_filter_against_numpy():
@@ -1055,3 +1058,48 @@ def test_high_order_sections_other_cases():
     imgs, outs, (path, _) = _run((64, 256), ints, dtype=np.int32, clamped=False)
     assert path != 3
     _check(imgs, outs, ints, False)
+
+
+# ---- f64 pixels on the fused kernels (256 x 32 tiles: the LDS footprint of a 256 x 64 tile of f32) ----
+@pytest.mark.parametrize("seed", range(8))
+def test_f64_on_the_fused_path(seed):
+    """Random filters (orders 1..3, every scan pattern), random heights and widths with partial last tiles, both borders:
+    f64 pixels through pass 1 / carries / residual / pass 2, against the f64 oracle at 1e-10."""
+    rng = np.random.default_rng(7100 + seed)
+    shape = (int(rng.integers(1, 300)), 4 * int(rng.integers(1, 260)))
+    clamped = bool(rng.integers(0, 2))
+    scans = rc.xy_pm(rc.GAUSS3 if seed % 2 else rc.GAUSS2) if seed % 3 == 0 else _random_filter(rng, 2)
+    imgs, outs, (path, tiles) = _run(shape, scans, dtype=np.float64, clamped=clamped, seed=seed, path=3)
+    assert path == 3 and (list(tiles)[1] == 32 or not any(s[0] == 1 for s in scans))
+    for im, o in zip(imgs, outs):
+        want = oracle.apply_filter(im.astype(np.float64), scans, clamped)
+        assert rc.rel_err_strict(o, want) < 1e-9 or rc.rel_err(o, want) < 1e-10
+
+
+def test_f64_fused_other_features():
+    """f64 on the fused path with a z stage behind (generic kernels for z), Tuple planes, row shards with slabs of different
+    heights, a pointwise epilogue; and the automatic choice for f64 (fused above the small-image limit)."""
+    import torch
+    import recfilter_amd as rfa
+    s3 = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    imgs, outs, (path, tiles) = _run((24, 96, 256), s3, dtype=np.float64, clamped=False, path=3)
+    assert path == 3
+    for im, o in zip(imgs, outs):
+        assert rc.rel_err(o, oracle.apply_filter(im.astype(np.float64), s3, False)) < 1e-10
+    scans = rc.xy_pm(rc.GAUSS2)
+    imgs, outs, (path, _) = _run((160, 512), scans, dtype=np.float64, clamped=True, planes=3, path=3)
+    assert path == 3
+    for im, o in zip(imgs, outs):
+        assert rc.rel_err(o, oracle.apply_filter(im.astype(np.float64), scans, True)) < 1e-10
+    full, got, (path, nex) = _run_sharded((64 + 160 + 96, 512), scans, True, 3, path=3, dtype=np.float64, extents=[64, 160, 96])
+    assert path == 3 and nex == 1
+    for im, o in zip(full, got):
+        assert rc.rel_err(o, oracle.apply_filter(im.astype(np.float64), scans, True)) < 1e-10
+    img = torch.rand((200, 768), device="cuda", dtype=torch.float64)
+    w = 0.5                                        # (the weights travel as f32: exactly representable ones)
+    with rfa.Plan((200, 768), scans, dtype=np.float64, clamped=True, epilogue=(-w, 1.0 + w, 0.0), path=3) as plan:
+        out = plan.execute([img])[0].cpu().numpy()
+    x = img.cpu().numpy()
+    assert np.abs(out - ((1.0 + w) * x - w * oracle.apply_filter(x, scans, True))).max() < 1e-10
+    with rfa.Plan((4096, 4096), scans, dtype=np.float64, clamped=True) as plan:
+        assert plan.path == 3 and list(plan.tiles)[:2] == [256, 32]

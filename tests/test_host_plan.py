@@ -312,7 +312,11 @@ def test_overlapped_tables_reproduce_oracle_on_reference_tests(name):
     shape = case["shape"]
     tile = [case["tile"] if any(s[0] == d for s in case["scans"]) else 0 for d in range(len(shape))]
     auto = _host_plan(shape, case["scans"], dtype=np.float64, clamped=case["clamped"], tile=tile)
-    assert auto.path == capi.RF_PATH_TILED_OVERLAPPED       # split() along >= 2 dimensions with small tiles
+    # split() along >= 2 dimensions: the fused kernels where they apply (these filters, any float / integer pixel type),
+    # the fully overlapped tiling otherwise -- e.g. a clamped filter of order 4
+    assert auto.path == capi.RF_PATH_TILED_FUSED
+    o4 = [(0, True, [0.5, 0.2, 0.1, 0.05, 0.02]), (1, False, [0.5, 0.2, 0.1, 0.05, 0.02])]
+    assert _host_plan((32, 32), o4, dtype=np.float64, clamped=True, tile=[8, 8]).path == capi.RF_PATH_TILED_OVERLAPPED
     p = _host_plan(shape, case["scans"], dtype=np.float64, clamped=case["clamped"], tile=tile, path=capi.RF_PATH_TILED_OVERLAPPED)
     assert p.path == capi.RF_PATH_TILED_OVERLAPPED and list(p.tiles) == tile
     img = rc.random_image(shape).astype(np.float64)
@@ -367,7 +371,8 @@ def test_high_order_scans_are_split_into_sections_for_the_fused_path(monkeypatch
             return plan.path_name
     assert path_of(xy(o5), clamped=False) == "tiled_fused"                 # 5 = 3 + 2: four scans per dimension
     assert path_of(xy(o5), clamped=True) != "tiled_fused"                  # clamped border: not the same filter
-    assert path_of(xy(o5), clamped=False, dtype=np.float64) != "tiled_fused"     # (f64 is not on the fused kernels)
+    assert path_of(xy(o5), clamped=False, dtype=np.float64) == "tiled_fused"     # f64 pixels: sections in f64
+    assert path_of(xy([1.0, 1.0, 0.0, 0.0, 1.0]), clamped=False, dtype=np.int32) != "tiled_fused"     # integer pixels: as given
     assert path_of(xy(o6c), clamped=False) != "tiled_fused"                # three conjugate pairs, twice: six scans per dimension
     assert path_of([(0, True, o6c), (1, True, o6c)], clamped=False) == "tiled_fused"
     monkeypatch.setenv("RF_NO_SECTIONS", "1")
