@@ -89,6 +89,9 @@ struct rf_plan {
     void *out[RF_MAX_PLANES] = {nullptr};
     hipStream_t stream = nullptr;
     int phase = 0;   // 0 idle, 1 begun
+    // 1-D signals whose length is not a multiple of 8192 on the fused path: zero-padded copies the kernels run on
+    int64_t padded_len = 0;
+    void *pad_in[RF_MAX_PLANES] = {nullptr}, *pad_out[RF_MAX_PLANES] = {nullptr};
 
     // host tables exposed through rf_plan_table
     std::map<std::string, std::vector<double>> tables;

@@ -27,6 +27,20 @@ int fused_order(const rf_plan *plan) {
 // A long 1-D signal runs on the fused path folded into rows: N = NY rows of NX samples, every row tiled like an
 // image row and the rows chained through their entering states ("chained rows").  Longest row first: fewer rows
 // to chain, and the blocked carry scan still finds NY * MX/16 waves of work.
+// A zero-border 1-D signal of any length is the same filter on the signal padded with zeros to the next multiple of 8192, as
+// long as no anticausal scan follows a causal one: a causal scan never sees what follows it, and an anticausal scan that runs
+// on untouched padding enters the signal with the zero state the padding leaves it in (fused_plan_applicable checks).
+// The padded length is chosen so that the signal folds into LONG rows (few rows to chain): the longest row length whose
+// 32-row granule costs at most 1/16 of padding.
+int64_t chained_padded_length(int64_t N) {
+    if (N % 8192 == 0) return N;
+    for (int64_t nx = 16384; nx >= kFusedTX; nx /= 2) {
+        const int64_t g = nx * 32, np = (N + g - 1) / g * g;
+        if (np - N <= N / 16) return np;
+    }
+    return (N + 8191) / 8192 * 8192;
+}
+
 int64_t chained_row_length(int64_t N) {
     for (int64_t nx = 16384; nx >= kFusedTX; nx /= 2)
         if (N % nx == 0 && (N / nx) % 64 == 0) return nx;
@@ -44,12 +58,14 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     DimInfo &dx = plan->dims[0];
     DimInfo no_y;
     DimInfo &dy = chained ? no_y : plan->dims[1];
-    const int64_t NX = chained ? chained_row_length(dx.N) : dx.N;
+    const int64_t N1 = chained ? chained_padded_length(dx.N) : dx.N;     // chained: the length the kernels see
+    const bool padded = chained && N1 != dx.N;
+    const int64_t NX = chained ? chained_row_length(N1) : dx.N;
     // Tuple planes of a 2-D filter ride in ONE launch per step, as the z planes of a volume whose planes are separate
     // buffers (FusedArgs::plane_batch): 5 launches instead of 5 per plane, which is most of the time of a small RGB image.
     const bool batch = plan->ndim == 2 && plan->n_planes > 1 && plan->n_planes <= kFusedMaxPlanes && plan->shard_world <= 1 &&
                        getenv("RF_NO_PLANE_BATCH") == nullptr;
-    const int64_t NY = chained ? dx.N / NX : dy.N, NZ = batch ? plan->n_planes : (plan->ndim > 2 ? plan->dims[2].N : 1);
+    const int64_t NY = chained ? N1 / NX : dy.N, NZ = batch ? plan->n_planes : (plan->ndim > 2 ? plan->dims[2].N : 1);
     const size_t first_begin_step = plan->begin_steps.size(), first_finish_step = plan->finish_steps.size();
     // tile height: 64 rows unless only 32 divides the height; any other height runs 64-row tiles (32 below 33 rows)
     // with a partial last tile row
@@ -91,7 +107,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const int TVy = (int)(NY - (int64_t)(MY - 1) * TY);            // rows of the last tile row, (0, TY]
     const int64_t NXP = (int64_t)MX * kFusedTX;                     // padded width: pitch of everything indexed by column
     const int64_t NYP = (int64_t)MY * TY;                           // padded height: pitch of everything indexed by row
-    dx.T = kFusedTX; dx.M = chained ? dx.N / kFusedTX : MX;
+    dx.T = kFusedTX; dx.M = chained ? N1 / kFusedTX : MX;
     dy.T = TY;       dy.M = MY;
     const int64_t Lx = NYP * NZ, Ly = NXP * NZ;
     const int outer = plan->ndim - 1;
@@ -304,16 +320,33 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // pass 1: tail extraction by contraction with the impulse responses (kernels_tails.hip)
     Step p1;
     p1.name = "fused_tails";
-    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy](int pl) {
+    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded](int pl) {
         const FusedArgs<Acc> a = fargs(pl);
         // images of whole 256 x 64 tiles stream through the LDS-DMA ring (kernels_stream.hip)
         if constexpr (std::is_same<P, float>::value) {
             if (stream_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, (int64_t)a.MX * a.MY * a.NZ, a.MX,
                                         a.NZ, a.nx * K, a.ny * K))
-                return launch_stream_tails(K, (const float *)plan->in[pl], a, d_Hx, d_Hy, plan->stream);
+                return launch_stream_tails(K, (const float *)(padded ? plan->pad_in[pl] : plan->in[pl]), a, d_Hx, d_Hy, plan->stream);
         }
-        return launch_fused_tails<P>(K, TY, plan->in[pl], plan->pw.in_u8, a, d_Hx, d_Hy, plan->stream);
+        return launch_fused_tails<P>(K, TY, padded ? plan->pad_in[pl] : plan->in[pl], plan->pw.in_u8, a, d_Hx, d_Hy, plan->stream);
     };
+    if (padded) {
+        // the zero-padded copies the kernels run on (the padding of the input copy is written once, here, and never again)
+        plan->padded_len = N1;
+        const size_t user_bytes = (size_t)dx.N * sizeof(P);
+        for (int pl = 0; pl < plan->n_planes; pl++) {
+            plan->pad_in[pl] = plan->alloc((size_t)N1 * sizeof(P), true, &status);
+            plan->pad_out[pl] = plan->alloc((size_t)N1 * sizeof(P), false, &status);
+        }
+        if (status != RF_OK) return status;
+        Step ci;
+        ci.name = "pad_copy_in";
+        ci.run = [plan, user_bytes](int pl) -> int {
+            RF_HIP_CHECK(hipMemcpyAsync(plan->pad_in[pl], plan->in[pl], user_bytes, hipMemcpyDeviceToDevice, plan->stream));
+            return (int)RF_OK;
+        };
+        plan->begin_steps.push_back(ci);
+    }
     plan->begin_steps.push_back(p1);
     if (nx > 0 && !chained) {
         Step cx;
@@ -417,16 +450,27 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     }
     Step p2;
     p2.name = "fused_pass2";
-    p2.run = [plan, fargs, K, TY, d_Yapply](int pl) {
+    p2.run = [plan, fargs, K, TY, d_Yapply, padded](int pl) {
         FusedArgs<Acc> a = fargs(pl);
         a.y_apply = d_Yapply;
         if constexpr (sizeof(Acc) == 4) {
             if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
         }
-        return launch_fused_pass2<P>(K, TY, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
+        return launch_fused_pass2<P>(K, TY, padded ? plan->pad_in[pl] : plan->in[pl], plan->pw.in_u8, (P *)(padded ? plan->pad_out[pl] : plan->out[pl]), a,
+                                     plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
     else plan->begin_steps.push_back(p2);
+    if (padded) {
+        const size_t user_bytes = (size_t)dx.N * sizeof(P);
+        Step co;
+        co.name = "pad_copy_out";
+        co.run = [plan, user_bytes](int pl) -> int {
+            RF_HIP_CHECK(hipMemcpyAsync(plan->out[pl], plan->pad_out[pl], user_bytes, hipMemcpyDeviceToDevice, plan->stream));
+            return (int)RF_OK;
+        };
+        plan->begin_steps.push_back(co);
+    }
 
     // ---- z (3-D): filtered after the fused x/y stage, reading and writing the output planes ----
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
@@ -463,7 +507,18 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
         if (plan->clamped) return no("1-D: clamped border not supported on the fused path");
         if (plan->shard_world > 1) return no("1-D: cannot be sharded");
         if (plan->dims[0].scan_ids.empty()) return no("no scans");
-        if (chained_row_length(plan->dims[0].N) == 0) return no("1-D: length must be a multiple of 8192");
+        if (plan->dims[0].N < 8192 || chained_row_length(chained_padded_length(plan->dims[0].N)) == 0)
+            return no("1-D: at least 8192 samples");
+        if (chained_padded_length(plan->dims[0].N) != plan->dims[0].N) {
+            // zero padding behind the signal: a causal scan rings on into it, and an anticausal scan AFTER a causal one
+            // would pick that ringing up -- such filters (and prologues, which turn the padding into their bias) run as given
+            if (plan->pw.in_u8 || plan->pw.pre) return no("1-D: a length that is not a multiple of 8192 cannot take a prologue");
+            bool seen_causal = false;
+            for (int id : plan->dims[0].scan_ids) {
+                if (plan->scans[id].causal) seen_causal = true;
+                else if (seen_causal) return no("1-D: an anticausal scan behind a causal one needs a length that is a multiple of 8192");
+            }
+        }
         if (plan->dims[0].k > kFusedMaxK) return no("feedback order above 3");
         if ((int)plan->dims[0].scan_ids.size() > kFusedMaxScans) return no("more than 4 scans");
         return true;

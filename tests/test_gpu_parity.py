@@ -597,8 +597,12 @@ def test_long_1d_signal_int32_prefix_sum_bit_exact_and_fallbacks():
     imgs, outs, (path, _) = _run((1 << 18,), scans, dtype=np.int32)
     assert path == 3
     np.testing.assert_array_equal(outs[0], np.cumsum(imgs[0].astype(np.int64)).astype(np.int32))
-    # lengths that do not fold into rows, and clamped borders, take the generic path
+    # lengths that do not fold into rows run on zero-padded copies (test_1d_fused_any_length); signals shorter than one row
+    # and clamped borders take the generic path
     imgs, outs, (path, _) = _run((8192 + 64,), scans)
+    assert path == 3
+    _check(imgs, outs, scans, False)
+    imgs, outs, (path, _) = _run((8000,), scans)
     assert path == 2
     _check(imgs, outs, scans, False)
     imgs, outs, (path, _) = _run((8192,), [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], clamped=True)
@@ -1103,3 +1107,26 @@ def test_f64_fused_other_features():
     assert np.abs(out - ((1.0 + w) * x - w * oracle.apply_filter(x, scans, True))).max() < 1e-10
     with rfa.Plan((4096, 4096), scans, dtype=np.float64, clamped=True) as plan:
         assert plan.path == 3 and list(plan.tiles)[:2] == [256, 32]
+
+
+@pytest.mark.parametrize("n", [10000, 12345, 8192 * 3 + 4, 100000, 1000003])
+def test_1d_fused_any_length(n):
+    """Zero-border 1-D signals whose length is not a multiple of 8192 (apps/audio use 10 000 000 samples): the fused kernels
+    run on zero-padded copies, as long as no anticausal scan follows a causal one (it would pick up the causal scan's ringing in
+    the padding): cascaded causal scans of orders 1..3 on two planes, anticausal scans first, an order-5 scan as sections; a
+    causal scan followed by an anticausal one keeps the generic path."""
+    scans = [(0, True, rc.GAUSS3), (0, True, rc.GAUSS2), (0, True, [0.7, 0.3])]
+    imgs, outs, (path, _) = _run((n,), scans, clamped=False, planes=2)
+    assert path == 3
+    _check(imgs, outs, scans, False)
+    scans = [(0, False, rc.GAUSS2), (0, False, [0.6, 0.4]), (0, True, rc.GAUSS3)]
+    imgs, outs, (path, _) = _run((n,), scans, clamped=False)
+    assert path == 3
+    _check(imgs, outs, scans, False)
+    o5 = _from_poles([0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j])
+    imgs, outs, (path, _) = _run((n,), [(0, False, o5)], clamped=False, inplace=True)
+    assert path == 3
+    scans = [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)]
+    imgs, outs, (path, _) = _run((n,), scans, clamped=False)
+    assert path != 3
+    _check(imgs, outs, scans, False)
