@@ -252,7 +252,12 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
             constexpr int PAT = YPAT > 2 ? YPAT - 2 : YPAT;
             constexpr bool EARLY = YPAT > 2;
             char *dpb_early = reinterpret_cast<char *>(dst + tile_off);
+            // (with the pointwise epilogue applied on the way out: EPI has this thread's input column in registers)
             auto row_out = [&](int m, Acc v) __attribute__((always_inline)) {
+                if constexpr (!PixelTraits<P>::is_integer) {
+                    if constexpr (EPI) v = a.post_f * v + (a.post_i * orig[m] + a.post_b);
+                    else if (a.pw_flags & 2) v = a.post_f * v + a.post_b;
+                }
                 __builtin_nontemporal_store(PixelTraits<P>::store(v),
                                             reinterpret_cast<P *>(dpb_early + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)m * a.row_bytes)));
             };
@@ -364,12 +369,17 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
     const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
     const int ypat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
-    bool early = true;        // no epilogue: rows can leave from inside the last scan
-    if constexpr (!PixelTraits<P>::is_integer) early = (a.pw_flags & 2) == 0;
+    bool early = true;        // rows can leave from inside the last scan (an affine epilogue is applied on the way out; one with
+                              // an input operand only where the column is in registers, i.e. the EPI variants)
+    if constexpr (!PixelTraits<P>::is_integer) early = (a.pw_flags & 2) == 0 || a.post_i == typename PixelTraits<P>::Acc(0);
 #define RF_CASE(KK, TT)                                                                                         \
     if (K == KK && TY == TT) {                                                                                  \
         if constexpr (!PixelTraits<P>::is_integer) {                                                            \
             if (epi && edge) return launch_fused_pass2_impl<P, KK, TT, true, true, PI>(src, dst, a, stream);    \
+            if constexpr (TT == 64 && std::is_same<P, PI>::value) {                                             \
+                if (epi && ypat == 1) return launch_fused_pass2_impl<P, KK, TT, true, false, PI, 3>(src, dst, a, stream); \
+                if (epi && ypat == 2) return launch_fused_pass2_impl<P, KK, TT, true, false, PI, 4>(src, dst, a, stream); \
+            }                                                                                                   \
             if (epi) return launch_fused_pass2_impl<P, KK, TT, true, false, PI>(src, dst, a, stream);           \
         }                                                                                                       \
         if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true, PI>(src, dst, a, stream);              \

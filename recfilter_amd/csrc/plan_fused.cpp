@@ -84,6 +84,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // order 2, cfg3: 0.624 -> 0.621; order 3, cfg4b: 2.25 -> 1.97 ms).
     // (integer pixels keep 64 rows as well: their final pass needs more registers than the 128-sample column leaves)
     if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && K >= 2 && !PixelTraits<P>::is_integer && NYB % 128 == 0 &&
+        !(plan->pw.post && plan->pw.post_i != 0.0 && K <= 2) &&     // (orders 1, 2: an epilogue with an input operand keeps the input
+                                                                    // column in registers, which a 128-sample column leaves no room for)
         getenv("RF_NO_TALL_TILES") == nullptr &&
         ((NX + kFusedTX - 1) / kFusedTX) * (NY / 128) * NZ >= 4096)
         TY = 128;
