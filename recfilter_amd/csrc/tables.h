@@ -86,6 +86,16 @@ struct DimTables {
 
 inline bool variant_clamps(int v, bool causal) { return causal ? (v & 1) != 0 : (v & 2) != 0; }
 
+// Memory position a tail entry of scan direction `causal` is read from.  An anticausal scan enters the image in the last
+// tile, at its last EXISTING sample (memory position Tv - 1), and leaves it at position 0; its tail is positions 0 .. k-1.
+// When the last tile has fewer samples than the order (Tv < k), the entries Tv .. k-1 are history from before the border:
+// zero for a zero border (the buffer is zero there), and for a clamped border the scan's first output -- taps that reach
+// before the first sample read that output (lib/recfilter.cpp:302-343) -- i.e. position Tv - 1.
+inline int tail_position(int m, bool causal, int variant, int Tv, bool clamped) {
+    if (!causal && (variant & 2) && clamped && m >= Tv) return Tv - 1;
+    return m;
+}
+
 // T_last: number of samples of the dimension's last tile (== T unless the extent is not a multiple of T); the
 // variants with bit1 set describe that tile.
 template <typename S>
@@ -122,6 +132,7 @@ DimTables<S> build_dim_tables(const std::vector<ScanS<S>> &scans, int k, int T, 
                 for (int r = 0; r < k; r++) {
                     int p = T - 1 - r;
                     int m = scans[s].causal ? p : T - 1 - p;
+                    m = tail_position(m, scans[s].causal, v, Tv, clamped);
                     for (int o = 0; o < k; o++) tail[r * k + o] = cols[o][m];
                 }
                 if (s == q) { if (v == 0) t.A[q] = tail; }
@@ -148,7 +159,7 @@ std::vector<S> build_tail_responses(const std::vector<ScanS<S>> &scans, int k, i
                 scan_tile<S>(vec.data(), T, k, scans[s], clamped && variant_clamps(v, scans[s].causal), nullptr, Tv);
                 for (int r = 0; r < k; r++) {
                     const int p = T - 1 - r;
-                    const int mm = scans[s].causal ? p : T - 1 - p;
+                    const int mm = tail_position(scans[s].causal ? p : T - 1 - p, scans[s].causal, v, Tv, clamped);
                     H[(((size_t)v * n + s) * k + r) * T + m] = vec[mm];
                 }
             }

@@ -1130,3 +1130,23 @@ def test_1d_fused_any_length(n):
     imgs, outs, (path, _) = _run((n,), scans, clamped=False)
     assert path != 3
     _check(imgs, outs, scans, False)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 65, 130, 8 * 64 + 1, 450])
+def test_last_tile_row_shorter_than_the_order(rows, monkeypatch):
+    """A partial last tile row with FEWER rows than the filter order under a clamped border: the tail the next tile receives
+    has entries from before the border, which read the scan's first output (tables.h, tail_position).  Found by
+    tools/stress_shapes.py at the end of round 2 (8641 x 5776: 135 tile rows and one row); the bug dated from round 1."""
+    scans = [(0, False, [0.5, -0.28, 0.42]), (1, True, [0.98, 0.53]), (1, False, [0.7, 0.23, -0.21, -0.38]),
+             (1, False, [0.6, 0.3, 0.2])]
+    for clamped in (True, False):
+        for ty in ("64", "32", "128"):
+            monkeypatch.setenv("RF_FUSED_TY", ty)
+            imgs, outs, (path, _) = _run((rows, 516), scans, clamped=clamped, planes=2)
+            assert path == 3
+            _check(imgs, outs, scans, clamped)
+    monkeypatch.delenv("RF_FUSED_TY")
+    ints = [(1, False, [1.0, 1.0, -1.0, 1.0]), (0, True, [1.0, 1.0])]
+    imgs, outs, (path, _) = _run((rows, 260), ints, dtype=np.int32, clamped=True)
+    assert path == 3
+    _check(imgs, outs, ints, True)
