@@ -11,7 +11,7 @@ import ref_cases as rc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big") else n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), 4 * int(rng.integers(1, 2400)))
@@ -103,3 +103,79 @@ if len(sys.argv) > 3 and sys.argv[3] == "big":
             print(f"{case:3d} {pf.path_name:13s} tiles={list(pf.tiles)} {str((rows, cols)):16s} scans={len(scans)} clamped={int(clamped)} err={err:.3e}",
                   "" if err < 2e-4 else "  <-- CHECK", flush=True)
     print("worst (big)", worst)
+
+# ---- f64 pixels on the fused kernels and 1-D signals of arbitrary length, against the untiled path ----
+if len(sys.argv) > 3 and sys.argv[3] in ("f64", "1d"):
+    mode = sys.argv[3]
+    worst = 0.0
+    for case in range(n_cases):
+        if mode == "f64":
+            shape = (int(rng.integers(1, 3000)), 4 * int(rng.integers(1, 900)))
+            dims = 2
+        else:
+            shape = (int(rng.integers(8192, 3000000)),)
+            dims = 1
+        scans = []
+        for d in range(dims):
+            for _ in range(int(rng.integers(1, 4)) if dims == 1 else int(rng.integers(0, 3)) + (1 if d == 0 else 0)):
+                k = int(rng.integers(1, 4))
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2)) if mode == "f64" else False
+        tdt = torch.float64 if mode == "f64" else torch.float32
+        npdt = np.float64 if mode == "f64" else np.float32
+        img = torch.rand(shape, device="cuda", dtype=tdt)
+        os.environ["RF_NO_LINE_SCANS"] = "1"            # the literal recurrence as the reference
+        with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped) as pf, rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1) as pu:
+            of, ou = pf.execute([img])[0], pu.execute([img])[0]
+            torch.cuda.synchronize()
+            peak = float(ou.abs().max().item())
+            err = float(((of - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
+            worst = max(worst, err)
+            tol = 1e-10 if mode == "f64" else 2e-4
+            print(f"{case:3d} {pf.path_name:13s} {str(shape):16s} scans={[(d, int(c), len(co) - 1) for d, c, co in scans]} clamped={int(clamped)} err={err:.3e}",
+                  "" if err < tol else "  <-- CHECK", flush=True)
+    print(f"worst ({mode})", worst)
+
+# ---- emulated ranks with slabs of different extents against the unsharded plan (fused 2-D rows / 3-D z slabs) ----
+if len(sys.argv) > 3 and sys.argv[3] == "shard":
+    worst = 0.0
+    for case in range(n_cases):
+        world = int(rng.integers(2, 6))
+        gran = int(rng.choice([32, 64, 128]))
+        ext = [gran * int(rng.integers(1, 5)) for _ in range(world)]
+        three = case % 3 == 0
+        shape = (sum(ext), int(rng.integers(1, 6)) * 32, 4 * int(rng.integers(16, 200))) if three else (sum(ext), 4 * int(rng.integers(16, 500)))
+        nd = len(shape)
+        scans = []
+        for d in range(nd):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(1, 4))
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        if rng.integers(0, 2): os.environ["RF_FUSED_TY"] = "128"
+        else: os.environ.pop("RF_FUSED_TY", None)
+        img = torch.rand(shape, device="cuda")
+        with rfa.Plan(shape, scans, clamped=clamped) as p1:
+            want = p1.execute([img])[0]
+        lo = [sum(ext[:r]) for r in range(world)]
+        plans = [rfa.Plan((ext[r],) + tuple(shape[1:]), scans, clamped=clamped, shard_rank=r, shard_world=world, shard_extents=ext) for r in range(world)]
+        ins = [img[lo[r]:lo[r] + ext[r]].contiguous() for r in range(world)]
+        outs = [torch.empty_like(t) for t in ins]
+        for r in range(world): plans[r].begin([ins[r]], [outs[r]])
+        for e in range(plans[0].num_exchanges):
+            nb = plans[0].exchange_bytes(e)
+            g = torch.empty(world * nb, dtype=torch.uint8, device="cuda")
+            for r in range(world): plans[r].exchange_local(e, g.data_ptr() + r * nb)
+            for r in range(world): plans[r].exchange_apply(e, g.data_ptr())
+        for r in range(world): plans[r].finish()
+        torch.cuda.synchronize()
+        got = torch.cat(outs, dim=0)
+        peak = float(want.abs().max().item())
+        err = float(((got - want).abs() / torch.clamp(want.abs(), min=1e-2 * peak)).max().item())
+        worst = max(worst, err)
+        print(f"{case:3d} {plans[0].path_name:13s} tiles={list(plans[0].tiles)} {str(shape):18s} ext={ext} scans={len(scans)} clamped={int(clamped)} nex={plans[0].num_exchanges} err={err:.3e}",
+              "" if err < 2e-4 else "  <-- CHECK", flush=True)
+        for p in plans: p.close()
+    print("worst (shard)", worst)
