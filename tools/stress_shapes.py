@@ -11,7 +11,7 @@ import ref_cases as rc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard") else n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), 4 * int(rng.integers(1, 2400)))
@@ -179,3 +179,49 @@ if len(sys.argv) > 3 and sys.argv[3] == "shard":
               "" if err < 2e-4 else "  <-- CHECK", flush=True)
         for p in plans: p.close()
     print("worst (shard)", worst)
+
+# ---- Tuple planes, pixel types, uint8 input and pointwise stages on random shapes, against the untiled path ----
+if len(sys.argv) > 3 and sys.argv[3] == "planes":
+    worst = 0.0
+    os.environ["RF_NO_LINE_SCANS"] = "1"
+    for case in range(n_cases):
+        shape = (int(rng.integers(1, 1500)), 4 * int(rng.integers(1, 700)))
+        planes = int(rng.integers(1, 6))
+        kind = ["f32", "i32", "i16", "u8", "f32pw"][case % 5]
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(0, 3)) + (1 if d == 0 else 0)):
+                k = int(rng.integers(1, 4))
+                if kind in ("i32", "i16"):
+                    scans.append((d, bool(rng.integers(0, 2)), [float(int(rng.integers(1, 3)))] + [float(int(rng.integers(-2, 3))) for _ in range(k)]))
+                else:
+                    a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                    scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        kw = {}
+        if kind == "i32":
+            imgs = [torch.randint(0, 64, shape, dtype=torch.int32, device="cuda") for _ in range(planes)]; npdt = np.int32
+        elif kind == "i16":
+            imgs = [torch.randint(0, 8, shape, dtype=torch.int16, device="cuda") for _ in range(planes)]; npdt = np.int16
+        elif kind == "u8":
+            imgs = [torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda") for _ in range(planes)]; npdt = np.float32
+            kw = dict(input_dtype=np.uint8, prologue=(1.0 / 255.0, 0.0))
+        else:
+            imgs = [torch.rand(shape, device="cuda") for _ in range(planes)]; npdt = np.float32
+            if kind == "f32pw":
+                kw = dict(prologue=(0.5, 0.25), epilogue=(float(np.float32(-0.75)), float(np.float32(1.75)) if case % 2 else 0.0, 0.125))
+        with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, planes=planes, **kw) as pf, \
+                rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, planes=planes, path=1, **kw) as pu:
+            of, ou = pf.execute(imgs), pu.execute(imgs)
+            torch.cuda.synchronize()
+            err = 0.0
+            for a_, b_ in zip(of, ou):
+                if kind in ("i32", "i16"):
+                    err = max(err, float((a_ != b_).sum().item()))
+                else:
+                    peak = float(b_.abs().max().item())
+                    err = max(err, float(((a_ - b_).abs() / torch.clamp(b_.abs(), min=1e-2 * peak)).max().item()))
+            worst = max(worst, err)
+            print(f"{case:3d} {pf.path_name:13s} {kind:6s} planes={planes} {str(shape):14s} scans={len(scans)} clamped={int(clamped)} err={err:.3e}",
+                  "" if err < (1 if kind in ("i32", "i16") else 2e-4) else "  <-- CHECK", flush=True)
+    print("worst (planes)", worst)
