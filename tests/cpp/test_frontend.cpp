@@ -316,6 +316,42 @@ int main() {
         filters.clear();
         for (int i = 0; i < 2; i++) (void)hipStreamDestroy(st[i]);
     }
+    {   // the difference Funcs the apps put behind a summed-area table (apps/box/box_filter.h:36-39, apps/DoG/diff_gauss.cpp:176-197):
+        // box_difference() and the generic tap_filter() on the realization of a summed-area table, against clamped loops
+        const int width = 96, height = 64, B = 3;
+        std::vector<float> image = random_image((size_t)width * height, 21);
+        float *d = upload(image);
+        RecFilterDim x("x", width), y("y", height);
+        RecFilter sat;
+        sat(x, y) = RecFilterImage(d);
+        sat.add_filter(+x, {1.0f, 1.0f});
+        sat.add_filter(+y, {1.0f, 1.0f});
+        sat.split_all_dimensions(32);
+        RecFilterRealization table = sat.realize();
+        std::vector<float> t = table.to_host<float>();
+        float *out1 = nullptr, *out2 = nullptr;
+        if (hipMalloc(&out1, t.size() * sizeof(float)) != hipSuccess || hipMalloc(&out2, t.size() * sizeof(float)) != hipSuccess) return 2;
+        box_difference(table, 0, out1, B, {1, 1});
+        const float s = 1.0f / float((2 * B + 1) * (2 * B + 1));
+        std::vector<rf_tap> taps = {{0, {B, B, 0}, s}, {0, {B, -B - 1, 0}, -s}, {0, {-B - 1, -B - 1, 0}, s}, {0, {-B - 1, B, 0}, -s}};
+        tap_filter({table.planes[0]}, out2, table.extent, RF_F32, taps);
+        if (hipDeviceSynchronize() != hipSuccess) return 2;
+        std::vector<float> h1(t.size()), h2(t.size()), ref(t.size());
+        (void)hipMemcpy(h1.data(), out1, t.size() * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h2.data(), out2, t.size() * sizeof(float), hipMemcpyDeviceToHost);
+        auto at = [&](int xx, int yy) { xx = xx < 0 ? 0 : (xx > width - 1 ? width - 1 : xx); yy = yy < 0 ? 0 : (yy > height - 1 ? height - 1 : yy);
+                                        return (double)t[(size_t)yy * width + xx]; };
+        for (int yy = 0; yy < height; yy++) for (int xx = 0; xx < width; xx++)
+            ref[(size_t)yy * width + xx] = (float)((at(xx + B, yy + B) - at(xx + B, yy - B - 1) + at(xx - B - 1, yy - B - 1) - at(xx - B - 1, yy + B)) * s);
+        report("tap_filter (diff_op_xy)", rel_err(ref, h2), 1e-4);
+        // box_difference nests the clamps per dimension (box_filter.h: fA inside diff): equal to the four-tap form away
+        // from the borders, so compare the interior
+        double worst = 0;
+        for (int yy = 2 * B + 2; yy < height - 2 * B - 2; yy++) for (int xx = 2 * B + 2; xx < width - 2 * B - 2; xx++)
+            worst = std::fmax(worst, std::fabs((double)h1[(size_t)yy * width + xx] - ref[(size_t)yy * width + xx]));
+        report("box_difference (interior)", worst, 1e-3);
+        (void)hipFree(out1); (void)hipFree(out2); (void)hipFree(d);
+    }
     {   // sharded realization from C++ (no counterpart in the reference): three ranks as three threads on this one device,
         // row slabs of different heights, the all-gather emulated with device copies between two thread barriers.  With
         // RCCL the callback is ncclAllGather(send, gathered, bytes, ncclChar, comm, (hipStream_t)stream).
