@@ -26,7 +26,8 @@ constexpr int kHalfRows = 64;
 // (a run-time direction inside the loop over the scans makes every sample of the column a phi of two register
 // assignments: a hundred and more register copies per scan and, on a 128-sample column, spills).
 // EARLY (whole tiles, one of the fixed patterns, no epilogue): the rows are stored from inside the last scan.
-template <typename P, int K, bool EDGE, typename PI, int YPAT, bool EARLY>
+// XFIX: the x scans have the same pattern as the y scans (YPAT), fixed at compile time as well.
+template <typename P, int K, bool EDGE, typename PI, int YPAT, bool EARLY, bool XFIX>
 __global__ void __launch_bounds__(kFusedThreads, 2)
 fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -207,10 +208,9 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                     v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
                 }
             }
-#pragma unroll 1
-            for (int s = 0; s < a.nx; s++) {
+            auto x_scan = [&](int s, auto causal_tag) __attribute__((always_inline)) {
+                constexpr bool causal = decltype(causal_tag)::value;
                 const FusedScan<Acc> &sc = a.xs[s];
-                const bool causal = sc.causal != 0;
                 const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
                 const bool first_lane = causal ? (l == 0) : (l == last_lane);
                 const bool clamp_first = a.clamped && tile_first && first_lane;
@@ -219,8 +219,22 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                 for (int n = 0; n < NR; n++)
 #pragma unroll
                     for (int j = 0; j < K; j++) cx[n][j] = cx_lds[(((h * kFusedMaxScans + s) * NR + n) * K + j) * 16 + slot];
-                if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
-                else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
+                if constexpr (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
+                else scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
+            };
+            // (the x scans' directions are compile-time too where they follow the y pattern: every row of the tile would
+            // otherwise be a phi of two register assignments per scan, as the column is in the y phase)
+            if constexpr (XFIX && YPAT == 1) {
+                x_scan(0, std::true_type{});
+            } else if constexpr (XFIX && YPAT == 2) {
+                x_scan(0, std::true_type{});
+                x_scan(1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int s = 0; s < a.nx; s++) {
+                    if (a.xs[s].causal != 0) x_scan(s, std::true_type{});
+                    else x_scan(s, std::false_type{});
+                }
             }
 #pragma unroll
             for (int n = 0; n < NR; n++) {
@@ -312,7 +326,7 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     }
 }
 
-template <typename P, int K, bool EDGE, typename PI, int YPAT, bool EARLY>
+template <typename P, int K, bool EDGE, typename PI, int YPAT, bool EARLY, bool XFIX = false>
 int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     // the half tile + the x carries of both halves ([2][4 scans][4 rows][K][16 slots])
@@ -324,12 +338,12 @@ int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::atomic<bool> &done = attr_set[dev & 63];
     if (!done.load(std::memory_order_acquire)) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY, XFIX>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY, XFIX>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -339,7 +353,10 @@ int launch_tall_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits
     const int pat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
     bool early = !EDGE && pat > 0;
     if constexpr (!PixelTraits<P>::is_integer) early = early && (a.pw_flags & 2) == 0;
+    const int xpat = (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
     if constexpr (!EDGE) {
+        if (early && pat == 1 && xpat == 1) return launch_tall_pat<P, K, EDGE, PI, 1, true, true>(src, dst, a, stream);
+        if (early && pat == 2 && xpat == 2) return launch_tall_pat<P, K, EDGE, PI, 2, true, true>(src, dst, a, stream);
         if (early && pat == 1) return launch_tall_pat<P, K, EDGE, PI, 1, true>(src, dst, a, stream);
         if (early && pat == 2) return launch_tall_pat<P, K, EDGE, PI, 2, true>(src, dst, a, stream);
     }
