@@ -41,7 +41,7 @@ namespace {
 // YPAT: the directions of the y scans when they are the usual ones -- 1: one causal scan, 2: causal then anticausal; 0: any.
 // With a run-time direction inside the loop over the scans every sample of the column is a phi of two register
 // assignments: ~TY register copies per scan (and spills on the 128-row tiles of kernels_fused_tall.hip).
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0>
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false>
 __global__ void __launch_bounds__(kFusedThreads, (EPI || PixelTraits<P>::is_integer) ? 2 : 1)
 fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -208,24 +208,40 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                 v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
             }
         }
+        if constexpr (XFIX) {
+            // the x scans follow the y pattern (YPAT): directions and carries picked at compile time -- no register copies
+            // at the merge of two scan directions, no select chain over the carries
+            static_assert(YPAT >= 1, "fixed x pattern only with a fixed y pattern");
+            constexpr int XP = YPAT > 2 ? YPAT - 2 : YPAT;
+            {
+                const bool first_lane = l == 0;
+                scan_rows16<Acc, true, K, NR>(v, a.xs[0], first_lane, a.clamped && tx == 0 && first_lane, CX[0]);
+            }
+            if constexpr (XP == 2) {
+                const bool first_lane = l == last_lane;
+                scan_rows16<Acc, false, K, NR>(v, a.xs[1], first_lane, a.clamped && tx == a.MX - 1 && first_lane, CX[1], l > last_lane,
+                                               EDGE ? entry_valid : kFusedSeg);
+            }
+        } else {
 #pragma unroll 1
-        for (int s = 0; s < a.nx; s++) {
-            const FusedScan<Acc> &sc = a.xs[s];
-            const bool causal = sc.causal != 0;
-            const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
-            const bool first_lane = causal ? (l == 0) : (l == last_lane);
-            const bool clamp_first = a.clamped && tile_first && first_lane;
-            Acc cx[NR][K];     // CX[s] with a run-time s: a select chain, not an indexed (scratch) array
+            for (int s = 0; s < a.nx; s++) {
+                const FusedScan<Acc> &sc = a.xs[s];
+                const bool causal = sc.causal != 0;
+                const bool tile_first = causal ? (tx == 0) : (tx == a.MX - 1);
+                const bool first_lane = causal ? (l == 0) : (l == last_lane);
+                const bool clamp_first = a.clamped && tile_first && first_lane;
+                Acc cx[NR][K];     // CX[s] with a run-time s: a select chain, not an indexed (scratch) array
 #pragma unroll
-            for (int n = 0; n < NR; n++)
+                for (int n = 0; n < NR; n++)
 #pragma unroll
-                for (int j = 0; j < K; j++) {
-                    cx[n][j] = CX[0][n][j];
+                    for (int j = 0; j < K; j++) {
+                        cx[n][j] = CX[0][n][j];
 #pragma unroll
-                    for (int q = 1; q < kFusedMaxScans; q++) cx[n][j] = (s == q) ? CX[q][n][j] : cx[n][j];
-                }
-            if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
-            else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
+                        for (int q = 1; q < kFusedMaxScans; q++) cx[n][j] = (s == q) ? CX[q][n][j] : cx[n][j];
+                    }
+                if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
+                else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
+            }
         }
 #pragma unroll
         for (int n = 0; n < NR; n++) {
@@ -337,7 +353,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     }
 }
 
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0>
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false>
 int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
@@ -349,12 +365,12 @@ int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename Pixe
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::atomic<bool> &done = attr_set[dev & 63];
     if (!done.load(std::memory_order_acquire)) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -369,6 +385,7 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
     const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
     const int ypat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
+    const int xpat = (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
     bool early = true;        // rows can leave from inside the last scan (an affine epilogue is applied on the way out; one with
                               // an input operand only where the column is in registers, i.e. the EPI variants)
     if constexpr (!PixelTraits<P>::is_integer) early = (a.pw_flags & 2) == 0 || a.post_i == typename PixelTraits<P>::Acc(0);
@@ -384,6 +401,8 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
         }                                                                                                       \
         if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true, PI>(src, dst, a, stream);              \
         if constexpr (TT == 64 && std::is_same<P, PI>::value) {        /* the usual y scans, directions fixed at compile time */ \
+            if (ypat == 1 && early && xpat == 1) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 3, true>(src, dst, a, stream); \
+            if (ypat == 2 && early && xpat == 2) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 4, true>(src, dst, a, stream); \
             if (ypat == 1 && early) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 3>(src, dst, a, stream); \
             if (ypat == 2 && early) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 4>(src, dst, a, stream); \
             if (ypat == 1) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 1>(src, dst, a, stream); \
