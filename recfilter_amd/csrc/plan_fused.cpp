@@ -80,10 +80,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // takes such a tile through the LDS in two halves and keeps its columns in registers (kernels_fused_tall.hip).
     // Needs whole 128-row tiles in y... and enough of them to fill the chip several times over.
     const int nx_early = (int)dx.scan_ids.size(), ny_early = (int)dy.scan_ids.size();
-    // Order 1 keeps 64 rows: its tails are small and the taller final pass costs more than they save (cfg4a: 1.63 -> 1.68 ms;
-    // order 2, cfg3: 0.624 -> 0.621; order 3, cfg4b: 2.25 -> 1.97 ms).
-    // (integer pixels keep 64 rows as well: their final pass needs more registers than the 128-sample column leaves)
-    if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && K >= 2 && !PixelTraits<P>::is_integer && NYB % 128 == 0 &&
+    // (end of round 2, same box, 64 against 128 rows: order 1, cfg4a 1.660 -> 1.636 ms, one bicubic plane 0.593 -> 0.575; order 2,
+    // cfg3 0.624 -> 0.601; order 3, cfg4b 2.25 -> 1.87 ms; below ~4096 tiles -- cfg2, 8192^2 -- the 64-row tiles stay ahead)
+    // (integer pixels keep 64 rows: their final pass needs more registers than the 128-sample column leaves)
+    if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && !PixelTraits<P>::is_integer && NYB % 128 == 0 &&
         !(plan->pw.post && plan->pw.post_i != 0.0 && K <= 2) &&     // (orders 1, 2: an epilogue with an input operand keeps the input
                                                                     // column in registers, which a 128-sample column leaves no room for)
         getenv("RF_NO_TALL_TILES") == nullptr &&

@@ -1007,7 +1007,7 @@ def test_tall_tiles_other_features(monkeypatch):
     want = (1.0 + w) * x - w * oracle.apply_filter(x, scans, True)
     assert np.abs(out - want).max() < 2e-5
     monkeypatch.delenv("RF_FUSED_TY")
-    for shape, sc, want_ty in (((16384, 8192), scans, 128), ((16384, 8192), rc.xy_pm([1.3, -0.3]), 64), ((2048, 2048), scans, 32),
+    for shape, sc, want_ty in (((16384, 8192), scans, 128), ((16384, 8192), rc.xy_pm([1.3, -0.3]), 128), ((2048, 2048), scans, 32),
                                ((8192, 8192), scans, 64), ((16384 + 64, 8192), scans, 64)):
         with rfa.Plan(shape, sc, clamped=True) as plan:
             assert list(plan.tiles)[:2] == [256, want_ty], (shape, plan.tiles)
