@@ -343,7 +343,7 @@ int rf_tap_filter(const void *const *in_planes, int n_in, void *out, int ndim, c
 }
 
 const char *rf_last_error_string(void) { return g_last_error.c_str(); }
-const char *rf_version(void) { return "recfilter_amd 0.1 (gfx950)"; }
+const char *rf_version(void) { return "recfilter_amd 0.2 (gfx950)"; }
 
 int rf_device_count(void) {
     int n = 0;
