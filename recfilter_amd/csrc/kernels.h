@@ -80,6 +80,8 @@ struct GenericDimArgs {
     const Acc *A;              // [s][r][j]
     const Acc *Apow;           // [s][i][r][j] = (A[s])^(i+1), i = 0..M-1: what the carry entering the slab adds to the
                                // tail of the i-th tile in scan direction (carry_apply); may be null (serial fallback)
+    int32_t tile_major;        // tails laid out [tile][line / 256][scan][r][256] (the y tails of the fused path) -- only the
+                               // blocked carry scan (kernels_carry.hip) reads this flag
 };
 
 template <typename P>

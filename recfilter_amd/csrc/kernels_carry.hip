@@ -42,12 +42,21 @@ __device__ __forceinline__ void matvec_acc(const Acc *__restrict__ m, const Acc 
 }
 
 struct CarryGeom {
+    uint32_t tile_major;     // tails are [tile][line / 256][scan][r][256] instead of [scan][tile][r][line]
     uint32_t lines;          // number of lines (all tails offsets fit 32 bits, checked on the host)
     int32_t M;               // tiles per line
     int32_t n_scans;
     int32_t first_is_border, last_is_border;
     uint32_t causal_mask;    // bit s = scan s is causal
 };
+
+// element offset of tail (scan s, tile tt, component r) of `line`
+template <int K>
+__device__ __forceinline__ uint32_t tail_off(const CarryGeom &g, int s, int tt, int r, uint32_t line) {
+    if (g.tile_major)
+        return ((((uint32_t)tt * (g.lines >> 8) + (line >> 8)) * (uint32_t)g.n_scans + (uint32_t)s) * K + (uint32_t)r) * 256u + (line & 255u);
+    return (((uint32_t)s * (uint32_t)g.M + (uint32_t)tt) * K + (uint32_t)r) * g.lines + line;
+}
 
 template <typename Acc, int K, int MAXC, int NCH>
 __global__ void __launch_bounds__(kCarryLines * NCH)
@@ -96,7 +105,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                 if (ii < nvalid) {
                     const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
 #pragma unroll
-                    for (int r = 0; r < K; r++) cur[ii][r] = tails[scan_base + (uint32_t)tt * tile_stride + (uint32_t)r * L];
+                    for (int r = 0; r < K; r++) cur[ii][r] = tails[tail_off<K>(g, s, tt, r, line)];
                 }
             }
             for (int q = 0; q < s; q++) {
@@ -115,7 +124,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                         } else {
                             const int tp = qc ? tt - 1 : tt + 1;
 #pragma unroll
-                            for (int o = 0; o < K; o++) c[o] = tails[q_base + (uint32_t)tp * tile_stride + (uint32_t)o * L];
+                            for (int o = 0; o < K; o++) c[o] = tails[tail_off<K>(g, q, tp, o, line)];
                         }
                         const Acc *Wm = Wtab + (((v * g.n_scans + q) * g.n_scans + s) * K) * K;
                         matvec_acc<Acc, K>(Wm, c, cur[ii]);
@@ -164,7 +173,7 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                         inc[r] = y[r];
                         cur[ii][r] = cur[ii][r] + y[r];
                         last_tail[r] = cur[ii][r];
-                        if (line_ok) tails[scan_base + (uint32_t)tt * tile_stride + (uint32_t)r * L] = cur[ii][r];
+                        if (line_ok) tails[tail_off<K>(g, s, tt, r, line)] = cur[ii][r];
                     }
                 }
             }
@@ -268,7 +277,7 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[MAXC][KP], int s, const C
             for (int r = 0; r < K; r++) {
                 inc[r] = y[r];
                 t[ii][r] = t[ii][r] + y[r];
-                if (line_ok) tails[base + (uint32_t)(t0 + ii) * tile_stride + (uint32_t)r * L] = t[ii][r];
+                if (line_ok) tails[tail_off<K>(g, s, t0 + ii, r, line)] = t[ii][r];
                 // the slab's exit carry: the completed tail of the last tile in scan direction
                 if (send != nullptr && line_ok && t0 + ii == (causal ? M - 1 : 0)) send[(uint32_t)r * L + line] = t[ii][r];
             }
@@ -316,7 +325,7 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
             for (int r = 0; r < KP; r++) t[ii][r] = Acc(0);
             if (ii < nvalid) {
 #pragma unroll
-                for (int r = 0; r < K; r++) t[ii][r] = tails[base + (uint32_t)(t0 + ii) * tile_stride + (uint32_t)r * L];
+                for (int r = 0; r < K; r++) t[ii][r] = tails[tail_off<K>(g, s, t0 + ii, r, line)];
             }
         }
     };
@@ -462,6 +471,8 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     }
     CarryGeom g{};
     g.lines = (uint32_t)a.g.lines;
+    g.tile_major = a.tile_major ? 1u : 0u;
+    if (g.tile_major && (a.g.lines % 256 != 0)) { set_error("carry: tile-major tails need whole 256-line tiles"); return RF_ERR_INVALID_ARG; }
     g.M = a.M; g.n_scans = a.n_scans;
     g.first_is_border = a.first_is_border; g.last_is_border = a.last_is_border;
     g.causal_mask = causal_mask;

@@ -77,6 +77,16 @@ struct FusedArgs {
     int32_t plane_batch;
     const void *in_planes[kFusedMaxPlanes];
     void *out_planes[kFusedMaxPlanes];
+    // Layout of the y tails.  0: [j][ty][r][column] -- a tile's rows are 1-KiB pieces a whole image row apart; 1: tile-major,
+    // [ty][z*MX + tx][j][r][256] -- every tile owns one contiguous block of ny*K KiB (what pass 1 writes and pass 2 reads in
+    // one piece; pass 1 is sensitive to how its tail stores reach memory).  Row shards keep layout 0.
+    int32_t yt_tile_major;
+    // element index of y tail (j, ty, r) of column `line` (= x + NXP * z)
+    __host__ __device__ int64_t yt_index(int j, int ty, int r, int K, int64_t line) const {
+        if (yt_tile_major)
+            return ((((int64_t)ty * (NXP * NZ / kFusedTX) + (line >> 8)) * ny + j) * K + r) * kFusedTX + (line & 255);
+        return (((int64_t)j * MY + ty) * K + r) * (NXP * NZ) + line;
+    }
 };
 
 // Register-column scans along a strided dimension (kernels_strided.hip), by value like FusedArgs.

@@ -114,7 +114,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                 } else {
                     const int tp = causal ? ty - 1 : ty + 1;
 #pragma unroll
-                    for (int r = 0; r < K; r++) CY[j][r] = a.yt[(((int64_t)j * a.MY + tp) * K + r) * Ly + line];
+                    for (int r = 0; r < K; r++) CY[j][r] = a.yt[a.yt_index(j, tp, r, K, line)];
                 }
             }
         }

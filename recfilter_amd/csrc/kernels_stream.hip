@@ -296,8 +296,8 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
         for (int gy = 0; gy < NGY; gy++) {
             const int jr = 4 * gy + j4;
             if (jr < nyk)
-                *reinterpret_cast<F4s *>(a.yt + (((int64_t)(jr / K) * a.MY + c.ty) * K + jr % K) * Ly + a.NXP * c.z +
-                                         (int64_t)c.tx * kFusedTX + 64 * w + (lane & ~3)) = acc[gy];
+                *reinterpret_cast<F4s *>(a.yt + a.yt_index(jr / K, c.ty, jr % K, K,
+                                                          a.NXP * c.z + (int64_t)c.tx * kFusedTX + 64 * w + (lane & ~3))) = acc[gy];
         }
     }
     lds_barrier();                                                  // final (the x waves flush the last stage behind it)

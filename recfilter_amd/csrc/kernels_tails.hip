@@ -224,7 +224,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
         const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;
 #pragma unroll
         for (int jr = 0; jr < kFusedMaxScans * K; jr++)
-            if (jr < nyk) a.yt[(((int64_t)(jr / K) * a.MY + ty) * K + jr % K) * Ly + line] = comb[jr];
+            if (jr < nyk) a.yt[a.yt_index(jr / K, ty, jr % K, K, line)] = comb[jr];
     }
 }
 
@@ -261,8 +261,8 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
     const int64_t z = b % a.NZ;
     const int ty = (int)(b / a.NZ);
     auto tile_of = [&](int r, int &jr, int &tx_out) { jr = jg * gj + r % gj; tx_out = xg * txp + r / gj; };
-    auto row_tile_index = [&](int jr, int tx_i) {      // yt is [j][ty][r][z][tx][256]
-        return ((((int64_t)(jr / K) * a.MY + ty) * K + jr % K) * a.NZ + z) * a.MX + tx_i;
+    auto row_tile_index = [&](int jr, int tx_i) {      // index of a run of 256 y-tail samples (FusedArgs::yt_index / 256)
+        return a.yt_index(jr / K, ty, jr % K, K, ((int64_t)z * a.MX + tx_i) * kFusedTX) >> 8;
     };
     A4 *yt4 = reinterpret_cast<A4 *>(a.yt);
     A4 tmp[4];

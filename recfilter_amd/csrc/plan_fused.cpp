@@ -272,6 +272,16 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         fbase.pre_s = (Acc)plan->pw.pre_s; fbase.pre_b = (Acc)plan->pw.pre_b;
         fbase.post_f = (Acc)plan->pw.post_f; fbase.post_i = (Acc)plan->pw.post_i; fbase.post_b = (Acc)plan->pw.post_b;
     }
+    // The y tails of an unsharded plan are tile-major, [tile row][tile column][scan][r][256]: the rows pass 1 stores for
+    // one tile, and the ones pass 2 loads, are then one run of ny * K * 1 KiB instead of ny * K runs a whole image width
+    // apart (FusedArgs::yt_index).  Slabs keep [scan][tile row][r][line], which the exchange kernels address, and so do
+    // order-3 filters: measured on 16384^2, order 2 gains 0.005 ms of 0.62 ms and order 3 loses 0.01-0.03 ms of 1.98 ms
+    // (its carry scan reads six rows per tile and line), order 1 is unchanged either way.
+    static const bool yt_row_major = getenv("RF_YT_ROW_MAJOR") != nullptr;      // A/B runs
+    static const bool yt_force_tile = getenv("RF_YT_TILE_MAJOR") != nullptr;    // A/B runs: order 3 too
+    const bool yt_tile_major = !yt_row_major && !y_sharded && ny > 0 && (K <= 2 || yt_force_tile) && Ly % kFusedTX == 0 &&
+                               Ly == NXP * (int64_t)NZ;
+    fbase.yt_tile_major = yt_tile_major ? 1 : 0;
     std::memset(fbase.xs, 0, sizeof(fbase.xs));
     std::memset(fbase.ys, 0, sizeof(fbase.ys));
     for (int s = 0; s < nx; s++) fbase.xs[s] = hxs[s];
@@ -307,6 +317,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     gy.T = TY; gy.M = MY; gy.k = K; gy.n_scans = ny; gy.clamped = fbase.clamped;
     gy.first_is_border = fbase.y_first_border; gy.last_is_border = fbase.y_last_border;
     gy.scans = d_yd; gy.W = d_Wy; gy.A = d_Ay; gy.Apow = hApowY.empty() ? nullptr : d_ApowY;
+    gy.tile_major = fbase.yt_tile_major;
     auto gyargs = [=](int pl) {
         GenericDimArgs<Acc> a = gy;
         a.tails = yt + (size_t)pl * yt_pp;
