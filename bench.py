@@ -207,8 +207,10 @@ def main():
     device = local_rank if args.device < 0 else args.device
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or "WORLD_SIZE" in os.environ:      # (a launcher with one rank still gets its process group: the
+        import torch.distributed as dist            #  barrier and the reduction of the step time then run over RCCL)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -317,8 +319,8 @@ def main():
                        "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
                        "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else "none",
                        "steps_in_flight": inflight,
-                       "backend": (args.backend if joined > 1 else "none"),
-                       "rccl_ranks": (joined if (joined > 1 and args.backend == "nccl") else 0)},
+                       "backend": (args.backend if dist is not None else "none"),
+                       "rccl_ranks": (joined if (dist is not None and args.backend == "nccl") else 0)},
             "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / joined, 4),
             "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
             "roofline": roofline,

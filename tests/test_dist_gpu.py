@@ -119,3 +119,65 @@ def test_bench_refuses_more_ranks_than_devices():
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode != 0 and "visible devices" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+_RCCL_CALLS = r"""
+import os, sys, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+# the exchange of ShardedFilter._run: byte buffers, all_gather_into_tensor issued under a side stream, twice in flight
+streams = [torch.cuda.Stream() for _ in range(2)]
+send = [torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, device="cuda") for _ in range(2)]
+got = [torch.zeros(1 << 20, dtype=torch.uint8, device="cuda") for _ in range(2)]
+for it in range(4):
+    st = streams[it % 2]
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        send[it % 2].add_(1)                                   # work queued ahead of the collective on the same stream
+        dist.all_gather_into_tensor(got[it % 2], send[it % 2])
+        got[it % 2].add_(0)                                    # ... and behind it
+for st in streams:
+    torch.cuda.current_stream().wait_stream(st)
+torch.cuda.synchronize()
+assert all(torch.equal(g, s) for g, s in zip(got, send))
+# bench.py's timing reduction and barrier
+t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t.item()) == 1.5 and dist.get_world_size() == 1
+dist.destroy_process_group()
+print("rccl-ok")
+"""
+
+
+def test_rccl_calls_single_rank():
+    """The torch.distributed calls of the sharded driver and of bench.py, as they make them, on the REAL backend
+    (nccl = RCCL) with the one rank this box allows: process group bound to the device, all-gather of uint8 exchange
+    buffers issued under side streams with work queued on either side, the float64 MAX all-reduce of the step time,
+    barrier.  Two ranks over RCCL need two devices; their arithmetic is what the gloo tests above cover."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_CALLS, str(_free_port())], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_bench_one_rank_over_rccl():
+    """bench.py launched the driver's way (`python -m torch.distributed.run … bench.py --gpus 1`) with the default backend:
+    process group on nccl (= RCCL) bound to the device, barriers and the max-over-ranks reduction through it."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--size", "2048", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["value"] > 0
