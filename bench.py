@@ -236,43 +236,22 @@ def main():
     filt = ShardedFilter(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, rank=rank, world=world,
                          path=args.path, dtype=np.float32, group=None, inflight=inflight)
 
-    def barrier():
-        filt.drain()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # A step = one execute of the whole filter on the resident image.  With --inflight D the steps are submitted round
-    # robin to D streams (recfilter_amd/dist.py): step i+1's pass 1 runs beside step i's carry kernels / all-gather.
-    for i in range(args.warmup):
-        filt.submit(inputs, output_sets[i % inflight])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        filt.submit(inputs, output_sets[i % inflight])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    joined = dist.get_world_size() if dist is not None else 1      # ranks that actually took part
-    ms_per_step = elapsed * 1000.0 / args.steps
-    total_px = samples_local * joined
-    value = total_px / (ms_per_step * 1e-3) / 1e6
-
-    # --- per-kernel timing with HIP events on the launch stream (rank 0, single-device plan) --------
+    # --- per-kernel timing with HIP events on the launch stream (single-device plan) -----------------
+    # Runs BEFORE the warm-up and the timed steps, on every rank (rank 0 reports): a GPU that starts from idle needs
+    # some 25 ms of load before its kernels run at their steady durations (tools/region_probe.py: cfg3 0.66 ms for the
+    # first execution, 0.63 over the first five, 0.59 after about forty), and the driver's 5 + 20 steps are 15 ms.
     roofline = None
     kernels = {}
-    if rank == 0:
+    if True:
         plan = filt.plan if world == 1 else rfa.Plan(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes,
                                                      path=args.path)
         reps = max(5, min(args.steps, 20))
         acc = {}
         order = []
-        for _ in range(reps):
+        for i in range(3 * reps):
             _, times = plan.execute_timed(inputs, outputs)
+            if i < 2 * reps:          # not recorded: the GPU is still on its way up (see above)
+                continue
             for name, ms in times:
                 if name not in acc:
                     acc[name] = []
@@ -306,6 +285,32 @@ def main():
         roofline["copy_ceiling_gbps"] = round(2 * 4 * (samples_local // planes) / (copy_ms * 1e-3) / 1e9, 1)
         if world > 1:
             plan.close()
+
+    def barrier():
+        filt.drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # A step = one execute of the whole filter on the resident image.  With --inflight D the steps are submitted round
+    # robin to D streams (recfilter_amd/dist.py): step i+1's pass 1 runs beside step i's carry kernels / all-gather.
+    for i in range(args.warmup):
+        filt.submit(inputs, output_sets[i % inflight])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        filt.submit(inputs, output_sets[i % inflight])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    joined = dist.get_world_size() if dist is not None else 1      # ranks that actually took part
+    ms_per_step = elapsed * 1000.0 / args.steps
+    total_px = samples_local * joined
+    value = total_px / (ms_per_step * 1e-3) / 1e6
 
     if rank == 0:
         whole = 8.0 * total_px / (ms_per_step * 1e-3) / 1e9      # 8 B per f32 sample per filter
