@@ -151,5 +151,9 @@ bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_
 int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, const float *Hx, const float *Hy, hipStream_t stream);
 // tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)
 template <typename Acc>
-int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream);
+int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream,
+                      const Acc *Wx = nullptr, const Acc *Ax = nullptr, Acc *xt_done = nullptr);
+// Wx / Ax / xt_done given: the launch also completes the x tails (the carry scan along x), into xt_done -- for images this
+// predicate accepts (few tiles per row: the separate carry launch is all launch and latency there)
+bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes);
 }  // namespace rf

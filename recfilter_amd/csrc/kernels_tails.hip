@@ -237,14 +237,27 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // touches every tail sample anyway; the y carry scan then needs no knowledge of x.  The G table of the
 // interior tile variant is staged in LDS next to the rows (its load overlaps the rows' load); the few
 // border tiles read their variant from memory.
-template <typename Acc, int K, bool EDGE, bool TALL>
-__global__ void __launch_bounds__(256, sizeof(Acc) == 8 ? 3 : 6)
-xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G) {
+//
+// XC (images of at most kXcMaxTiles tiles per row): the kernel also COMPLETES the x tails it reads, i.e. it is the carry
+// scan along x (carry_block_kernel on xt) as well.  On such images that launch is a dozen microseconds of launch and
+// latency around 1-2 MiB of tails; here every workgroup takes the x tails of its tile row (nx * MX * K strips of TY
+// rows, 16 KiB) into LDS, one thread per row runs the serial recurrence over the row's tiles -- the same sums as
+// carry_block_kernel: own tail + W * (completed carries of the earlier scans entering the tile) + A * (completed tail of
+// the previous tile) -- and the first workgroup of the tile row stores the completed tails for the final pass, into
+// a second array (xt_done): the other workgroups of the tile row read the incomplete ones whenever they get to run.  The
+// workgroups of a tile row repeat that recurrence (redundant, but it needs no hand-off between them).
+constexpr int kXcMaxTiles = 16;
+
+template <typename Acc, int K, bool EDGE, bool TALL, bool XC = false>
+__global__ void __launch_bounds__(256, XC ? (sizeof(Acc) == 8 ? 2 : 3) : (sizeof(Acc) == 8 ? 3 : 6))
+xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G,
+                  const Acc *__restrict__ Wx = nullptr, const Acc *__restrict__ Ax = nullptr, Acc *__restrict__ xt_done = nullptr) {
     using A4 = typename Vec4<Acc>::type;
     __shared__ __attribute__((aligned(16))) Acc rows[16 * kFusedTX];
     extern __shared__ __attribute__((aligned(16))) unsigned char g_raw[];                  // G[variant 0][q][o][x]: nx * K
     Acc *g_lds = reinterpret_cast<Acc *>(g_raw);                                           // rows of 256 (dynamic: more
                                                                                            // workgroups per CU with few scans)
+    Acc *xc = g_lds + a.nx * K * kFusedTX;                                                 // XC: [q][tx][o][TY] behind it
     A4 *rows4 = reinterpret_cast<A4 *>(rows);
     const int t = threadIdx.x;
     const int cc = t & 63, rg = t >> 6;
@@ -271,6 +284,96 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
         int jr_i, tx_i;
         tile_of(rg + 4 * i, jr_i, tx_i);
         tmp[i] = (tx_i < a.MX) ? yt4[row_tile_index(jr_i, tx_i) * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+    }
+    if constexpr (XC) {
+        const int64_t Lx = a.NYP * a.NZ;
+        const int64_t ybase = (int64_t)ty * TY + a.NYP * z;
+        const int MX = a.MX;
+        const int n_strips = a.nx * MX * K, cps = TY / 4;                 // 16-byte chunks per strip
+        A4 *xc4 = reinterpret_cast<A4 *>(xc);
+        for (int e = t; e < n_strips * cps; e += 256)
+            xc4[e] = *reinterpret_cast<const A4 *>(a.xt + (int64_t)(e / cps) * Lx + ybase + 4 * (e % cps));
+        __syncthreads();
+        if (t < TY) {
+            // No branch inside the loops over the row's tiles (a uniform branch per tile would serialise the LDS and
+            // table latencies): tiles beyond MX are computed on clamped indices and never stored or carried on.
+            const int y = t;
+#pragma unroll 1
+            for (int s = 0; s < a.nx; s++) {
+                const bool causal = a.xs[s].causal != 0;
+                Acc cur[kXcMaxTiles][K];                    // the row's tails of scan s, in scan order
+#pragma unroll
+                for (int i = 0; i < kXcMaxTiles; i++) {
+                    const int ic = i < MX ? i : MX - 1;
+                    const int tt = causal ? ic : MX - 1 - ic;
+#pragma unroll
+                    for (int r = 0; r < K; r++) cur[i][r] = xc[((s * MX + tt) * K + r) * TY + y];
+                }
+#pragma unroll 1
+                for (int q = 0; q < s; q++) {               // chaining on the completed carries of the earlier scans
+                    const bool qc = a.xs[q].causal != 0;
+                    Acc Wv[4][K * K], entering[K];          // the four border variants of W[q -> s] (uniform)
+#pragma unroll
+                    for (int v = 0; v < 4; v++)
+#pragma unroll
+                        for (int e = 0; e < K * K; e++) Wv[v][e] = Wx[(((v * a.nx + q) * a.nx + s) * K) * K + e];
+#pragma unroll
+                    for (int o = 0; o < K; o++) entering[o] = a.x_incoming[(int64_t)(q * K + o) * Lx + ybase + y];
+#pragma unroll
+                    for (int i = 0; i < kXcMaxTiles; i++) {
+                        const int ic = i < MX ? i : MX - 1;
+                        const int tt = causal ? ic : MX - 1 - ic;
+                        const bool t_first = tt == 0, t_last = tt == MX - 1;
+                        const bool q_first = qc ? t_first : t_last;
+                        const int tp = q_first ? tt : (qc ? tt - 1 : tt + 1);
+                        Acc c[K];
+#pragma unroll
+                        for (int o = 0; o < K; o++) {
+                            const Acc from_tile = xc[((q * MX + tp) * K + o) * TY + y];
+                            c[o] = q_first ? entering[o] : from_tile;
+                        }
+#pragma unroll
+                        for (int r = 0; r < K; r++)
+#pragma unroll
+                            for (int o = 0; o < K; o++) {
+                                const int e = r * K + o;
+                                const Acc w = t_first ? (t_last ? Wv[3][e] : Wv[1][e]) : (t_last ? Wv[2][e] : Wv[0][e]);
+                                cur[i][r] = cur[i][r] + w * c[o];
+                            }
+                    }
+                }
+                Acc A[K][K];
+#pragma unroll
+                for (int r = 0; r < K; r++)
+#pragma unroll
+                    for (int o = 0; o < K; o++) A[r][o] = Ax[(s * K + r) * K + o];
+                Acc state[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) state[r] = Acc(0);
+#pragma unroll
+                for (int i = 0; i < kXcMaxTiles; i++) {
+#pragma unroll
+                    for (int r = 0; r < K; r++)
+#pragma unroll
+                        for (int o = 0; o < K; o++) cur[i][r] = cur[i][r] + A[r][o] * state[o];
+#pragma unroll
+                    for (int r = 0; r < K; r++) state[r] = cur[i][r];
+                }
+#pragma unroll
+                for (int i = 0; i < kXcMaxTiles; i++) {
+                    const int tt = causal ? i : MX - 1 - i;
+                    if (i < MX) {
+#pragma unroll
+                        for (int r = 0; r < K; r++) xc[((s * MX + tt) * K + r) * TY + y] = cur[i][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (xg == 0 && jg == 0) {      // one workgroup of the tile row publishes the completed tails (the final pass reads them)
+            for (int e = t; e < n_strips * cps; e += 256)
+                *reinterpret_cast<A4 *>(xt_done + (int64_t)(e / cps) * Lx + ybase + 4 * (e % cps)) = xc4[e];
+        }
     }
     int jr, tx;
     tile_of(row, jr, tx);
@@ -304,8 +407,10 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
 #pragma unroll
                         for (int o = 0; o < K; o++) {
                             A4 c = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
-                            if (!q_first && lane_in)
-                                c = *reinterpret_cast<const A4 *>(a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + y0);
+                            if (!q_first && lane_in) {
+                                if constexpr (XC) c = *reinterpret_cast<const A4 *>(xc + ((q * a.MX + tp) * K + o) * TY + blk + 4 * l);
+                                else c = *reinterpret_cast<const A4 *>(a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + y0);
+                            }
                             tv[q * K + o] = tv[q * K + o] + (hy.x * c.x + hy.y * c.y + hy.z * c.z + hy.w * c.w);
                         }
                     }
@@ -424,8 +529,22 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     return RF_ERR_UNSUPPORTED;
 }
 
+bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes) {
+    static const bool off = getenv("RF_NO_MERGED_CARRY_X") != nullptr;      // A/B runs
+    // Order 1 only: the recurrence runs in ONE wave per workgroup (a thread per row), 60 instructions per tile at order 1
+    // and some 250 at order 3 with chaining, repeated by every workgroup of the tile row.  Measured (tools/ab_mcx.sh,
+    // summed-area table / bicubic prefilter / order-2 and order-3 Gaussians, 1280^2 ... 4096^2): order 1 gains 2.0-2.5 us
+    // of 22-54 us, order 2 breaks even, order 3 loses up to 13 us at 4096^2 -- those keep the separate launch.
+    if (off || K != 1 || nx <= 0 || ny <= 0 || MX > kXcMaxTiles || TY > 64 || TY % 4 != 0) return false;
+    // rows + G + the tile row's x tails within the 64 KiB of LDS a kernel gets without asking for more
+    const size_t lds = ((size_t)16 * kFusedTX + (size_t)nx * K * kFusedTX + (size_t)nx * MX * K * TY) * acc_bytes;
+    if (lds > 64 * 1024) return false;
+    return true;
+}
+
 template <typename Acc>
-int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream) {
+int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream,
+                      const Acc *Wx, const Acc *Ax, Acc *xt_done) {
     // yt is [j][ty][r][x + NX*z]: every run of 256 consecutive samples is one combined row of one x tile
     const int n_jr = a.ny * K;
     if (n_jr <= 0 || a.MY <= 0 || a.MX <= 0 || a.NZ <= 0 || a.nx == 0) return RF_OK;
@@ -439,6 +558,21 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
     const unsigned grid = (unsigned)blocks;
     const bool edge = a.last_cols != kFusedTX;       // images of whole tiles keep the lean kernel
     const size_t g_bytes = (size_t)a.nx * K * kFusedTX * sizeof(Acc);
+    if (Wx != nullptr) {      // the kernel completes the x tails too (XC)
+        if (G == nullptr || Ax == nullptr || xt_done == nullptr || TY > 64 || a.MX > kXcMaxTiles) { set_error("xscan rows: merged carry scan misconfigured"); return RF_ERR_INVALID_ARG; }
+        const size_t xc_bytes = g_bytes + (size_t)a.nx * a.MX * K * TY * sizeof(Acc);
+#define RF_CASE(KK)                                                                                                        \
+        if (K == KK) {                                                                                                     \
+            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, false, true>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done);  \
+            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, false, true>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done); \
+            RF_HIP_CHECK(hipGetLastError());                                                                               \
+            return RF_OK;                                                                                                  \
+        }
+        RF_CASE(1)
+#undef RF_CASE
+        set_error("xscan rows: the merged carry scan is built for order 1");
+        return RF_ERR_UNSUPPORTED;
+    }
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \
         if (TY > 64) {      /* 128-row tiles: two 64-row blocks of the carry strips per lane */                            \
@@ -463,8 +597,8 @@ template int launch_fused_tails<int32_t>(int, int, const void *, bool, const Fus
 template int launch_fused_tails<int16_t>(int, int, const void *, bool, const FusedArgs<uint32_t> &, const uint32_t *,
                                          const uint32_t *, hipStream_t);
 template int launch_fused_tails<double>(int, int, const void *, bool, const FusedArgs<double> &, const double *, const double *, hipStream_t);
-template int launch_xscan_rows<float>(int, int, const FusedArgs<float> &, const float *, const float *, hipStream_t);
-template int launch_xscan_rows<uint32_t>(int, int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t);
-template int launch_xscan_rows<double>(int, int, const FusedArgs<double> &, const double *, const double *, hipStream_t);
+template int launch_xscan_rows<float>(int, int, const FusedArgs<float> &, const float *, const float *, hipStream_t, const float *, const float *, float *);
+template int launch_xscan_rows<uint32_t>(int, int, const FusedArgs<uint32_t> &, const uint32_t *, const uint32_t *, hipStream_t, const uint32_t *, const uint32_t *, uint32_t *);
+template int launch_xscan_rows<double>(int, int, const FusedArgs<double> &, const double *, const double *, hipStream_t, const double *, const double *, double *);
 
 }  // namespace rf

@@ -249,7 +249,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const size_t xt_pp = (size_t)nx * MX * K * Lx, yt_pp = (size_t)ny * MY * K * Ly;
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
     const int np = batch ? 1 : plan->n_planes;         // batched planes are inside Lx / Ly already (NZ)
+    // few tiles per row: xscan_rows completes the x tails itself, into a second array (kernels_tails.hip, XC)
+    const bool merged_cx = !chained && xscan_completes_x_tails(K, TY, (int)MX, nx, ny, sizeof(Acc));
     Acc *xt = (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status);
+    Acc *xt_done = merged_cx ? (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status) : nullptr;
     Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);
     Acc *xin = (Acc *)plan->alloc(xin_pp * np * sizeof(Acc), true, &status);
     Acc *yin = (Acc *)plan->alloc(yin_pp * np * sizeof(Acc), true, &status);
@@ -361,7 +364,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->begin_steps.push_back(ci);
     }
     plan->begin_steps.push_back(p1);
-    if (nx > 0 && !chained) {
+    if (nx > 0 && !chained && !merged_cx) {
         Step cx;
         cx.name = "carry_x";
         cx.run = [plan, gxargs, K, nx, d_ACx, Cx, xmask](int pl) {
@@ -403,8 +406,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         // completed x carries (lib/split.cpp:1215-1633)
         Step xs;
         xs.name = "xscan_rows";
-        xs.run = [plan, fargs, K, TY, d_Hy, d_G](int pl) {
+        xs.run = [plan, fargs, K, TY, d_Hy, d_G, merged_cx, d_Wx, d_Ax, xt_done, xt_pp](int pl) {
             static const bool no_res = getenv("RF_DEBUG_NO_RESIDUAL") != nullptr;      // timing experiments only
+            if (merged_cx)
+                return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, d_G, plan->stream, d_Wx, d_Ax, xt_done + (size_t)pl * xt_pp);
             return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, no_res ? (const Acc *)nullptr : d_G, plan->stream);
         };
         plan->begin_steps.push_back(xs);
@@ -463,9 +468,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     }
     Step p2;
     p2.name = "fused_pass2";
-    p2.run = [plan, fargs, K, TY, d_Yapply, padded](int pl) {
+    p2.run = [plan, fargs, K, TY, d_Yapply, padded, merged_cx, xt_done, xt_pp](int pl) {
         FusedArgs<Acc> a = fargs(pl);
         a.y_apply = d_Yapply;
+        if (merged_cx) a.xt = xt_done + (size_t)pl * xt_pp;
         if constexpr (sizeof(Acc) == 4) {
             if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
         }

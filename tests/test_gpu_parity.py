@@ -1150,3 +1150,28 @@ def test_last_tile_row_shorter_than_the_order(rows, monkeypatch):
     imgs, outs, (path, _) = _run((rows, 260), ints, dtype=np.int32, clamped=True)
     assert path == 3
     _check(imgs, outs, ints, True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32, np.float64], ids=["f32", "i32", "f64"])
+@pytest.mark.parametrize("shape,planes,clamped", [((192, 4096), 1, False), ((200, 3004), 1, True), ((96, 1280), 3, True),
+                                                  ((130, 260), 1, False)])
+def test_order1_x_carry_scan_inside_xscan_rows(shape, planes, clamped, dtype):
+    """Order-1 filters on images of at most 16 tiles per row: `xscan_rows` completes the x tails itself (kernels_tails.hip,
+    XC) and the plan has no `carry_x` launch.  Whole and partial tiles, 16 tiles per row, Tuple planes, both borders,
+    causal + anticausal x scans (the chaining terms) -- against the oracle like every other case."""
+    import torch
+    import recfilter_amd as rfa
+    if np.issubdtype(dtype, np.integer):
+        scans = [(0, True, [1.0, 1.0]), (0, False, [1.0, 2.0]), (1, True, [1.0, 1.0]), (1, False, [2.0, -1.0])]
+        clamped = False
+    else:
+        a = float(rc.BICUBIC_COEFF[1])
+        scans = [(0, True, [1.0 - a, a]), (0, False, [1.0 - a, a]), (1, True, [1.0 - a, a]), (1, False, [0.7, 0.3])]
+    imgs = [rc.random_image(shape, dtype, 40 + p) for p in range(planes)]
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes, path=3) as plan:
+        dev = [torch.from_numpy(im).cuda() for im in imgs]
+        outs, times = plan.execute_timed(dev)
+        names = [n for n, _ in times]
+        outs = [o.cpu().numpy() for o in outs]
+    assert "carry_x" not in names and "xscan_rows" in names, names
+    _check(imgs, outs, scans, clamped)
