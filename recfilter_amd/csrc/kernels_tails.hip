@@ -241,12 +241,13 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // XC (images of at most kXcMaxTiles tiles per row): the kernel also COMPLETES the x tails it reads, i.e. it is the carry
 // scan along x (carry_block_kernel on xt) as well.  On such images that launch is a dozen microseconds of launch and
 // latency around 1-2 MiB of tails; here every workgroup takes the x tails of its tile row (nx * MX * K strips of TY
-// rows, 16 KiB) into LDS, one thread per row runs the serial recurrence over the row's tiles -- the same sums as
+// rows, 16 KiB) into LDS, runs the recurrence over each row's tiles (blocked over the four waves) -- the same sums as
 // carry_block_kernel: own tail + W * (completed carries of the earlier scans entering the tile) + A * (completed tail of
 // the previous tile) -- and the first workgroup of the tile row stores the completed tails for the final pass, into
 // a second array (xt_done): the other workgroups of the tile row read the incomplete ones whenever they get to run.  The
 // workgroups of a tile row repeat that recurrence (redundant, but it needs no hand-off between them).
 constexpr int kXcMaxTiles = 16;
+constexpr int kXcChunk = 4;       // tiles per wave (four waves)
 
 template <typename Acc, int K, bool EDGE, bool TALL, bool XC = false>
 __global__ void __launch_bounds__(256, XC ? (sizeof(Acc) == 8 ? 2 : 3) : (sizeof(Acc) == 8 ? 3 : 6))
@@ -294,20 +295,28 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
         for (int e = t; e < n_strips * cps; e += 256)
             xc4[e] = *reinterpret_cast<const A4 *>(a.xt + (int64_t)(e / cps) * Lx + ybase + 4 * (e % cps));
         __syncthreads();
-        if (t < TY) {
-            // No branch inside the loops over the row's tiles (a uniform branch per tile would serialise the LDS and
-            // table latencies): tiles beyond MX are computed on clamped indices and never stored or carried on.
-            const int y = t;
+        {
+            // Blocked like carry_block_kernel: wave c owns the tiles [c*C, (c+1)*C) of every row in scan order (C = ceil(MX/4)
+            // <= 4), runs the recurrence inside its chunk from a zero state, the chunks' exit states are combined through LDS
+            // with A^C, and the entering state is propagated through the chunk.  No branch inside the loops over a chunk's
+            // tiles (a uniform branch per tile would serialise the LDS and table latencies): tiles beyond MX are computed
+            // on clamped indices and never stored.
+            const int y = t & 63, ch = __builtin_amdgcn_readfirstlane(t >> 6);
+            const bool y_ok = y < TY;
+            const int yc = y_ok ? y : TY - 1;
+            const int C = (MX + 3) / 4;
+            Acc *exits = reinterpret_cast<Acc *>(rows);             // [4][64][K]; the rows buffer is not in use yet
 #pragma unroll 1
             for (int s = 0; s < a.nx; s++) {
                 const bool causal = a.xs[s].causal != 0;
-                Acc cur[kXcMaxTiles][K];                    // the row's tails of scan s, in scan order
+                Acc cur[kXcChunk][K];                       // the row's tails of scan s, this wave's chunk, in scan order
 #pragma unroll
-                for (int i = 0; i < kXcMaxTiles; i++) {
-                    const int ic = i < MX ? i : MX - 1;
+                for (int ii = 0; ii < kXcChunk; ii++) {
+                    const int i = ch * C + ii;
+                    const int ic = (ii < C && i < MX) ? i : MX - 1;
                     const int tt = causal ? ic : MX - 1 - ic;
 #pragma unroll
-                    for (int r = 0; r < K; r++) cur[i][r] = xc[((s * MX + tt) * K + r) * TY + y];
+                    for (int r = 0; r < K; r++) cur[ii][r] = xc[((s * MX + tt) * K + r) * TY + yc];
                 }
 #pragma unroll 1
                 for (int q = 0; q < s; q++) {               // chaining on the completed carries of the earlier scans
@@ -318,10 +327,11 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
 #pragma unroll
                         for (int e = 0; e < K * K; e++) Wv[v][e] = Wx[(((v * a.nx + q) * a.nx + s) * K) * K + e];
 #pragma unroll
-                    for (int o = 0; o < K; o++) entering[o] = a.x_incoming[(int64_t)(q * K + o) * Lx + ybase + y];
+                    for (int o = 0; o < K; o++) entering[o] = a.x_incoming[(int64_t)(q * K + o) * Lx + ybase + yc];
 #pragma unroll
-                    for (int i = 0; i < kXcMaxTiles; i++) {
-                        const int ic = i < MX ? i : MX - 1;
+                    for (int ii = 0; ii < kXcChunk; ii++) {
+                        const int i = ch * C + ii;
+                        const int ic = (ii < C && i < MX) ? i : MX - 1;
                         const int tt = causal ? ic : MX - 1 - ic;
                         const bool t_first = tt == 0, t_last = tt == MX - 1;
                         const bool q_first = qc ? t_first : t_last;
@@ -329,7 +339,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
                         Acc c[K];
 #pragma unroll
                         for (int o = 0; o < K; o++) {
-                            const Acc from_tile = xc[((q * MX + tp) * K + o) * TY + y];
+                            const Acc from_tile = xc[((q * MX + tp) * K + o) * TY + yc];
                             c[o] = q_first ? entering[o] : from_tile;
                         }
 #pragma unroll
@@ -338,35 +348,82 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
                             for (int o = 0; o < K; o++) {
                                 const int e = r * K + o;
                                 const Acc w = t_first ? (t_last ? Wv[3][e] : Wv[1][e]) : (t_last ? Wv[2][e] : Wv[0][e]);
-                                cur[i][r] = cur[i][r] + w * c[o];
+                                cur[ii][r] = cur[ii][r] + w * c[o];
                             }
                     }
                 }
-                Acc A[K][K];
+                Acc A[K][K], AC[K][K];                      // A and A^C (uniform)
 #pragma unroll
                 for (int r = 0; r < K; r++)
 #pragma unroll
-                    for (int o = 0; o < K; o++) A[r][o] = Ax[(s * K + r) * K + o];
+                    for (int o = 0; o < K; o++) { A[r][o] = Ax[(s * K + r) * K + o]; AC[r][o] = A[r][o]; }
+                for (int p = 1; p < C; p++) {
+                    Acc nxt[K][K];
+#pragma unroll
+                    for (int r = 0; r < K; r++)
+#pragma unroll
+                        for (int o = 0; o < K; o++) {
+                            Acc acc = Acc(0);
+#pragma unroll
+                            for (int m = 0; m < K; m++) acc = acc + A[r][m] * AC[m][o];
+                            nxt[r][o] = acc;
+                        }
+#pragma unroll
+                    for (int r = 0; r < K; r++)
+#pragma unroll
+                        for (int o = 0; o < K; o++) AC[r][o] = nxt[r][o];
+                }
+                // chunk-local recurrence from a zero state (tiles beyond the chunk's end must not move the state)
                 Acc state[K];
 #pragma unroll
                 for (int r = 0; r < K; r++) state[r] = Acc(0);
 #pragma unroll
-                for (int i = 0; i < kXcMaxTiles; i++) {
+                for (int ii = 0; ii < kXcChunk; ii++) {
+                    const bool live = ii < C && ch * C + ii < MX;
 #pragma unroll
                     for (int r = 0; r < K; r++)
 #pragma unroll
-                        for (int o = 0; o < K; o++) cur[i][r] = cur[i][r] + A[r][o] * state[o];
+                        for (int o = 0; o < K; o++) cur[ii][r] = cur[ii][r] + A[r][o] * state[o];
 #pragma unroll
-                    for (int r = 0; r < K; r++) state[r] = cur[i][r];
+                    for (int r = 0; r < K; r++) state[r] = live ? cur[ii][r] : state[r];
+                }
+                // (a partial last chunk: its exit state is never read -- no chunk follows it)
+#pragma unroll
+                for (int r = 0; r < K; r++) exits[(ch * 64 + y) * K + r] = state[r];
+                __syncthreads();
+                Acc inc[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) inc[r] = Acc(0);
+                for (int c = 0; c < ch; c++) {
+                    Acc nx[K];
+#pragma unroll
+                    for (int r = 0; r < K; r++) nx[r] = exits[(c * 64 + y) * K + r];
+#pragma unroll
+                    for (int r = 0; r < K; r++)
+#pragma unroll
+                        for (int o = 0; o < K; o++) nx[r] = nx[r] + AC[r][o] * inc[o];
+#pragma unroll
+                    for (int r = 0; r < K; r++) inc[r] = nx[r];
                 }
 #pragma unroll
-                for (int i = 0; i < kXcMaxTiles; i++) {
-                    const int tt = causal ? i : MX - 1 - i;
-                    if (i < MX) {
+                for (int ii = 0; ii < kXcChunk; ii++) {
+                    Acc yv[K];
 #pragma unroll
-                        for (int r = 0; r < K; r++) xc[((s * MX + tt) * K + r) * TY + y] = cur[i][r];
+                    for (int r = 0; r < K; r++) {
+                        yv[r] = Acc(0);
+#pragma unroll
+                        for (int o = 0; o < K; o++) yv[r] = yv[r] + A[r][o] * inc[o];
+                    }
+                    const int i = ch * C + ii;
+                    const int tt = causal ? i : MX - 1 - i;
+                    const bool live = ii < C && i < MX;
+#pragma unroll
+                    for (int r = 0; r < K; r++) {
+                        inc[r] = yv[r];
+                        if (live && y_ok) xc[((s * MX + tt) * K + r) * TY + y] = cur[ii][r] + yv[r];
                     }
                 }
+                __syncthreads();      // scan s + 1 chains on these; the exit states may be overwritten
             }
         }
         __syncthreads();
@@ -531,11 +588,13 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
 
 bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes) {
     static const bool off = getenv("RF_NO_MERGED_CARRY_X") != nullptr;      // A/B runs
-    // Order 1 only: the recurrence runs in ONE wave per workgroup (a thread per row), 60 instructions per tile at order 1
-    // and some 250 at order 3 with chaining, repeated by every workgroup of the tile row.  Measured (tools/ab_mcx.sh,
-    // summed-area table / bicubic prefilter / order-2 and order-3 Gaussians, 1280^2 ... 4096^2): order 1 gains 2.0-2.5 us
-    // of 22-54 us, order 2 breaks even, order 3 loses up to 13 us at 4096^2 -- those keep the separate launch.
-    if (off || K != 1 || nx <= 0 || ny <= 0 || MX > kXcMaxTiles || TY > 64 || TY % 4 != 0) return false;
+    // Measured (tools/ab_mcx.sh; summed-area table, bicubic prefilter x 3 planes, order-2 and order-3 x 3 planes Gaussians at
+    // 1280^2 ... 4096^2): orders 1 and 2 gain 2-5 us of 22-78 us at every size; order 3 gains 1-5 us up to 2048^2 and
+    // loses 3 us of 186 at 4096^2 (three planes: the launch is then 1152 workgroups of 47 KiB of LDS, a round and a half),
+    // so order 3 takes this path up to 8 tiles per row.
+    static const bool all = getenv("RF_MERGED_CARRY_X_ALL") != nullptr;     // A/B runs: order 3 up to 16 tiles per row too
+    if (off || nx <= 0 || ny <= 0 || MX > kXcMaxTiles || TY > 64 || TY % 4 != 0) return false;
+    if (K >= 3 && MX > 8 && !all) return false;
     // rows + G + the tile row's x tails within the 64 KiB of LDS a kernel gets without asking for more
     const size_t lds = ((size_t)16 * kFusedTX + (size_t)nx * K * kFusedTX + (size_t)nx * MX * K * TY) * acc_bytes;
     if (lds > 64 * 1024) return false;
@@ -568,10 +627,8 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
             RF_HIP_CHECK(hipGetLastError());                                                                               \
             return RF_OK;                                                                                                  \
         }
-        RF_CASE(1)
+        RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
-        set_error("xscan rows: the merged carry scan is built for order 1");
-        return RF_ERR_UNSUPPORTED;
     }
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \

@@ -566,7 +566,7 @@ def test_unsharp_mask_front_end():
     with pytest.raises(rfa.RecFilterUsageError):
         B.compute_at(rfa.Pointwise())                              # already has a consumer
     out = B.realize()[0].cpu().numpy()
-    assert B.plan().path_name == "tiled_fused" and B.plan().num_kernels == 5
+    assert B.plan().path_name == "tiled_fused" and B.plan().num_kernels == 4      # (two tiles per row: no carry_x launch)
     blur = oracle.apply_filter(img.astype(np.float64), B._contents["scans"], True)
     want = (1.0 + weight) * img - weight * blur
     # The mask is a difference of two O(1) terms, so the 1e-4 bar is taken relative to the terms it combines
@@ -792,7 +792,7 @@ def test_batched_planes_match_the_per_plane_launches(planes, shape, dtype, monke
     with rfa.Plan(shape, scans, dtype=dtype, clamped=not integer, planes=planes) as plan:
         assert plan.path_name == "tiled_fused"
         outs, timed = plan.execute_timed(dev)
-        assert len(timed) == 5                                       # launches per step, not per plane
+        assert [n for n, _ in timed] == ["fused_tails", "xscan_rows", "carry_y", "fused_pass2"]      # launches per step, not per plane (few tiles per row: no carry_x)
         batched = [o.cpu().numpy() for o in outs]
         inplace = [d.clone() for d in dev]
         plan.execute(inplace, inplace)
@@ -1155,18 +1155,22 @@ def test_last_tile_row_shorter_than_the_order(rows, monkeypatch):
 @pytest.mark.parametrize("dtype", [np.float32, np.int32, np.float64], ids=["f32", "i32", "f64"])
 @pytest.mark.parametrize("shape,planes,clamped", [((192, 4096), 1, False), ((200, 3004), 1, True), ((96, 1280), 3, True),
                                                   ((130, 260), 1, False)])
-def test_order1_x_carry_scan_inside_xscan_rows(shape, planes, clamped, dtype):
-    """Order-1 filters on images of at most 16 tiles per row: `xscan_rows` completes the x tails itself (kernels_tails.hip,
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_x_carry_scan_inside_xscan_rows(shape, planes, clamped, dtype, order):
+    """Images of at most 16 tiles per row (8 at order 3): `xscan_rows` completes the x tails itself (kernels_tails.hip,
     XC) and the plan has no `carry_x` launch.  Whole and partial tiles, 16 tiles per row, Tuple planes, both borders,
     causal + anticausal x scans (the chaining terms) -- against the oracle like every other case."""
     import torch
     import recfilter_amd as rfa
     if np.issubdtype(dtype, np.integer):
-        scans = [(0, True, [1.0, 1.0]), (0, False, [1.0, 2.0]), (1, True, [1.0, 1.0]), (1, False, [2.0, -1.0])]
+        fb = [[1.0], [2.0, -1.0], [1.0, -1.0, 1.0]][order - 1]
+        scans = [(0, True, [1.0] + fb), (0, False, [1.0, 2.0]), (1, True, [1.0, 1.0]), (1, False, [2.0] + fb)]
         clamped = False
     else:
-        a = float(rc.BICUBIC_COEFF[1])
-        scans = [(0, True, [1.0 - a, a]), (0, False, [1.0 - a, a]), (1, True, [1.0 - a, a]), (1, False, [0.7, 0.3])]
+        co = [rc.BICUBIC_COEFF, rc.GAUSS2, rc.GAUSS3][order - 1]
+        scans = [(0, True, co), (0, False, co), (1, True, co), (1, False, [0.7, 0.3])]
+    if order == 3 and shape[1] > 2048:
+        shape = (shape[0], shape[1] // 8 * 4)
     imgs = [rc.random_image(shape, dtype, 40 + p) for p in range(planes)]
     with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes, path=3) as plan:
         dev = [torch.from_numpy(im).cuda() for im in imgs]
