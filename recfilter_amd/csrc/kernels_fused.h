@@ -155,5 +155,5 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
                       const Acc *Wx = nullptr, const Acc *Ax = nullptr, Acc *xt_done = nullptr);
 // Wx / Ax / xt_done given: the launch also completes the x tails (the carry scan along x), into xt_done -- for images this
 // predicate accepts (few tiles per row: the separate carry launch is all launch and latency there)
-bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes);
+bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes, int64_t tile_rows /* MY * NZ */);
 }  // namespace rf

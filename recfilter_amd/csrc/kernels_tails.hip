@@ -586,15 +586,21 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     return RF_ERR_UNSUPPORTED;
 }
 
-bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes) {
+bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes, int64_t tile_rows) {
     static const bool off = getenv("RF_NO_MERGED_CARRY_X") != nullptr;      // A/B runs
-    // Measured (tools/ab_mcx.sh; summed-area table, bicubic prefilter x 3 planes, order-2 and order-3 x 3 planes Gaussians at
-    // 1280^2 ... 4096^2): orders 1 and 2 gain 2-5 us of 22-78 us at every size; order 3 gains 1-5 us up to 2048^2 and
-    // loses 3 us of 186 at 4096^2 (three planes: the launch is then 1152 workgroups of 47 KiB of LDS, a round and a half),
-    // so order 3 takes this path up to 8 tiles per row.
-    static const bool all = getenv("RF_MERGED_CARRY_X_ALL") != nullptr;     // A/B runs: order 3 up to 16 tiles per row too
+    // Measured (tools/ab_mcx.sh, tools/mid_probe.py; summed-area table, bicubic prefilter x 3 planes, order-2 and order-3
+    // Gaussians at 1280^2 ... 4096^2): orders 1 and 2 gain 2-5 us of 22-78 us at every size; order 3 gains 10 us of 90 on
+    // one plane of 2112^2 ... 4096^2 and loses 3 us of 186 on three planes of 4096^2 -- that launch is 1152 workgroups
+    // of 47 KiB of LDS, a round and a half -- so order 3 takes this path while the launch fits one round.
+    static const bool all = getenv("RF_MERGED_CARRY_X_ALL") != nullptr;     // A/B runs: order 3 whatever the launch size
     if (off || nx <= 0 || ny <= 0 || MX > kXcMaxTiles || TY > 64 || TY % 4 != 0) return false;
-    if (K >= 3 && MX > 8 && !all) return false;
+    if (K >= 3 && !all) {
+        int gj = 1;
+        while (gj < 16 && (ny * K) % (2 * gj) == 0) gj *= 2;
+        const int txp = 16 / gj;
+        const int64_t blocks = tile_rows * (ny * K / gj) * ((MX + txp - 1) / txp);      // (launch_xscan_rows)
+        if (blocks > 768) return false;
+    }
     // rows + G + the tile row's x tails within the 64 KiB of LDS a kernel gets without asking for more
     const size_t lds = ((size_t)16 * kFusedTX + (size_t)nx * K * kFusedTX + (size_t)nx * MX * K * TY) * acc_bytes;
     if (lds > 64 * 1024) return false;

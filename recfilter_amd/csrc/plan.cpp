@@ -360,11 +360,12 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         int64_t max_extent = 0;
         for (int d = 0; d < desc->ndim; d++) max_extent = std::max<int64_t>(max_extent, plan->dims[d].N);
         const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (tuning / tests; 0 = the automatic path never picks the line kernels)
-        // ... up to 1792 for order-3 filters with four or more scans, whose five tiled launches are the heaviest (C++ caller,
-        // gaussian_3xy: 1152^2 47 -> 33 us, 1536^2 50 -> 45 us, even at 2048^2; order 1 and 2 cross over at 1024..1152)
+        // ... up to 1984 for order-3 filters with four or more scans, whose tiled launches are the heaviest (C++ caller,
+        // gaussian_3xy: 1152^2 47 -> 33 us, 1536^2 49 -> 45 us, 1920^2 56 -> 51 us, even at 2048^2; order 1 and 2 cross over
+        // at 1024..1152)
         int max_order = 0;
         for (const Scan &sc : plan->scans) max_order = std::max(max_order, sc.order);
-        const int64_t long_limit = (small_limit == 1024 && max_order >= 3 && plan->scans.size() >= 4) ? 1792 : small_limit;
+        const int64_t long_limit = (small_limit == 1024 && max_order >= 3 && plan->scans.size() >= 4) ? 1984 : small_limit;
         bool user_tiles = false;
         for (int d = 0; d < desc->ndim; d++) user_tiles = user_tiles || desc->tile[d] > 0;
         const bool fused_ok = fused_plan_applicable(plan.get(), desc, &why);

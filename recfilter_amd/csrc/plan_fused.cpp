@@ -75,7 +75,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     int TY = (NYB % 64 == 0) ? 64 : (NYB % 32 == 0 || NYB < 32) ? 32 : 64;
     // a small image has too few 256 x 64 tiles to fill 256 CUs: half-height tiles double the workgroups
     // (2048^2: 43.5 -> 40.8 us, 1024^2: 38 -> 34.6 us; at 4096^2, 1024 tiles, the 64-row tiles win again)
-    if (TY == 64 && NY % 32 == 0 && !rows_sharded && ((NX + kFusedTX - 1) / kFusedTX) * (NY / 64) * NZ <= 384) TY = 32;
+    // (order 3 keeps 64 rows when 32-row tiles would be more than 64 per column: its carry scan along y then runs in two
+    //  blocks -- 2112^2: 28 against 17 us, 80.7 against 75.1 us per filter, tools/mid_probe.py)
+    if (TY == 64 && NY % 32 == 0 && !rows_sharded && ((NX + kFusedTX - 1) / kFusedTX) * (NY / 64) * NZ <= 384 &&
+        !(K >= 3 && NY / 32 > 64))
+        TY = 32;
     // Large images: 128-row tiles halve the y tails and the kernels that walk them between the passes; the final pass
     // takes such a tile through the LDS in two halves and keeps its columns in registers (kernels_fused_tall.hip).
     // Needs whole 128-row tiles in y... and enough of them to fill the chip several times over.
@@ -250,7 +254,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const size_t xin_pp = (size_t)nx * K * Lx, yin_pp = (size_t)ny * K * Ly;
     const int np = batch ? 1 : plan->n_planes;         // batched planes are inside Lx / Ly already (NZ)
     // few tiles per row: xscan_rows completes the x tails itself, into a second array (kernels_tails.hip, XC)
-    const bool merged_cx = !chained && xscan_completes_x_tails(K, TY, (int)MX, nx, ny, sizeof(Acc));
+    const bool merged_cx = !chained && xscan_completes_x_tails(K, TY, (int)MX, nx, ny, sizeof(Acc), (int64_t)MY * NZ);
     Acc *xt = (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status);
     Acc *xt_done = merged_cx ? (Acc *)plan->alloc(xt_pp * np * sizeof(Acc), false, &status) : nullptr;
     Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);

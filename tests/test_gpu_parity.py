@@ -900,7 +900,7 @@ def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
     for n, want in ((256, 1), (1024, 1), (1536, 3), (2048, 3)):
         with rfa.Plan((n, n), scans, clamped=True) as plan:
             assert plan.path == want, (n, plan.path_name)
-    for n, want in ((1024, 1), (1536, 1), (1792, 1), (2048, 3)):        # order 3, four scans: the line kernels up to 1792
+    for n, want in ((1024, 1), (1536, 1), (1984, 1), (2048, 3)):        # order 3, four scans: the line kernels up to 1984
         with rfa.Plan((n, n), rc.xy_pm(rc.GAUSS3), clamped=True) as plan:
             assert plan.path == want, (n, plan.path_name)
     imgs, outs, (path, _) = _run((512, 512), scans, clamped=True)
