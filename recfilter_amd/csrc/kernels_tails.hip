@@ -246,10 +246,10 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 // the previous tile) -- and the first workgroup of the tile row stores the completed tails for the final pass, into
 // a second array (xt_done): the other workgroups of the tile row read the incomplete ones whenever they get to run.  The
 // workgroups of a tile row repeat that recurrence (redundant, but it needs no hand-off between them).
-constexpr int kXcMaxTiles = 16;
-constexpr int kXcChunk = 4;       // tiles per wave (four waves)
+constexpr int kXcMaxTiles = 32;   // XC = tiles per wave (four waves): 4 up to 16 tiles per row, 8 up to 32 (order 1)
 
-template <typename Acc, int K, bool EDGE, bool TALL, bool XC = false>
+
+template <typename Acc, int K, bool EDGE, bool TALL, int XC = 0>
 __global__ void __launch_bounds__(256, XC ? (sizeof(Acc) == 8 ? 2 : 3) : (sizeof(Acc) == 8 ? 3 : 6))
 xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G,
                   const Acc *__restrict__ Wx = nullptr, const Acc *__restrict__ Ax = nullptr, Acc *__restrict__ xt_done = nullptr) {
@@ -286,7 +286,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
         tile_of(rg + 4 * i, jr_i, tx_i);
         tmp[i] = (tx_i < a.MX) ? yt4[row_tile_index(jr_i, tx_i) * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
     }
-    if constexpr (XC) {
+    if constexpr (XC > 0) {
         const int64_t Lx = a.NYP * a.NZ;
         const int64_t ybase = (int64_t)ty * TY + a.NYP * z;
         const int MX = a.MX;
@@ -297,7 +297,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
         __syncthreads();
         {
             // Blocked like carry_block_kernel: wave c owns the tiles [c*C, (c+1)*C) of every row in scan order (C = ceil(MX/4)
-            // <= 4), runs the recurrence inside its chunk from a zero state, the chunks' exit states are combined through LDS
+            // <= XC), runs the recurrence inside its chunk from a zero state, the chunks' exit states are combined through LDS
             // with A^C, and the entering state is propagated through the chunk.  No branch inside the loops over a chunk's
             // tiles (a uniform branch per tile would serialise the LDS and table latencies): tiles beyond MX are computed
             // on clamped indices and never stored.
@@ -309,9 +309,9 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
 #pragma unroll 1
             for (int s = 0; s < a.nx; s++) {
                 const bool causal = a.xs[s].causal != 0;
-                Acc cur[kXcChunk][K];                       // the row's tails of scan s, this wave's chunk, in scan order
+                Acc cur[XC][K];                       // the row's tails of scan s, this wave's chunk, in scan order
 #pragma unroll
-                for (int ii = 0; ii < kXcChunk; ii++) {
+                for (int ii = 0; ii < XC; ii++) {
                     const int i = ch * C + ii;
                     const int ic = (ii < C && i < MX) ? i : MX - 1;
                     const int tt = causal ? ic : MX - 1 - ic;
@@ -329,7 +329,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
 #pragma unroll
                     for (int o = 0; o < K; o++) entering[o] = a.x_incoming[(int64_t)(q * K + o) * Lx + ybase + yc];
 #pragma unroll
-                    for (int ii = 0; ii < kXcChunk; ii++) {
+                    for (int ii = 0; ii < XC; ii++) {
                         const int i = ch * C + ii;
                         const int ic = (ii < C && i < MX) ? i : MX - 1;
                         const int tt = causal ? ic : MX - 1 - ic;
@@ -378,7 +378,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
 #pragma unroll
                 for (int r = 0; r < K; r++) state[r] = Acc(0);
 #pragma unroll
-                for (int ii = 0; ii < kXcChunk; ii++) {
+                for (int ii = 0; ii < XC; ii++) {
                     const bool live = ii < C && ch * C + ii < MX;
 #pragma unroll
                     for (int r = 0; r < K; r++)
@@ -406,7 +406,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
                     for (int r = 0; r < K; r++) inc[r] = nx[r];
                 }
 #pragma unroll
-                for (int ii = 0; ii < kXcChunk; ii++) {
+                for (int ii = 0; ii < XC; ii++) {
                     Acc yv[K];
 #pragma unroll
                     for (int r = 0; r < K; r++) {
@@ -465,7 +465,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
                         for (int o = 0; o < K; o++) {
                             A4 c = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
                             if (!q_first && lane_in) {
-                                if constexpr (XC) c = *reinterpret_cast<const A4 *>(xc + ((q * a.MX + tp) * K + o) * TY + blk + 4 * l);
+                                if constexpr (XC > 0) c = *reinterpret_cast<const A4 *>(xc + ((q * a.MX + tp) * K + o) * TY + blk + 4 * l);
                                 else c = *reinterpret_cast<const A4 *>(a.xt + (((int64_t)q * a.MX + tp) * K + o) * Lx + y0);
                             }
                             tv[q * K + o] = tv[q * K + o] + (hy.x * c.x + hy.y * c.y + hy.z * c.z + hy.w * c.w);
@@ -593,7 +593,9 @@ bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_b
     // one plane of 2112^2 ... 4096^2 and loses 3 us of 186 on three planes of 4096^2 -- that launch is 1152 workgroups
     // of 47 KiB of LDS, a round and a half -- so order 3 takes this path while the launch fits one round.
     static const bool all = getenv("RF_MERGED_CARRY_X_ALL") != nullptr;     // A/B runs: order 3 whatever the launch size
-    if (off || nx <= 0 || ny <= 0 || MX > kXcMaxTiles || TY > 64 || TY % 4 != 0) return false;
+    // (beyond 16 tiles per row only order 1 still gains: summed-area table 8192^2 160.5 -> 158.2 us, bicubic x 3 planes 6144^2
+    //  272 -> 266 us; order 2 loses 3 us at 6144^2 and 8 us at 8192^2, where every workgroup repeats a 32-tile recurrence)
+    if (off || nx <= 0 || ny <= 0 || MX > (K == 1 ? kXcMaxTiles : 16) || TY > 64 || TY % 4 != 0) return false;
     if (K >= 3 && !all) {
         int gj = 1;
         while (gj < 16 && (ny * K) % (2 * gj) == 0) gj *= 2;
@@ -626,15 +628,17 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
     if (Wx != nullptr) {      // the kernel completes the x tails too (XC)
         if (G == nullptr || Ax == nullptr || xt_done == nullptr || TY > 64 || a.MX > kXcMaxTiles) { set_error("xscan rows: merged carry scan misconfigured"); return RF_ERR_INVALID_ARG; }
         const size_t xc_bytes = g_bytes + (size_t)a.nx * a.MX * K * TY * sizeof(Acc);
-#define RF_CASE(KK)                                                                                                        \
-        if (K == KK) {                                                                                                     \
-            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, false, true>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done);  \
-            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, false, true>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done); \
+#define RF_CASE(KK, CH)                                                                                                    \
+        if (K == KK && (a.MX + 3) / 4 <= CH) {                                                                             \
+            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, false, CH>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done);  \
+            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, false, CH>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done); \
             RF_HIP_CHECK(hipGetLastError());                                                                               \
             return RF_OK;                                                                                                  \
         }
-        RF_CASE(1) RF_CASE(2) RF_CASE(3)
+        RF_CASE(1, 4) RF_CASE(2, 4) RF_CASE(3, 4) RF_CASE(1, 8)
 #undef RF_CASE
+        set_error("xscan rows: no merged carry scan for order %d at %d tiles per row", K, (int)a.MX);
+        return RF_ERR_UNSUPPORTED;
     }
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \

@@ -1154,10 +1154,10 @@ def test_last_tile_row_shorter_than_the_order(rows, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.int32, np.float64], ids=["f32", "i32", "f64"])
 @pytest.mark.parametrize("shape,planes,clamped", [((192, 4096), 1, False), ((200, 3004), 1, True), ((96, 1280), 3, True),
-                                                  ((130, 260), 1, False)])
+                                                  ((130, 260), 1, False), ((64, 8192), 1, True), ((96, 6400), 1, False)])
 @pytest.mark.parametrize("order", [1, 2, 3])
 def test_x_carry_scan_inside_xscan_rows(shape, planes, clamped, dtype, order):
-    """Images of at most 16 tiles per row (8 at order 3): `xscan_rows` completes the x tails itself (kernels_tails.hip,
+    """Images of at most 16 tiles per row (32 at order 1): `xscan_rows` completes the x tails itself (kernels_tails.hip,
     XC) and the plan has no `carry_x` launch.  Whole and partial tiles, 16 tiles per row, Tuple planes, both borders,
     causal + anticausal x scans (the chaining terms) -- against the oracle like every other case."""
     import torch
@@ -1171,6 +1171,10 @@ def test_x_carry_scan_inside_xscan_rows(shape, planes, clamped, dtype, order):
         scans = [(0, True, co), (0, False, co), (1, True, co), (1, False, [0.7, 0.3])]
     if order == 3 and shape[1] > 2048:
         shape = (shape[0], shape[1] // 8 * 4)
+    if order == 3 and dtype == np.float64 and shape[1] > 2048:
+        shape = (shape[0], 2048)                                  # (f64, order 3: 16 tiles per row of tails do not fit the LDS)
+    if order >= 2 and shape[1] > 4096:
+        shape = (shape[0], 4096 - 256 + shape[1] % 256)          # (more than 16 tiles per row: order 1 only)
     imgs = [rc.random_image(shape, dtype, 40 + p) for p in range(planes)]
     with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes, path=3) as plan:
         dev = [torch.from_numpy(im).cuda() for im in imgs]
