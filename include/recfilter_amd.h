@@ -63,7 +63,9 @@ typedef enum {
     RF_PATH_AUTO = 0,      /* fastest path the shape admits                                        */
     RF_PATH_UNTILED = 1,   /* one serial recurrence per line (a filter that was never split())      */
     RF_PATH_TILED_GENERIC = 2, /* tiled, any tile width dividing the extent (split(x,tx,..))        */
-    RF_PATH_TILED_FUSED = 3,   /* tiled, LDS-staged fused x/y tiles with fixed MI355X tile shapes   */
+    RF_PATH_TILED_FUSED = 3,   /* tiled, LDS-staged fused x/y tiles with fixed MI355X tile shapes; a filter with more
+                                * than four scans in a dimension runs as successive stages of such plans inside the
+                                * one plan (stage 0 reads the input, later stages filter the output planes in place) */
     RF_PATH_TILED_OVERLAPPED = 4 /* tiled, ALL dimensions in one pass 1 / one pass 2 with the cross-dimension
                                   * residuals of lib/split.cpp:1215-1633 between every pair of dimensions (x->y, x->z,
                                   * y->z): the reference's fully overlapped N-D tiling.  Needs an explicit tile width

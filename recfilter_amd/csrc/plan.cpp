@@ -196,6 +196,100 @@ int build_for_pixel(rf_plan *plan, const rf_filter_desc *desc, int path) {
     return build_generic<P, S>(plan, desc);
 }
 
+// ---- in-plan cascade ---------------------------------------------------------------------------------------------
+// Scans of different dimensions commute and the scans of one dimension are successive in-place passes by definition
+// (lib/recfilter.cpp:302-343), so any split of the scan list that keeps every dimension's order is the same filter
+// (the reference's cascade(), lib/reorder.cpp:28-229, is this split done by the caller).  Stage of every scan of `desc`:
+// at most kFusedMaxScans sections per dimension and stage (a scan of order n > 3 becomes up to ceil(n/2) sections,
+// sections.h), and for a 1-D signal that gets zero-padded (length not a multiple of 8192) a new stage before an
+// anticausal scan that follows a causal one -- every stage copies only the signal out of its padded buffer, so the
+// ringing a causal scan leaves in the padding never reaches a later stage.
+std::vector<int> cascade_stage_of_scans(const rf_filter_desc *desc) {
+    const bool sections_ok = desc->border == RF_BORDER_ZERO && (desc->dtype == RF_F32 || desc->dtype == RF_F64) &&
+                             getenv("RF_NO_SECTIONS") == nullptr;
+    const bool padded_1d = desc->ndim == 1 && desc->border == RF_BORDER_ZERO && desc->extent[0] % 8192 != 0;
+    std::vector<int> stage((size_t)desc->n_scans, 0);
+    for (int d = 0; d < desc->ndim; d++) {
+        int cur = 0, used = 0;
+        bool seen_causal = false;
+        for (int i = 0; i < desc->n_scans; i++) {
+            const rf_scan_desc &r = desc->scans[i];
+            if (r.dim != d) continue;
+            if (r.order > kFusedMaxK && !sections_ok) return {};
+            const int w = r.order <= kFusedMaxK ? 1 : (r.order + 1) / 2;
+            if (w > kFusedMaxScans) return {};
+            if (used + w > kFusedMaxScans || (padded_1d && !r.causal && seen_causal)) { cur++; used = 0; seen_causal = false; }
+            stage[(size_t)i] = cur;
+            used += w;
+            seen_causal = seen_causal || r.causal != 0;
+        }
+    }
+    return stage;
+}
+
+int build_cascade(const rf_filter_desc *desc, const std::vector<int> &stage_of, rf_plan *parent) {
+    int n_stages = 0;
+    for (int st : stage_of) n_stages = std::max(n_stages, st + 1);
+    std::vector<std::unique_ptr<rf_plan>> children;
+    for (int st = 0; st < n_stages; st++) {
+        std::vector<rf_scan_desc> sub;
+        for (int i = 0; i < desc->n_scans; i++)
+            if (stage_of[(size_t)i] == st) sub.push_back(desc->scans[i]);
+        rf_filter_desc cd = *desc;
+        cd.scans = sub.data();
+        cd.n_scans = (int32_t)sub.size();
+        if (st > 0) { cd.pointwise.flags &= ~RF_POINTWISE_PRE; cd.pointwise.in_dtype = RF_IN_PIXEL; }    // stage > 0 reads the output planes
+        if (st + 1 < n_stages) cd.pointwise.flags &= ~RF_POINTWISE_POST;
+        rf_plan *child = nullptr;
+        int rc = build_plan(&cd, &child);
+        if (rc != RF_OK) return rc;
+        children.emplace_back(child);
+        // the point of the split is the fused (or, for small images, the line-parallel) kernels: a stage that would still
+        // run on the per-dimension generic passes means something else keeps this filter off them
+        if (child->path == RF_PATH_TILED_GENERIC || child->path == RF_PATH_TILED_OVERLAPPED) {
+            set_error("cascade: stage %d would not run on the fused kernels", st);
+            return RF_ERR_UNSUPPORTED;
+        }
+    }
+    bool any_fused = false;
+    parent->workspace_bytes = 0;
+    for (auto &c : children) {
+        any_fused = any_fused || c->path == RF_PATH_TILED_FUSED;
+        parent->workspace_bytes += c->workspace_bytes;
+        for (auto &ex : c->exchanges) ex.send = ex.scratch;       // single device: nothing leaves the stage
+    }
+    parent->path = any_fused ? (int)RF_PATH_TILED_FUSED : children[0]->path;
+    for (int d = 0; d < RF_MAX_DIMS; d++) { parent->dims[d].T = children[0]->dims[d].T; parent->dims[d].M = children[0]->dims[d].M; }
+    parent->tables = children[0]->tables;
+    for (int st = 0; st < n_stages; st++) {
+        rf_plan *child = children[(size_t)st].get();
+        std::vector<const Step *> steps;
+        for (const Step &s : child->begin_steps) steps.push_back(&s);
+        for (const auto &ex : child->exchange_local_steps)
+            for (const Step &s : ex) steps.push_back(&s);
+        for (const Step &s : child->finish_steps) steps.push_back(&s);
+        for (size_t k = 0; k < steps.size(); k++) {
+            const Step *sp = steps[k];
+            Step w;
+            w.name = st == 0 ? sp->name : "stage" + std::to_string(st) + "." + sp->name;
+            const bool first = k == 0;
+            w.run = [parent, child, sp, st, first](int pl) {
+                if (first && pl == 0) {        // the stage's context, all planes (a batched stage launches them from plane 0)
+                    for (int q = 0; q < parent->n_planes; q++) {
+                        child->in[q] = child->orig_in[q] = st == 0 ? parent->orig_in[q] : (const void *)parent->out[q];
+                        child->out[q] = parent->out[q];
+                    }
+                    child->stream = parent->stream;
+                }
+                return sp->run(pl);
+            };
+            parent->begin_steps.push_back(w);
+        }
+    }
+    parent->stages = std::move(children);
+    return RF_OK;
+}
+
 }  // namespace
 
 int build_plan(const rf_filter_desc *desc, rf_plan **out) {
@@ -346,6 +440,26 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
                     plan->scans = original;
                     for (int d = 0; d < RF_MAX_DIMS; d++) plan->dims[d] = saved[d];
                 }
+            }
+        }
+    }
+
+    // What the fused kernels cannot take in one piece because of the NUMBER or the ORDER of its scans runs as a cascade of
+    // plans inside this one (build_cascade above) -- not on the generic path, whose carry scans are one thread per line
+    // (five biquads over 10,000,000 samples: 59.6 ms there, 0.26 ms as two stages).
+    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && world == 1 && desc->n_scans > 1 &&
+        !(plan->pw.post && plan->pw.post_i != 0.0) && getenv("RF_NO_CASCADE") == nullptr) {
+        std::string why_not;
+        if (!fused_plan_applicable(plan.get(), desc, &why_not)) {
+            const std::vector<int> stage_of = cascade_stage_of_scans(desc);
+            int n_stages = 0;
+            for (int st : stage_of) n_stages = std::max(n_stages, st + 1);
+            if (n_stages > 1) {
+                const int rc = build_cascade(desc, stage_of, plan.get());
+                if (rc == RF_OK) { *out = plan.release(); return RF_OK; }
+                if (desc->path == RF_PATH_TILED_FUSED) return rc;
+                plan->begin_steps.clear();          // (auto: the paths below run the scans as given)
+                plan->stages.clear();
             }
         }
     }

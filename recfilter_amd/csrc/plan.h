@@ -93,6 +93,12 @@ struct rf_plan {
     int64_t padded_len = 0;
     void *pad_in[RF_MAX_PLANES] = {nullptr}, *pad_out[RF_MAX_PLANES] = {nullptr};
 
+    // In-plan cascade (plan.cpp, build_cascade): a filter the fused kernels cannot take in one piece -- more than four scans in
+    // a dimension, or a 1-D signal of any length whose anticausal scans follow causal ones -- runs as successive plans
+    // ("stages"), each on a subset of the scans; stage 0 reads the input, every later stage filters the output in place.
+    // The parent's steps are the stages' steps in order (so every entry point of the C ABI drives it like any plan).
+    std::vector<std::unique_ptr<rf_plan>> stages;
+
     // host tables exposed through rf_plan_table
     std::map<std::string, std::vector<double>> tables;
 

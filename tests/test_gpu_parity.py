@@ -1042,8 +1042,8 @@ def test_high_order_scans_run_as_sections_on_the_fused_path(name, poles):
 
 def test_high_order_sections_other_cases():
     """One causal scan of order 8 per dimension (three sections each), a 1-D signal of order 9 on the chained-rows path,
-    and filters the rewrite must leave alone: three conjugate pairs twice per dimension (six sections > four scans),
-    integer pixels."""
+    three conjugate pairs twice per dimension (six sections > four scans: an in-plan cascade of two stages), and a filter
+    the rewrite must leave alone: integer pixels."""
     import recfilter_amd as rfa
     o8 = _from_poles([0.8, -0.7, 0.5, -0.3, 0.3 + 0.6j, 0.3 - 0.6j, -0.1 + 0.7j, -0.1 - 0.7j], b=0.2)
     scans = [(0, True, o8), (1, True, o8)]
@@ -1056,7 +1056,7 @@ def test_high_order_sections_other_cases():
     o6c = _from_poles([0.6 + 0.2j, 0.6 - 0.2j, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j])
     scans = [(0, True, o6c), (0, False, o6c), (1, True, o6c)]
     imgs, outs, (path, _) = _run((128, 256), scans, clamped=False)
-    assert path != 3
+    assert path == 3                                                               # (two stages of an in-plan cascade)
     _check(imgs, outs, scans, False)
     ints = [(0, True, [1.0, 1.0, 0.0, 0.0, 1.0]), (1, True, [1.0, 1.0])]
     imgs, outs, (path, _) = _run((64, 256), ints, dtype=np.int32, clamped=False)
@@ -1114,7 +1114,7 @@ def test_1d_fused_any_length(n):
     """Zero-border 1-D signals whose length is not a multiple of 8192 (apps/audio use 10 000 000 samples): the fused kernels
     run on zero-padded copies, as long as no anticausal scan follows a causal one (it would pick up the causal scan's ringing in
     the padding): cascaded causal scans of orders 1..3 on two planes, anticausal scans first, an order-5 scan as sections; a
-    causal scan followed by an anticausal one keeps the generic path."""
+    causal scan followed by an anticausal one runs as two such stages inside the plan."""
     scans = [(0, True, rc.GAUSS3), (0, True, rc.GAUSS2), (0, True, [0.7, 0.3])]
     imgs, outs, (path, _) = _run((n,), scans, clamped=False, planes=2)
     assert path == 3
@@ -1128,7 +1128,7 @@ def test_1d_fused_any_length(n):
     assert path == 3
     scans = [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)]
     imgs, outs, (path, _) = _run((n,), scans, clamped=False)
-    assert path != 3
+    assert path == 3                    # two stages of an in-plan cascade: each copies only the signal out of its padding
     _check(imgs, outs, scans, False)
 
 
@@ -1183,3 +1183,60 @@ def test_x_carry_scan_inside_xscan_rows(shape, planes, clamped, dtype, order):
         outs = [o.cpu().numpy() for o in outs]
     assert "carry_x" not in names and "xscan_rows" in names, names
     _check(imgs, outs, scans, clamped)
+
+
+_BIQUAD = [0.05, 1.6, -0.7]
+_CASCADE_CASES = {
+    "five_biquads_1d": dict(shape=(1_000_000,), scans=[(0, True, _BIQUAD)] * 5),
+    "nine_biquads_1d": dict(shape=(300_000,), scans=[(0, True, _BIQUAD)] * 9),
+    "mixed_causality_padded_1d": dict(shape=(100_000,), scans=[(0, True, _BIQUAD), (0, False, _BIQUAD)]),
+    "mixed_causality_padded_1d_four": dict(shape=(123_456,), scans=[(0, True, _BIQUAD), (0, False, _BIQUAD), (0, True, [0.5, 0.5]),
+                                                                  (0, False, [0.5, 0.5])]),
+    "six_x_two_y_clamped": dict(shape=(300, 1024), scans=[(0, True, [0.5, 0.5])] * 3 + [(0, False, [0.5, 0.5])] * 3 +
+                                [(1, True, [0.6, 0.4])] * 2, clamped=True),
+    "five_x_int32": dict(shape=(300, 1024), scans=[(0, True, [1.0, 1.0])] * 5 + [(1, True, [1.0, 1.0])], dtype=np.int32),
+    "five_x_two_z_volume": dict(shape=(64, 96, 512), scans=[(0, True, [0.5, 0.5])] * 5 + [(2, True, [0.6, 0.4])] * 2),
+    "six_x_rgb_partial_tiles": dict(shape=(250, 500), scans=[(0, True, [0.5, 0.5])] * 6 + [(1, False, [0.6, 0.4])], planes=3, clamped=True),
+    "five_x_f64": dict(shape=(256, 512), scans=[(0, True, [0.5, 0.3, 0.2])] * 5 + [(1, False, [0.6, 0.4])], dtype=np.float64),
+    "five_x_small_line_kernels": dict(shape=(96, 128), scans=[(0, True, [0.5, 0.5])] * 5 + [(1, False, [0.6, 0.4])], small=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_CASCADE_CASES))
+def test_in_plan_cascade(name, monkeypatch):
+    """Filters the fused kernels cannot take in one piece -- more than four scans in a dimension; a zero-padded 1-D signal
+    whose anticausal scans follow causal ones -- run as successive stages inside one plan (plan.cpp, build_cascade): stage 0
+    reads the input, later stages filter the output planes in place.  Against the oracle on the scans as given."""
+    import torch
+    import recfilter_amd as rfa
+    case = dict(_CASCADE_CASES[name])
+    shape, scans = case["shape"], case["scans"]
+    dtype, clamped, planes = case.get("dtype", np.float32), case.get("clamped", False), case.get("planes", 1)
+    if case.get("small"):
+        monkeypatch.delenv("RF_SMALL_LIMIT", raising=False)        # (the suite pins the automatic path off the line kernels)
+    imgs = [rc.random_image(shape, dtype, 60 + p) for p in range(planes)]
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes) as plan:
+        dev = [torch.from_numpy(im).cuda() for im in imgs]
+        outs, timed = plan.execute_timed(dev)
+        assert any(n.startswith("stage1.") for n, _ in timed), [n for n, _ in timed]
+        assert plan.path_name == ("untiled" if case.get("small") else "tiled_fused")
+        inplace = [d.clone() for d in dev]
+        plan.execute(inplace, inplace)                              # the caller's buffers may be the same, too
+        outs = [o.cpu().numpy() for o in outs]
+        for a, b in zip(outs, inplace):
+            assert np.array_equal(a, b.cpu().numpy())
+    _check(imgs, outs, scans, clamped)
+
+
+def test_in_plan_cascade_keeps_prologue_and_epilogue():
+    """The prologue belongs to the first stage, an epilogue without an input operand to the last one."""
+    import torch
+    import recfilter_amd as rfa
+    shape, scans = (256, 512), [(0, True, [0.5, 0.5])] * 5 + [(1, True, [0.5, 0.5])]
+    img = rc.random_image(shape, np.float32, 5)
+    with rfa.Plan(shape, scans, prologue=(2.0, 0.5), epilogue=(0.5, 0.0, 1.0)) as plan:
+        out, timed = plan.execute_timed([torch.from_numpy(img).cuda()])
+        assert any(n.startswith("stage1.") for n, _ in timed)
+        got = out[0].cpu().numpy()
+    want = 0.5 * oracle.apply_filter(2.0 * img.astype(np.float64) + 0.5, scans, False) + 1.0
+    assert rc.rel_err(got, want) < TOL

@@ -373,7 +373,44 @@ def test_high_order_scans_are_split_into_sections_for_the_fused_path(monkeypatch
     assert path_of(xy(o5), clamped=True) != "tiled_fused"                  # clamped border: not the same filter
     assert path_of(xy(o5), clamped=False, dtype=np.float64) == "tiled_fused"     # f64 pixels: sections in f64
     assert path_of(xy([1.0, 1.0, 0.0, 0.0, 1.0]), clamped=False, dtype=np.int32) != "tiled_fused"     # integer pixels: as given
-    assert path_of(xy(o6c), clamped=False) != "tiled_fused"                # three conjugate pairs, twice: six scans per dimension
+    assert path_of(xy(o6c), clamped=False) == "tiled_fused"                # three conjugate pairs, twice: six sections per
+                                                                           # dimension -> two stages of an in-plan cascade
+    monkeypatch.setenv("RF_NO_CASCADE", "1")
+    assert path_of(xy(o6c), clamped=False) != "tiled_fused"                # (without the cascade: as given, another path)
+    monkeypatch.delenv("RF_NO_CASCADE")
     assert path_of([(0, True, o6c), (1, True, o6c)], clamped=False) == "tiled_fused"
     monkeypatch.setenv("RF_NO_SECTIONS", "1")
     assert path_of(xy(o5), clamped=False) != "tiled_fused"
+
+
+def test_in_plan_cascade_decisions(monkeypatch):
+    """More than four scans in a dimension, or a zero-padded 1-D signal whose anticausal scans follow causal ones, run as
+    successive fused stages inside one plan (plan.cpp, build_cascade) instead of on the generic path; decided on the host."""
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    monkeypatch.setenv("RF_SMALL_LIMIT", "0")
+
+    def plan_of(shape, scans, **kw):
+        return rfa.Plan(shape, scans, device=capi.RF_DEVICE_HOST_ONLY, **kw)
+    bq = [0.05, 1.6, -0.7]
+    with plan_of((1_000_000,), [(0, True, bq)] * 4) as four, plan_of((1_000_000,), [(0, True, bq)] * 5) as five, \
+         plan_of((1_000_000,), [(0, True, bq)] * 9) as nine:
+        assert four.path_name == five.path_name == nine.path_name == "tiled_fused"
+        assert five.num_kernels > four.num_kernels and nine.num_kernels > five.num_kernels
+    # 1-D, length not a multiple of 8192: causal then anticausal is two stages (each copies only the signal out of its padding)
+    with plan_of((100_000,), [(0, True, bq), (0, False, bq)]) as mixed, plan_of((100_000,), [(0, True, bq)]) as one, \
+         plan_of((8192 * 12,), [(0, True, bq), (0, False, bq)]) as whole:       # (no padding: one stage)
+        assert mixed.path_name == "tiled_fused" and mixed.num_kernels == 2 * one.num_kernels
+        assert whole.path_name == "tiled_fused" and whole.num_kernels < mixed.num_kernels
+    # 2-D: six x scans and one y scan
+    with plan_of((256, 512), [(0, True, [0.5, 0.5])] * 6 + [(1, False, [0.6, 0.4])], clamped=True) as p:
+        assert p.path_name == "tiled_fused"
+    # an epilogue that reads the input cannot be cascaded (the last stage no longer sees it): as before
+    with plan_of((256, 512), [(0, True, [0.5, 0.5])] * 5, epilogue=(1.0, 1.0, 0.0)) as p:
+        assert p.path_name != "tiled_fused"
+    # clamped 1-D signals stay off the fused kernels whatever the split
+    with plan_of((100_000,), [(0, True, bq)] * 5, clamped=True) as p:
+        assert p.path_name != "tiled_fused"
+    monkeypatch.setenv("RF_NO_CASCADE", "1")
+    with plan_of((1_000_000,), [(0, True, bq)] * 5) as p:
+        assert p.path_name != "tiled_fused"
