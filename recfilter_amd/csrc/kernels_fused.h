@@ -81,6 +81,10 @@ struct FusedArgs {
     // [ty][z*MX + tx][j][r][256] -- every tile owns one contiguous block of ny*K KiB (what pass 1 writes and pass 2 reads in
     // one piece; pass 1 is sensitive to how its tail stores reach memory).  Row shards keep layout 0.
     int32_t yt_tile_major;
+    // A long 1-D signal folded into rows whose length is not a whole number of rows (plan_fused.cpp, "chained rows"): the
+    // image the kernels see is the signal followed by zeros, but only its first lin_limit samples exist in the caller's
+    // buffers -- loads beyond them yield zeros, stores beyond them are dropped.  0: every sample of the image exists.
+    int64_t lin_limit;
     // element index of y tail (j, ty, r) of column `line` (= x + NXP * z)
     __host__ __device__ int64_t yt_index(int j, int ty, int r, int K, int64_t line) const {
         if (yt_tile_major)

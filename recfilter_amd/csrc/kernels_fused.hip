@@ -162,7 +162,19 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         A4 tmp[TY / 4];
         const bool chunk_in = 4 * cc < last_cols;            // this thread's 16-byte chunk exists in the image
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
-        if (rows_here == TY) {
+        // a folded 1-D signal that ends inside or before this tile (FusedArgs::lin_limit): zeros from its end on
+        const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;
+        if (a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit) {       // (tile-uniform)
+#pragma unroll
+            for (int i = 0; i < TY / 4; i++) {
+                const int64_t idx = lin0 + (int64_t)(rg + 4 * i) * a.NX + 4 * cc;
+                A4 v = idx < a.lin_limit ? ld(4 * i) : zero4;
+                if (idx + 1 >= a.lin_limit) v.y = Acc(0);
+                if (idx + 2 >= a.lin_limit) v.z = Acc(0);
+                if (idx + 3 >= a.lin_limit) v.w = Acc(0);
+                tmp[i] = v;
+            }
+        } else if (rows_here == TY) {
 #pragma unroll
             for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? ld(4 * i) : zero4;
         } else {
@@ -337,15 +349,22 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
             // by this filter: non-temporal stores
             char *dpb = reinterpret_cast<char *>(dp);
             const uint32_t row_bytes = a.row_bytes;
+            // rows of this column that exist: all of the tile's, or (folded 1-D signal) those before the signal's end
+            int my_rows = rows_here;
+            if (a.lin_limit > 0) {
+                const int64_t first = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX + t;
+                const int64_t left = a.lin_limit > first ? (a.lin_limit - first + a.NX - 1) / a.NX : 0;
+                my_rows = left < (int64_t)rows_here ? (int)left : rows_here;
+            }
             if (t < last_cols) {
-                if (rows_here == TY) {
+                if (my_rows == TY) {
 #pragma unroll
                     for (int i = 0; i < TY; i++)
                         __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)));
                 } else {
 #pragma unroll
                     for (int i = 0; i < TY; i++)
-                        if (i < rows_here)
+                        if (i < my_rows)
                             __builtin_nontemporal_store(PixelTraits<P>::store(col[i]), reinterpret_cast<P *>(dpb + ((uint32_t)t * (uint32_t)sizeof(P) + (uint32_t)i * row_bytes)));
                 }
             }
@@ -384,6 +403,10 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
     bool epi = false;
     const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
+    if (a.lin_limit > 0 && (a.ny != 0 || a.NZ != 1 || a.plane_batch || epi || edge)) {
+        set_error("fused pass 2: a signal that ends inside the image needs a 1-D plan of whole tiles without an input-operand epilogue");
+        return RF_ERR_INVALID_ARG;
+    }
     const int ypat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
     const int xpat = (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
     bool early = true;        // rows can leave from inside the last scan (an affine epilogue is applied on the way out; one with

@@ -80,8 +80,23 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     A4 pre[NL];
     // rows of this half that exist (the last tile row may be partial): the fast path when all of them do
     const int rows_here = (ty == a.MY - 1) ? a.last_rows : TY;
+    // a folded 1-D signal that ends inside or before this tile (FusedArgs::lin_limit): samples from the end on are zeros
+    const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;         // linear index of the tile's first sample
+    const bool lin_cut = a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit;      // (tile-uniform)
     auto load_half = [&](int half) {
         const int r0 = kTailRows * half + rg;
+        if (lin_cut) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                const int64_t idx = lin0 + (int64_t)(r0 + 4 * i) * a.NX + 4 * cc;
+                A4 v = idx < a.lin_limit ? ld(kTailRows * half + 4 * i) : zero4;
+                if (idx + 1 >= a.lin_limit) v.y = Acc(0);
+                if (idx + 2 >= a.lin_limit) v.z = Acc(0);
+                if (idx + 3 >= a.lin_limit) v.w = Acc(0);
+                pre[i] = v;
+            }
+            return;
+        }
         if (rows_here == TY) {
 #pragma unroll
             for (int i = 0; i < NL; i++) pre[i] = chunk_in ? ld(kTailRows * half + 4 * i) : zero4;

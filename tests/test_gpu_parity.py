@@ -1240,3 +1240,24 @@ def test_in_plan_cascade_keeps_prologue_and_epilogue():
         got = out[0].cpu().numpy()
     want = 0.5 * oracle.apply_filter(2.0 * img.astype(np.float64) + 0.5, scans, False) + 1.0
     assert rc.rel_err(got, want) < TOL
+
+
+@pytest.mark.parametrize("n", [12345, 100_001, 1_000_003, 8192 * 3 + 2])
+def test_1d_signal_end_is_masked_not_copied(n):
+    """A 1-D signal whose length is not a whole number of rows runs on the caller's buffers (FusedArgs::lin_limit): what
+    lies behind the signal's end in the input buffer must not reach the result (NaNs there), and nothing may be written
+    behind its end in the output buffer (sentinels there)."""
+    import torch
+    import recfilter_amd as rfa
+    scans = [(0, True, rc.GAUSS2), (0, True, [0.7, 0.3])]
+    sig = rc.random_image((n,), np.float32, 3)
+    big_in = torch.full((n + 64,), float("nan"), device="cuda")
+    big_in[:n] = torch.from_numpy(sig).cuda()
+    big_out = torch.full((n + 64,), -7.0, device="cuda")
+    with rfa.Plan((n,), scans) as plan:
+        assert plan.path_name == "tiled_fused"
+        _, timed = plan.execute_timed([big_in[:n]], [big_out[:n]])
+        assert not any("pad_copy" in name for name, _ in timed)
+    got = big_out.cpu().numpy()
+    assert np.all(got[n:] == -7.0)
+    _check([sig], [got[:n]], scans, False)
