@@ -430,7 +430,127 @@ row_chain_kernel(const Acc *__restrict__ exit_states, Acc *__restrict__ incoming
     }
 }
 
+// The same chain and what follows it in ONE launch: every workgroup walks the rows' exit states itself (wave 0, the
+// algorithm above; NY k-vectors, a few KiB), keeps the state entering every row in LDS, and then propagates it through its
+// share of the rows' tails -- tail(i) += A^(i+1) * entering state, the powers tabulated on the host (GenericDimArgs::Apow),
+// like carry_apply_parallel_kernel (kernels_generic.hip).  Redundant across workgroups, but a long signal's carry stage is
+// launch-bound: three launches per scan become two.  The first workgroup also stores the entering states (the chaining
+// terms of the next scan and the final pass read them).
+constexpr int kChainApplyTiles = 8;
+template <typename Acc, int K>
+__global__ void __launch_bounds__(256)
+chain_apply_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ exit_states, Acc *__restrict__ incoming, int causal,
+                   const Acc *__restrict__ AM, const Acc *__restrict__ AMS, int S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_raw[];
+    Acc *entering = reinterpret_cast<Acc *>(chain_raw);        // [row][K]
+    __shared__ Acc lane_exit[64][K];
+    const int NY = (int)a.g.lines;
+    const int l = threadIdx.x;
+    const int i0 = l * S;
+    int i1 = i0 + S;
+    i1 = i1 > NY ? NY : i1;
+    if (l < 64) {
+        Acc x[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) x[r] = Acc(0);
+        for (int i = i0; i < i1; i++) {
+            const int row = causal ? i : NY - 1 - i;
+            Acc nx[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) nx[r] = exit_states[(size_t)r * NY + row];
+            matvec_acc<Acc, K>(AM, x, nx);
+#pragma unroll
+            for (int r = 0; r < K; r++) x[r] = nx[r];
+        }
+#pragma unroll
+        for (int r = 0; r < K; r++) lane_exit[l][r] = x[r];
+    }
+    __syncthreads();
+    if (l < 64) {
+        Acc inc[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) inc[r] = Acc(0);
+        for (int c = 0; c < l; c++) {               // lanes before l own full segments of S rows
+            Acc nx[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) nx[r] = lane_exit[c][r];
+            matvec_acc<Acc, K>(AMS, inc, nx);
+#pragma unroll
+            for (int r = 0; r < K; r++) inc[r] = nx[r];
+        }
+        const bool publish = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int i = i0; i < i1; i++) {
+            const int row = causal ? i : NY - 1 - i;
+            Acc nx[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                entering[row * K + r] = inc[r];
+                if (publish) incoming[(size_t)r * NY + row] = inc[r];
+                nx[r] = exit_states[(size_t)r * NY + row];
+            }
+            matvec_acc<Acc, K>(AM, inc, nx);
+#pragma unroll
+            for (int r = 0; r < K; r++) inc[r] = nx[r];
+        }
+    }
+    __syncthreads();
+    const int line = (int)blockIdx.x * 256 + l;
+    if (line >= NY) return;
+    Acc x[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) x[j] = entering[line * K + j];
+    const int t0 = (int)blockIdx.y * kChainApplyTiles;
+    const size_t L = (size_t)NY;
+    // all loads of the chunk first, then the stores (interleaved, every store could alias the next load)
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        Acc cur[kChainApplyTiles];
+#pragma unroll
+        for (int u = 0; u < kChainApplyTiles; u++) {
+            const int i = t0 + u;
+            const int tt = causal ? i : a.M - 1 - i;
+            cur[u] = i < a.M ? a.tails[(((size_t)s * a.M + tt) * K + r) * L + line] : Acc(0);
+        }
+#pragma unroll
+        for (int u = 0; u < kChainApplyTiles; u++) {
+            const int i = t0 + u;
+            if (i < a.M) {
+                const int tt = causal ? i : a.M - 1 - i;
+                const Acc *Ap = a.Apow + ((size_t)s * a.M + i) * K * K;          // wave-uniform
+                Acc add = Acc(0);
+#pragma unroll
+                for (int j = 0; j < K; j++) add = add + Ap[r * K + j] * x[j];
+                a.tails[(((size_t)s * a.M + tt) * K + r) * L + line] = cur[u] + add;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+bool chain_apply_applies(int K, int64_t NY, size_t acc_bytes) {
+    static const bool off = getenv("RF_NO_CHAIN_APPLY") != nullptr;      // A/B runs: row_chain + carry_apply as two launches
+    return !off && K >= 1 && K <= 3 && NY > 0 && (size_t)NY * K * acc_bytes <= 48 * 1024;
+}
+
+template <typename Acc>
+int launch_chain_apply(int K, const GenericDimArgs<Acc> &a, int s, const Acc *exit_states, Acc *incoming, bool causal,
+                       const Acc *AM, const Acc *AMS, int S, hipStream_t stream) {
+    const int NY = (int)a.g.lines;
+    if (NY <= 0 || a.M <= 0) return RF_OK;
+    if (a.Apow == nullptr || a.tile_major) { set_error("chain apply: needs the tabulated powers and row-major tails"); return RF_ERR_INVALID_ARG; }
+    if (S < 1 || (int64_t)S * 64 < NY) { set_error("chain apply: segment length %d does not cover %d rows", S, NY); return RF_ERR_INVALID_ARG; }
+    dim3 grid((unsigned)((NY + 255) / 256), (unsigned)((a.M + kChainApplyTiles - 1) / kChainApplyTiles));
+    const size_t lds = (size_t)NY * K * sizeof(Acc);
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((chain_apply_kernel<Acc, KK>), grid, dim3(256), lds, stream, a, s, exit_states, incoming, causal ? 1 : 0, AM, AMS, S); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+#undef RF_CASE
+    set_error("chain apply: unsupported order %d", K);
+    return RF_ERR_UNSUPPORTED;
+}
+template int launch_chain_apply<float>(int, const GenericDimArgs<float> &, int, const float *, float *, bool, const float *, const float *, int, hipStream_t);
+template int launch_chain_apply<uint32_t>(int, const GenericDimArgs<uint32_t> &, int, const uint32_t *, uint32_t *, bool, const uint32_t *, const uint32_t *, int, hipStream_t);
+template int launch_chain_apply<double>(int, const GenericDimArgs<double> &, int, const double *, double *, bool, const double *, const double *, int, hipStream_t);
 
 template <typename Acc>
 int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool causal, const Acc *AM, const Acc *AMS,

@@ -133,6 +133,11 @@ template <typename Acc>
 int launch_row_chain(int K, const Acc *exit_states, Acc *incoming, int NY, bool causal, const Acc *AM, const Acc *AMS,
                      int S, hipStream_t stream);
 int carry_chunk_count(int64_t M, int64_t lines, int C, int K = 1);
+// row chain + propagation through the rows' tails in one launch (when the rows' entering states fit the LDS)
+bool chain_apply_applies(int K, int64_t NY, size_t acc_bytes);
+template <typename Acc>
+int launch_chain_apply(int K, const GenericDimArgs<Acc> &a, int s, const Acc *exit_states, Acc *incoming, bool causal,
+                       const Acc *AM, const Acc *AMS, int S, hipStream_t stream);
 
 // pass 2: the final correction pass (kernels_fused.hip)
 // (src_u8: the input plane holds unsigned bytes, rf_pointwise_desc.in_dtype == RF_IN_U8; float pixels only)

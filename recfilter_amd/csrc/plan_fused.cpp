@@ -396,6 +396,19 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                                                plan->stream);
             };
             plan->begin_steps.push_back(cs);
+            if (chain_apply_applies(K, Lx, sizeof(Acc)) && !hApowX.empty()) {
+                // the chain over the rows and the propagation through their tails in one launch (kernels_carry.hip)
+                Step ca;
+                ca.name = "chain_apply" + std::to_string(s);
+                const Acc *AMs = d_AMx + (size_t)s * K * K, *AMSs = d_AMSx + (size_t)s * K * K;
+                ca.run = [plan, gxargs, K, s, causal, row_exit, xin, xin_pp, Lx, AMs, AMSs, chain_S](int pl) {
+                    Acc *inc = xin + (size_t)pl * xin_pp + (size_t)s * K * Lx;
+                    return launch_chain_apply<Acc>(K, gxargs(pl), s, row_exit + (size_t)pl * K * Lx, inc, causal, AMs, AMSs, chain_S,
+                                                   plan->stream);
+                };
+                plan->begin_steps.push_back(ca);
+                continue;
+            }
             Step rc;
             rc.name = "row_chain" + std::to_string(s);
             const Acc *AMs = d_AMx + (size_t)s * K * K, *AMSs = d_AMSx + (size_t)s * K * K;
