@@ -58,13 +58,19 @@ __device__ __forceinline__ uint32_t tail_off(const CarryGeom &g, int s, int tt, 
     return (((uint32_t)s * (uint32_t)g.M + (uint32_t)tt) * K + (uint32_t)r) * g.lines + line;
 }
 
-template <typename Acc, int K, int MAXC, int NCH>
+// PRE (long 1-D signals folded into rows, plan_fused.cpp "chained rows"): before its own scan s_begin the launch finishes
+// scan s_begin - 1 -- the chain over the rows' exit states and its propagation through the rows' tails, what
+// chain_apply_kernel below does as a launch of its own: every workgroup walks the exit states (wave 0), keeps the states
+// entering the rows in LDS, and updates the tails of ITS lines.  n scans then take n + 1 launches instead of 2 n.
+template <typename Acc, int K, int MAXC, int NCH, bool PRE = false>
 __global__ void __launch_bounds__(kCarryLines * NCH)
 carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
                    const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC,
-                   Acc *__restrict__ send, int C) {
+                   Acc *__restrict__ send, int C, ChainPre<Acc> pre = ChainPre<Acc>{}) {
     __shared__ Acc exits[NCH][kCarryLines][K];
     __shared__ Acc carry_in[kCarryLines][K];
+    extern __shared__ __attribute__((aligned(16))) unsigned char pre_raw[];
+    Acc *entering_prev = reinterpret_cast<Acc *>(pre_raw);      // PRE: [line][K]
 
     const int ln = threadIdx.x & (kCarryLines - 1);
     const int ch = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kCarryLines);    // wave-uniform
@@ -77,6 +83,80 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     const int n_chunks = (int)blockDim.x / kCarryLines;      // <= NCH; fewer when a line has few tiles
     const int tiles_per_block = n_chunks * C;
     const int n_blocks = (M + tiles_per_block - 1) / tiles_per_block;
+
+    if constexpr (PRE) {
+        const int NY = (int)L, sp = s_begin - 1;
+        const bool pc = pre.causal_prev != 0;
+        Acc (*lane_exit)[K] = exits[0];                       // [64][K]: not in use yet
+        const int l = (int)threadIdx.x;
+        const int i0 = l * pre.S;
+        int i1 = i0 + pre.S;
+        i1 = i1 > NY ? NY : i1;
+        if (l < 64) {
+            Acc x[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) x[r] = Acc(0);
+            for (int i = i0; i < i1; i++) {
+                const int row = pc ? i : NY - 1 - i;
+                Acc nx[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) nx[r] = pre.exit_states[(size_t)r * NY + row];
+                matvec_acc<Acc, K>(pre.AM, x, nx);
+#pragma unroll
+                for (int r = 0; r < K; r++) x[r] = nx[r];
+            }
+#pragma unroll
+            for (int r = 0; r < K; r++) lane_exit[l][r] = x[r];
+        }
+        __syncthreads();
+        if (l < 64) {
+            Acc inc[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) inc[r] = Acc(0);
+            for (int c = 0; c < l; c++) {
+                Acc nx[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) nx[r] = lane_exit[c][r];
+                matvec_acc<Acc, K>(pre.AMS, inc, nx);
+#pragma unroll
+                for (int r = 0; r < K; r++) inc[r] = nx[r];
+            }
+            for (int i = i0; i < i1; i++) {
+                const int row = pc ? i : NY - 1 - i;
+                Acc nx[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) {
+                    entering_prev[row * K + r] = inc[r];
+                    if (blockIdx.x == 0) pre.incoming_prev[(size_t)r * NY + row] = inc[r];
+                    nx[r] = pre.exit_states[(size_t)r * NY + row];
+                }
+                matvec_acc<Acc, K>(pre.AM, inc, nx);
+#pragma unroll
+                for (int r = 0; r < K; r++) inc[r] = nx[r];
+            }
+        }
+        __syncthreads();
+        // tails of scan sp of this workgroup's lines: tile tt += A^(i+1) * entering state, i = the tile's position in scan order
+        Acc xin[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) xin[j] = entering_prev[line * K + j];
+        for (int tt = ch; tt < M; tt += n_chunks) {
+            const int i = pc ? tt : M - 1 - tt;
+            const Acc *Ap = pre.Apow + (size_t)i * K * K;                  // wave-uniform
+            Acc cur[K];
+#pragma unroll
+            for (int r = 0; r < K; r++) cur[r] = tails[tail_off<K>(g, sp, tt, r, line)];
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                Acc add = Acc(0);
+#pragma unroll
+                for (int j = 0; j < K; j++) add = add + Ap[r * K + j] * xin[j];
+                if (line_ok) tails[tail_off<K>(g, sp, tt, r, line)] = cur[r] + add;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 
     for (int s = s_begin; s < s_end; s++) {
         const bool causal = ((g.causal_mask >> s) & 1u) != 0;
@@ -119,8 +199,11 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                         const bool q_first = qc ? (tt == 0) : (tt == M - 1);
                         Acc c[K];
                         if (q_first) {
+                            bool from_lds = false;
+                            if constexpr (PRE) from_lds = q == s_begin - 1;        // (another workgroup may not have stored it yet)
 #pragma unroll
-                            for (int o = 0; o < K; o++) c[o] = incoming[(uint32_t)(q * K + o) * L + line];
+                            for (int o = 0; o < K; o++)
+                                c[o] = from_lds ? entering_prev[line * K + o] : incoming[(uint32_t)(q * K + o) * L + line];
                         } else {
                             const int tp = qc ? tt - 1 : tt + 1;
 #pragma unroll
@@ -581,7 +664,7 @@ int carry_chunk_count(int64_t M, int64_t lines, int C, int K) {
 
 template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
-                       const Acc *AC, int C, hipStream_t stream) {
+                       const Acc *AC, int C, hipStream_t stream, const ChainPre<Acc> *pre) {
     if (a.g.lines <= 0 || a.M <= 0 || s_end <= s_begin) return RF_OK;
     if (C < 1 || C > (K <= 3 ? kCarryMaxC : kCarryMaxCHigh)) { set_error("carry: chunk length %d out of range", C); return RF_ERR_INVALID_ARG; }
     const uint64_t total = (uint64_t)a.n_scans * a.M * a.k * a.g.lines;
@@ -600,6 +683,13 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
     int n_chunks = carry_chunk_count(a.M, a.g.lines, C, K);
     const unsigned threads = (unsigned)(kCarryLines * n_chunks);
+    if (pre != nullptr) {      // chained rows: finish scan s_begin - 1 first (PRE)
+        if (s_begin < 1 || s_end != s_begin + 1 || K > 3 || a.tile_major) { set_error("carry: misplaced chain prologue"); return RF_ERR_INVALID_ARG; }
+        const size_t lds = (size_t)a.g.lines * K * sizeof(Acc);
+#define RF_CASE(KK) if (K == KK) { hipLaunchKernelGGL((carry_block_kernel<Acc, KK, kCarryMaxC, kCarryChunks, true>), dim3(grid), dim3(threads), lds, stream, g, s_begin, s_end, a.tails, (const Acc *)a.incoming, a.W, a.A, AC, send, C, *pre); RF_HIP_CHECK(hipGetLastError()); return RF_OK; }
+        RF_CASE(1) RF_CASE(2) RF_CASE(3)
+#undef RF_CASE
+    }
     // two scans of order <= 2, every line's tiles in one block of chunks: the register-chained pair kernel
     // (order 3 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
     if constexpr (sizeof(Acc) == 4) {
@@ -649,10 +739,10 @@ int carry_chunk_length(int64_t M, int64_t lines, int K) {
 }
 
 template int launch_carry_block<float>(int, const GenericDimArgs<float> &, uint32_t, int, int, float *, const float *, int,
-                                       hipStream_t);
+                                       hipStream_t, const ChainPre<float> *);
 template int launch_carry_block<uint32_t>(int, const GenericDimArgs<uint32_t> &, uint32_t, int, int, uint32_t *,
-                                          const uint32_t *, int, hipStream_t);
+                                          const uint32_t *, int, hipStream_t, const ChainPre<uint32_t> *);
 template int launch_carry_block<double>(int, const GenericDimArgs<double> &, uint32_t, int, int, double *, const double *, int,
-                                        hipStream_t);
+                                        hipStream_t, const ChainPre<double> *);
 
 }  // namespace rf

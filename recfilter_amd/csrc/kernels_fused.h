@@ -122,9 +122,19 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
 
 // Blocked parallel carry scan over the tails of one dimension (kernels_carry.hip); scans
 // [s_begin, s_end) of the dimension in one launch.  AC[s] = A[s]^C, C = carry_chunk_length(M, lines).
+// chained-rows plans (long 1-D signals): a carry launch that first finishes the previous scan (kernels_carry.hip, PRE)
+template <typename Acc>
+struct ChainPre {
+    const Acc *exit_states;    // [K][lines] of scan s_begin - 1 (NOT the buffer this launch publishes its own exits to)
+    Acc *incoming_prev;        // [K][lines]: the states entering the rows for scan s_begin - 1 (workgroup 0 stores them)
+    const Acc *AM, *AMS;       // A^MX and (A^MX)^S of scan s_begin - 1
+    const Acc *Apow;           // [i][K][K] = A^(i+1) of scan s_begin - 1
+    int32_t S, causal_prev;
+};
+
 template <typename Acc>
 int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask, int s_begin, int s_end, Acc *send,
-                       const Acc *AC, int C, hipStream_t stream);
+                       const Acc *AC, int C, hipStream_t stream, const ChainPre<Acc> *pre = nullptr);
 int carry_chunk_length(int64_t M, int64_t lines, int K = 1);   // chunk length depends on the order only above 3
 // Chains the rows of a 1-D signal folded into NY rows (kernels_carry.hip): from the rows' local exit states
 // exit[r][y] it forms the state entering every row, incoming[r][y] (entry of the next row = AM * entry + exit,

@@ -265,7 +265,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Acc *yt = (Acc *)plan->alloc(yt_pp * np * sizeof(Acc), false, &status);
     Acc *xin = (Acc *)plan->alloc(xin_pp * np * sizeof(Acc), true, &status);
     Acc *yin = (Acc *)plan->alloc(yin_pp * np * sizeof(Acc), true, &status);
-    Acc *row_exit = chained ? (Acc *)plan->alloc((size_t)K * Lx * np * sizeof(Acc), true, &status) : nullptr;
+    // (two of them: with the chain of scan s folded into the carry launch of scan s + 1 that launch reads one and writes the other)
+    Acc *row_exit = chained ? (Acc *)plan->alloc((size_t)2 * K * Lx * np * sizeof(Acc), true, &status) : nullptr;
     if (status != RF_OK) return status;
 
     FusedArgs<Acc> fbase{};
@@ -387,24 +388,43 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         // rows' exit states, (2) the chain over the rows -> state entering every row, (3) that state propagated through
         // the row's tails.  The same three steps as a sharded dimension (exchange_local / gather / exchange_apply),
         // with rows in the role of slabs.  Scan s+1 chains on scan s's completed carries, hence scan by scan.
+        // Where the rows' entering states fit the LDS the chain and its propagation are not launches of their own: scan s's
+        // are done by the carry launch of scan s + 1 before its own scan (carry_block_kernel PRE), the last scan's by
+        // chain_apply_kernel -- n + 1 launches for n scans.
+        static const bool no_pre = getenv("RF_NO_CHAIN_PRE") != nullptr;        // A/B runs: chain_apply after every scan
+        const bool one_launch_chain = chain_apply_applies(K, Lx, sizeof(Acc)) && !hApowX.empty();
+        const size_t exit_pp = (size_t)K * Lx;            // one buffer of exit states (two per plane, by scan parity)
         for (int s = 0; s < nx; s++) {
             const bool causal = hxs[s].causal != 0;
+            const bool fold_prev = one_launch_chain && !no_pre && s > 0;
             Step cs;
             cs.name = "carry_x" + std::to_string(s);
-            cs.run = [plan, gxargs, K, s, d_ACx, Cx, xmask, row_exit, Lx](int pl) {
-                return launch_carry_block<Acc>(K, gxargs(pl), xmask, s, s + 1, row_exit + (size_t)pl * K * Lx, d_ACx, Cx,
-                                               plan->stream);
+            ChainPre<Acc> pre{};
+            if (fold_prev) {
+                pre.AM = d_AMx + (size_t)(s - 1) * K * K; pre.AMS = d_AMSx + (size_t)(s - 1) * K * K;
+                pre.Apow = d_ApowX + (size_t)(s - 1) * MX * K * K;
+                pre.S = chain_S; pre.causal_prev = hxs[s - 1].causal != 0 ? 1 : 0;
+            }
+            cs.run = [plan, gxargs, K, s, d_ACx, Cx, xmask, row_exit, exit_pp, xin, xin_pp, Lx, pre, fold_prev](int pl) {
+                Acc *mine = row_exit + ((size_t)pl * 2 + (s & 1)) * exit_pp;
+                if (!fold_prev)
+                    return launch_carry_block<Acc>(K, gxargs(pl), xmask, s, s + 1, mine, d_ACx, Cx, plan->stream);
+                ChainPre<Acc> p = pre;
+                p.exit_states = row_exit + ((size_t)pl * 2 + ((s - 1) & 1)) * exit_pp;
+                p.incoming_prev = xin + (size_t)pl * xin_pp + (size_t)(s - 1) * K * Lx;
+                return launch_carry_block<Acc>(K, gxargs(pl), xmask, s, s + 1, mine, d_ACx, Cx, plan->stream, &p);
             };
             plan->begin_steps.push_back(cs);
-            if (chain_apply_applies(K, Lx, sizeof(Acc)) && !hApowX.empty()) {
+            if (one_launch_chain) {
+                if (!no_pre && s + 1 < nx) continue;          // the next scan's carry launch finishes this one
                 // the chain over the rows and the propagation through their tails in one launch (kernels_carry.hip)
                 Step ca;
                 ca.name = "chain_apply" + std::to_string(s);
                 const Acc *AMs = d_AMx + (size_t)s * K * K, *AMSs = d_AMSx + (size_t)s * K * K;
-                ca.run = [plan, gxargs, K, s, causal, row_exit, xin, xin_pp, Lx, AMs, AMSs, chain_S](int pl) {
+                ca.run = [plan, gxargs, K, s, causal, row_exit, exit_pp, xin, xin_pp, Lx, AMs, AMSs, chain_S](int pl) {
                     Acc *inc = xin + (size_t)pl * xin_pp + (size_t)s * K * Lx;
-                    return launch_chain_apply<Acc>(K, gxargs(pl), s, row_exit + (size_t)pl * K * Lx, inc, causal, AMs, AMSs, chain_S,
-                                                   plan->stream);
+                    return launch_chain_apply<Acc>(K, gxargs(pl), s, row_exit + ((size_t)pl * 2 + (s & 1)) * exit_pp, inc, causal, AMs,
+                                                   AMSs, chain_S, plan->stream);
                 };
                 plan->begin_steps.push_back(ca);
                 continue;
@@ -412,9 +432,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             Step rc;
             rc.name = "row_chain" + std::to_string(s);
             const Acc *AMs = d_AMx + (size_t)s * K * K, *AMSs = d_AMSx + (size_t)s * K * K;
-            rc.run = [plan, K, s, causal, row_exit, xin, xin_pp, Lx, AMs, AMSs, chain_S](int pl) {
+            rc.run = [plan, K, s, causal, row_exit, exit_pp, xin, xin_pp, Lx, AMs, AMSs, chain_S](int pl) {
                 Acc *inc = xin + (size_t)pl * xin_pp + (size_t)s * K * Lx;
-                return launch_row_chain<Acc>(K, row_exit + (size_t)pl * K * Lx, inc, (int)Lx, causal, AMs, AMSs, chain_S,
+                return launch_row_chain<Acc>(K, row_exit + ((size_t)pl * 2 + (s & 1)) * exit_pp, inc, (int)Lx, causal, AMs, AMSs, chain_S,
                                              plan->stream);
             };
             plan->begin_steps.push_back(rc);
