@@ -1261,3 +1261,24 @@ def test_1d_signal_end_is_masked_not_copied(n):
     got = big_out.cpu().numpy()
     assert np.all(got[n:] == -7.0)
     _check([sig], [got[:n]], scans, False)
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int16], ids=["i32", "i16"])
+@pytest.mark.parametrize("n", [12345, 100_001, 8192 * 5 + 7])
+def test_1d_integer_signals_any_length(n, dtype):
+    """Integer 1-D signals whose length is not a whole number of rows: bit-exact against the untiled path (ring arithmetic
+    either way), nothing written behind the signal's end (8-byte chunks for int16 pixels)."""
+    import torch
+    import recfilter_amd as rfa
+    tdt = torch.int32 if dtype == np.int32 else torch.int16
+    scans = [(0, True, [1.0, 1.0]), (0, True, [2.0, -1.0, 1.0])]
+    big_in = torch.randint(-50, 50, (n + 64,), dtype=tdt, device="cuda")
+    fused = torch.full((n + 64,), -7, dtype=tdt, device="cuda")
+    plain = torch.full((n + 64,), -7, dtype=tdt, device="cuda")
+    with rfa.Plan((n,), scans, dtype=dtype) as pf, rfa.Plan((n,), scans, dtype=dtype, path=1) as pu:
+        assert pf.path_name == "tiled_fused"
+        pf.execute([big_in[:n]], [fused[:n]])
+        pu.execute([big_in[:n]], [plain[:n]])
+        torch.cuda.synchronize()
+    assert torch.equal(fused, plain)
+    np.testing.assert_array_equal(fused[:n].cpu().numpy(), oracle.apply_filter(big_in[:n].cpu().numpy(), scans, False))
