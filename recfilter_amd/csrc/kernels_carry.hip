@@ -79,7 +79,6 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
     const bool line_ok = line_raw < L;
     const uint32_t line = line_ok ? line_raw : L - 1;     // out-of-range lanes shadow the last line, stores masked
     const int M = g.M;
-    const uint32_t tile_stride = (uint32_t)K * L;          // elements between consecutive tiles of one scan
     const int n_chunks = (int)blockDim.x / kCarryLines;      // <= NCH; fewer when a line has few tiles
     const int tiles_per_block = n_chunks * C;
     const int n_blocks = (M + tiles_per_block - 1) / tiles_per_block;
@@ -162,7 +161,6 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
         const bool causal = ((g.causal_mask >> s) & 1u) != 0;
         const Acc *Am = Atab + s * K * K;
         const Acc *ACm = AC + s * K * K;
-        const uint32_t scan_base = (uint32_t)s * (uint32_t)M * tile_stride + line;
         if (ch == 0) {
 #pragma unroll
             for (int r = 0; r < K; r++) carry_in[ln][r] = Acc(0);
@@ -190,7 +188,6 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
             }
             for (int q = 0; q < s; q++) {
                 const bool qc = ((g.causal_mask >> q) & 1u) != 0;
-                const uint32_t q_base = (uint32_t)q * (uint32_t)M * tile_stride + line;
 #pragma unroll
                 for (int ii = 0; ii < MAXC; ii++) {
                     if (ii < nvalid) {
@@ -297,7 +294,6 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[MAXC][KP], int s, const C
                                           uint32_t line, bool line_ok, Acc *__restrict__ send) {
     const int M = g.M;
     const uint32_t L = g.lines;
-    const uint32_t tile_stride = (uint32_t)K * L;
     constexpr bool causal = CAUSAL;     // compile time: the owned tiles stay statically indexed registers
     const Acc *Am = Atab + s * K * K;
     const Acc *ACm = AC + s * K * K;
@@ -347,7 +343,6 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[MAXC][KP], int s, const C
         }
     }
     // propagate through the chunk and store
-    const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
 #pragma unroll
     for (int p = 0; p < MAXC; p++) {
         const int ii = causal ? p : MAXC - 1 - p;
@@ -392,7 +387,6 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     const bool line_ok = line_raw < L;
     const uint32_t line = line_ok ? line_raw : L - 1;
     const int M = g.M;
-    const uint32_t tile_stride = (uint32_t)K * L;
     const int n_chunks = (int)blockDim.x / kCarryLines;
     const int t0 = ch * C;                                   // first owned tile (memory order)
     int nvalid = M - t0;
@@ -401,7 +395,6 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     constexpr int KP = K < 2 ? 2 : K;
     Acc ta[MAXC][KP], tb[MAXC][KP];              // owned tiles of scan s0 / s0+1
     auto load_scan = [&](Acc (&t)[MAXC][KP], int s) {
-        const uint32_t base = (uint32_t)s * (uint32_t)M * tile_stride + line;
 #pragma unroll
         for (int ii = 0; ii < MAXC; ii++) {
 #pragma unroll

@@ -166,7 +166,7 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
     // the same banks (4-way conflict on every read: profiles/r2/pmc_shader.json, 34 % of this kernel's LDS cycles).
     for (int i = tid; i < 4 * nyk * kStreamTY; i += 512) hy_lds[(i / kStreamTY) * kHyPitch + i % kStreamTY] = Hy[i];
 
-    const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
+    const int64_t Lx = a.NYP * a.NZ;
     const int w = wave & 3;                                          // column group 64w .. 64w+63
 
     if (wave < 4) {

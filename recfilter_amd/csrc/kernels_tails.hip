@@ -68,7 +68,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
     const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
     auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
-    const int64_t Lx = a.NYP * a.NZ, Ly = a.NXP * a.NZ;
+    const int64_t Lx = a.NYP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (4 * cc < a.last_cols);
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
