@@ -55,24 +55,48 @@ def algorithmic_bytes_per_launch(kernel_name, samples, itemsize):
     return 0
 
 
+def kernel_sources_sha16():
+    """Identity of the code that is running: sha256 over the kernel and plan sources (recfilter_amd/csrc/*.hip|*.h|*.cpp,
+    sorted by name), first 16 hex digits.  tools/pmc_summary.py stores the same digest in the PMC summary it writes, so a
+    summary collected on other kernels than the ones running is recognised without git (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "recfilter_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))):
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_name, workload, shape):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950).
     rocprofv3 cannot run inside the bench, so this is a LOOKUP in the newest committed summary, not a measurement of
-    the run that prints it -- the bench line names the file (`traffic_source`).  Only valid for the exact workload the
-    counters were collected on (cfg3 at full size); else (None, None)."""
+    the run that prints it -- the bench line names the file (`traffic_source`), the commit it was collected at
+    (`traffic_head`) and the digest of the kernel sources it was collected on.  `traffic` is null when that digest is
+    not the digest of the sources that are running (a kernel changed since: the old bytes would be a guess), and for
+    every workload but the one the counters were collected on (cfg3 at full size).
+    Returns (traffic, info dict)."""
+    info = {"traffic_source": None, "traffic_head": None, "traffic_sources_sha16": None, "running_sources_sha16": kernel_sources_sha16()}
     if workload != "cfg3" or tuple(shape) != (16384, 16384):
-        return None, None
-    for rnd in ("r2", "r1"):
+        return None, info
+    for rnd in ("r3", "r2", "r1"):
         rel = os.path.join("profiles", rnd, "pmc_traffic.json")
         try:
-            table = json.load(open(os.path.join(ROOT, rel)))["kernels"]
+            doc = json.load(open(os.path.join(ROOT, rel)))
+            table = doc["kernels"]
         except Exception:
             continue
         for key, entry in table.items():
             if key.startswith(kernel_name):
-                return entry["fetch_bytes_corrected"] + entry["write_bytes"], rel
-    return None, None
+                info.update(traffic_source=rel, traffic_head=doc.get("git_head"), traffic_sources_sha16=doc.get("kernel_sources_sha16"))
+                if doc.get("kernel_sources_sha16") != info["running_sources_sha16"]:
+                    info["traffic_note"] = "stale: collected on other kernel sources than the ones running"
+                    return None, info
+                return entry["fetch_bytes_corrected"] + entry["write_bytes"], info
+        break          # the newest summary has no such kernel: older rounds' bytes are not this code's
+    return None, info
 
 
 def cpu_model():
@@ -181,6 +205,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's shape is the GLOBAL image, every rank "
                     "owns 1/N of its outermost dimension (BASELINE config 5: 2048^3 z-sharded over 8 GPUs); default is weak "
                     "scaling, every rank owns a full-size slab")
+    ap.add_argument("--force-stepping", action="store_true", help="one rank: drive the sharded protocol anyway (begin, exit carries, "
+                    "all-gather over the process group, interior, entering carries, finish) on a plan built with "
+                    "RF_PLAN_FORCE_EXCHANGE -- what every rank of an N-GPU run executes, on a box with one GPU")
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU, each on its own HIP stream with its own "
                     "plan and output planes (1 = strictly one after the other on one stream; 0 = auto: 1 on one GPU, so "
                     "that per-kernel durations under rocprofv3 are those of kernels running alone, 2 on several GPUs, "
@@ -233,19 +260,50 @@ def main():
     samples_local = int(np.prod(shape)) * planes
 
     from recfilter_amd.dist import ShardedFilter
+    stepping = world > 1 or (args.force_stepping and dist is not None)
+    if args.force_stepping and dist is None:
+        raise SystemExit("--force-stepping needs a process group: launch with torch.distributed.run --nproc-per-node=1")
     filt = ShardedFilter(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, rank=rank, world=world,
-                         path=args.path, dtype=np.float32, group=None, inflight=inflight)
+                         path=args.path, dtype=np.float32, group=None, inflight=inflight, force_exchange=stepping and world == 1)
+
+    def barrier():
+        filt.drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed_region():
+        """W untimed steps, then exactly K steps between barriers; max over ranks.  A step = one execute of the whole filter
+        on the resident image; with --inflight D the steps are submitted round robin to D streams (recfilter_amd/dist.py)."""
+        for i in range(args.warmup):
+            filt.submit(inputs, output_sets[i % inflight])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            filt.submit(inputs, output_sets[i % inflight])
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # --- cold: the driver's W + K steps on a GPU that has run nothing yet (reported as ms_per_step_cold) ----------
+    elapsed_cold = timed_region()
 
     # --- per-kernel timing with HIP events on the launch stream (single-device plan) -----------------
     # Runs BEFORE the warm-up and the timed steps, on every rank (rank 0 reports): a GPU that starts from idle needs
     # some 25 ms of load before its kernels run at their steady durations (tools/region_probe.py: cfg3 0.66 ms for the
     # first execution, 0.63 over the first five, 0.59 after about forty), and the driver's 5 + 20 steps are 15 ms.
-    roofline = None
-    kernels = {}
-    if True:
-        plan = filt.plan if world == 1 else rfa.Plan(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes,
-                                                     path=args.path)
+    # Every rank runs it (the clocks of every GPU have to come up); a rank whose own plan is sharded (or forced into the
+    # stepping protocol) times an unsharded plan of the same slab, which has the same kernels.
+    def per_kernel_pass():
+        own_plan = world == 1 and not stepping
+        plan = filt.plan if own_plan else rfa.Plan(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, path=args.path)
         reps = max(5, min(args.steps, 20))
+        preheat = 3 * reps
         acc = {}
         order = []
         for i in range(3 * reps):
@@ -262,15 +320,15 @@ def main():
         passes = [n for n in order if algorithmic_bytes_per_launch(n, 1, 4) > 0] or order
         dom = max(passes, key=lambda n: kernels[n])
         # the Tuple planes of a 2-D filter ride in one launch per step; otherwise one launch per plane
-        batched = len(shape) == 2 and 1 < planes <= 16 and os.environ.get("RF_NO_PLANE_BATCH") is None
+        batched = len(shape) == 2 and 1 < planes <= 16
         launches = 1 if batched else planes
         alg = algorithmic_bytes_per_launch(dom, samples_local // launches, 4)
         avg_ms = kernels[dom] / launches
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_source = pmc_traffic(dom, args.workload, shape)
+        traffic, traffic_info = pmc_traffic(dom, args.workload, shape)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic": traffic, **traffic_info,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg}
         # device-to-device copy of the same image with torch's own kernel, timed with HIP events: what a plain
         # read-once/write-once pass reaches on this box (SURVEY 8d asks for a measured stream-copy ceiling)
@@ -283,30 +341,14 @@ def main():
         torch.cuda.synchronize()
         copy_ms = e0.elapsed_time(e1) / 5
         roofline["copy_ceiling_gbps"] = round(2 * 4 * (samples_local // planes) / (copy_ms * 1e-3) / 1e9, 1)
-        if world > 1:
+        if not own_plan:
             plan.close()
+        return roofline, kernels, preheat
 
-    def barrier():
-        filt.drain()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    roofline, kernels, preheat = per_kernel_pass()
 
-    # A step = one execute of the whole filter on the resident image.  With --inflight D the steps are submitted round
-    # robin to D streams (recfilter_amd/dist.py): step i+1's pass 1 runs beside step i's carry kernels / all-gather.
-    for i in range(args.warmup):
-        filt.submit(inputs, output_sets[i % inflight])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        filt.submit(inputs, output_sets[i % inflight])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # --- steady: the same W + K steps once the GPU runs at its steady clocks (value, ms_per_step) -------------------
+    elapsed = timed_region()
     joined = dist.get_world_size() if dist is not None else 1      # ranks that actually took part
     ms_per_step = elapsed * 1000.0 / args.steps
     total_px = samples_local * joined
@@ -317,12 +359,22 @@ def main():
         line = {
             "metric": metric_name(args.workload, cfg["shape"], planes),
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": joined, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # what ran before the W warm-up steps of the timed region: one cold region of W + K steps (its per-step time is
+            # ms_per_step_cold: the driver's arguments on a GPU straight from idle) and the per-kernel HIP-event pass
+            "ms_per_step_cold": round(elapsed_cold * 1000.0 / args.steps, 4),
+            "preheat_executions": preheat + args.warmup + args.steps, "preheat_copies": 6,
+            "higher_is_better": True,
             "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
                                    f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
                        "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
-                       "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else "none",
+                       "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else
+                                   ("none (one rank driven through the sharded protocol: exit carries, all-gather, entering carries)"
+                                    if stepping else "none"),
+                       "exchange": ("stepping" if stepping else "none"),
+                       "collectives_per_step": (filt.plan.num_exchanges if stepping else 0),
+                       "interior_beside_collective": bool(stepping and filt.plan.has_interior),
                        "steps_in_flight": inflight,
                        "backend": (args.backend if dist is not None else "none"),
                        "rccl_ranks": (joined if (dist is not None and args.backend == "nccl") else 0)},

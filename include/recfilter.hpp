@@ -178,14 +178,20 @@ class RecFilter {
         void *stream = nullptr;                  // HIP stream of enqueue() / realize() (set_stream); null = default stream
         std::vector<void *> out;                 // device buffers of the last realization
         int shard_rank = 0, shard_world = 1;     // shard(): this object describes ONE rank's slab of a larger image
+        uint32_t plan_flags = 0;                 // plan_options(): rf_filter_desc.flags (RF_PLAN_*)
         std::vector<int64_t> shard_extents;      // ... the slab extents of all ranks (empty: all equal)
         std::vector<void *> xsend, xgathered;    // exchange buffers of realize_sharded(), one pair per exchange
+        hipStream_t xstream = nullptr;           // side stream of the collective when the plan has exchange-independent work
+        hipEvent_t xev_sent = nullptr, xev_got = nullptr;
         std::shared_ptr<std::vector<std::string>> schedule_log = std::make_shared<std::vector<std::string>>();
         ~Contents() {
             if (plan) rf_plan_destroy(plan);
             for (void *p : out) if (p) (void)hipFree(p);
             for (void *p : xsend) if (p) (void)hipFree(p);
             for (void *p : xgathered) if (p) (void)hipFree(p);
+            if (xev_sent) (void)hipEventDestroy(xev_sent);
+            if (xev_got) (void)hipEventDestroy(xev_got);
+            if (xstream) (void)hipStreamDestroy(xstream);
         }
     };
     std::shared_ptr<Contents> c;
@@ -411,6 +417,7 @@ public:
         d.path = c->tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
         d.device = -1; d.shard_rank = c->shard_rank; d.shard_world = c->shard_world;
         d.shard_extents = c->shard_extents.empty() ? nullptr : c->shard_extents.data();
+        d.flags = c->plan_flags;
         if (!c->source && !c->inputs.empty() && c->inputs[0].bytes) d.pointwise.in_dtype = RF_IN_U8;
         if (!c->source && !c->inputs.empty() && (c->inputs[0].scale != 1.0f || c->inputs[0].bias != 0.0f)) {
             d.pointwise.flags |= RF_POINTWISE_PRE;
@@ -452,6 +459,10 @@ public:
         c->compiled = false;
     }
 
+    /** Not in the reference: options of the plan behind realize() (rf_filter_desc.flags, RF_PLAN_* of recfilter_amd.h) --
+     *  e.g. RF_PLAN_TILED_ONLY, or RF_PLAN_FORCE_EXCHANGE to drive a one-rank shard through enqueue_sharded(). */
+    void plan_options(uint32_t flags) { c->plan_flags = flags; c->compiled = false; }
+
     /** `all_gather(send, gathered, bytes_per_rank, stream)`: every rank contributes `bytes_per_rank` device bytes and
      *  receives all ranks' contributions rank-major, ordered on `stream` (ncclAllGather(send, gathered, bytes, ncclChar,
      *  comm, (hipStream_t)stream) is exactly that). */
@@ -472,7 +483,7 @@ public:
             c->out.assign(in.size(), nullptr);
             for (auto &p : c->out) if (hipMalloc(&p, bytes) != hipSuccess) fail("hipMalloc failed");
         }
-        if (c->shard_world <= 1) {
+        if (c->shard_world <= 1 && !(c->plan_flags & RF_PLAN_FORCE_EXCHANGE)) {
             if (rf_plan_execute(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
         } else {
             if (rf_plan_begin(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
@@ -490,7 +501,24 @@ public:
             }
             for (int e = 0; e < nex; e++) {
                 if (rf_plan_exchange_local(c->plan, e, c->xsend[(size_t)e]) != RF_OK) fail(rf_last_error_string());
-                all_gather(c->xsend[(size_t)e], c->xgathered[(size_t)e], rf_plan_exchange_bytes(c->plan, e), c->stream);
+                if (e == nex - 1 && rf_plan_has_interior(c->plan)) {
+                    // exchange-independent work (the x/y stage of a z-sharded volume): the collective goes to a side stream
+                    // behind the exit carries, rf_plan_interior runs beside it, the apply step waits for it
+                    if (!c->xstream) {
+                        if (hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->xev_sent, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->xev_got, hipEventDisableTiming) != hipSuccess)
+                            fail("hipStreamCreate failed");
+                    }
+                    if (hipEventRecord(c->xev_sent, (hipStream_t)c->stream) != hipSuccess || hipStreamWaitEvent(c->xstream, c->xev_sent, 0) != hipSuccess)
+                        fail("hipEventRecord failed");
+                    all_gather(c->xsend[(size_t)e], c->xgathered[(size_t)e], rf_plan_exchange_bytes(c->plan, e), c->xstream);
+                    if (hipEventRecord(c->xev_got, c->xstream) != hipSuccess) fail("hipEventRecord failed");
+                    if (rf_plan_interior(c->plan) != RF_OK) fail(rf_last_error_string());
+                    if (hipStreamWaitEvent((hipStream_t)c->stream, c->xev_got, 0) != hipSuccess) fail("hipStreamWaitEvent failed");
+                } else {
+                    all_gather(c->xsend[(size_t)e], c->xgathered[(size_t)e], rf_plan_exchange_bytes(c->plan, e), c->stream);
+                }
                 if (rf_plan_exchange_apply(c->plan, e, c->xgathered[(size_t)e]) != RF_OK) fail(rf_last_error_string());
             }
             if (rf_plan_finish(c->plan) != RF_OK) fail(rf_last_error_string());

@@ -104,6 +104,41 @@ typedef struct {
     int32_t in_dtype;                 /* rf_input_dtype */
 } rf_pointwise_desc;
 
+/* Plan options (rf_filter_desc.flags).  The library reads NO environment variable: what a caller (or a test) wants
+ * to choose about a plan is chosen here.  (A/B timing switches of the kernel developers exist only in builds made
+ * with -DRF_AB_KNOBS, tools/; the shipped library has none.)
+ *   RF_PLAN_FORCE_EXCHANGE  build the sharded structure -- per-scan launches around the exchange points, exit carries,
+ *                           the gather walk, the correction of the slab -- even for shard_world == 1, and insist on the
+ *                           stepping calls.  The all-gather of one rank is the identity, so the result is the plain
+ *                           filter; it lets a box with ONE GPU drive begin / exchange_local / all-gather (RCCL) /
+ *                           exchange_apply / finish exactly as every rank of an N-GPU run does.
+ *   RF_PLAN_TILED_ONLY      RF_PATH_AUTO never resolves to the line-parallel untiled kernels it prefers for images up
+ *                           to 1024^2 (launch-bound regime): small images take the tiled kernels too.
+ *   RF_PLAN_NO_CASCADE      a filter the fused kernels cannot take in one piece (more than four scans per dimension)
+ *                           is not split into successive fused stages inside the plan; it runs as given on another path.
+ *   RF_PLAN_NO_SECTIONS     scans of order 4..8 are not rewritten into sections of order <= 3.
+ *   RF_PLAN_NO_PLANE_BATCH  the planes of a 2-D Tuple run as separate launches instead of one batched launch per step.
+ *   RF_PLAN_STREAM_PASS1 /  pass 1 of the fused path as the LDS-DMA streaming kernel wherever its shape rules allow,
+ *   RF_PLAN_STAGED_PASS1    whatever the image size / never (default: single planes of at least 2048 tiles).
+ *   RF_PLAN_LATE_EXCHANGE   a z-sharded volume exchanges the carries of the x/y-FILTERED data, after its x/y stage
+ *                           (nothing runs beside the all-gather); default: the carries of the raw input first, the x/y
+ *                           stage beside the all-gather (rf_plan_interior below).
+ *   RF_PLAN_TILE_ROWS(n) /  n = 32, 64 or 128: tile height of the fused x/y stage / tile width of the strided z stage,
+ *   RF_PLAN_TILE_PLANES(n)  where the shape admits it (default: chosen from the image size; rf_plan_tiles reports it).
+ *                           rf_filter_desc.tile[] stays what RecFilter::split passes: binding on the generic and
+ *                           overlapped paths, a hint on the fused path (the tile size never changes the result). */
+#define RF_PLAN_FORCE_EXCHANGE  0x01u
+#define RF_PLAN_TILED_ONLY      0x02u
+#define RF_PLAN_NO_CASCADE      0x04u
+#define RF_PLAN_NO_SECTIONS     0x08u
+#define RF_PLAN_NO_PLANE_BATCH  0x10u
+#define RF_PLAN_STREAM_PASS1    0x20u
+#define RF_PLAN_STAGED_PASS1    0x40u
+#define RF_PLAN_LATE_EXCHANGE   0x80u
+#define RF_PLAN_ALL_FLAGS       0xffu
+#define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
+#define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
+
 typedef struct {
     int32_t  ndim;                    /* 1..RF_MAX_DIMS                                          */
     int64_t  extent[RF_MAX_DIMS];     /* extent[0] = width (x)                                   */
@@ -125,6 +160,7 @@ typedef struct {
      * the same array: the tile width along the sharded dimension is chosen from their common divisor so that
      * every rank tiles alike. */
     const int64_t *shard_extents;
+    uint32_t flags;                   /* RF_PLAN_* options below; 0 = the defaults                 */
 } rf_filter_desc;
 
 typedef struct rf_plan rf_plan;
@@ -149,9 +185,12 @@ int rf_plan_num_kernels(const rf_plan *plan);
  * hundred KB, the workspace ~8 % of one image) and independent.  recfilter_amd.dist.ShardedFilter(inflight=D) does
  * exactly that.  The C entry points are not re-entrant per plan; distinct plans may be used from distinct threads.
  *
- * in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan on the fused
- * path (rf_plan_path() == RF_PATH_TILED_FUSED) needs 16-byte aligned planes (4-byte for RF_IN_U8 input planes) and
- * returns RF_ERR_INVALID_ARG otherwise; the other paths take any element-aligned pointer. */
+ * in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan whose kernels
+ * move 16 bytes per lane -- the fused path (rf_plan_path() == RF_PATH_TILED_FUSED) and the line-parallel untiled
+ * kernels RF_PATH_AUTO / RF_PATH_UNTILED use for orders <= 3 with extents that are multiples of 16 -- needs 16-byte
+ * aligned planes (4-byte for RF_IN_U8 input planes) and returns RF_ERR_INVALID_ARG otherwise (hipMalloc and torch
+ * allocations are 256-byte aligned; only offset views are affected).  The generic and overlapped tiled paths take any
+ * element-aligned pointer. */
 int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes,
                     void *stream);
 
@@ -174,6 +213,14 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
  *         rf_plan_exchange_apply(e, gathered)    forms the incoming carry; what it adds to the slab's tails is
  *                                                applied here, or by the final pass as it loads a carry (fused 2-D)
  *     rf_plan_finish(...)                        final correction pass
+ * Work that does not depend on the exchange: between ISSUING the last all-gather and WAITING for it, call
+ *     rf_plan_interior(plan)
+ * A z-sharded volume (fused x/y stage + strided z stage, merged exchange, no pointwise stages) exchanges the z carries
+ * of the RAW input -- the z operators commute with the x/y filter -- so its whole x/y stage is such work and runs beside
+ * the collective; afterwards exchange_apply filters the few carry planes along x/y.  A caller whose all-gather is
+ * asynchronous with respect to the begin() stream (RCCL on its own stream; torch.distributed with async_op=True) gets a
+ * step of max(kernels, exchange) instead of their sum.  rf_plan_has_interior() tells whether a plan has such work; the
+ * call is optional -- exchange_apply / finish run whatever is still pending -- and a no-op for plans without any.
  * `send` and `gathered` are caller-owned device buffers.  With shard_world == 1 the apply step
  * is a no-op and may be skipped.  Slabs may have different extents along the sharded dimension
  * (rf_filter_desc.shard_extents: a slab's exit carry is propagated across the slabs between it and the
@@ -183,6 +230,8 @@ size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange);
 int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream);
 int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send);
 int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered);
+int rf_plan_has_interior(const rf_plan *plan);
+int rf_plan_interior(rf_plan *plan);
 int rf_plan_finish(rf_plan *plan);
 
 /* ---- plan tables (host side of the tiling algebra; also what the CPU tests inspect) ------- */

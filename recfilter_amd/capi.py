@@ -27,6 +27,19 @@ RF_BORDER_ZERO, RF_BORDER_CLAMP = 0, 1
 RF_POINTWISE_PRE, RF_POINTWISE_POST = 1, 2
 RF_IN_PIXEL, RF_IN_U8 = 0, 1
 RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED, RF_PATH_TILED_OVERLAPPED = range(5)
+# rf_filter_desc.flags (plan options; the library reads no environment variable)
+RF_PLAN_FORCE_EXCHANGE, RF_PLAN_TILED_ONLY, RF_PLAN_NO_CASCADE, RF_PLAN_NO_SECTIONS = 0x01, 0x02, 0x04, 0x08
+RF_PLAN_NO_PLANE_BATCH, RF_PLAN_STREAM_PASS1, RF_PLAN_STAGED_PASS1, RF_PLAN_LATE_EXCHANGE = 0x10, 0x20, 0x40, 0x80
+
+
+def RF_PLAN_TILE_ROWS(n: int) -> int:
+    return (int(n) & 0xff) << 8
+
+
+def RF_PLAN_TILE_PLANES(n: int) -> int:
+    return (int(n) & 0xff) << 16
+
+
 PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
               RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused",
               RF_PATH_TILED_OVERLAPPED: "tiled_overlapped"}
@@ -36,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "rf_plan_create", "rf_plan_destroy", "rf_plan_workspace_bytes", "rf_plan_path", "rf_plan_tiles",
     "rf_plan_num_kernels", "rf_plan_execute", "rf_plan_execute_timed", "rf_plan_num_exchanges",
     "rf_plan_exchange_bytes",
-    "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_finish",
+    "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_has_interior", "rf_plan_interior", "rf_plan_finish",
     "rf_plan_table", "rf_plan_debug_buffer", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
     "rf_gaussian_box_filter", "rf_box_difference", "rf_tap_filter", "rf_last_error_string", "rf_version", "rf_device_count",
 ]
@@ -59,7 +72,8 @@ class FilterDesc(ctypes.Structure):
                 ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDesc)),
                 ("tile", ctypes.c_int32 * RF_MAX_DIMS), ("path", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
-                ("pointwise", PointwiseDesc), ("shard_extents", ctypes.POINTER(ctypes.c_int64))]
+                ("pointwise", PointwiseDesc), ("shard_extents", ctypes.POINTER(ctypes.c_int64)),
+                ("flags", ctypes.c_uint32)]
 
 
 class Tap(ctypes.Structure):
@@ -117,6 +131,8 @@ def lib() -> ctypes.CDLL:
     L.rf_plan_exchange_local.argtypes = [vp, ctypes.c_int, vp]
     L.rf_plan_exchange_apply.argtypes = [vp, ctypes.c_int, vp]
     L.rf_plan_finish.argtypes = [vp]
+    L.rf_plan_has_interior.argtypes = [vp]
+    L.rf_plan_interior.argtypes = [vp]
     L.rf_plan_table.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,
                                 ctypes.POINTER(ctypes.c_size_t)]
     L.rf_plan_debug_buffer.argtypes = [vp, ctypes.c_int, vpp, ctypes.POINTER(ctypes.c_size_t)]

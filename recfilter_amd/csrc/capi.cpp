@@ -39,11 +39,12 @@ int set_context(rf_plan *plan, const void *const *in_planes, void *const *out_pl
             set_error("plane %d: a pointwise epilogue that reads the input needs out != in", pl);
             return RF_ERR_INVALID_ARG;
         }
-        // the fused kernels move 16 bytes per lane (4 for unsigned-byte input planes)
-        if (plan->path == RF_PATH_TILED_FUSED) {
+        // the fused kernels and the line-parallel untiled kernels move 16 bytes per lane (4 for unsigned-byte input planes)
+        if (plan->vector_access) {
             const uintptr_t in_mask = plan->pw.in_u8 ? 3u : 15u;
             if (((uintptr_t)in_planes[pl] & in_mask) != 0 || ((uintptr_t)out_planes[pl] & 15u) != 0) {
-                set_error("plane %d: the fused path needs 16-byte aligned image pointers (4-byte for uint8 inputs)", pl);
+                set_error("plane %d: this plan's kernels (%s) need 16-byte aligned image pointers (4-byte for uint8 inputs)", pl,
+                          plan->path == RF_PATH_TILED_FUSED ? "fused path" : "line-parallel untiled kernels");
                 return RF_ERR_INVALID_ARG;
             }
         }
@@ -61,8 +62,18 @@ std::vector<const Step *> flat_steps(const rf_plan *plan) {
     for (const Step &s : plan->begin_steps) v.push_back(&s);
     for (const auto &ex : plan->exchange_local_steps)
         for (const Step &s : ex) v.push_back(&s);
+    for (const Step &s : plan->interior_steps) v.push_back(&s);
+    for (const auto &ex : plan->exchange_apply_steps)         // (non-empty only for plans built with the exchange structure)
+        for (const Step &s : ex) v.push_back(&s);
     for (const Step &s : plan->finish_steps) v.push_back(&s);
     return v;
+}
+
+// the exchange-independent work of this execute, if the caller has not asked for it yet
+int run_pending_interior(rf_plan *plan) {
+    if (!plan->interior_pending) return RF_OK;
+    plan->interior_pending = false;
+    return run_steps(plan, plan->interior_steps);
 }
 
 }  // namespace
@@ -97,7 +108,7 @@ int rf_plan_num_exchanges(const rf_plan *plan) { return plan ? (int)plan->exchan
 int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
     int rc = set_context(plan, in_planes, out_planes, stream);
     if (rc) return rc;
-    if (plan->shard_world > 1) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
+    if (plan->sharded()) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
     for (auto &ex : plan->exchanges) ex.send = ex.scratch;
     for (const Step *st : flat_steps(plan))
         for (int pl = 0; pl < plan->n_planes; pl++)
@@ -109,7 +120,7 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
                           float *ms_out, const char **names_out, int capacity) {
     int rc = set_context(plan, in_planes, out_planes, stream);
     if (rc) return rc;
-    if (plan->shard_world > 1) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
+    if (plan->sharded()) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
     for (auto &ex : plan->exchanges) ex.send = ex.scratch;
     auto steps = flat_steps(plan);
     if (capacity < (int)steps.size() || !ms_out) { set_error("ms_out too small: need %zu", steps.size()); return RF_ERR_INVALID_ARG; }
@@ -145,7 +156,15 @@ int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_
     if (rc) return rc;
     rc = run_steps(plan, plan->begin_steps);
     plan->phase = rc == RF_OK ? 1 : 0;
+    plan->interior_pending = rc == RF_OK && !plan->interior_steps.empty();
     return rc;
+}
+
+int rf_plan_has_interior(const rf_plan *plan) { return plan && !plan->interior_steps.empty() ? 1 : 0; }
+
+int rf_plan_interior(rf_plan *plan) {
+    if (!plan || plan->phase != 1) { set_error("rf_plan_interior before rf_plan_begin"); return RF_ERR_STATE; }
+    return run_pending_interior(plan);
 }
 
 size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange) {
@@ -156,7 +175,7 @@ size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange) {
 int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send) {
     if (!plan || plan->phase != 1) { set_error("rf_plan_exchange_local before rf_plan_begin"); return RF_ERR_STATE; }
     if (exchange < 0 || exchange >= (int)plan->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
-    if (!send && plan->shard_world > 1) { set_error("null send buffer"); return RF_ERR_INVALID_ARG; }
+    if (!send && plan->sharded()) { set_error("null send buffer"); return RF_ERR_INVALID_ARG; }
     plan->exchanges[exchange].send = send ? send : plan->exchanges[exchange].scratch;
     return run_steps(plan, plan->exchange_local_steps[exchange]);
 }
@@ -164,9 +183,11 @@ int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send) {
 int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
     if (!plan || plan->phase != 1) { set_error("rf_plan_exchange_apply before rf_plan_begin"); return RF_ERR_STATE; }
     if (exchange < 0 || exchange >= (int)plan->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
-    if (plan->shard_world <= 1) return RF_OK;   // nothing comes in from a neighbour
+    if (!plan->sharded()) return RF_OK;   // nothing comes in from a neighbour
     if (!gathered) { set_error("null gathered buffer"); return RF_ERR_INVALID_ARG; }
-    int rc = plan->exchanges[exchange].form_incoming(gathered);
+    int rc = run_pending_interior(plan);      // (a caller that never called rf_plan_interior: nothing overlaps, same result)
+    if (rc) return rc;
+    rc = plan->exchanges[exchange].form_incoming(gathered);
     if (rc) return rc;
     return run_steps(plan, plan->exchange_apply_steps[exchange]);
 }
@@ -174,6 +195,8 @@ int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
 int rf_plan_finish(rf_plan *plan) {
     if (!plan || plan->phase != 1) { set_error("rf_plan_finish before rf_plan_begin"); return RF_ERR_STATE; }
     plan->phase = 0;
+    int rc = run_pending_interior(plan);
+    if (rc) return rc;
     return run_steps(plan, plan->finish_steps);
 }
 

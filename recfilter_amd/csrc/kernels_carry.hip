@@ -605,7 +605,7 @@ chain_apply_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ exit_st
 }  // namespace
 
 bool chain_apply_applies(int K, int64_t NY, size_t acc_bytes) {
-    static const bool off = getenv("RF_NO_CHAIN_APPLY") != nullptr;      // A/B runs: row_chain + carry_apply as two launches
+    static const bool off = RF_KNOB("RF_NO_CHAIN_APPLY") != nullptr;      // A/B runs: row_chain + carry_apply as two launches
     return !off && K >= 1 && K <= 3 && NY > 0 && (size_t)NY * K * acc_bytes <= 48 * 1024;
 }
 
@@ -686,7 +686,7 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     // two scans of order <= 2, every line's tiles in one block of chunks: the register-chained pair kernel
     // (order 3 and f64 do not fit its register budget at 16 waves and stay on the general kernel)
     if constexpr (sizeof(Acc) == 4) {
-        static const bool pair_off = getenv("RF_CARRY_NO_PAIR") != nullptr;     // tuning knob: always the general kernel
+        static const bool pair_off = RF_KNOB("RF_CARRY_NO_PAIR") != nullptr;     // tuning knob: always the general kernel
         if (s_end - s_begin == 2 && K <= 2 && (int64_t)n_chunks * C >= a.M && !pair_off) {
             if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1, kCarryMaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
                                            (const Acc *)a.incoming, a.W, a.A, AC, C, send);
@@ -695,7 +695,7 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
         }
-        static const bool pair3_off = getenv("RF_CARRY_NO_PAIR3") != nullptr;
+        static const bool pair3_off = RF_KNOB("RF_CARRY_NO_PAIR3") != nullptr;
         if (s_end - s_begin == 2 && K == 3 && a.M > 64 && C <= kCarryPair3MaxC && (int64_t)n_chunks * C >= a.M && !pair_off && !pair3_off) {
             hipLaunchKernelGGL((carry_pair_kernel<Acc, 3, kCarryPair3MaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
                                (const Acc *)a.incoming, a.W, a.A, AC, C, send);
@@ -716,8 +716,8 @@ int carry_chunk_length(int64_t M, int64_t lines, int K) {
     // order 3: chunks of at most 8 tiles whenever 16 of them cover the line, so that two scans of a dimension fit the
     // register-chained pair kernel
     // (long lines only: at 64 tiles per line the general kernel is as fast)
-    if (K == 3 && M > 64 && M <= (int64_t)kCarryChunks * kCarryPair3MaxC && getenv("RF_CARRY_NO_PAIR3") == nullptr &&
-        getenv("RF_CARRY_NO_PAIR") == nullptr)
+    if (K == 3 && M > 64 && M <= (int64_t)kCarryChunks * kCarryPair3MaxC && RF_KNOB("RF_CARRY_NO_PAIR3") == nullptr &&
+        RF_KNOB("RF_CARRY_NO_PAIR") == nullptr)
         return (int)((M + kCarryChunks - 1) / kCarryChunks);
     const int max_c = K <= 3 ? kCarryMaxC : kCarryMaxCHigh;
     const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;

@@ -166,7 +166,7 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
                        hipStream_t stream);
 // the same pass as a streaming kernel (kernels_stream.hip): persistent workgroups, LDS-DMA ring, loader wave
 bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t n_tiles, int MX,
-                             int64_t NZ, int nxk, int nyk);
+                             int64_t NZ, int nxk, int nyk, int mode /* +1 RF_PLAN_STREAM_PASS1, -1 RF_PLAN_STAGED_PASS1 */);
 int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, const float *Hx, const float *Hy, hipStream_t stream);
 // tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)
 template <typename Acc>

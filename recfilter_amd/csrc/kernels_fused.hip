@@ -159,6 +159,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
         const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
         auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
+        auto ld_head = [&](int row, int n) { return load_chunk_head<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), n); };
         A4 tmp[TY / 4];
         const bool chunk_in = 4 * cc < last_cols;            // this thread's 16-byte chunk exists in the image
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
@@ -168,11 +169,8 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
 #pragma unroll
             for (int i = 0; i < TY / 4; i++) {
                 const int64_t idx = lin0 + (int64_t)(rg + 4 * i) * a.NX + 4 * cc;
-                A4 v = idx < a.lin_limit ? ld(4 * i) : zero4;
-                if (idx + 1 >= a.lin_limit) v.y = Acc(0);
-                if (idx + 2 >= a.lin_limit) v.z = Acc(0);
-                if (idx + 3 >= a.lin_limit) v.w = Acc(0);
-                tmp[i] = v;
+                // (the one chunk the end falls into is loaded sample by sample: nothing behind the end is read)
+                tmp[i] = idx + 3 < a.lin_limit ? ld(4 * i) : idx < a.lin_limit ? ld_head(4 * i, (int)(a.lin_limit - idx)) : zero4;
             }
         } else if (rows_here == TY) {
 #pragma unroll

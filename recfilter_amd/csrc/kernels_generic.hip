@@ -713,7 +713,7 @@ int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t
     }
     // 2-D tables: the streaming kernel, when its ring of table rows fits 64 KiB of LDS and a thread has at most one
     // halo column to fetch
-    if (a.order[2] == 0 && (a.order[0] > 0 || a.order[1] > 0) && getenv("RF_BOX_GATHER") == nullptr) {
+    if (a.order[2] == 0 && (a.order[0] > 0 || a.order[1] > 0) && RF_KNOB("RF_BOX_GATHER") == nullptr) {
         const int halo = a.order[0] * (2 * a.radius + 1);
         const int batch = a.order[1] <= 1 ? 16 : 8;      // rows in flight; the second-order window is twice as tall
         const int window = a.order[1] * (2 * a.radius + 1) + batch;

@@ -308,12 +308,12 @@ int launch_line_scans(int K, bool strided, const P *src, P *dst, const LineScanA
         RF_HIP_CHECK(hipGetLastError());                                                                              \
         return RF_OK;                                                                                                 \
     }
-    static const bool no_short = getenv("RF_LINES_NO_SHORT") != nullptr;          // A/B runs against the walking kernel
+    static const bool no_short = RF_KNOB("RF_LINES_NO_SHORT") != nullptr;          // A/B runs against the walking kernel
     if (!no_short && (sizeof(typename PixelTraits<P>::Acc) == 4 || mt <= 2)) {       // (f64: 32 registers per tile and lane)
         RF_SHORT(1, 1) RF_SHORT(2, 1) RF_SHORT(3, 1) RF_SHORT(1, 2) RF_SHORT(2, 2) RF_SHORT(3, 2) RF_SHORT(1, 4) RF_SHORT(2, 4) RF_SHORT(3, 4)
         // lines of up to 2048 samples: 128 registers of samples per lane, one workgroup per CU (136 KiB of LDS when strided)
         if constexpr (sizeof(typename PixelTraits<P>::Acc) == 4) {
-            static const bool no_long = getenv("RF_LINES_NO_SHORT8") != nullptr;
+            static const bool no_long = RF_KNOB("RF_LINES_NO_SHORT8") != nullptr;
             if (!no_long) { RF_SHORT(1, 8) RF_SHORT(2, 8) RF_SHORT(3, 8) }
         }
     }

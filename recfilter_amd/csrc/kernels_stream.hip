@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kStreamThreads, 6)
 stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
                     const float *__restrict__ Hx,     // [vx][s][r][256]
                     const float *__restrict__ Hy,     // [vy][j][r][64]
-                    uint32_t n_tiles, int K, int debug_mode) {
+                    uint32_t n_tiles, int K) {
     static_assert(AHEAD >= 1 && AHEAD < SLOTS && 16 * AHEAD <= 63, "ring geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [ring: SLOTS x 16 KiB][x-tail stage: 2 tiles x 4 waves x nx*K x 64][Hy table: 4 variants x ny*K x 64]
@@ -126,7 +126,6 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
     if (wave == 8) {
         // ------------------------------------------------ loader wave ------------------------------------------------
         auto issue = [&](int g) {
-            if (debug_mode & 2) return;                              // timing experiments: no loads
             const TileCoord c = tile_coord(a, first + (uint32_t)(g / kQPerTile) * G);
             const float *plane = a.plane_batch ? reinterpret_cast<const float *>(a.in_planes[c.z]) : src + c.z * a.NX * a.NY;
             const char *base = reinterpret_cast<const char *>(plane + (int64_t)c.ty * kStreamTY * a.NX + (int64_t)c.tx * kFusedTX) +
@@ -137,14 +136,9 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
                 // LDS position `lane` of row r receives the chunk that slot_pos maps there (an involution per row)
                 const uint32_t lane_off = (uint32_t)slot_pos(r, lane) * 16u;
                 // each sample is read once by this pass: non-temporal (leaves L2 / the memory-side cache to the tails)
-                if (debug_mode & 16)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(base + ((uint32_t)r * row_bytes + lane_off)),
-                        (__attribute__((address_space(3))) void *)(slot + r * (kFusedTX * 4)), 16, 0, 0);
-                else
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(base + ((uint32_t)r * row_bytes + lane_off)),
-                        (__attribute__((address_space(3))) void *)(slot + r * (kFusedTX * 4)), 16, 0, /*nt*/ 2);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(base + ((uint32_t)r * row_bytes + lane_off)),
+                    (__attribute__((address_space(3))) void *)(slot + r * (kFusedTX * 4)), 16, 0, /*nt*/ 2);
             }
         };
         for (int g = 0; g < AHEAD && g < nq; g++) issue(g);
@@ -214,7 +208,7 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
                 const int g = n * kQPerTile + q;
                 lds_barrier();                                          // B_g: slot g landed, slot g-1 free
                 if (q == 0 && n > 0) flush_xtails(n - 1);               // every wave's stage writes of tile n-1 are behind B_g
-                if ((debug_mode & 5) || nxk == 0) continue;              // (timing experiments: no arithmetic)
+                if (nxk == 0) continue;
                 const unsigned char *slot = smem + (g % SLOTS) * kSlotBytes;
                 F4s av[4];
 #pragma unroll
@@ -267,7 +261,7 @@ stream_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
         for (int q = 0; q < kQPerTile; q++) {
             const int g = n * kQPerTile + q;
             lds_barrier();                                          // B_g
-            if ((debug_mode & 9) || nyk == 0) continue;
+            if (nyk == 0) continue;
             const unsigned char *slot = smem + (g % SLOTS) * kSlotBytes;
             float px[kQRows];
 #pragma unroll
@@ -314,7 +308,7 @@ int stream_grid_size(int64_t n_tiles, int MX) {
         cus = prop.multiProcessorCount;
     }
     int64_t g = 2ll * cus;
-    if (const char *env = getenv("RF_STREAM_GRID")) g = atoll(env);
+    if (const char *env = RF_KNOB("RF_STREAM_GRID")) g = atoll(env);
     if (g >= n_tiles) return (int)n_tiles;        // one tile per walker
     if (g < MX) return 0;
     g -= g % MX;
@@ -328,14 +322,17 @@ int stream_grid_size(int64_t n_tiles, int MX) {
 // (launch ramp and tail of its 16384 short workgroups) but at 5.9-6.0 TB/s once a launch is three times as long
 // (3 planes, volumes).  So: single planes with at most four tails per dimension stream, everything else is staged.
 bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t n_tiles, int MX,
-                             int64_t NZ, int nxk, int nyk) {
-    static const bool off = getenv("RF_NO_STREAM_TAILS") != nullptr;      // A/B runs against fused_tails_kernel
-    const bool force = getenv("RF_STREAM_FORCE") != nullptr;              // ... and the other way (tests: every shape class; read per call)
+                             int64_t NZ, int nxk, int nyk, int mode) {
+    // mode: rf_filter_desc.flags -- RF_PLAN_STREAM_PASS1 (+1: wherever the shape rules allow, whatever the size; the tests
+    // cover every shape class that way), RF_PLAN_STAGED_PASS1 (-1: never), 0: single planes of at least 2048 tiles
+    static const bool off = RF_KNOB("RF_NO_STREAM_TAILS") != nullptr;      // A/B runs against fused_tails_kernel
+    if (mode < 0) return false;
+    const bool force = mode > 0 || RF_KNOB("RF_STREAM_FORCE") != nullptr;
     if (off || src_u8 || (pw_flags & 1) || TY != kStreamTY || last_cols != kFusedTX || last_rows != TY) return false;
     if (K < 1 || K > 3) return false;
     if (!force && (NZ != 1 || nxk > 4 || nyk > 4)) return false;
-    const char *mt = getenv("RF_STREAM_MIN_TILES");              // (read per call: the tests lower it to cover small shapes)
-    const int64_t min_tiles = mt ? atoll(mt) : 2048;
+    const char *mt = RF_KNOB("RF_STREAM_MIN_TILES");              // (read per call: the tests lower it to cover small shapes)
+    const int64_t min_tiles = mode > 0 ? 1 : mt ? atoll(mt) : 2048;
     if (n_tiles < min_tiles) return false;      // below that a walker has too few tiles to amortise its pipeline fill
     return stream_grid_size(n_tiles, MX) > 0;
 }
@@ -346,8 +343,7 @@ int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, cons
     if (n_tiles >= (1ll << 31)) { set_error("stream tails: too many tiles"); return RF_ERR_UNSUPPORTED; }
     const int grid = stream_grid_size(n_tiles, a.MX);
     if (grid <= 0) { set_error("stream tails: no device properties"); return RF_ERR_HIP; }
-    static const int debug_mode = getenv("RF_STREAM_DEBUG") ? atoi(getenv("RF_STREAM_DEBUG")) : 0;   // timing experiments
-    static const int ring = getenv("RF_STREAM_RING") ? atoi(getenv("RF_STREAM_RING")) : 4;           // ring slots (tuning)
+    static const int ring = RF_KNOB("RF_STREAM_RING") ? atoi(RF_KNOB("RF_STREAM_RING")) : 4;           // ring slots (tuning)
     const int nxk = a.nx * K;
     const size_t lds_rest = (size_t)2 * 4 * (nxk > 0 ? nxk : 1) * kStreamTY * sizeof(float) +
                             (size_t)4 * (a.ny * K > 0 ? a.ny * K : 1) * kHyPitch * sizeof(float);
@@ -364,7 +360,7 @@ int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, cons
             attr_set[dev & 63].store(true, std::memory_order_release);                                                   \
         }                                                                                                                \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kStreamThreads), (size_t)SLOTS * kSlotBytes + lds_rest, stream, src, a, Hx, \
-                           Hy, (uint32_t)n_tiles, K, debug_mode);                                                        \
+                           Hy, (uint32_t)n_tiles, K);                                                                    \
         RF_HIP_CHECK(hipGetLastError());                                                                                 \
         return RF_OK;                                                                                                    \
     }

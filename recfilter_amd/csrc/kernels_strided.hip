@@ -127,7 +127,7 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
     // Workgroups per CU: these kernels stream 64 or 128 rows per wave that lie a whole plane apart; beyond three waves
     // per SIMD more rows in flight make the memory system slower, not faster (2048^3, 64 samples per thread: 5.7 ms at
     // three waves per SIMD, 6.9 ms at six).  An unused LDS allocation bounds the residency.
-    static const int wgs_per_cu = getenv("RF_STRIDED_WGS") ? atoi(getenv("RF_STRIDED_WGS")) : 3;
+    static const int wgs_per_cu = RF_KNOB("RF_STRIDED_WGS") ? atoi(RF_KNOB("RF_STRIDED_WGS")) : 3;
     const size_t pad_lds = wgs_per_cu >= 1 && wgs_per_cu <= 8 ? (size_t)(160 * 1024 / wgs_per_cu) & ~(size_t)1023 : 0;
     const size_t lds_bytes = pad_lds > 64 * 1024 ? 64 * 1024 : pad_lds;      // (more than 64 KiB would need an opt-in per kernel)
 #define RF_LAUNCH(KK, TT, FF, UU, PP)                                                                                \

@@ -68,6 +68,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
     const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
     auto ld = [&](int row) { return load_chunk<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes)); };
+    auto ld_head = [&](int row, int n) { return load_chunk_head<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), n); };
     const int64_t Lx = a.NYP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (4 * cc < a.last_cols);
@@ -89,11 +90,9 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 #pragma unroll
             for (int i = 0; i < NL; i++) {
                 const int64_t idx = lin0 + (int64_t)(r0 + 4 * i) * a.NX + 4 * cc;
-                A4 v = idx < a.lin_limit ? ld(kTailRows * half + 4 * i) : zero4;
-                if (idx + 1 >= a.lin_limit) v.y = Acc(0);
-                if (idx + 2 >= a.lin_limit) v.z = Acc(0);
-                if (idx + 3 >= a.lin_limit) v.w = Acc(0);
-                pre[i] = v;
+                // (the one chunk the end falls into is loaded sample by sample: nothing behind the end is read)
+                pre[i] = idx + 3 < a.lin_limit ? ld(kTailRows * half + 4 * i)
+                         : idx < a.lin_limit   ? ld_head(kTailRows * half + 4 * i, (int)(a.lin_limit - idx)) : zero4;
             }
             return;
         }
@@ -576,7 +575,7 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
     if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    static const size_t pad_bytes = getenv("RF_TAILS_PAD_LDS") ? (size_t)atoi(getenv("RF_TAILS_PAD_LDS")) : 0;     // A/B: bounds the residency
+    static const size_t pad_bytes = RF_KNOB("RF_TAILS_PAD_LDS") ? (size_t)atoi(RF_KNOB("RF_TAILS_PAD_LDS")) : 0;     // A/B: bounds the residency
     const size_t hx_bytes = (size_t)(a.nx > 0 ? a.nx : 1) * K * kFusedTX * sizeof(typename PixelTraits<P>::Acc) + pad_bytes;
 #define RF_CASE(KK, TT)                                                                                             \
     if (K == KK && TY == TT) {                                                                                       \
@@ -602,12 +601,12 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
 }
 
 bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_bytes, int64_t tile_rows) {
-    static const bool off = getenv("RF_NO_MERGED_CARRY_X") != nullptr;      // A/B runs
+    static const bool off = RF_KNOB("RF_NO_MERGED_CARRY_X") != nullptr;      // A/B runs
     // Measured (tools/ab_mcx.sh, tools/mid_probe.py; summed-area table, bicubic prefilter x 3 planes, order-2 and order-3
     // Gaussians at 1280^2 ... 4096^2): orders 1 and 2 gain 2-5 us of 22-78 us at every size; order 3 gains 10 us of 90 on
     // one plane of 2112^2 ... 4096^2 and loses 3 us of 186 on three planes of 4096^2 -- that launch is 1152 workgroups
     // of 47 KiB of LDS, a round and a half -- so order 3 takes this path while the launch fits one round.
-    static const bool all = getenv("RF_MERGED_CARRY_X_ALL") != nullptr;     // A/B runs: order 3 whatever the launch size
+    static const bool all = RF_KNOB("RF_MERGED_CARRY_X_ALL") != nullptr;     // A/B runs: order 3 whatever the launch size
     // (beyond 16 tiles per row only order 1 still gains: summed-area table 8192^2 160.5 -> 158.2 us, bicubic x 3 planes 6144^2
     //  272 -> 266 us; order 2 loses 3 us at 6144^2 and 8 us at 8192^2, where every workgroup repeats a 32-tile recurrence)
     if (off || nx <= 0 || ny <= 0 || MX > (K == 1 ? kXcMaxTiles : 16) || TY > 64 || TY % 4 != 0) return false;

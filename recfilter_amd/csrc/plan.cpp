@@ -37,8 +37,8 @@ double cast_coeff(double c, int dtype) {
 // arithmetic, orders <= 3, <= 4 scans per dimension, extents that are multiples of 16 (a lane owns 16 samples; the
 // lines of a strided dimension are moved 16 at a time).
 bool line_scans_applicable(const rf_plan *plan) {
-    if (plan->shard_world > 1 || plan->scans.empty()) return false;
-    if (getenv("RF_NO_LINE_SCANS") != nullptr) return false;          // A/B runs against the one-thread-per-line kernel
+    if (plan->sharded() || plan->scans.empty()) return false;
+    if (RF_KNOB("RF_NO_LINE_SCANS") != nullptr) return false;          // A/B runs against the one-thread-per-line kernel
     bool strided = false;
     for (int d = 0; d < plan->ndim; d++) {
         const DimInfo &di = plan->dims[d];
@@ -54,6 +54,7 @@ template <typename P, typename S>
 int build_line_scans(rf_plan *plan) {
     using Acc = typename PixelTraits<P>::Acc;
     bool first = true;
+    plan->vector_access = true;          // load16 / store16 / load_lines16 of kernels_lines.hip
     for (int d = 0; d < plan->ndim; d++) {
         const DimInfo &di = plan->dims[d];
         if (di.scan_ids.empty()) continue;
@@ -80,7 +81,7 @@ int build_line_scans(rf_plan *plan) {
 template <typename P>
 int build_untiled(rf_plan *plan) {
     using Acc = typename PixelTraits<P>::Acc;
-    if (plan->shard_world > 1) {
+    if (plan->sharded()) {
         set_error("the untiled path cannot be sharded across devices");
         return RF_ERR_UNSUPPORTED;
     }
@@ -128,7 +129,7 @@ int build_generic(rf_plan *plan, const rf_filter_desc *desc) {
     for (int d = 0; d < plan->ndim; d++)
         if (!plan->dims[d].scan_ids.empty()) last_scan_dim = d;
     if (last_scan_dim < 0) return build_untiled<P>(plan);
-    if (plan->shard_world > 1 && plan->ndim < 2) {
+    if (plan->sharded() && plan->ndim < 2) {
         set_error("sharding needs at least two dimensions");
         return RF_ERR_UNSUPPORTED;
     }
@@ -206,7 +207,7 @@ int build_for_pixel(rf_plan *plan, const rf_filter_desc *desc, int path) {
 // ringing a causal scan leaves in the padding never reaches a later stage.
 std::vector<int> cascade_stage_of_scans(const rf_filter_desc *desc) {
     const bool sections_ok = desc->border == RF_BORDER_ZERO && (desc->dtype == RF_F32 || desc->dtype == RF_F64) &&
-                             getenv("RF_NO_SECTIONS") == nullptr;
+                             !(desc->flags & RF_PLAN_NO_SECTIONS);
     const bool padded_1d = desc->ndim == 1 && desc->border == RF_BORDER_ZERO && desc->extent[0] % 8192 != 0;
     std::vector<int> stage((size_t)desc->n_scans, 0);
     for (int d = 0; d < desc->ndim; d++) {
@@ -246,7 +247,9 @@ int build_cascade(const rf_filter_desc *desc, const std::vector<int> &stage_of, 
         children.emplace_back(child);
         // the point of the split is the fused (or, for small images, the line-parallel) kernels: a stage that would still
         // run on the per-dimension generic passes means something else keeps this filter off them
-        if (child->path == RF_PATH_TILED_GENERIC || child->path == RF_PATH_TILED_OVERLAPPED) {
+        // (an untiled stage must be the line-parallel kind: the one-thread-per-line kernel is what the split is meant to avoid)
+        if (child->path == RF_PATH_TILED_GENERIC || child->path == RF_PATH_TILED_OVERLAPPED ||
+            (child->path == RF_PATH_UNTILED && !child->vector_access)) {
             set_error("cascade: stage %d would not run on the fused kernels", st);
             return RF_ERR_UNSUPPORTED;
         }
@@ -255,12 +258,17 @@ int build_cascade(const rf_filter_desc *desc, const std::vector<int> &stage_of, 
     parent->workspace_bytes = 0;
     for (auto &c : children) {
         any_fused = any_fused || c->path == RF_PATH_TILED_FUSED;
+        parent->vector_access = parent->vector_access || c->vector_access;
         parent->workspace_bytes += c->workspace_bytes;
         for (auto &ex : c->exchanges) ex.send = ex.scratch;       // single device: nothing leaves the stage
     }
     parent->path = any_fused ? (int)RF_PATH_TILED_FUSED : children[0]->path;
-    for (int d = 0; d < RF_MAX_DIMS; d++) { parent->dims[d].T = children[0]->dims[d].T; parent->dims[d].M = children[0]->dims[d].M; }
-    parent->tables = children[0]->tables;
+    // rf_plan_tiles / rf_plan_table report the first FUSED stage (stage 0 may be an untiled line-kernel stage without tiles)
+    const rf_plan *shown = children[0].get();
+    for (auto &c : children)
+        if (c->path == RF_PATH_TILED_FUSED) { shown = c.get(); break; }
+    for (int d = 0; d < RF_MAX_DIMS; d++) { parent->dims[d].T = shown->dims[d].T; parent->dims[d].M = shown->dims[d].M; }
+    parent->tables = shown->tables;
     for (int st = 0; st < n_stages; st++) {
         rf_plan *child = children[(size_t)st].get();
         std::vector<const Step *> steps;
@@ -331,6 +339,10 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         set_error("pointwise stages need a floating-point pixel type");
         return RF_ERR_UNSUPPORTED;
     }
+    if (desc->flags & ~(RF_PLAN_ALL_FLAGS | 0x00ffff00u)) { set_error("unknown plan flags 0x%x", desc->flags); return RF_ERR_INVALID_ARG; }
+    for (int v : {(int)((desc->flags >> 8) & 0xffu), (int)((desc->flags >> 16) & 0xffu)})
+        if (v != 0 && v != 32 && v != 64 && v != 128) { set_error("RF_PLAN_TILE_ROWS / RF_PLAN_TILE_PLANES take 32, 64 or 128"); return RF_ERR_INVALID_ARG; }
+    if ((desc->flags & RF_PLAN_STREAM_PASS1) && (desc->flags & RF_PLAN_STAGED_PASS1)) { set_error("RF_PLAN_STREAM_PASS1 and RF_PLAN_STAGED_PASS1 exclude each other"); return RF_ERR_INVALID_ARG; }
     int world = desc->shard_world < 1 ? 1 : desc->shard_world;
     if (desc->shard_rank < 0 || desc->shard_rank >= world) { set_error("shard_rank out of range"); return RF_ERR_INVALID_ARG; }
 
@@ -356,6 +368,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     plan->device = device;
     plan->shard_rank = desc->shard_rank;
     plan->shard_world = world;
+    plan->flags = desc->flags;
     plan->pw.pre = (pwd.flags & RF_POINTWISE_PRE) != 0;
     plan->pw.post = (pwd.flags & RF_POINTWISE_POST) != 0;
     plan->pw.in_u8 = pwd.in_dtype == RF_IN_U8;
@@ -410,7 +423,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     // the other (sections.h), and those the fused kernels take -- as long as no dimension ends up with more than four scans.
     // The rewrite is kept only if it makes the fused path applicable; every other path runs the scans as given.
     if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && !plan->clamped &&
-        (plan->dtype == RF_F32 || plan->dtype == RF_F64) && getenv("RF_NO_SECTIONS") == nullptr) {
+        (plan->dtype == RF_F32 || plan->dtype == RF_F64) && !(desc->flags & RF_PLAN_NO_SECTIONS)) {
         bool high = false;
         for (const Scan &sc : plan->scans) high = high || sc.order > kFusedMaxK;
         if (high) {
@@ -447,8 +460,8 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     // What the fused kernels cannot take in one piece because of the NUMBER or the ORDER of its scans runs as a cascade of
     // plans inside this one (build_cascade above) -- not on the generic path, whose carry scans are one thread per line
     // (five biquads over 10,000,000 samples: 59.6 ms there, 0.26 ms as two stages).
-    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && world == 1 && desc->n_scans > 1 &&
-        !(plan->pw.post && plan->pw.post_i != 0.0) && getenv("RF_NO_CASCADE") == nullptr) {
+    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && !plan->sharded() && desc->n_scans > 1 &&
+        !(plan->pw.post && plan->pw.post_i != 0.0) && !(desc->flags & RF_PLAN_NO_CASCADE)) {
         std::string why_not;
         if (!fused_plan_applicable(plan.get(), desc, &why_not)) {
             const std::vector<int> stage_of = cascade_stage_of_scans(desc);
@@ -473,7 +486,8 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         // line-parallel untiled kernels need one launch per filtered dimension (kernels_lines.hip)
         int64_t max_extent = 0;
         for (int d = 0; d < desc->ndim; d++) max_extent = std::max<int64_t>(max_extent, plan->dims[d].N);
-        const int64_t small_limit = getenv("RF_SMALL_LIMIT") ? atoll(getenv("RF_SMALL_LIMIT")) : 1024;     // (tuning / tests; 0 = the automatic path never picks the line kernels)
+        // (RF_PLAN_TILED_ONLY: the automatic path never picks the line kernels; the limit itself is a developer knob)
+        const int64_t small_limit = (desc->flags & RF_PLAN_TILED_ONLY) ? 0 : RF_KNOB("RF_SMALL_LIMIT") ? atoll(RF_KNOB("RF_SMALL_LIMIT")) : 1024;
         // ... up to 1984 for order-3 filters with four or more scans, whose tiled launches are the heaviest (C++ caller,
         // gaussian_3xy: 1152^2 47 -> 33 us, 1536^2 49 -> 45 us, 1920^2 56 -> 51 us, even at 2048^2; order 1 and 2 cross over
         // at 1024..1152)
@@ -485,7 +499,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         const bool fused_ok = fused_plan_applicable(plan.get(), desc, &why);
         // (where the fused kernels apply, split() widths are hints -- the tile size never changes the result -- so a small
         // split() filter takes the line kernels too: the reference's own sweep, scripts/profile_app.sh, tiles at 32)
-        if (fused_ok && world == 1 && max_extent <= long_limit && plan->total * plan->n_planes <= long_limit * long_limit * 4 &&
+        if (fused_ok && !plan->sharded() && max_extent <= long_limit && plan->total * plan->n_planes <= long_limit * long_limit * 4 &&
             plan->pw.pre == false && plan->pw.post == false && line_scans_applicable(plan.get()))
             path = RF_PATH_UNTILED;
         else if (fused_ok) path = RF_PATH_TILED_FUSED;
@@ -494,7 +508,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         else if (filtered_dims >= 2 && overlap_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_OVERLAPPED;
         // what the fused kernels do not take (f64 pixels): the line-parallel untiled kernels beat the per-dimension tiled
         // passes of the generic path at every size measured (profiles/r2/paths_4096.txt), unless the user tiled the filter
-        else if (!user_tiles && world == 1 && small_limit > 0 && line_scans_applicable(plan.get()))
+        else if (!user_tiles && !plan->sharded() && small_limit > 0 && line_scans_applicable(plan.get()))
             path = RF_PATH_UNTILED;
         else path = RF_PATH_TILED_GENERIC;
     }
@@ -521,13 +535,13 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         return RF_ERR_INVALID_ARG;
     };
     int rc = build(path);
-    if (rc == RF_ERR_UNSUPPORTED && desc->path == RF_PATH_AUTO && path != RF_PATH_UNTILED && world == 1) {
+    if (rc == RF_ERR_UNSUPPORTED && desc->path == RF_PATH_AUTO && path != RF_PATH_UNTILED && !plan->sharded()) {
         // auto mode: a shape no tile fits falls back to the untiled recurrence (still on the GPU)
         std::unique_ptr<rf_plan> fresh(new rf_plan);
         // rebuild the description part
         fresh->ndim = plan->ndim; fresh->dtype = plan->dtype; fresh->n_planes = plan->n_planes;
         fresh->clamped = plan->clamped; fresh->device = plan->device; fresh->host_only = plan->host_only;
-        fresh->shard_rank = plan->shard_rank; fresh->shard_world = plan->shard_world;
+        fresh->shard_rank = plan->shard_rank; fresh->shard_world = plan->shard_world; fresh->flags = plan->flags;
         fresh->shard_extents = plan->shard_extents; fresh->shard_common = plan->shard_common;
         fresh->scans = plan->scans; fresh->total = plan->total; fresh->pw = plan->pw;
         fresh->pw.pre_fused = fresh->pw.post_fused = false;

@@ -55,13 +55,21 @@ struct rf_plan {
     int device = 0;
     bool host_only = false;               // tables only, no device memory, cannot execute
     int shard_rank = 0, shard_world = 1;
+    uint32_t flags = 0;                   // rf_filter_desc.flags (RF_PLAN_*)
+    // built with the exchange structure of a sharded dimension: several slabs, or one slab driven like one of several
+    bool sharded() const { return shard_world > 1 || (flags & RF_PLAN_FORCE_EXCHANGE) != 0; }
+    int fused_tile_rows() const { return (int)((flags >> 8) & 0xffu); }     // RF_PLAN_TILE_ROWS(n), 0 = automatic
+    int strided_tile_planes() const { return (int)((flags >> 16) & 0xffu); }  // RF_PLAN_TILE_PLANES(n), 0 = automatic
     std::vector<int64_t> shard_extents;   // extent of every rank's slab along the outermost dimension (size shard_world)
     int64_t shard_common = 0;             // their greatest common divisor: what the tile width of that dimension must divide
     // extent that decides the tile width of dimension d: the slabs' common divisor for the sharded one
-    int64_t tile_basis(int d) const { return (shard_world > 1 && d == ndim - 1) ? shard_common : dims[d].N; }
+    int64_t tile_basis(int d) const { return (sharded() && d == ndim - 1) ? shard_common : dims[d].N; }
     // tiles of slab h along the sharded dimension, given the tile width
     int64_t slab_tiles(int h, int64_t T) const { return shard_extents[(size_t)h] / T; }
     rf::Pointwise pw;
+    // the kernels of this plan (or of a stage of its cascade) move 16 bytes per lane: the fused path and the line-parallel
+    // untiled kernels; rf_plan_execute / rf_plan_begin then refuse planes that are not 16-byte aligned
+    bool vector_access = false;
     std::vector<rf::Scan> scans;          // grouped by dimension, otherwise in call order
     rf::DimInfo dims[RF_MAX_DIMS];
     int64_t total = 1;                    // elements per plane
@@ -75,6 +83,14 @@ struct rf_plan {
     std::vector<std::vector<rf::Step>> exchange_local_steps; // per exchange
     std::vector<std::vector<rf::Step>> exchange_apply_steps; // per exchange (after gather)
     std::vector<rf::Step> finish_steps;                      // final correction pass
+    // Work of a sharded execute that does NOT depend on the exchange (rf_plan_interior): a z-sharded volume exchanges the
+    // carries of the RAW input first -- the z operators commute with the x/y filter -- so its whole x/y stage runs beside
+    // the all-gather (plan_strided.h, "early exchange").  Run by rf_plan_interior, or by the first exchange_apply / finish
+    // of an execute whose caller never asked for it.
+    std::vector<rf::Step> interior_steps;
+    bool interior_pending = false;
+    // plans this one drives as steps of its own (the x/y filter of the carry planes after an early exchange)
+    std::vector<std::unique_ptr<rf_plan>> helpers;
     struct Exchange {
         void *send = nullptr;      // caller's buffer for the current call, [plane][r][line]
         void *scratch = nullptr;   // plan-owned buffer used when the caller passes none (single device)

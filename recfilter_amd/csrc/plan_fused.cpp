@@ -53,6 +53,7 @@ template <typename P, typename S>
 int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     using Acc = typename PixelTraits<P>::Acc;
     int status = RF_OK;
+    plan->vector_access = true;                  // 16-byte chunks per lane in both passes
     const int K = fused_order(plan);
     const bool chained = plan->ndim == 1;        // 1-D signal folded into chained rows
     DimInfo &dx = plan->dims[0];
@@ -62,20 +63,20 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // ... and whether they run on zero-padded COPIES (an epilogue that re-reads the input, RF_PAD_COPIES=1 for A/B runs) or on
     // the caller's buffers with the samples behind the signal's end masked (FusedArgs::lin_limit: no copy in, no copy out --
     // 34 us of 98 for one biquad over 10,000,000 samples)
-    static const bool pad_copies_env = getenv("RF_PAD_COPIES") != nullptr;
+    static const bool pad_copies_env = RF_KNOB("RF_PAD_COPIES") != nullptr;
     const bool in_place_tail = chained && N1 != dx.N && !pad_copies_env && !(plan->pw.post && plan->pw.post_i != 0.0);
     const bool padded = chained && N1 != dx.N && !in_place_tail;
     const int64_t NX = chained ? chained_row_length(N1) : dx.N;
     // Tuple planes of a 2-D filter ride in ONE launch per step, as the z planes of a volume whose planes are separate
     // buffers (FusedArgs::plane_batch): 5 launches instead of 5 per plane, which is most of the time of a small RGB image.
-    const bool batch = plan->ndim == 2 && plan->n_planes > 1 && plan->n_planes <= kFusedMaxPlanes && plan->shard_world <= 1 &&
-                       getenv("RF_NO_PLANE_BATCH") == nullptr;
+    const bool batch = plan->ndim == 2 && plan->n_planes > 1 && plan->n_planes <= kFusedMaxPlanes && !plan->sharded() &&
+                       !(plan->flags & RF_PLAN_NO_PLANE_BATCH) && RF_KNOB("RF_NO_PLANE_BATCH") == nullptr;
     const int64_t NY = chained ? N1 / NX : dy.N, NZ = batch ? plan->n_planes : (plan->ndim > 2 ? plan->dims[2].N : 1);
     const size_t first_begin_step = plan->begin_steps.size(), first_finish_step = plan->finish_steps.size();
     // tile height: 64 rows unless only 32 divides the height; any other height runs 64-row tiles (32 below 33 rows)
     // with a partial last tile row
     // (row shards: decided on the slabs' common divisor, so that every rank tiles alike)
-    const bool rows_sharded = plan->ndim == 2 && plan->shard_world > 1;
+    const bool rows_sharded = plan->ndim == 2 && plan->sharded();
     const int64_t NYB = rows_sharded ? plan->shard_common : NY;
     int TY = (NYB % 64 == 0) ? 64 : (NYB % 32 == 0 || NYB < 32) ? 32 : 64;
     // a small image has too few 256 x 64 tiles to fill 256 CUs: half-height tiles double the workgroups
@@ -95,11 +96,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && !PixelTraits<P>::is_integer && NYB % 128 == 0 &&
         !(plan->pw.post && plan->pw.post_i != 0.0 && K <= 2) &&     // (orders 1, 2: an epilogue with an input operand keeps the input
                                                                     // column in registers, which a 128-sample column leaves no room for)
-        getenv("RF_NO_TALL_TILES") == nullptr &&
+        RF_KNOB("RF_NO_TALL_TILES") == nullptr &&
         ((NX + kFusedTX - 1) / kFusedTX) * (NY / 128) * NZ >= 4096)
         TY = 128;
-    if (const char *env = getenv("RF_FUSED_TY")) {     // tuning knob: tile height of the fused path
-        const int want = atoi(env);
+    if (const int want = plan->fused_tile_rows() ? plan->fused_tile_rows() : RF_KNOB("RF_FUSED_TY") ? atoi(RF_KNOB("RF_FUSED_TY")) : 0) {
+        // RF_PLAN_TILE_ROWS(n): the caller's tile height, where the shape admits it
         if (want == 32 || want == 64 || (want == 128 && !chained && (!rows_sharded || NYB % 128 == 0))) TY = want;
     }
     // f64 pixels: a 256 x 32 tile is the 64 KiB of LDS a 256 x 64 tile of f32 takes (any height: partial last tile row)
@@ -123,7 +124,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const int64_t Lx = NYP * NZ, Ly = NXP * NZ;
     const int outer = plan->ndim - 1;
     const bool y_is_exchange_dim = (outer == 1);
-    const bool y_sharded = y_is_exchange_dim && plan->shard_world > 1;
+    const bool y_sharded = y_is_exchange_dim && plan->sharded();
 
     // ---- tables -------------------------------------------------------------------------
     auto table_scans = [&](const std::vector<int> &ids) {
@@ -290,8 +291,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // apart (FusedArgs::yt_index).  Slabs keep [scan][tile row][r][line], which the exchange kernels address, and so do
     // order-3 filters: measured on 16384^2, order 2 gains 0.005 ms of 0.62 ms and order 3 loses 0.01-0.03 ms of 1.98 ms
     // (its carry scan reads six rows per tile and line), order 1 is unchanged either way.
-    static const bool yt_row_major = getenv("RF_YT_ROW_MAJOR") != nullptr;      // A/B runs
-    static const bool yt_force_tile = getenv("RF_YT_TILE_MAJOR") != nullptr;    // A/B runs: order 3 too
+    static const bool yt_row_major = RF_KNOB("RF_YT_ROW_MAJOR") != nullptr;      // A/B runs
+    static const bool yt_force_tile = RF_KNOB("RF_YT_TILE_MAJOR") != nullptr;    // A/B runs: order 3 too
     const bool yt_tile_major = !yt_row_major && !y_sharded && ny > 0 && (K <= 2 || yt_force_tile) && Ly % kFusedTX == 0 &&
                                Ly == NXP * (int64_t)NZ;
     fbase.yt_tile_major = yt_tile_major ? 1 : 0;
@@ -347,12 +348,14 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // pass 1: tail extraction by contraction with the impulse responses (kernels_tails.hip)
     Step p1;
     p1.name = "fused_tails";
-    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded](int pl) {
+    const int stream_mode = (plan->flags & RF_PLAN_STREAM_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
+    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode](int pl) {
         const FusedArgs<Acc> a = fargs(pl);
+        (void)stream_mode;
         // images of whole 256 x 64 tiles stream through the LDS-DMA ring (kernels_stream.hip)
         if constexpr (std::is_same<P, float>::value) {
             if (a.lin_limit == 0 && stream_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, (int64_t)a.MX * a.MY * a.NZ, a.MX,
-                                        a.NZ, a.nx * K, a.ny * K))
+                                        a.NZ, a.nx * K, a.ny * K, stream_mode))
                 return launch_stream_tails(K, (const float *)(padded ? plan->pad_in[pl] : plan->in[pl]), a, d_Hx, d_Hy, plan->stream);
         }
         return launch_fused_tails<P>(K, TY, padded ? plan->pad_in[pl] : plan->in[pl], plan->pw.in_u8, a, d_Hx, d_Hy, plan->stream);
@@ -391,7 +394,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         // Where the rows' entering states fit the LDS the chain and its propagation are not launches of their own: scan s's
         // are done by the carry launch of scan s + 1 before its own scan (carry_block_kernel PRE), the last scan's by
         // chain_apply_kernel -- n + 1 launches for n scans.
-        static const bool no_pre = getenv("RF_NO_CHAIN_PRE") != nullptr;        // A/B runs: chain_apply after every scan
+        static const bool no_pre = RF_KNOB("RF_NO_CHAIN_PRE") != nullptr;        // A/B runs: chain_apply after every scan
         const bool one_launch_chain = chain_apply_applies(K, Lx, sizeof(Acc)) && !hApowX.empty();
         const size_t exit_pp = (size_t)K * Lx;            // one buffer of exit states (two per plane, by scan parity)
         for (int s = 0; s < nx; s++) {
@@ -450,10 +453,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         Step xs;
         xs.name = "xscan_rows";
         xs.run = [plan, fargs, K, TY, d_Hy, d_G, merged_cx, d_Wx, d_Ax, xt_done, xt_pp](int pl) {
-            static const bool no_res = getenv("RF_DEBUG_NO_RESIDUAL") != nullptr;      // timing experiments only
             if (merged_cx)
                 return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, d_G, plan->stream, d_Wx, d_Ax, xt_done + (size_t)pl * xt_pp);
-            return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, no_res ? (const Acc *)nullptr : d_G, plan->stream);
+            return launch_xscan_rows<Acc>(K, TY, fargs(pl), d_Hy, d_G, plan->stream);
         };
         plan->begin_steps.push_back(xs);
     }
@@ -470,7 +472,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     } else if (merged_exchange_applies(ny, K, plan->shard_world)) {
         // one all-gather for all y scans (plan_generic.h, "merged exchange")
         // ... whose correction of the tails is left to pass 2 (FusedArgs::y_apply): no launch between gather and pass 2
-        static const bool separate_apply = getenv("RF_SHARD_SEPARATE_APPLY") != nullptr;     // A/B runs
+        static const bool separate_apply = RF_KNOB("RF_SHARD_SEPARATE_APPLY") != nullptr;     // A/B runs
         int rc = add_merged_exchange<S, Acc>(plan, ty, "y", MY, TY, Ly, ymask, gyargs, yin, yin_pp, d_ACy, Cy, "carry_y",
                                              separate_apply ? nullptr : &d_Yapply);
         if (rc != RF_OK) return rc;
@@ -538,7 +540,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
         int rc;
         if constexpr (sizeof(Acc) == 4)
-            rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false)
+            rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false, desc, first_begin_step)
                                            : add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
         else rc = add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);      // (f64: no strided kernels)
         if (rc != RF_OK) return rc;
@@ -567,7 +569,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
     if (plan->ndim == 1) {
         // a long 1-D signal folded into chained rows (zero border only: the clamped prologue would differ per row)
         if (plan->clamped) return no("1-D: clamped border not supported on the fused path");
-        if (plan->shard_world > 1) return no("1-D: cannot be sharded");
+        if (plan->sharded()) return no("1-D: cannot be sharded");
         if (plan->dims[0].scan_ids.empty()) return no("no scans");
         if (plan->dims[0].N < 8192 || chained_row_length(chained_padded_length(plan->dims[0].N)) == 0)
             return no("1-D: at least 8192 samples");
@@ -587,7 +589,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
     if (plan->dims[0].N % 4 != 0) return no("width must be a multiple of 4 (16-byte rows)");
-    if (plan->ndim == 2 && plan->shard_world > 1 && plan->shard_common % 32 != 0)
+    if (plan->ndim == 2 && plan->sharded() && plan->shard_common % 32 != 0)
         return no("row-sharded slabs must be whole tiles (height a multiple of 32)");
     const int K = fused_order(plan);
     if (K > kFusedMaxK) return no("feedback order above 3");

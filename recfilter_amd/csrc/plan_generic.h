@@ -168,7 +168,7 @@ std::vector<Acc> slab_powers(const rf_plan *plan, const std::vector<std::vector<
 }
 
 inline bool merged_exchange_applies(int n_scans, int k, int world) {
-    return world > 1 && n_scans >= 1 && n_scans <= 4 && k >= 1 && k <= 3 && n_scans * world * k <= 128;
+    return world >= 1 && n_scans >= 1 && n_scans <= 4 && k >= 1 && k <= 3 && n_scans * world * k <= 128;
 }
 
 // Exchange structure of a sharded dimension with ONE all-gather: the local step completes every scan with zero
@@ -338,7 +338,7 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
         const Acc *dAMp = (const Acc *)plan->upload(hAM.data(), hAM.size() * sizeof(Acc), &status);
         const Acc *dACp = (const Acc *)plan->upload(hAC.data(), hAC.size() * sizeof(Acc), &status);
         const Acc *dApow = nullptr;
-        if (d == outer && plan->shard_world > 1) {
+        if (d == outer && plan->sharded()) {
             std::vector<Acc> hApow = carry_apply_powers<S, Acc>(tab.A, di.M, k);
             dApow = (const Acc *)plan->upload(hApow.data(), hApow.size() * sizeof(Acc), &status);
         }
@@ -348,7 +348,7 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
         Acc *incoming = (Acc *)plan->alloc(inc_per_plane * plan->n_planes * sizeof(Acc), true, &status);
         if (status != RF_OK) return status;
 
-        const bool sharded_dim = (d == outer) && plan->shard_world > 1;
+        const bool sharded_dim = (d == outer) && plan->sharded();
         GenericDimArgs<Acc> base{};
         base.g = LineGeom{di.N, di.stride, di.lines};
         base.T = T; base.M = (int32_t)di.M; base.k = k; base.n_scans = n;

@@ -14,7 +14,7 @@ namespace rf {
 
 bool overlap_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why) {
     auto no = [&](const char *msg) { if (why) *why = msg; return false; };
-    if (plan->shard_world > 1) return no("the overlapped path runs on one device");
+    if (plan->sharded()) return no("the overlapped path runs on one device");
     int filtered = 0;
     int64_t vol = 1;
     for (int d = 0; d < plan->ndim; d++) {

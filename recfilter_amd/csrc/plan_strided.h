@@ -16,8 +16,8 @@ inline int strided_tile(const rf_plan *plan, int d) {
     if (di.scan_ids.empty() || di.k > kFusedMaxK || (int)di.scan_ids.size() > kFusedMaxScans) return 0;
     if (plan->dtype != RF_F32 && plan->dtype != RF_I32 && plan->dtype != RF_I16) return 0;
     const int64_t basis = plan->tile_basis(d);       // sharded dimension: every rank's slab must tile alike
-    if (const char *env = getenv("RF_STRIDED_TZ")) {      // tuning knob
-        const int want = atoi(env);
+    if (const int want = plan->strided_tile_planes() ? plan->strided_tile_planes() : RF_KNOB("RF_STRIDED_TZ") ? atoi(RF_KNOB("RF_STRIDED_TZ")) : 0) {
+        // RF_PLAN_TILE_PLANES(n): the caller's tile width of the strided stage, where it divides the extent
         if ((want == 32 || want == 64 || want == 128) && basis % want == 0) return want;
     }
     // large volumes: 128 samples per thread halve the tails of this dimension and its carry scan (2048^3: carry_z 1.21 ->
@@ -28,8 +28,21 @@ inline int strided_tile(const rf_plan *plan, int d) {
     return 0;
 }
 
+// Early exchange (a z-sharded volume whose x/y stage precedes this dimension).  The operators of this dimension -- tail
+// extraction, carry recurrence, the correction by the entering carries -- act along z alone and identically on every
+// (x, y) line; the x/y filter F acts on every z plane alone and identically: they commute, borders included (everything
+// is linear).  So the carries of the x/y-FILTERED volume are F applied to the carry planes of the RAW volume:
+//     begin      pass 1 of this dimension on the raw input, slab-local carries, exit carries -> send
+//     <all-gather>   ||   interior: the whole x/y stage (what rf_plan_interior runs beside the collective)
+//     apply      entering carries from the gathered exits, correction of the (raw) tails, then F over the k * scans *
+//                (tiles + 1) carry planes, in place -- a fused x/y plan of its own over those few planes
+//     finish     pass 2 of this dimension on the x/y-filtered output with the filtered carries
+// The exchange no longer waits for the x/y stage and the x/y stage no longer waits for the exchange: a rank's step is
+// max(kernels, exchange) instead of their sum, for (tiles + 1) * scans * k / planes of extra x/y work (cfg5 on 8 GPUs:
+// 12 carry planes beside 256).  `xy_begin` .. end of plan->begin_steps are the x/y stage's steps at the time of the call.
+// Needs: the merged exchange, no pointwise stages (a prologue's bias is not linear), the x/y stage in front.
 template <typename P, typename S>
-int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
+int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter_desc *desc = nullptr, size_t xy_begin = (size_t)-1) {
     using Acc = typename PixelTraits<P>::Acc;
     int status = RF_OK;
     DimInfo &di = plan->dims[d];
@@ -39,7 +52,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     di.M = di.N / TZ;
     const int n = (int)di.scan_ids.size(), K = di.k, M = (int)di.M;
     const int outer = plan->ndim - 1;
-    const bool sharded = (d == outer) && plan->shard_world > 1;
+    const bool sharded = (d == outer) && plan->sharded();
     const int np = plan->n_planes;
     std::string dn(1, "xyz"[d]);
 
@@ -95,8 +108,23 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
         d_Apow = (const Acc *)plan->upload(hApow.data(), hApow.size() * sizeof(Acc), &status);
     }
     const size_t tails_pp = (size_t)n * M * K * di.lines, inc_pp = (size_t)n * K * di.lines;
-    Acc *tails = (Acc *)plan->alloc(tails_pp * np * sizeof(Acc), false, &status);
-    Acc *incoming = (Acc *)plan->alloc(inc_pp * np * sizeof(Acc), true, &status);
+    const bool early = sharded && !from_input && desc != nullptr && xy_begin != (size_t)-1 && d == 2 &&
+                       merged_exchange_applies(n, K, plan->shard_world) && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 &&
+                       !(plan->flags & RF_PLAN_LATE_EXCHANGE) && di.lines == plan->dims[0].N * plan->dims[1].N &&
+                       sizeof(P) == sizeof(Acc);      // (the carry planes are filtered as pixels: f32 / i32)
+    // early exchange: the tails and the entering carries of a plane are ONE run of (tiles + 1) * scans * k carry planes,
+    // which the x/y filter then takes as a volume of that many z planes
+    const size_t chunk_pp = early ? tails_pp + inc_pp : 0;
+    Acc *tails, *incoming;
+    size_t tails_stride = tails_pp, inc_stride = inc_pp;
+    if (early) {
+        tails = (Acc *)plan->alloc(chunk_pp * np * sizeof(Acc), true, &status);
+        incoming = tails ? tails + tails_pp : nullptr;
+        tails_stride = inc_stride = chunk_pp;
+    } else {
+        tails = (Acc *)plan->alloc(tails_pp * np * sizeof(Acc), false, &status);
+        incoming = (Acc *)plan->alloc(inc_pp * np * sizeof(Acc), true, &status);
+    }
     if (status != RF_OK) return status;
 
     base.n = di.N; base.inner = di.stride; base.lines = di.lines; base.M = M; base.n_scans = n;
@@ -105,8 +133,8 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     base.last_is_border = (!sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
     auto sargs = [=](int pl) {
         StridedArgs<Acc> a = base;
-        a.tails = tails + (size_t)pl * tails_pp;
-        a.incoming = incoming + (size_t)pl * inc_pp;
+        a.tails = tails + (size_t)pl * tails_stride;
+        a.incoming = incoming + (size_t)pl * inc_stride;
         return a;
     };
     GenericDimArgs<Acc> gb{};
@@ -116,17 +144,22 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     gb.scans = d_scans; gb.W = d_W; gb.A = d_A; gb.Apow = d_Apow;
     auto gargs = [=](int pl) {
         GenericDimArgs<Acc> a = gb;
-        a.tails = tails + (size_t)pl * tails_pp;
-        a.incoming = incoming + (size_t)pl * inc_pp;
+        a.tails = tails + (size_t)pl * tails_stride;
+        a.incoming = incoming + (size_t)pl * inc_stride;
         return a;
     };
 
     Step p1;
     p1.name = "strided_pass1_" + dn;
-    p1.run = [plan, sargs, K, TZ, from_input](int pl) {
-        const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
+    p1.run = [plan, sargs, K, TZ, from_input, early](int pl) {
+        const P *src = (from_input || early) ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
         return launch_strided_pass<P>(false, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
     };
+    if (early) {
+        // the x/y stage leaves the begin phase: it is what runs beside the all-gather
+        plan->interior_steps.assign(plan->begin_steps.begin() + (std::ptrdiff_t)xy_begin, plan->begin_steps.end());
+        plan->begin_steps.resize(xy_begin);
+    }
     plan->begin_steps.push_back(p1);
 
     if (!sharded) {
@@ -139,6 +172,48 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
     } else if (merged_exchange_applies(n, K, plan->shard_world)) {
         int rc = add_merged_exchange<S, Acc>(plan, tab, dn, M, TZ, di.lines, mask, gargs, incoming, inc_pp, d_AC, C, "carry_" + dn);
         if (rc != RF_OK) return rc;
+        if (early) {
+            // F over the carry planes: the x/y scans of this filter on a volume of (tiles + 1) * scans * k planes, in place
+            std::vector<rf_scan_desc> xy;
+            for (int i = 0; i < desc->n_scans; i++)
+                if (desc->scans[i].dim != d) xy.push_back(desc->scans[i]);
+            rf_filter_desc cd = *desc;
+            cd.scans = xy.data();
+            cd.n_scans = (int32_t)xy.size();
+            cd.extent[2] = (int64_t)n * K * (M + 1);
+            cd.n_planes = 1;
+            cd.tile[2] = 0;
+            cd.path = RF_PATH_TILED_FUSED;
+            cd.device = plan->host_only ? RF_DEVICE_HOST_ONLY : plan->device;
+            cd.shard_rank = 0; cd.shard_world = 1; cd.shard_extents = nullptr;
+            cd.flags = (desc->flags & (RF_PLAN_STREAM_PASS1 | RF_PLAN_STAGED_PASS1 | 0x0000ff00u)) | RF_PLAN_TILED_ONLY | RF_PLAN_NO_CASCADE;
+            rf_plan *child = nullptr;
+            rc = build_plan(&cd, &child);
+            if (rc != RF_OK) return rc;
+            plan->helpers.emplace_back(child);
+            plan->workspace_bytes += child->workspace_bytes;
+            std::vector<Step> &apply = plan->exchange_apply_steps.back();
+            std::vector<const Step *> steps;
+            for (const Step &s : child->begin_steps) steps.push_back(&s);
+            for (const auto &ex : child->exchange_local_steps)
+                for (const Step &s : ex) steps.push_back(&s);
+            for (const Step &s : child->finish_steps) steps.push_back(&s);
+            for (size_t i = 0; i < steps.size(); i++) {
+                const Step *sp = steps[i];
+                Step w;
+                w.name = "carry_planes." + sp->name;
+                const bool first = i == 0;
+                w.run = [plan, child, sp, first, tails, chunk_pp](int pl) {
+                    if (first) {        // the helper's context: this plane's run of carry planes, filtered in place
+                        child->in[0] = child->orig_in[0] = tails + (size_t)pl * chunk_pp;
+                        child->out[0] = tails + (size_t)pl * chunk_pp;
+                        child->stream = plan->stream;
+                    }
+                    return sp->run(0);
+                };
+                apply.push_back(w);
+            }
+        }
     } else {
         for (int s = 0; s < n; s++) {
             const int64_t plane_stride = (int64_t)K * di.lines, rank_stride = (int64_t)np * K * di.lines;
@@ -173,6 +248,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input) {
         }
     }
 
+    (void)inc_pp;
     Step p2;
     p2.name = "strided_pass2_" + dn;
     p2.run = [plan, sargs, K, TZ, from_input](int pl) {

@@ -11,6 +11,16 @@
 
 #include "../../include/recfilter_amd.h"
 
+// Developer A/B switches.  The shipped library reads NO environment variable: RF_KNOB("RF_...") is a null pointer unless the
+// library is built with -DRF_AB_KNOBS (make AB=1 -> librecfilter_amd_ab.so, which the scripts under tools/ load through
+// RECFILTER_AMD_LIB); what a caller may choose about a plan is rf_filter_desc.flags (include/recfilter_amd.h).
+#ifdef RF_AB_KNOBS
+#include <cstdlib>
+#define RF_KNOB(name) getenv(name)
+#else
+#define RF_KNOB(name) ((const char *)nullptr)
+#endif
+
 namespace rf {
 
 void set_error(const char *fmt, ...);

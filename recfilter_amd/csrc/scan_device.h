@@ -289,6 +289,19 @@ __device__ __forceinline__ typename Vec4<Acc>::type load_chunk(const char *p) {
     }
 }
 
+// The chunk of a folded 1-D signal that straddles the signal's end (FusedArgs::lin_limit): only its first `n_valid` (1..3)
+// samples exist in the caller's buffer, so they are loaded one by one -- nothing behind the end is read -- and the rest
+// of the chunk is zeros.
+template <typename PI, typename Acc>
+__device__ __forceinline__ typename Vec4<Acc>::type load_chunk_head(const char *p, int n_valid) {
+    using A4 = typename Vec4<Acc>::type;
+    const PI *q = reinterpret_cast<const PI *>(p);
+    A4 v = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+    v.x = (Acc)q[0];
+    if (n_valid > 1) v.y = (Acc)q[1];
+    if (n_valid > 2) v.z = (Acc)q[2];
+    return v;
+}
 
 }  // namespace
 }  // namespace rf

@@ -44,15 +44,25 @@ class ShardedFilter:
 
     def __init__(self, local_shape: Sequence[int], scans, clamped: bool = False, planes: int = 1,
                  rank: int = 0, world: int = 1, path: int = capi.RF_PATH_AUTO, dtype=np.float32,
-                 tile=None, group=None, engine=None, inflight: int = 1, slab_extents: Optional[Sequence[int]] = None):
+                 tile=None, group=None, engine=None, inflight: int = 1, slab_extents: Optional[Sequence[int]] = None,
+                 force_exchange: bool = False, flags: int = 0, collective=None):
+        """force_exchange: with world == 1, still build the plan with the exchange structure (RF_PLAN_FORCE_EXCHANGE) and
+        drive begin / exchange_local / all-gather / interior / exchange_apply / finish -- what every rank of an N-GPU run
+        does, on a box with one GPU (the all-gather of one rank over RCCL is the identity).
+        collective(gathered, send) -> work-or-None replaces torch.distributed.all_gather_into_tensor (timing probes that
+        stand a delay kernel in for the collective); default: the process group's all-gather, asynchronous."""
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.force_exchange = bool(force_exchange) and int(world) == 1
+        self.collective = collective
+        flags = int(flags) | (capi.RF_PLAN_FORCE_EXCHANGE if self.force_exchange else 0)
         self.inflight = max(1, int(inflight))
         if engine is not None and self.inflight > 1:
             raise ValueError("inflight > 1 builds its own plans: pass no engine")
 
         def make():
+            from . import plan as _plan
             return Plan(local_shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path,
-                        shard_rank=rank, shard_world=world, shard_extents=slab_extents)
+                        shard_rank=rank, shard_world=world, shard_extents=slab_extents, flags=_plan.DEFAULT_FLAGS | flags)
         self.plans = [engine if engine is not None else make()]
         self.plans += [make() for _ in range(self.inflight - 1)]
         self.plan = self.plans[0]
@@ -72,14 +82,23 @@ class ShardedFilter:
     def _run(self, slot, inputs, outputs, stream=None):
         plan = self.plans[slot]
         kw = {} if stream is None else {"stream": stream}       # (the numpy stand-in of the CPU tests has no streams)
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return plan.execute(inputs, outputs, **kw)
-        import torch.distributed as dist
         plan.begin(inputs, outputs, **kw)
-        for i in range(plan.num_exchanges):
+        n_ex = plan.num_exchanges
+        for i in range(n_ex):
             send, gathered = self._buffers((slot, i), plan, inputs[0])
             plan.exchange_local(i, send.data_ptr())
-            dist.all_gather_into_tensor(gathered, send, group=self.group)      # ordered after / before the current stream
+            # issued after what the current stream holds (the exit carries); asynchronous to what follows on it
+            if self.collective is not None:
+                work = self.collective(gathered, send)
+            else:
+                import torch.distributed as dist
+                work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
+            if i == n_ex - 1 and getattr(plan, "has_interior", False):
+                plan.interior()          # exchange-independent work (a z-sharded volume's x/y stage) beside the collective
+            if work is not None:
+                work.wait()              # the current stream waits for the gathered carries
             plan.exchange_apply(i, gathered.data_ptr())
         plan.finish()
         return outputs

@@ -15,6 +15,11 @@ from . import capi
 
 Scan = Tuple[int, bool, Sequence[float]]   # (dim, causal, [feedfwd, fb1..fbk]); dim 0 = x
 
+# rf_filter_desc.flags of plans created without an explicit `flags`.  0 as shipped.  tests/conftest.py sets
+# capi.RF_PLAN_TILED_ONLY: most parity tests use small shapes on purpose and mean the TILED kernels when they ask for the
+# automatic path (which sends images up to 1024^2 to the line kernels); tests/test_shipped_defaults.py resets it to 0.
+DEFAULT_FLAGS = 0
+
 _NP_DTYPES = {np.dtype(np.float32): capi.RF_F32, np.dtype(np.float64): capi.RF_F64,
               np.dtype(np.int32): capi.RF_I32, np.dtype(np.int16): capi.RF_I16}
 
@@ -42,11 +47,12 @@ class Plan:
                  planes: int = 1, tile: Optional[Sequence[int]] = None, path: int = capi.RF_PATH_AUTO,
                  device: int = -1, shard_rank: int = 0, shard_world: int = 1, shard_extents: Optional[Sequence[int]] = None,
                  prologue: Optional[Tuple[float, float]] = None,
-                 epilogue: Optional[Tuple[float, float, float]] = None, input_dtype=None):
+                 epilogue: Optional[Tuple[float, float, float]] = None, input_dtype=None, flags: Optional[int] = None):
         """prologue = (scale, bias): x' = scale*in + bias before the first scan;
         epilogue = (w_filtered, w_input, bias): out = w_filtered*F(x') + w_input*x' + bias
         (rf_pointwise_desc; fused into pass 1 / pass 2 on the fused path).  input_dtype=np.uint8 (with dtype float32):
-        the input planes are unsigned bytes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8)."""
+        the input planes are unsigned bytes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8).
+        flags: rf_filter_desc.flags (capi.RF_PLAN_*); None = recfilter_amd.plan.DEFAULT_FLAGS (0 as shipped)."""
         L = capi.lib()
         shape = tuple(int(s) for s in shape)
         if not 1 <= len(shape) <= capi.RF_MAX_DIMS:
@@ -101,6 +107,7 @@ class Plan:
             self.input_np_dtype = np.dtype(np.uint8)
         elif input_dtype is not None and _dtype_code(input_dtype) != d.dtype:
             raise TypeError(f"unsupported input type {input_dtype} for pixel type {dtype}")
+        d.flags = int(DEFAULT_FLAGS if flags is None else flags)
         self._desc = d
         self.shape = shape
         self.planes = int(planes)
@@ -231,6 +238,15 @@ class Plan:
 
     def exchange_apply(self, i: int, gathered_ptr: int) -> None:
         capi.check(capi.lib().rf_plan_exchange_apply(self._h, i, ctypes.c_void_p(gathered_ptr)))
+
+    @property
+    def has_interior(self) -> bool:
+        return bool(capi.lib().rf_plan_has_interior(self._h))
+
+    def interior(self) -> None:
+        """rf_plan_interior: the work of this execute that does not depend on the exchange (the x/y stage of a z-sharded
+        volume) -- call it between issuing the last all-gather and waiting for it."""
+        capi.check(capi.lib().rf_plan_interior(self._h))
 
     def finish(self):
         capi.check(capi.lib().rf_plan_finish(self._h))

@@ -8,10 +8,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-# RF_PATH_AUTO sends images up to 1024^2 to the line-parallel untiled kernels (launch-bound regime).  Most parity tests
-# use small shapes on purpose and mean the TILED kernels when they ask for the automatic path, so the suite switches that
-# choice off; the tests of the small-image path ask for it explicitly (path=1) or re-enable it (monkeypatch.delenv).
-os.environ.setdefault("RF_SMALL_LIMIT", "0")
+# The library reads no environment variable.  RF_PATH_AUTO sends images up to 1024^2 to the line-parallel untiled kernels
+# (launch-bound regime); most parity tests use small shapes on purpose and mean the TILED kernels when they ask for the
+# automatic path, so plans the suite creates WITHOUT explicit flags get rf_filter_desc.flags = RF_PLAN_TILED_ONLY.  The
+# shipped default (flags = 0) is what tests/test_shipped_defaults.py runs the same small cases on, and what the tests
+# that take the `shipped_defaults` fixture see.
+import recfilter_amd.plan as _rf_plan
+from recfilter_amd import capi as _rf_capi
+
+_rf_plan.DEFAULT_FLAGS = _rf_capi.RF_PLAN_TILED_ONLY
+
+
+@pytest.fixture
+def plan_flags():
+    """plan_flags(f): plans created without explicit flags get rf_filter_desc.flags = f for the rest of the test."""
+    saved = _rf_plan.DEFAULT_FLAGS
+
+    def set_flags(flags):
+        _rf_plan.DEFAULT_FLAGS = int(flags)
+    yield set_flags
+    _rf_plan.DEFAULT_FLAGS = saved
+
+
+@pytest.fixture
+def shipped_defaults(plan_flags):
+    """The test runs on the defaults a user gets: rf_filter_desc.flags = 0."""
+    plan_flags(0)
 
 
 def pytest_configure(config):

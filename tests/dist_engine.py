@@ -25,7 +25,13 @@ def _view(ptr: int, n: int) -> np.ndarray:
 
 
 class NumpySlabEngine:
-    def __init__(self, local_shape, scans, clamped, planes, rank, world, tile=None, slab_extents=None):
+    def __init__(self, local_shape, scans, clamped, planes, rank, world, tile=None, slab_extents=None, early=False,
+                 force_exchange=False):
+        """early=True: the "early exchange" of a sharded outermost dimension (recfilter_amd/csrc/plan_strided.h): the
+        carries of the RAW slab are exchanged, the inner dimensions are filtered beside the all-gather (`interior`), and
+        the completed carry planes are filtered along the inner dimensions afterwards -- the operators of the outermost
+        dimension commute with the filter of the inner ones."""
+        self.early = bool(early)
         self.shape, self.scans, self.clamped = tuple(local_shape), list(scans), clamped
         self.planes, self.rank, self.world = planes, rank, world
         nd = len(self.shape)
@@ -33,7 +39,8 @@ class NumpySlabEngine:
             tile = [0] * nd
         self.plan = rfa.Plan(self.shape, scans, dtype=np.float64, clamped=clamped, planes=planes, tile=tile,
                              path=capi.RF_PATH_TILED_GENERIC, device=capi.RF_DEVICE_HOST_ONLY,
-                             shard_rank=rank, shard_world=world, shard_extents=slab_extents)
+                             shard_rank=rank, shard_world=world, shard_extents=slab_extents,
+                             flags=capi.RF_PLAN_FORCE_EXCHANGE if (force_exchange and world == 1) else 0)
         self.slab_extents = list(slab_extents) if slab_extents is not None else [self.shape[0]] * world
         self.tiles = self.plan.tiles
         self.outer = nd - 1
@@ -50,7 +57,7 @@ class NumpySlabEngine:
         self.lines = int(np.prod(self.shape[1:])) if nd > 1 else 1
         # merged exchange (one all-gather for all scans): the plan publishes the cross-scan transfers Y / X
         self.merged = False
-        if self.n and world > 1:
+        if self.n and (world > 1 or force_exchange):
             try:
                 name = "xyz"[self.outer]
                 self.Y = self.plan.table("Y_" + name).reshape(self.n, self.n, self.M, self.k, self.k)
@@ -87,24 +94,43 @@ class NumpySlabEngine:
         tp = t - 1 if self.outer_scans[s][0] else t + 1
         return [self.tails[pl][s, tp, j] for j in range(self.k)]
 
+    def _inner(self, img):
+        """the slab-local filter of the inner dimensions on an array whose LAST axes are the slab's inner axes (same
+        tables as the product plan)"""
+        nd = len(self.shape)
+        for d in range(nd - 1):
+            dim_scans = [(c, co) for (dd, c, co) in self.scans if dd == d]
+            if not dim_scans:
+                continue
+            axis = img.ndim - 1 - d
+            moved = np.moveaxis(img, axis, -1)
+            flat = np.ascontiguousarray(moved).reshape(-1, moved.shape[-1])
+            name = "xyz"[d]
+            res = emulate_dimension(flat, dim_scans, self.tiles[d], self.clamped,
+                                    self.plan.table("W_" + name), self.plan.table("A_" + name))
+            img = np.moveaxis(res.reshape(moved.shape), -1, axis)
+        return img
+
+    @property
+    def has_interior(self):
+        return self.early and self.n > 0
+
+    def interior(self):
+        """exchange-independent work: the inner dimensions of the slab (early exchange only)"""
+        if self._interior_done:
+            return
+        self._interior_done = True
+        self.data = [np.ascontiguousarray(self._inner(d.T.reshape(self.shape))).reshape(self.N, self.lines).T.copy()
+                     for d in self.data]
+
     def begin(self, inputs, outputs, stream=None):
         self.outputs = outputs
-        nd = len(self.shape)
         self.data = []
+        self._interior_done = not self.has_interior
         for pl in range(self.planes):
             img = inputs[pl].numpy().astype(np.float64)
-            # inner dimensions are slab-local: run them completely (same tables as the product plan)
-            for d in range(nd - 1):
-                dim_scans = [(c, co) for (dd, c, co) in self.scans if dd == d]
-                if not dim_scans:
-                    continue
-                axis = nd - 1 - d
-                moved = np.moveaxis(img, axis, -1)
-                flat = np.ascontiguousarray(moved).reshape(-1, moved.shape[-1])
-                name = "xyz"[d]
-                res = emulate_dimension(flat, dim_scans, self.tiles[d], self.clamped,
-                                        self.plan.table("W_" + name), self.plan.table("A_" + name))
-                img = np.moveaxis(res.reshape(moved.shape), -1, axis)
+            if not self.has_interior:
+                img = self._inner(img)          # inner dimensions first; the exchange then carries filtered data
             self.data.append(np.ascontiguousarray(img).reshape(self.N, self.lines).T.copy())   # [lines, N]
         if not self.n:
             return
@@ -187,7 +213,23 @@ class NumpySlabEngine:
                     for q in range(s + 1):
                         self.tails[pl][s, t] += self.Y[q, s, t] @ ins[q, self.rank]
 
+    def _filter_carry_planes(self):
+        """early exchange: every completed tail / entering carry is a plane of the inner dimensions; filtered along them
+        it is the carry of the FILTERED slab"""
+        inner_shape = self.shape[1:]
+        for pl in range(self.planes):
+            t = self.tails[pl]
+            self.tails[pl] = self._inner(t.reshape(t.shape[:3] + inner_shape)).reshape(t.shape)
+            for s in range(self.n):
+                for j in range(self.k):
+                    self.incoming[pl][s][j] = self._inner(self.incoming[pl][s][j].reshape(inner_shape)).reshape(-1)
+
     def exchange_apply(self, s, gathered_ptr):
+        if self.has_interior:
+            self.interior()                      # (a driver that never asked for it)
+            assert self.merged, "early exchange needs the merged exchange"
+            self._merged_apply(gathered_ptr)
+            return self._filter_carry_planes()
         if self.merged:
             return self._merged_apply(gathered_ptr)
         k, M = self.k, self.M
@@ -211,6 +253,7 @@ class NumpySlabEngine:
     def finish(self):
         k, M, T = self.k, self.M, self.T
         import torch
+        self.interior()
         for pl in range(self.planes):
             out = self.data[pl]
             if self.n:

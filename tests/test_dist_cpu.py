@@ -45,8 +45,11 @@ def _worker(rank, world, port, case, result_dir):
         inputs = [torch.from_numpy(np.ascontiguousarray(f[lo:lo + n])) for f in full]
         outputs = [torch.empty_like(t) for t in inputs]
         engine = NumpySlabEngine(local_shape, scans, clamped, planes, rank, world, tile=tile,
-                                 slab_extents=extents if case.get("extents") else None)
-        filt = ShardedFilter(local_shape, scans, clamped=clamped, planes=planes, rank=rank, world=world, engine=engine)
+                                 slab_extents=extents if case.get("extents") else None, early=case.get("early", False),
+                                 force_exchange=case.get("force_exchange", False))
+        filt = ShardedFilter(local_shape, scans, clamped=clamped, planes=planes, rank=rank, world=world, engine=engine,
+                             force_exchange=case.get("force_exchange", False))
+        assert engine.has_interior == bool(case.get("early", False))
         filt.execute(inputs, outputs)
         filt.execute(inputs, outputs)          # a second execute reuses the exchange buffers
         for p in range(planes):
@@ -55,7 +58,7 @@ def _worker(rank, world, port, case, result_dir):
             assert err < 1e-5, f"rank {rank} plane {p}: rel err {err}"
         n_outer = sum(1 for s in scans if s[0] == len(shape) - 1)
         assert engine.num_exchanges == (1 if engine.merged else n_outer)
-        assert engine.merged == (world > 1 and 1 <= n_outer <= 4)       # every case here has order <= 3
+        assert engine.merged == ((world > 1 or case.get("force_exchange", False)) and 1 <= n_outer <= 4)       # every case here has order <= 3
         if case.get("extents"):
             assert engine.tiles[len(shape) - 1] == case["tile"][len(shape) - 1]     # every rank tiles alike
         open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
@@ -93,6 +96,34 @@ def test_sharded_filter_over_gloo(name, world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,clamped", [("generic_xyz", False), ("generic_xyz", True), ("gauss2_xy_clamped", True)])
+def test_early_exchange_over_gloo(name, clamped, world, tmp_path):
+    """The early exchange of a sharded outermost dimension (recfilter_amd/csrc/plan_strided.h; what a z-sharded volume
+    does on the GPU): the slabs exchange the carries of their RAW data, filter the inner dimensions beside the
+    all-gather (ShardedFilter calls `interior` between issuing the collective and waiting for it), and filter the
+    completed carry planes along the inner dimensions afterwards.  Same result as the oracle on the whole image -- the
+    operators of the outermost dimension commute with the filter of the inner ones, clamped borders included."""
+    import torch.multiprocessing as mp
+    case = dict(CASES[name])
+    case["scans"], case["clamped"], case["early"] = _scans(name), clamped, True
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+@pytest.mark.parametrize("early", [False, True])
+def test_one_rank_with_forced_exchange_over_gloo(early, tmp_path):
+    """world == 1 with the exchange structure forced (RF_PLAN_FORCE_EXCHANGE): the one rank still runs begin /
+    exchange_local / all-gather / interior / exchange_apply / finish; the all-gather of one rank is the identity."""
+    import torch.multiprocessing as mp
+    case = dict(CASES["generic_xyz"])
+    case["scans"], case["early"], case["force_exchange"] = _scans("generic_xyz"), early, True
+    port = _free_port()
+    mp.spawn(_worker, args=(1, port, case, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok0")
 
 
 UNEQUAL = {       # name -> (base case, {world: slab extents}): whole tiles, different counts per rank

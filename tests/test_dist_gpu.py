@@ -165,6 +165,90 @@ def test_rccl_calls_single_rank():
     assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stderr[-3000:]
 
 
+_RCCL_SHARDED = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+ROOT, HERE = sys.argv[2], sys.argv[3]
+sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+import oracle
+import ref_cases as rc
+from recfilter_amd import capi
+from recfilter_amd.dist import ShardedFilter
+issued = [0]
+real = dist.all_gather_into_tensor
+def counting(*a, **k):
+    issued[0] += 1
+    return real(*a, **k)
+dist.all_gather_into_tensor = counting
+cases = [("rows_2d", (512, 1024), rc.xy_pm(rc.GAUSS2), True, 2, False),
+         ("z_slab_3d", (64, 96, 512), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1, True)]
+for name, shape, scans, clamped, planes, interior in cases:
+    imgs = [rc.random_image(shape, np.float32, 400 + p) for p in range(planes)]
+    dev = [torch.from_numpy(i).cuda() for i in imgs]
+    want = [oracle.apply_filter(i.astype(np.float64), scans, clamped) for i in imgs]
+    for inflight in (1, 2):
+        filt = ShardedFilter(shape, scans, clamped=clamped, planes=planes, rank=0, world=1, force_exchange=True,
+                             inflight=inflight, flags=capi.RF_PLAN_TILED_ONLY)
+        assert filt.plan.path_name == "tiled_fused" and filt.plan.num_exchanges == 1 and filt.plan.has_interior == interior, name
+        before = issued[0]
+        sets = [[torch.zeros_like(t) for t in dev] for _ in range(inflight)]
+        for i in range(2 * inflight + 1):
+            filt.submit(dev, sets[i % inflight])
+        filt.drain()
+        torch.cuda.synchronize()
+        assert issued[0] - before == 2 * inflight + 1, "one RCCL all-gather per execute"
+        for outs in sets:
+            for o, w in zip(outs, want):
+                err = rc.rel_err(o.cpu().numpy(), w)
+                assert err < 1e-4, (name, inflight, err)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-sharded-ok", issued[0])
+"""
+
+
+def test_sharded_protocol_over_rccl_one_rank():
+    """recfilter_amd.dist.ShardedFilter._run -- begin, exit carries, the all-gather ISSUED ON RCCL (backend nccl, bound
+    to the device, asynchronous), the exchange-independent work beside it, entering carries, final pass -- on plans built
+    with RF_PLAN_FORCE_EXCHANGE, with the one rank this box allows.  A row-sharded 2-D image (merged exchange, the
+    correction inside pass 2) and a z-sharded volume (early exchange: x/y stage beside the collective), one and two
+    executes in flight; against the oracle.  A fresh child process: it must own the GPU from its first HIP call."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_SHARDED, str(_free_port()), ROOT, HERE], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0 and "rccl-sharded-ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_bench_forced_stepping_one_rank_over_rccl():
+    """`python -m torch.distributed.run --nproc-per-node=1 bench.py --gpus 1 --force-stepping`: the bench's timed steps go
+    through the sharded protocol with its all-gather on RCCL (config.exchange == "stepping", one collective per step)."""
+    import json
+    import subprocess
+    for extra in (["--size", "2048"], ["--workload", "cfg5", "--size", "256"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--force-stepping"] + extra
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        c = d["config"]
+        assert d["n_gpus"] == 1 and c["backend"] == "nccl" and c["rccl_ranks"] == 1 and d["value"] > 0
+        assert c["exchange"] == "stepping" and c["collectives_per_step"] == 1 and c["path"] == "tiled_fused"
+        assert c["interior_beside_collective"] == ("cfg5" in extra)
+        assert d["ms_per_step_cold"] > 0 and d["preheat_executions"] >= 3 * 5
+
+
 def test_bench_one_rank_over_rccl():
     """bench.py launched the driver's way (`python -m torch.distributed.run … bench.py --gpus 1`) with the default backend:
     process group on nccl (= RCCL) bound to the device, barriers and the max-over-ranks reduction through it."""

@@ -48,11 +48,11 @@ def _floor_err(out, want, rows=512):
     return worst
 
 
-def _gpu(shape, scans, clamped, img, dtype=np.float32):
+def _gpu(shape, scans, clamped, img, dtype=np.float32, flags=None):
     import torch
     import recfilter_amd as rfa
     dev = torch.from_numpy(img).cuda()
-    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped) as plan:
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, flags=flags) as plan:
         assert plan.path == 3, plan.path_name                 # the fused kernels, i.e. what bench.py times
         out = plan.execute([dev])[0]
         torch.cuda.synchronize()
@@ -236,36 +236,38 @@ def test_cfg5_256_cubed_separable_matches_direct_oracle():
 
 
 @pytest.mark.parametrize("name", ["gauss2_clamped", "gauss3_clamped", "generic_xy_zero", "sat", "x_only", "y_only", "single_tile"])
-def test_streaming_pass1_on_small_shapes(name, monkeypatch):
+def test_streaming_pass1_on_small_shapes(name):
     """The streaming pass 1 (kernels_stream.hip: LDS-DMA ring, matrix-core contractions) normally takes images of
     >= 2048 tiles; lowered to one tile here so that border variants, few-tile walkers (fewer slots than the ring is
-    deep) and every scan mix go through it at sizes the oracle checks in full."""
-    monkeypatch.setenv("RF_STREAM_MIN_TILES", "1")
-    monkeypatch.setenv("RF_STREAM_FORCE", "1")
+    deep) and every scan mix go through it at sizes the oracle checks in full (RF_PLAN_STREAM_PASS1, on the 64-row tiles
+    the kernel is written for)."""
     import torch
     import recfilter_amd as rfa
+    from recfilter_amd import capi
+    flags = capi.RF_PLAN_TILED_ONLY | capi.RF_PLAN_STREAM_PASS1 | capi.RF_PLAN_TILE_ROWS(64)
     case = rc.FUSED_CASES[name]
     for shape in (case["shape"], (192, 1024), (64 * 5, 256 * 3)):
         if shape[0] % 64 or shape[1] % 256:
             continue
         img = rc.random_image(shape, np.float32, 21)
-        got = _gpu(shape, case["scans"], case["clamped"], img)
+        got = _gpu(shape, case["scans"], case["clamped"], img, flags=flags)
         want = oracle.apply_filter(img.astype(np.float64), case["scans"], case["clamped"])
         assert rc.rel_err(got, want) < TOL, (name, shape)
 
 
-def test_streaming_pass1_3d_and_planes(monkeypatch):
-    monkeypatch.setenv("RF_STREAM_MIN_TILES", "1")
-    monkeypatch.setenv("RF_STREAM_FORCE", "1")          # volumes, plane batches and > 4 tails per dimension are staged by default
+def test_streaming_pass1_3d_and_planes():
     import torch
     import recfilter_amd as rfa
+    from recfilter_amd import capi
+    # volumes, plane batches and > 4 tails per dimension are staged by default
+    flags = capi.RF_PLAN_TILED_ONLY | capi.RF_PLAN_STREAM_PASS1 | capi.RF_PLAN_TILE_ROWS(64)
     scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
     img = rc.random_image((24, 128, 512), np.float32, 22)
-    got = _gpu((24, 128, 512), scans, False, img)
+    got = _gpu((24, 128, 512), scans, False, img, flags=flags)
     assert rc.rel_err(got, oracle.apply_filter(img.astype(np.float64), scans, False)) < TOL
     c = rc.BASELINE_CONFIGS["cfg4b_gaussian3_rgb"]
     imgs = [rc.random_image((128, 768), np.float32, 30 + p) for p in range(3)]
-    with rfa.Plan((128, 768), c["scans"], clamped=True, planes=3) as plan:
+    with rfa.Plan((128, 768), c["scans"], clamped=True, planes=3, flags=flags) as plan:
         outs = plan.execute([torch.from_numpy(i).cuda() for i in imgs])
         torch.cuda.synchronize()
     for im, o in zip(imgs, outs):

@@ -7,15 +7,18 @@ import ref_cases as rc
 
 pytestmark = pytest.mark.gpu
 
+from recfilter_amd import capi
+
 TOL = 1e-4     # north_star: 1e-4 relative for floating point; integers bit-exact
+TILED = capi.RF_PLAN_TILED_ONLY      # what tests/conftest.py makes the default of plans created without explicit flags
 
 
-def _run(shape, scans, dtype=np.float32, clamped=False, planes=1, tile=None, path=0, seed=1234, inplace=False):
+def _run(shape, scans, dtype=np.float32, clamped=False, planes=1, tile=None, path=0, seed=1234, inplace=False, flags=None):
     import torch
     import recfilter_amd as rfa
     imgs = [rc.random_image(shape, dtype, seed + i) for i in range(planes)]
     dev = [torch.from_numpy(im).cuda() for im in imgs]
-    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path) as plan:
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path, flags=flags) as plan:
         outs = plan.execute(dev, dev if inplace else None)
         torch.cuda.synchronize()
         info = (plan.path, plan.tiles)
@@ -291,7 +294,8 @@ def test_fused_matches_untiled_gpu_at_full_size_properties():
 
 
 # ---- sharded execution (stepping API of the C ABI), all "ranks" emulated on the one GPU of the test box ----
-def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32, extents=None, tile=None):
+def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32, extents=None, tile=None, flags=None,
+                 interior=True):
     import torch
     import recfilter_amd as rfa
     if np.issubdtype(dtype, np.integer):
@@ -302,7 +306,7 @@ def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32,
     assert sum(ext) == shape[0] and len(ext) == world
     lo = [sum(ext[:r]) for r in range(world)]
     plans = [rfa.Plan((ext[r],) + tuple(shape[1:]), scans, dtype=dtype, clamped=clamped, planes=planes, path=path, tile=tile,
-                      shard_rank=r, shard_world=world, shard_extents=extents)
+                      shard_rank=r, shard_world=world, shard_extents=extents, flags=flags)
              for r in range(world)]
     ins = [[torch.from_numpy(np.ascontiguousarray(f[lo[r]:lo[r] + ext[r]])).cuda() for f in full] for r in range(world)]
     outs = [[torch.empty_like(t) for t in ins[r]] for r in range(world)]
@@ -314,6 +318,9 @@ def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32,
         gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda")
         for r in range(world):                         # "all-gather": every rank's send lands rank-major
             plans[r].exchange_local(e, gathered.data_ptr() + r * nbytes)
+        if interior and e == nex - 1:                  # what a driver runs beside the collective (rf_plan_interior);
+            for r in range(world):                     # without the call exchange_apply / finish run it themselves
+                plans[r].interior()
         for r in range(world):
             plans[r].exchange_apply(e, gathered.data_ptr())
     for r in range(world):
@@ -321,6 +328,7 @@ def _run_sharded(shape, scans, clamped, world, path, planes=1, dtype=np.float32,
     torch.cuda.synchronize()
     got = [np.concatenate([outs[r][p].cpu().numpy() for r in range(world)], axis=0) for p in range(planes)]
     info = (plans[0].path, nex)
+    _run_sharded.has_interior = plans[0].has_interior
     for p in plans:
         p.close()
     return full, got, info
@@ -383,6 +391,66 @@ def test_sharded_3d_z_slabs(world):
     full, got, (path, nex) = _run_sharded((16 * world, 64, 256), scans, False, world, path=0)
     assert path == 3 and nex == 1
     _check(full, got, scans, False)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("clamped", [False, True])
+def test_sharded_3d_early_exchange(world, clamped):
+    """A z-sharded volume on the strided z stage exchanges the z carries of the RAW input (the z operators commute with the
+    x/y filter), runs its x/y stage as the exchange-independent work (rf_plan_interior) and filters the completed carry
+    planes along x/y afterwards (plan_strided.h, "early exchange").  Emulated ranks; against the oracle on the whole
+    volume, and equal within rounding to the late exchange (RF_PLAN_LATE_EXCHANGE: carries of the filtered data).
+    world = 1: one slab built with the exchange structure (RF_PLAN_FORCE_EXCHANGE)."""
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    force = capi.RF_PLAN_FORCE_EXCHANGE if world == 1 else 0
+    for shape, extents, planes in (((32 * world, 64, 256), None, 1), ((64 * world + 64, 40, 516), [128] + [64] * (world - 1), 2)):
+        if extents is not None and world == 1:
+            extents = None
+        full, got, (path, nex) = _run_sharded(shape, scans, clamped, world, path=0, planes=planes, extents=extents, flags=TILED | force)
+        assert path == 3 and nex == 1 and _run_sharded.has_interior, (shape, path, nex)
+        _check(full, got, scans, clamped)
+        # the driver that never calls rf_plan_interior: exchange_apply runs the pending work itself
+        _, lazy, _ = _run_sharded(shape, scans, clamped, world, path=0, planes=planes, extents=extents, flags=TILED | force, interior=False)
+        for a, b in zip(got, lazy):
+            assert np.array_equal(a, b)
+        _, late, _ = _run_sharded(shape, scans, clamped, world, path=0, planes=planes, extents=extents,
+                                  flags=TILED | force | capi.RF_PLAN_LATE_EXCHANGE)
+        assert not _run_sharded.has_interior
+        for a, b in zip(got, late):
+            assert rc.rel_err(a, b.astype(np.float64)) < 1e-5
+    # integer pixels: the ring arithmetic commutes exactly -- bit-exact against the oracle
+    ints = [(0, True, [1.0, 1.0]), (1, True, [1.0, 2.0, -1.0]), (2, True, [1.0, 1.0]), (2, False, [1.0, 1.0, -1.0])]
+    full, got, (path, nex) = _run_sharded((32 * world, 32, 256), ints, False, world, path=0, dtype=np.int32, flags=TILED | force)
+    assert path == 3 and nex == 1 and _run_sharded.has_interior
+    _check(full, got, ints, False)
+    # a prologue is not linear in the carries (its bias): such plans keep the late exchange
+    import recfilter_amd as rfa
+    with rfa.Plan((64, 64, 256), scans, shard_rank=0, shard_world=2, prologue=(0.5, 0.25)) as plan:
+        assert plan.path == 3 and not plan.has_interior
+
+
+@pytest.mark.parametrize("case", ["rows_2d", "rows_2d_int", "generic_2d"])
+def test_forced_exchange_on_one_slab(case):
+    """RF_PLAN_FORCE_EXCHANGE: ONE slab built and driven like one of several -- per-scan launches around the exchange
+    point, exit carries, the gather walk (over one slab: zero entering carries), the correction inside the final pass --
+    gives the plain filter.  What lets a one-GPU box run every call of an N-GPU rank, the RCCL all-gather included
+    (tests/test_dist_gpu.py)."""
+    import torch
+    import recfilter_amd as rfa
+    if case == "rows_2d":
+        shape, scans, clamped, dtype, path = (256, 768), rc.xy_pm(rc.GAUSS2), True, np.float32, 0
+    elif case == "rows_2d_int":
+        shape, scans, clamped, dtype, path = (192, 516), [(0, True, [1.0, 1.0]), (1, True, [1.0, 2.0, -1.0]), (1, False, [1.0, 1.0])], False, np.int32, 0
+    else:
+        shape, scans, clamped, dtype, path = (48, 40), rc.REFERENCE_TESTS["test_generic_xy"]["scans"], False, np.float32, 2
+    full, got, (p, nex) = _run_sharded(shape, scans, clamped, 1, path=path, planes=2, dtype=dtype, tile=[8, 8] if path == 2 else None,
+                                       flags=TILED | capi.RF_PLAN_FORCE_EXCHANGE)
+    assert p == (3 if path == 0 else 2) and nex == 1
+    _check(full, got, scans, clamped)
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, flags=TILED | capi.RF_PLAN_FORCE_EXCHANGE, path=path,
+                  tile=[8, 8] if path == 2 else None) as plan:
+        with pytest.raises(rfa.RecFilterError, match="begin/exchange/finish"):           # insists on the stepping calls
+            plan.execute([torch.zeros(shape, device="cuda", dtype=torch.int32 if dtype == np.int32 else torch.float32)])
 
 
 def test_sharded_generic_path_uneven_scans():
@@ -772,13 +840,34 @@ def test_fused_path_rejects_misaligned_planes():
     with rfa.Plan((n, n), scans, clamped=True, path=2) as plan:          # the generic path has no such requirement
         out = plan.execute([shifted])[0].cpu().numpy()
     assert rc.rel_err(out, oracle.apply_filter(shifted.cpu().numpy().astype(np.float64), scans, True)) < TOL
+    # the line-parallel untiled kernels (what the automatic path picks for an image this small, and path=1) move 16 bytes
+    # per lane as well: same refusal, same message; aligned planes run
+    for kw in (dict(flags=0), dict(path=1)):
+        with rfa.Plan((n, n), scans, clamped=True, **kw) as plan:
+            assert plan.path_name == "untiled"
+            with pytest.raises(rfa.RecFilterError, match="aligned"):
+                plan.execute([shifted])
+            with pytest.raises(rfa.RecFilterError, match="aligned"):
+                plan.execute([aligned], [shifted])
+            out = plan.execute([aligned])[0].cpu().numpy()
+        assert rc.rel_err(out, want) < TOL
+    # an untiled filter the line kernels do not take (a width that is not a multiple of 16) runs one thread per line: any pointer
+    odd = buf[1:1 + 250 * 200].view(200, 250)
+    with rfa.Plan((200, 250), scans, clamped=True, path=1) as plan:
+        out = plan.execute([odd])[0].cpu().numpy()
+    assert rc.rel_err(out, oracle.apply_filter(odd.cpu().numpy().astype(np.float64), scans, True)) < TOL
+    # a cascade whose stages are all line-kernel stages inherits the requirement
+    five = [(0, True, rc.GAUSS2)] * 5
+    with rfa.Plan((n, n), five, flags=0) as plan:
+        with pytest.raises(rfa.RecFilterError, match="aligned"):
+            plan.execute([shifted])
 
 
 # ---- Tuple planes batched into one launch per step (FusedArgs::plane_batch) ------------------------------------------
 @pytest.mark.parametrize("planes,shape,dtype", [(3, (128, 512), np.float32), (5, (75, 464), np.float32),
                                                 (4, (96, 300), np.int32), (16, (64, 256), np.float32)],
                          ids=["rgb", "five_partial", "int_partial", "max_planes"])
-def test_batched_planes_match_the_per_plane_launches(planes, shape, dtype, monkeypatch):
+def test_batched_planes_match_the_per_plane_launches(planes, shape, dtype):
     """All planes of a 2-D filter ride in one launch per step, as the z planes of a volume whose planes are separate
     buffers: same results bit for bit as one launch per plane, the oracle's within tolerance, in place too."""
     import torch
@@ -798,8 +887,8 @@ def test_batched_planes_match_the_per_plane_launches(planes, shape, dtype, monke
         plan.execute(inplace, inplace)
         for a, b in zip(batched, inplace):
             assert np.array_equal(a, b.cpu().numpy())
-    monkeypatch.setenv("RF_NO_PLANE_BATCH", "1")
-    with rfa.Plan(shape, scans, dtype=dtype, clamped=not integer, planes=planes) as plan:
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=not integer, planes=planes,
+                  flags=rfa.capi.RF_PLAN_TILED_ONLY | rfa.capi.RF_PLAN_NO_PLANE_BATCH) as plan:
         single = [o.cpu().numpy() for o in plan.execute(dev)]
     for a, b in zip(batched, single):
         assert np.array_equal(a, b)
@@ -892,10 +981,9 @@ def test_line_parallel_untiled_kernels(dtype, shape, clamped):
         assert [n for n, _ in times] == ["line_scans_" + "xyz"[d] for d in range(nd)]      # one launch per dimension
 
 
-def test_auto_path_sends_small_images_to_the_line_kernels(monkeypatch):
+def test_auto_path_sends_small_images_to_the_line_kernels(shipped_defaults):
     import torch
     import recfilter_amd as rfa
-    monkeypatch.delenv("RF_SMALL_LIMIT", raising=False)          # (tests/conftest.py switches the choice off for the suite)
     scans = rc.xy_pm(rc.GAUSS2)
     for n, want in ((256, 1), (1024, 1), (1536, 3), (2048, 3)):
         with rfa.Plan((n, n), scans, clamped=True) as plan:
@@ -951,11 +1039,11 @@ def test_tap_filter_against_numpy():
 
 # ---- 256 x 128 tiles (kernels_fused_tall.hip): what RF_PATH_AUTO picks for large images of order >= 2, forced here on small ones ----
 @pytest.mark.parametrize("seed", range(10))
-def test_tall_tiles_random_filters_and_shapes(seed, monkeypatch):
+def test_tall_tiles_random_filters_and_shapes(seed, plan_flags):
     """The 128-row final pass (two 64-row halves through the LDS, the column in registers), the 128-row tail extraction and
     the two-block residual: random filters (every y scan pattern, orders 1..3), heights and widths with partial last tiles
     (a last tile row of fewer than 64 rows leaves the second half empty), float against the oracle, integers bit-exact."""
-    monkeypatch.setenv("RF_FUSED_TY", "128")
+    plan_flags(TILED | capi.RF_PLAN_TILE_ROWS(128))
     rng = np.random.default_rng(5100 + seed)
     shape = (int(rng.integers(1, 420)), 4 * int(rng.integers(1, 200)))
     clamped = bool(rng.integers(0, 2))
@@ -975,13 +1063,13 @@ def test_tall_tiles_random_filters_and_shapes(seed, monkeypatch):
     _check(imgs, outs, scans, clamped)
 
 
-def test_tall_tiles_other_features(monkeypatch):
+def test_tall_tiles_other_features(plan_flags):
     """128-row tiles with the rest of the fused path: row shards (the entering carries applied by the final pass, slabs of
     different heights), a 3-D volume with a z stage behind, batched Tuple planes, uint8 input and a pointwise epilogue,
     int16 pixels; and what the automatic choice is."""
     import torch
     import recfilter_amd as rfa
-    monkeypatch.setenv("RF_FUSED_TY", "128")
+    plan_flags(TILED | capi.RF_PLAN_TILE_ROWS(128))
     scans = rc.xy_pm(rc.GAUSS2)
     full, got, (path, nex) = _run_sharded((128 + 384 + 256, 512), scans, True, 3, path=0, planes=2, extents=[128, 384, 256])
     assert path == 3 and nex == 1
@@ -1006,7 +1094,7 @@ def test_tall_tiles_other_features(monkeypatch):
     x = img8.cpu().numpy().astype(np.float64) / 255.0
     want = (1.0 + w) * x - w * oracle.apply_filter(x, scans, True)
     assert np.abs(out - want).max() < 2e-5
-    monkeypatch.delenv("RF_FUSED_TY")
+    plan_flags(TILED)
     for shape, sc, want_ty in (((16384, 8192), scans, 128), ((16384, 8192), rc.xy_pm([1.3, -0.3]), 128), ((2048, 2048), scans, 32),
                                ((8192, 8192), scans, 64), ((16384 + 64, 8192), scans, 64)):
         with rfa.Plan(shape, sc, clamped=True) as plan:
@@ -1133,19 +1221,19 @@ def test_1d_fused_any_length(n):
 
 
 @pytest.mark.parametrize("rows", [1, 2, 65, 130, 8 * 64 + 1, 450])
-def test_last_tile_row_shorter_than_the_order(rows, monkeypatch):
+def test_last_tile_row_shorter_than_the_order(rows, plan_flags):
     """A partial last tile row with FEWER rows than the filter order under a clamped border: the tail the next tile receives
     has entries from before the border, which read the scan's first output (tables.h, tail_position).  Found by
     tools/stress_shapes.py at the end of round 2 (8641 x 5776: 135 tile rows and one row); the bug dated from round 1."""
     scans = [(0, False, [0.5, -0.28, 0.42]), (1, True, [0.98, 0.53]), (1, False, [0.7, 0.23, -0.21, -0.38]),
              (1, False, [0.6, 0.3, 0.2])]
     for clamped in (True, False):
-        for ty in ("64", "32", "128"):
-            monkeypatch.setenv("RF_FUSED_TY", ty)
+        for ty in (64, 32, 128):
+            plan_flags(TILED | capi.RF_PLAN_TILE_ROWS(ty))
             imgs, outs, (path, _) = _run((rows, 516), scans, clamped=clamped, planes=2)
             assert path == 3
             _check(imgs, outs, scans, clamped)
-    monkeypatch.delenv("RF_FUSED_TY")
+    plan_flags(TILED)
     ints = [(1, False, [1.0, 1.0, -1.0, 1.0]), (0, True, [1.0, 1.0])]
     imgs, outs, (path, _) = _run((rows, 260), ints, dtype=np.int32, clamped=True)
     assert path == 3
@@ -1203,7 +1291,7 @@ _CASCADE_CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(_CASCADE_CASES))
-def test_in_plan_cascade(name, monkeypatch):
+def test_in_plan_cascade(name, plan_flags):
     """Filters the fused kernels cannot take in one piece -- more than four scans in a dimension; a zero-padded 1-D signal
     whose anticausal scans follow causal ones -- run as successive stages inside one plan (plan.cpp, build_cascade): stage 0
     reads the input, later stages filter the output planes in place.  Against the oracle on the scans as given."""
@@ -1213,7 +1301,7 @@ def test_in_plan_cascade(name, monkeypatch):
     shape, scans = case["shape"], case["scans"]
     dtype, clamped, planes = case.get("dtype", np.float32), case.get("clamped", False), case.get("planes", 1)
     if case.get("small"):
-        monkeypatch.delenv("RF_SMALL_LIMIT", raising=False)        # (the suite pins the automatic path off the line kernels)
+        plan_flags(0)        # (the shipped defaults: the suite pins the automatic path off the line kernels)
     imgs = [rc.random_image(shape, dtype, 60 + p) for p in range(planes)]
     with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes) as plan:
         dev = [torch.from_numpy(im).cuda() for im in imgs]

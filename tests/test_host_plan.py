@@ -352,12 +352,12 @@ def test_overlapped_path_preconditions():
     assert _host_plan((16, 16, 16), scans).path != capi.RF_PATH_TILED_OVERLAPPED
 
 
-def test_high_order_scans_are_split_into_sections_for_the_fused_path(monkeypatch):
+def test_high_order_scans_are_split_into_sections_for_the_fused_path():
     """Plan rewrite of sections.h, decided on the host: zero border + float pixels + at most four scans per dimension after
     the split -> fused; otherwise the scans run as given on another path."""
     import recfilter_amd as rfa
     from recfilter_amd import capi
-    monkeypatch.setenv("RF_SMALL_LIMIT", "0")
+    T = capi.RF_PLAN_TILED_ONLY
 
     def from_poles(poles, b=0.3):
         p = np.poly(poles).real
@@ -367,6 +367,7 @@ def test_high_order_scans_are_split_into_sections_for_the_fused_path(monkeypatch
     xy = lambda co: [(0, True, co), (0, False, co), (1, True, co), (1, False, co)]
 
     def path_of(scans, **kw):
+        kw.setdefault("flags", T)
         with rfa.Plan((512, 512), scans, device=capi.RF_DEVICE_HOST_ONLY, **kw) as plan:
             return plan.path_name
     assert path_of(xy(o5), clamped=False) == "tiled_fused"                 # 5 = 3 + 2: four scans per dimension
@@ -375,22 +376,20 @@ def test_high_order_scans_are_split_into_sections_for_the_fused_path(monkeypatch
     assert path_of(xy([1.0, 1.0, 0.0, 0.0, 1.0]), clamped=False, dtype=np.int32) != "tiled_fused"     # integer pixels: as given
     assert path_of(xy(o6c), clamped=False) == "tiled_fused"                # three conjugate pairs, twice: six sections per
                                                                            # dimension -> two stages of an in-plan cascade
-    monkeypatch.setenv("RF_NO_CASCADE", "1")
-    assert path_of(xy(o6c), clamped=False) != "tiled_fused"                # (without the cascade: as given, another path)
-    monkeypatch.delenv("RF_NO_CASCADE")
+    assert path_of(xy(o6c), clamped=False, flags=T | capi.RF_PLAN_NO_CASCADE) != "tiled_fused"     # (without the cascade: as given, another path)
     assert path_of([(0, True, o6c), (1, True, o6c)], clamped=False) == "tiled_fused"
-    monkeypatch.setenv("RF_NO_SECTIONS", "1")
-    assert path_of(xy(o5), clamped=False) != "tiled_fused"
+    assert path_of(xy(o5), clamped=False, flags=T | capi.RF_PLAN_NO_SECTIONS) != "tiled_fused"
 
 
-def test_in_plan_cascade_decisions(monkeypatch):
+def test_in_plan_cascade_decisions():
     """More than four scans in a dimension, or a zero-padded 1-D signal whose anticausal scans follow causal ones, run as
     successive fused stages inside one plan (plan.cpp, build_cascade) instead of on the generic path; decided on the host."""
     import recfilter_amd as rfa
     from recfilter_amd import capi
-    monkeypatch.setenv("RF_SMALL_LIMIT", "0")
+    T = capi.RF_PLAN_TILED_ONLY
 
     def plan_of(shape, scans, **kw):
+        kw.setdefault("flags", T)
         return rfa.Plan(shape, scans, device=capi.RF_DEVICE_HOST_ONLY, **kw)
     bq = [0.05, 1.6, -0.7]
     with plan_of((1_000_000,), [(0, True, bq)] * 4) as four, plan_of((1_000_000,), [(0, True, bq)] * 5) as five, \
@@ -411,6 +410,5 @@ def test_in_plan_cascade_decisions(monkeypatch):
     # clamped 1-D signals stay off the fused kernels whatever the split
     with plan_of((100_000,), [(0, True, bq)] * 5, clamped=True) as p:
         assert p.path_name != "tiled_fused"
-    monkeypatch.setenv("RF_NO_CASCADE", "1")
-    with plan_of((1_000_000,), [(0, True, bq)] * 5) as p:
+    with plan_of((1_000_000,), [(0, True, bq)] * 5, flags=T | capi.RF_PLAN_NO_CASCADE) as p:
         assert p.path_name != "tiled_fused"

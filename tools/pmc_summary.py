@@ -34,7 +34,13 @@ def agg(path):
 def main():
     fetch, write, out = sys.argv[1:4]
     fa, wa = agg(fetch), agg(write)
-    res = {"note": __doc__.strip().splitlines()[0], "kernels": {}}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    # kernel_sources_sha16: digest of recfilter_amd/csrc at collection time -- bench.py reports these bytes only while
+    # the running sources have the same digest; git_head is stamped afterwards, where .git exists (tools/stamp_head.py)
+    res = {"note": __doc__.strip().splitlines()[0], "kernel_sources_sha16": bench.kernel_sources_sha16(), "git_head": None,
+           "kernels": {}}
     for k in sorted(fa):
         fs, n = fa[k]
         ws, _ = wa.get(k, (0.0, 0))
