@@ -301,7 +301,8 @@ def main():
     # stepping protocol) times an unsharded plan of the same slab, which has the same kernels.
     def per_kernel_pass():
         own_plan = world == 1 and not stepping
-        plan = filt.plan if own_plan else rfa.Plan(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, path=args.path)
+        # (an unsharded plan on the path the sharded one resolved to: the same kernels)
+        plan = filt.plan if own_plan else rfa.Plan(shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, path=filt.plan.path)
         reps = max(5, min(args.steps, 20))
         preheat = 3 * reps
         acc = {}

@@ -202,13 +202,12 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
                 const Step *sp = steps[i];
                 Step w;
                 w.name = "carry_planes." + sp->name;
-                const bool first = i == 0;
-                w.run = [plan, child, sp, first, tails, chunk_pp](int pl) {
-                    if (first) {        // the helper's context: this plane's run of carry planes, filtered in place
-                        child->in[0] = child->orig_in[0] = tails + (size_t)pl * chunk_pp;
-                        child->out[0] = tails + (size_t)pl * chunk_pp;
-                        child->stream = plan->stream;
-                    }
+                w.run = [plan, child, sp, tails, chunk_pp](int pl) {
+                    // the helper's context: this plane's run of carry planes, filtered in place (set per step: the steps of
+                    // an execute run plane by plane inside every step)
+                    child->in[0] = child->orig_in[0] = tails + (size_t)pl * chunk_pp;
+                    child->out[0] = tails + (size_t)pl * chunk_pp;
+                    child->stream = plan->stream;
                     return sp->run(0);
                 };
                 apply.push_back(w);

@@ -93,6 +93,20 @@ ANCHORS_ALL_ONES = {
     "test_causal_anticausal": (13.24756, 7.571615, 26.47968, 436.836525),
 }
 
+# The apps' own check loops (apps/summed_table/summed_table.cpp:66-84; apps/bspline/bicubic_filter.cpp:109-158 and the
+# identical loops of biquintic_cascaded_filter.cpp:143-190 / biquintic_overlapped_filter.cpp with the apps' coefficients
+# {1+a, -a} and {1+a, -a, 0.1}, a = 2 - sqrt 3), evaluated in float32 as the apps do on a 24 x 32 image: all ones (what the
+# reference's generate_random_image returns) and the exactly representable ramp (x % 7) + 2 (y % 5).  (first, last,
+# centre, sum).  The apps apply +x, +y, -x, -y; the filter is +x, -x, +y, -y -- x and y commute up to rounding.
+APP_ANCHORS = {
+    ("summed_table", "ones"): (1.0, 768.0, 221.0, 158400.0),
+    ("summed_table", "ramp"): (0.0, 5104.0, 1367.0, 1016400.0),
+    ("bicubic", "ones"): (1.0, 1.0, 1.0, 768.0),
+    ("bicubic", "ramp"): (-0.8462355136871338, 9.72153091430664, 5.829268932342529, 5098.764333099127),
+    ("biquintic", "ones"): (1.435629963874817, 1.426071047782898, 1.3890289068222046, 1068.92553794384),
+    ("biquintic", "ramp"): (-0.17553919553756714, 13.785110473632812, 7.76296329498291, 7105.855566650629),
+}
+
 # Coefficient known answers, values of the reference's iir_coeff.cpp quoted in
 # SURVEY.md section 8 (a-14).
 GAUSS_SIGMA5 = {

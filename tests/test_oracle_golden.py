@@ -69,6 +69,82 @@ def test_clamped_app_loops(coeff):
     assert rc.rel_err(got, want) < 5e-5   # scan order differs (x/y commute up to rounding)
 
 
+@pytest.mark.parametrize("app,image", sorted(rc.APP_ANCHORS))
+def test_app_check_loop_anchors(app, image):
+    """The apps' own check loops as anchors (ref_cases.APP_ANCHORS): the oracle on the apps' filters and the stored values
+    of those loops; the loops themselves (ref_loops.py) are re-run as well, so a drift of either side shows."""
+    yy, xx = np.mgrid[0:24, 0:32]
+    img = np.ones((24, 32), np.float32) if image == "ones" else ((xx % 7) + 2 * (yy % 5)).astype(np.float32)
+    if app == "summed_table":
+        scans, clamped = rc.BASELINE_CONFIGS["cfg2_summed_table"]["scans"], False
+        loops = ref_loops.summed_table_loops(img)
+    else:
+        coeff = list(rc.BICUBIC_COEFF) + ([0.1] if app == "biquintic" else [])     # biquintic_cascaded_filter.cpp:48
+        scans, clamped = rc.xy_pm(coeff), True
+        loops = ref_loops.clamped_xy_loops(img, coeff)
+    want = rc.APP_ANCHORS[(app, image)]
+    np.testing.assert_allclose(_anchors(loops), want, rtol=1e-6, atol=1e-6)
+    got = oracle.apply_filter(img, scans, clamped)
+    np.testing.assert_allclose(_anchors(got), want, rtol=2e-5, atol=2e-5)
+    assert rc.rel_err(got, loops) < 5e-5
+
+
+def _lfilter_scan(x, causal, coeff):
+    """One zero-border scan y[i] = b x[i] + sum_j a_j y[i -/+ (j+1)] with scipy.signal.lfilter: transfer function
+    b / (1 - a_1 z^-1 - ... - a_k z^-k), anticausal = the causal filter on the flipped line."""
+    from scipy.signal import lfilter
+    b, a = [float(coeff[0])], [1.0] + [-float(c) for c in coeff[1:]]
+    return lfilter(b, a, x, axis=-1) if causal else lfilter(b, a, x[..., ::-1], axis=-1)[..., ::-1]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_zero_border_scans_against_scipy_lfilter(seed):
+    """An implementation nobody here wrote: scipy.signal.lfilter (direct-form IIR, zero initial state) is the reference's
+    zero-border scan (lib/recfilter.cpp:337-340: taps before the border contribute 0).  Random f64 lines, orders 1..6,
+    causal and anticausal, scans chained in place as add_filter chains them, along x and along y."""
+    rng = np.random.default_rng(9000 + seed)
+    img = rng.standard_normal((int(rng.integers(1, 9)), int(rng.integers(1, 200))))
+    scans, want = [], img.copy()
+    for _ in range(int(rng.integers(1, 6))):
+        k = int(rng.integers(1, 7))
+        poles = rng.uniform(-0.85, 0.85, size=k)
+        coeff = [float(rng.uniform(0.2, 1.5))] + [float(-c) for c in np.poly(poles)[1:]]      # stable: poles inside the unit circle
+        dim, causal = int(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        scans.append((dim, causal, coeff))
+        if dim == 0:
+            want = _lfilter_scan(want, causal, coeff)
+        else:
+            want = _lfilter_scan(want.T, causal, coeff).T
+    # (f64 pixels: the oracle keeps the coefficients as the C ABI delivers them, float32 -- so does the comparison)
+    scans32 = [(d, c, [float(np.float32(v)) for v in co]) for d, c, co in scans]
+    want32 = img.copy()
+    for d, c, co in scans32:
+        want32 = _lfilter_scan(want32, c, co) if d == 0 else _lfilter_scan(want32.T, c, co).T
+    got = oracle.apply_filter(img, scans32, clamped=False)
+    assert np.max(np.abs(got - want32)) <= 1e-9 * max(1.0, float(np.max(np.abs(want32))))
+
+
+def test_clamped_scan_against_lfilter_with_initial_state():
+    """The clamped border (lib/recfilter.cpp:330-336) through lfilter as well: the scan reads the partially updated
+    buffer, so at r = 0 every tap reads the old f[0] -- y[0] = (b + sum a) x[0] -- and from r = 1 on the taps beyond the
+    border read y[0].  That is lfilter on x[1:] with the initial condition "all previous outputs equal y[0]"."""
+    from scipy.signal import lfilter, lfiltic
+    rng = np.random.default_rng(77)
+    for k in (1, 2, 3):
+        coeff = [0.4] + [float(-c) for c in np.poly(rng.uniform(-0.8, 0.8, size=k))[1:]]
+        coeff = [float(np.float32(v)) for v in coeff]
+        x = rng.standard_normal(150)
+        b, a = [coeff[0]], [1.0] + [-c for c in coeff[1:]]
+        y0 = (coeff[0] + sum(coeff[1:])) * x[0]
+        zi = lfiltic(b, a, y=[y0] * k)
+        rest, _ = lfilter(b, a, x[1:], zi=zi)
+        want = np.concatenate([[y0], rest])
+        got = oracle.apply_filter(x, [(0, True, coeff)], clamped=True)
+        assert np.max(np.abs(got - want)) < 1e-10
+        got_rev = oracle.apply_filter(x[::-1].copy(), [(0, False, coeff)], clamped=True)
+        assert np.max(np.abs(got_rev[::-1] - want)) < 1e-10
+
+
 def test_clamped_constant_is_fixed_point():
     # any clamped filter with b + sum(a) = 1 maps constants to themselves (SURVEY 8c)
     img = np.full((16, 32), 3.0, dtype=np.float64)
