@@ -40,7 +40,8 @@ int set_context(rf_plan *plan, const void *const *in_planes, void *const *out_pl
             return RF_ERR_INVALID_ARG;
         }
         // the fused kernels and the line-parallel untiled kernels move 16 bytes per lane (4 for unsigned-byte input planes)
-        if (plan->vector_access) {
+        // (an image whose width is not a multiple of 4 has element-aligned rows anyway: any element-aligned plane)
+        if (plan->vector_access && !(plan->path == RF_PATH_TILED_FUSED && plan->ndim >= 2 && plan->dims[0].N % 4 != 0)) {
             const uintptr_t in_mask = plan->pw.in_u8 ? 3u : 15u;
             if (((uintptr_t)in_planes[pl] & in_mask) != 0 || ((uintptr_t)out_planes[pl] & 15u) != 0) {
                 set_error("plane %d: this plan's kernels (%s) need 16-byte aligned image pointers (4-byte for uint8 inputs)", pl,

@@ -49,7 +49,7 @@ struct FusedArgs {
     int64_t NXP;             // MX * 256: pitch of the y tails / y carries (the last tile of a row may be partial)
     int32_t MX, MY;          // tiles along x / y
     int32_t last_lane;       // x phase: lane holding the last existing segment of a row's last tile (15 when full)
-    int32_t last_cols;       // columns that exist in a row's last tile (256 when full; a multiple of 4)
+    int32_t last_cols;       // columns that exist in a row's last tile (256 when full; any number for 4- and 8-byte pixels)
     uint32_t row_bytes;      // NX * sizeof(pixel): image pitch in bytes, for 32-bit offset arithmetic inside a tile
     int64_t NYP;             // MY * TY: pitch of the x tails / x carries (the last tile row may be partial)
     int32_t last_rows;       // rows that exist in the last tile row (TY when full)

@@ -162,6 +162,10 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         auto ld_head = [&](int row, int n) { return load_chunk_head<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), n); };
         A4 tmp[TY / 4];
         const bool chunk_in = 4 * cc < last_cols;            // this thread's 16-byte chunk exists in the image
+        // ... and when the width is not a multiple of 4 the last of them is partial (tile-uniform flag; scan_device.h)
+        const bool odd_cols = (last_cols & 3) != 0;
+        const int cols_valid = last_cols - 4 * cc;
+        auto ld_cols = [&](int row) { return load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), cols_valid); };
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
         // a folded 1-D signal that ends inside or before this tile (FusedArgs::lin_limit): zeros from its end on
         const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;
@@ -172,6 +176,9 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                 // (the one chunk the end falls into is loaded sample by sample: nothing behind the end is read)
                 tmp[i] = idx + 3 < a.lin_limit ? ld(4 * i) : idx < a.lin_limit ? ld_head(4 * i, (int)(a.lin_limit - idx)) : zero4;
             }
+        } else if (odd_cols) {
+#pragma unroll
+            for (int i = 0; i < TY / 4; i++) tmp[i] = rg + 4 * i < rows_here ? ld_cols(4 * i) : zero4;
         } else if (rows_here == TY) {
 #pragma unroll
             for (int i = 0; i < TY / 4; i++) tmp[i] = chunk_in ? ld(4 * i) : zero4;
@@ -189,6 +196,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
                     const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
                     tmp[i].x = s * tmp[i].x + b; tmp[i].y = s * tmp[i].y + b;
                     tmp[i].z = s * tmp[i].z + b; tmp[i].w = s * tmp[i].w + b;
+                    if (odd_cols) clear_dead_cols<A4, Acc>(tmp[i], cols_valid);
                 }
             }
         }

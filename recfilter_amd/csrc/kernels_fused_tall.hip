@@ -108,6 +108,9 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
     const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
     const bool chunk_in = 4 * cc < last_cols;
+    // ... and when the width is not a multiple of 4 the last of them is partial (tile-uniform flag; scan_device.h)
+    const bool odd_cols = EDGE && (last_cols & 3) != 0;
+    const int cols_valid = last_cols - 4 * cc;
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
 
     Acc col[TY];              // this thread's column, all 128 rows
@@ -164,7 +167,8 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
         for (int i = 0; i < TL / 4; i++) {
             const int row = TL * h + rg + 4 * i;
             const bool in = chunk_in && (!EDGE || row < rows_here);
-            tmp[h][i] = in ? load_chunk<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes)) : zero4;
+            if (odd_cols) tmp[h][i] = in ? load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes), cols_valid) : zero4;
+            else tmp[h][i] = in ? load_chunk<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes)) : zero4;
         }
     };
 
@@ -190,6 +194,7 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                     const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
                     tmp[h][i].x = s * tmp[h][i].x + b; tmp[h][i].y = s * tmp[h][i].y + b;
                     tmp[h][i].z = s * tmp[h][i].z + b; tmp[h][i].w = s * tmp[h][i].w + b;
+                    if (odd_cols) clear_dead_cols<A4, Acc>(tmp[h][i], cols_valid);
                 }
             }
         }

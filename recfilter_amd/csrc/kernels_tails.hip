@@ -72,6 +72,10 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const int64_t Lx = a.NYP * a.NZ;
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (4 * cc < a.last_cols);
+    // ... and when the width is not a multiple of 4 the last of them is partial (tile-uniform flag; scan_device.h)
+    const bool odd_cols = tx == a.MX - 1 && (a.last_cols & 3) != 0;
+    const int cols_valid = a.last_cols - 4 * cc;
+    auto ld_cols = [&](int row) { return load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), cols_valid); };
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
 
     Acc comb[kFusedMaxScans * K];
@@ -96,7 +100,10 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
             }
             return;
         }
-        if (rows_here == TY) {
+        if (odd_cols) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) pre[i] = r0 + 4 * i < rows_here ? ld_cols(kTailRows * half + 4 * i) : zero4;
+        } else if (rows_here == TY) {
 #pragma unroll
             for (int i = 0; i < NL; i++) pre[i] = chunk_in ? ld(kTailRows * half + 4 * i) : zero4;
         } else {
@@ -125,6 +132,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
                     const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
                     pre[i].x = s * pre[i].x + b; pre[i].y = s * pre[i].y + b;
                     pre[i].z = s * pre[i].z + b; pre[i].w = s * pre[i].w + b;
+                    if (odd_cols) clear_dead_cols<A4, Acc>(pre[i], cols_valid);
                 }
             }
         }

@@ -588,7 +588,11 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
         return true;
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
-    if (plan->dims[0].N % 4 != 0) return no("width must be a multiple of 4 (16-byte rows)");
+    // rows of 4- and 8-byte pixels only have to be element-aligned: a width that is not a multiple of 4 ends every row in a
+    // partial chunk, loaded sample by sample (scan_device.h, load_chunk_cols); 2-byte pixels and unsigned-byte inputs are
+    // moved in 8- and 4-byte pieces and keep the rule
+    if (plan->dims[0].N % 4 != 0 && (plan->dtype == RF_I16 || plan->pw.in_u8))
+        return no("int16 pixels / uint8 inputs: width must be a multiple of 4");
     if (plan->ndim == 2 && plan->sharded() && plan->shard_common % 32 != 0)
         return no("row-sharded slabs must be whole tiles (height a multiple of 32)");
     const int K = fused_order(plan);

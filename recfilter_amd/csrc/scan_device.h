@@ -303,5 +303,25 @@ __device__ __forceinline__ typename Vec4<Acc>::type load_chunk_head(const char *
     return v;
 }
 
+// A chunk of a row's LAST tile when the image width is not a multiple of 4: `valid` of its four samples exist
+// (<= 0: none, zeros; >= 4: all).  The samples behind a row's end belong to the next row (or lie behind the plane),
+// so a partial chunk is loaded sample by sample.  Rows of such an image are only element-aligned: the 16-byte loads of the
+// full chunks are dword-aligned accesses, which global memory instructions take.
+template <typename PI, typename Acc>
+__device__ __forceinline__ typename Vec4<Acc>::type load_chunk_cols(const char *p, int valid) {
+    using A4 = typename Vec4<Acc>::type;
+    if (valid >= 4) return load_chunk<PI, Acc>(p);
+    if (valid <= 0) return A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+    return load_chunk_head<PI, Acc>(p, valid);
+}
+// ... and after a prologue with a bias its samples that do not exist are zeros again
+template <typename A4, typename Acc>
+__device__ __forceinline__ void clear_dead_cols(A4 &v, int valid) {
+    if (valid < 4) v.w = Acc(0);
+    if (valid < 3) v.z = Acc(0);
+    if (valid < 2) v.y = Acc(0);
+    if (valid < 1) v.x = Acc(0);
+}
+
 }  // namespace
 }  // namespace rf

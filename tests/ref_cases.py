@@ -175,6 +175,14 @@ FUSED_CASES = {
     "partial_w4_mixed_zero": dict(shape=(33, 20), scans=REFERENCE_TESTS["test_generic_xy"]["scans"], clamped=False),
     "partial_w4_x_scans": dict(shape=(32, 268), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.6, 0.3]),
                                                        (0, True, [0.9, 0.05]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
+    # widths that are not multiples of 4: rows are only element-aligned and end in a partial 16-byte chunk
+    "odd_w_gauss2_clamped": dict(shape=(64, 301), scans=xy_pm(GAUSS2), clamped=True),
+    "odd_w_gauss3_clamped": dict(shape=(50, 1001), scans=xy_pm(GAUSS3), clamped=True),
+    "odd_w_mixed_zero": dict(shape=(33, 21), scans=REFERENCE_TESTS["test_generic_xy"]["scans"], clamped=False),
+    "odd_w_x_scans": dict(shape=(32, 270), scans=[(0, True, [0.5, 0.4, -0.1]), (0, False, [0.6, 0.3]),
+                                                  (0, True, [0.9, 0.05]), (0, False, [0.5, 0.4, -0.1])], clamped=True),
+    "odd_w_one_past_a_tile": dict(shape=(70, 257), scans=xy_pm(GAUSS2), clamped=True),
+    "odd_w_tiny": dict(shape=(3, 1), scans=xy_pm(GAUSS2), clamped=True),
     # heights that are not multiples of 32: the last tile row is partial
     "partial_y_gauss2_clamped": dict(shape=(100, 512), scans=xy_pm(GAUSS2), clamped=True),
     "partial_xy_gauss3_clamped": dict(shape=(135, 240), scans=xy_pm(GAUSS3), clamped=True),

@@ -863,6 +863,69 @@ def test_fused_path_rejects_misaligned_planes():
             plan.execute([shifted])
 
 
+# ---- widths that are not multiples of 4: element-aligned rows, a partial chunk at every row's end ----------------------
+@pytest.mark.parametrize("seed", range(16))
+def test_fused_odd_widths_random(seed):
+    """Any width on the fused kernels for 4- and 8-byte pixels (the reference only asks that the tile divide the extent,
+    lib/recfilter.h:311): random filters, shapes, pixel types, planes; 64- and 128-row tiles; in place; a plane that is
+    only element-aligned (rows of such an image are not 16-byte aligned anyway)."""
+    import torch
+    import recfilter_amd as rfa
+    rng = np.random.default_rng(8800 + seed)
+    shape = (int(rng.integers(1, 300)), int(rng.integers(1, 1100)) | 1 if seed % 2 else int(rng.integers(1, 1100)))
+    if shape[1] % 4 == 0:
+        shape = (shape[0], shape[1] + int(rng.integers(1, 4)))
+    clamped = bool(rng.integers(0, 2))
+    dtype = [np.float32, np.float32, np.int32, np.float64][seed % 4]
+    if dtype == np.int32:
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(1, 4))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.integers(1, 3))] + [float(rng.integers(-2, 3)) for _ in range(k)]))
+    else:
+        scans = _random_filter(rng, 2)
+    flags = TILED | (capi.RF_PLAN_TILE_ROWS(128) if seed % 3 == 0 and dtype == np.float32 else 0)
+    planes = 1 + seed % 3
+    imgs, outs, (path, tiles) = _run(shape, scans, dtype=dtype, clamped=clamped, planes=planes, seed=seed, flags=flags, inplace=bool(seed % 2))
+    assert path == 3, (shape, dtype)
+    _check(imgs, outs, scans, clamped)
+    if dtype == np.float32:
+        # an element-aligned plane (4 bytes off a 16-byte boundary), prologue + epilogue
+        n = shape[0] * shape[1]
+        buf = torch.rand(n + 8, device="cuda")
+        view = buf[1:1 + n].view(shape)
+        pre, post = (0.5, 0.25), (-0.7, 1.7, 0.1)
+        with rfa.Plan(shape, scans, clamped=clamped, prologue=pre, epilogue=post) as plan:
+            assert plan.path == 3
+            out = plan.execute([view])[0].cpu().numpy()
+        x = view.cpu().numpy().astype(np.float64) * pre[0] + pre[1]
+        want = post[0] * oracle.apply_filter(x, scans, clamped) + post[1] * x + post[2]
+        assert rc.rel_err(out, want) < TOL
+
+
+def test_fused_odd_widths_other_features():
+    """Odd widths with the rest of the fused path: a volume with a z stage, row shards, Tuple planes of order 3; int16 pixels
+    and uint8 inputs keep the multiple-of-4 rule (they are moved in 8- and 4-byte pieces)."""
+    import torch
+    import recfilter_amd as rfa
+    s3 = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    imgs, outs, (path, _) = _run((40, 50, 263), s3, clamped=False)
+    assert path == 3
+    _check(imgs, outs, s3, False)
+    scans = rc.xy_pm(rc.GAUSS3)
+    imgs, outs, (path, _) = _run((200, 1027), scans, clamped=True, planes=3)
+    assert path == 3
+    _check(imgs, outs, scans, True)
+    full, got, (path, nex) = _run_sharded((64 + 128 + 64, 517), rc.xy_pm(rc.GAUSS2), True, 3, path=0, planes=2, extents=[64, 128, 64])
+    assert path == 3 and nex == 1
+    _check(full, got, rc.xy_pm(rc.GAUSS2), True)
+    with rfa.Plan((64, 301), [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], dtype=np.int16) as plan:
+        assert plan.path != 3
+    with pytest.raises(rfa.RecFilterError):
+        rfa.Plan((64, 301), rc.xy_pm(rc.GAUSS2), input_dtype=np.uint8, path=3)
+
+
 # ---- Tuple planes batched into one launch per step (FusedArgs::plane_batch) ------------------------------------------
 @pytest.mark.parametrize("planes,shape,dtype", [(3, (128, 512), np.float32), (5, (75, 464), np.float32),
                                                 (4, (96, 300), np.int32), (16, (64, 256), np.float32)],

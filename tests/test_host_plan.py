@@ -220,10 +220,15 @@ def test_fused_plan_tables_reproduce_oracle(name):
 
 
 def test_fused_not_applicable_falls_back_in_auto_mode():
-    p = _host_plan((100, 302), rc.xy_pm(rc.GAUSS2), clamped=True)       # width not a multiple of 4: rows not 16-byte aligned
+    # a width that is not a multiple of 4: fused for 4- and 8-byte pixels (rows end in a partial chunk); int16 pixels are
+    # moved in 8-byte pieces and keep the rule
+    p = _host_plan((100, 302), rc.xy_pm(rc.GAUSS2), clamped=True)
+    assert p.path == capi.RF_PATH_TILED_FUSED
+    ints = [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])]
+    p = _host_plan((100, 302), ints, dtype=np.int16)
     assert p.path == capi.RF_PATH_TILED_GENERIC
     with pytest.raises(rfa.RecFilterError) as e:
-        _host_plan((100, 302), rc.xy_pm(rc.GAUSS2), clamped=True, path=capi.RF_PATH_TILED_FUSED)
+        _host_plan((100, 302), ints, dtype=np.int16, path=capi.RF_PATH_TILED_FUSED)
     assert e.value.status == capi.RF_ERR_UNSUPPORTED
     p = _host_plan((64, 512), rc.xy_pm(rc.GAUSS2), clamped=True)
     assert p.path == capi.RF_PATH_TILED_FUSED
@@ -283,9 +288,10 @@ def test_unsigned_byte_input_planes_are_a_prologue():
     plain = _host_plan((64, 256), scans, clamped=True)
     u8 = _host_plan((64, 256), scans, clamped=True, input_dtype=np.uint8, prologue=(1 / 255.0, 0.0))
     assert u8.path_name == "tiled_fused" and u8.num_kernels == plain.num_kernels
-    gen = _host_plan((64, 250), scans, clamped=True)
+    # (a width that is not a multiple of 4: uint8 inputs are moved in 4-byte pieces and leave the fused kernels)
+    gen = _host_plan((64, 250), scans, clamped=True, path=capi.RF_PATH_TILED_GENERIC)
     gen_u8 = _host_plan((64, 250), scans, clamped=True, input_dtype=np.uint8)
-    assert gen.path_name == "tiled_generic" and gen_u8.num_kernels == gen.num_kernels + 1
+    assert gen_u8.path_name == "tiled_generic" and gen_u8.num_kernels == gen.num_kernels + 1
 
 
 def test_second_order_sections_reproduce_the_scan():
