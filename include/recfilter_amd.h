@@ -171,6 +171,8 @@ int rf_plan_destroy(rf_plan *plan);
 
 /* bytes of device workspace the plan allocated for tails/carries (owned by the plan) */
 size_t rf_plan_workspace_bytes(const rf_plan *plan);
+/* execution instances the plan holds right now: 1 + the replicas concurrent executes made it build (see rf_plan_execute) */
+int rf_plan_num_instances(rf_plan *plan);
 /* which rf_path the plan resolved to, and the tile widths it uses (0 for an untiled dim) */
 int rf_plan_path(const rf_plan *plan);
 int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]);
@@ -178,12 +180,15 @@ int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]);
 int rf_plan_num_kernels(const rf_plan *plan);
 
 /* ---- execution (replaces Func::realize) --------------------------------------------------- */
-/* One execution in flight per plan: a plan owns ONE tail/carry workspace and keeps the per-execute context (plane
- * pointers, stream, stepping phase) inside the handle, so two executes of the same plan may only overlap when the
- * second is enqueued on the SAME stream (stream order then separates them).  To run executions concurrently -- on
- * different streams or from different host threads -- create one plan per stream; plans are cheap (tables are a few
- * hundred KB, the workspace ~8 % of one image) and independent.  recfilter_amd.dist.ShardedFilter(inflight=D) does
- * exactly that.  The C entry points are not re-entrant per plan; distinct plans may be used from distinct threads.
+/* Concurrent executions.  A plan is a description plus tables (immutable after rf_plan_create); an EXECUTION needs a
+ * tail/carry workspace and a context (plane pointers, stream, stepping phase).  The plan holds one of each; an execute
+ * that arrives on another stream while the previous one may still be in flight runs on a replica of the plan -- the same
+ * description built again, with its own workspace (~8 % of one image) -- created on first need and kept for later
+ * executes; an execute finds the instance that last ran on its stream (stream order separates the two), else one whose
+ * last execution has finished (hipEventQuery), else builds a replica.  So rf_plan_execute may be called on distinct
+ * streams, and from distinct host threads, without the executions waiting for one another (the call that builds a replica
+ * synchronises the device once).  rf_plan_workspace_bytes reports one instance.  The stepping calls below belong to the
+ * host thread that called rf_plan_begin, until its rf_plan_finish.
  *
  * in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan whose kernels
  * move 16 bytes per lane -- the fused path (rf_plan_path() == RF_PATH_TILED_FUSED) and the line-parallel untiled

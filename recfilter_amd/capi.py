@@ -46,7 +46,7 @@ PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
 
 # every symbol include/recfilter_amd.h declares
 EXPORTED_SYMBOLS = [
-    "rf_plan_create", "rf_plan_destroy", "rf_plan_workspace_bytes", "rf_plan_path", "rf_plan_tiles",
+    "rf_plan_create", "rf_plan_destroy", "rf_plan_workspace_bytes", "rf_plan_num_instances", "rf_plan_path", "rf_plan_tiles",
     "rf_plan_num_kernels", "rf_plan_execute", "rf_plan_execute_timed", "rf_plan_num_exchanges",
     "rf_plan_exchange_bytes",
     "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_has_interior", "rf_plan_interior", "rf_plan_finish",
@@ -119,6 +119,7 @@ def lib() -> ctypes.CDLL:
     L.rf_plan_destroy.argtypes = [vp]
     L.rf_plan_workspace_bytes.argtypes = [vp]
     L.rf_plan_workspace_bytes.restype = ctypes.c_size_t
+    L.rf_plan_num_instances.argtypes = [vp]
     L.rf_plan_path.argtypes = [vp]
     L.rf_plan_tiles.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.rf_plan_num_kernels.argtypes = [vp]

@@ -70,6 +70,55 @@ std::vector<const Step *> flat_steps(const rf_plan *plan) {
     return v;
 }
 
+// ---- concurrent executions -------------------------------------------------------------------------------------------
+// The instance of `plan` an execution on `stream` runs on, with its enqueue lock held (plan.h): the instance that last ran
+// on this stream (stream order separates the two executions); else one whose last execution has finished; else a new
+// replica.  release_instance() records the completion event and drops the lock.
+rf_plan *acquire_instance(rf_plan *plan, hipStream_t stream) {
+    if (plan->host_only) { plan->enqueue_mu.lock(); return plan; }
+    std::unique_lock<std::mutex> pool(plan->pool_mu);
+    std::vector<rf_plan *> all{plan};
+    for (auto &r : plan->replicas) all.push_back(r.get());
+    for (rf_plan *inst : all)
+        if (inst->used && inst->last_stream == stream) {
+            pool.unlock();
+            inst->enqueue_mu.lock();             // (another host thread may be enqueueing on it: behind that one)
+            return inst;
+        }
+    for (rf_plan *inst : all) {
+        const bool idle = !inst->used || inst->done == nullptr || hipEventQuery(inst->done) == hipSuccess;
+        if (idle && inst->enqueue_mu.try_lock()) { inst->used = true; inst->last_stream = stream; return inst; }
+    }
+    (void)hipGetLastError();                     // (hipEventQuery reports "not ready" as an error code)
+    rf_filter_desc d = plan->saved.d;
+    d.scans = plan->saved.scans.data();
+    d.shard_extents = plan->saved.extents.empty() ? nullptr : plan->saved.extents.data();
+    d.device = plan->device;
+    rf_plan *fresh = nullptr;
+    if (build_plan(&d, &fresh) != RF_OK) return nullptr;
+    fresh->used = true;
+    fresh->last_stream = stream;
+    fresh->enqueue_mu.lock();
+    plan->replicas.emplace_back(fresh);
+    return fresh;
+}
+
+void release_instance(rf_plan *inst, bool ran) {
+    if (ran && !inst->host_only) {
+        if (inst->done == nullptr && hipEventCreateWithFlags(&inst->done, hipEventDisableTiming) != hipSuccess) inst->done = nullptr;
+        if (inst->done != nullptr) (void)hipEventRecord(inst->done, inst->stream);
+    }
+    inst->enqueue_mu.unlock();
+}
+
+// stepping API: the instance rf_plan_begin acquired on this host thread, until rf_plan_finish
+thread_local std::map<const rf_plan *, rf_plan *> g_stepping;
+
+rf_plan *stepping_instance(rf_plan *plan) {
+    auto it = g_stepping.find(plan);
+    return it == g_stepping.end() ? nullptr : it->second;
+}
+
 // the exchange-independent work of this execute, if the caller has not asked for it yet
 int run_pending_interior(rf_plan *plan) {
     if (!plan->interior_pending) return RF_OK;
@@ -95,6 +144,11 @@ int rf_plan_destroy(rf_plan *plan) {
 }
 
 size_t rf_plan_workspace_bytes(const rf_plan *plan) { return plan ? plan->workspace_bytes : 0; }
+int rf_plan_num_instances(rf_plan *plan) {
+    if (!plan) return 0;
+    std::lock_guard<std::mutex> pool(plan->pool_mu);
+    return 1 + (int)plan->replicas.size();
+}
 int rf_plan_path(const rf_plan *plan) { return plan ? plan->path : -1; }
 
 int rf_plan_tiles(const rf_plan *plan, int32_t tile_out[RF_MAX_DIMS]) {
@@ -107,32 +161,47 @@ int rf_plan_num_kernels(const rf_plan *plan) { return plan ? (int)flat_steps(pla
 int rf_plan_num_exchanges(const rf_plan *plan) { return plan ? (int)plan->exchanges.size() : 0; }
 
 int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
-    int rc = set_context(plan, in_planes, out_planes, stream);
-    if (rc) return rc;
+    if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
     if (plan->sharded()) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
-    for (auto &ex : plan->exchanges) ex.send = ex.scratch;
-    for (const Step *st : flat_steps(plan))
-        for (int pl = 0; pl < plan->n_planes; pl++)
-            if ((rc = st->run(pl)) != RF_OK) return rc;
-    return RF_OK;
+    rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
+    if (!inst) return RF_ERR_NOMEM;
+    int rc = set_context(inst, in_planes, out_planes, stream);
+    if (rc == RF_OK) {
+        for (auto &ex : inst->exchanges) ex.send = ex.scratch;
+        for (const Step *st : flat_steps(inst)) {
+            for (int pl = 0; pl < inst->n_planes && rc == RF_OK; pl++) rc = st->run(pl);
+            if (rc != RF_OK) break;
+        }
+    }
+    release_instance(inst, rc == RF_OK);
+    return rc;
 }
 
 int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream,
                           float *ms_out, const char **names_out, int capacity) {
-    int rc = set_context(plan, in_planes, out_planes, stream);
-    if (rc) return rc;
+    if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
     if (plan->sharded()) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
-    for (auto &ex : plan->exchanges) ex.send = ex.scratch;
-    auto steps = flat_steps(plan);
+    rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
+    if (!inst) return RF_ERR_NOMEM;
+    struct Release {
+        rf_plan *inst; bool ran = false;
+        ~Release() { release_instance(inst, ran); }
+    } guard{inst};
+    int rc = set_context(inst, in_planes, out_planes, stream);
+    if (rc) return rc;
+    for (auto &ex : inst->exchanges) ex.send = ex.scratch;
+    auto steps = flat_steps(inst);
     if (capacity < (int)steps.size() || !ms_out) { set_error("ms_out too small: need %zu", steps.size()); return RF_ERR_INVALID_ARG; }
     // events are destroyed on every return path; outputs are fully written even when a step fails
     struct Events {
         std::vector<hipEvent_t> ev;
         ~Events() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
     } events;
+    // (names: the primary's steps have the same names and live as long as the plan)
+    auto names = flat_steps(plan);
     for (size_t i = 0; i < steps.size(); i++) {
         ms_out[i] = 0.0f;
-        if (names_out) names_out[i] = steps[i]->name.c_str();
+        if (names_out) names_out[i] = names[i]->name.c_str();
     }
     for (size_t i = 0; i < steps.size() + 1; i++) {
         hipEvent_t e;
@@ -140,10 +209,11 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
         events.ev.push_back(e);
     }
     std::vector<hipEvent_t> &ev = events.ev;
-    RF_HIP_CHECK(hipEventRecord(ev[0], plan->stream));
+    RF_HIP_CHECK(hipEventRecord(ev[0], inst->stream));
+    guard.ran = true;
     for (size_t i = 0; i < steps.size() && rc == RF_OK; i++) {
-        for (int pl = 0; pl < plan->n_planes && rc == RF_OK; pl++) rc = steps[i]->run(pl);
-        if (rc == RF_OK && hipEventRecord(ev[i + 1], plan->stream) != hipSuccess) rc = RF_ERR_HIP;
+        for (int pl = 0; pl < inst->n_planes && rc == RF_OK; pl++) rc = steps[i]->run(pl);
+        if (rc == RF_OK && hipEventRecord(ev[i + 1], inst->stream) != hipSuccess) rc = RF_ERR_HIP;
     }
     if (rc == RF_OK && hipEventSynchronize(ev.back()) != hipSuccess) rc = RF_ERR_HIP;
     for (size_t i = 0; i < steps.size() && rc == RF_OK; i++)
@@ -153,19 +223,25 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
 }
 
 int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
-    int rc = set_context(plan, in_planes, out_planes, stream);
-    if (rc) return rc;
-    rc = run_steps(plan, plan->begin_steps);
-    plan->phase = rc == RF_OK ? 1 : 0;
-    plan->interior_pending = rc == RF_OK && !plan->interior_steps.empty();
-    return rc;
+    if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    if (stepping_instance(plan) != nullptr) { set_error("rf_plan_begin: the previous execute of this thread was not finished"); return RF_ERR_STATE; }
+    rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
+    if (!inst) return RF_ERR_NOMEM;
+    int rc = set_context(inst, in_planes, out_planes, stream);
+    if (rc == RF_OK) rc = run_steps(inst, inst->begin_steps);
+    if (rc != RF_OK) { release_instance(inst, false); return rc; }
+    inst->phase = 1;
+    inst->interior_pending = !inst->interior_steps.empty();
+    g_stepping[plan] = inst;            // held (enqueue lock included) until rf_plan_finish on this thread
+    return RF_OK;
 }
 
 int rf_plan_has_interior(const rf_plan *plan) { return plan && !plan->interior_steps.empty() ? 1 : 0; }
 
 int rf_plan_interior(rf_plan *plan) {
-    if (!plan || plan->phase != 1) { set_error("rf_plan_interior before rf_plan_begin"); return RF_ERR_STATE; }
-    return run_pending_interior(plan);
+    rf_plan *inst = plan ? stepping_instance(plan) : nullptr;
+    if (!inst || inst->phase != 1) { set_error("rf_plan_interior before rf_plan_begin"); return RF_ERR_STATE; }
+    return run_pending_interior(inst);
 }
 
 size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange) {
@@ -174,31 +250,36 @@ size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange) {
 }
 
 int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send) {
-    if (!plan || plan->phase != 1) { set_error("rf_plan_exchange_local before rf_plan_begin"); return RF_ERR_STATE; }
-    if (exchange < 0 || exchange >= (int)plan->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
-    if (!send && plan->sharded()) { set_error("null send buffer"); return RF_ERR_INVALID_ARG; }
-    plan->exchanges[exchange].send = send ? send : plan->exchanges[exchange].scratch;
-    return run_steps(plan, plan->exchange_local_steps[exchange]);
+    rf_plan *inst = plan ? stepping_instance(plan) : nullptr;
+    if (!inst || inst->phase != 1) { set_error("rf_plan_exchange_local before rf_plan_begin"); return RF_ERR_STATE; }
+    if (exchange < 0 || exchange >= (int)inst->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
+    if (!send && inst->sharded()) { set_error("null send buffer"); return RF_ERR_INVALID_ARG; }
+    inst->exchanges[exchange].send = send ? send : inst->exchanges[exchange].scratch;
+    return run_steps(inst, inst->exchange_local_steps[exchange]);
 }
 
 int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
-    if (!plan || plan->phase != 1) { set_error("rf_plan_exchange_apply before rf_plan_begin"); return RF_ERR_STATE; }
-    if (exchange < 0 || exchange >= (int)plan->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
-    if (!plan->sharded()) return RF_OK;   // nothing comes in from a neighbour
+    rf_plan *inst = plan ? stepping_instance(plan) : nullptr;
+    if (!inst || inst->phase != 1) { set_error("rf_plan_exchange_apply before rf_plan_begin"); return RF_ERR_STATE; }
+    if (exchange < 0 || exchange >= (int)inst->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
+    if (!inst->sharded()) return RF_OK;   // nothing comes in from a neighbour
     if (!gathered) { set_error("null gathered buffer"); return RF_ERR_INVALID_ARG; }
-    int rc = run_pending_interior(plan);      // (a caller that never called rf_plan_interior: nothing overlaps, same result)
+    int rc = run_pending_interior(inst);      // (a caller that never called rf_plan_interior: nothing overlaps, same result)
     if (rc) return rc;
-    rc = plan->exchanges[exchange].form_incoming(gathered);
+    rc = inst->exchanges[exchange].form_incoming(gathered);
     if (rc) return rc;
-    return run_steps(plan, plan->exchange_apply_steps[exchange]);
+    return run_steps(inst, inst->exchange_apply_steps[exchange]);
 }
 
 int rf_plan_finish(rf_plan *plan) {
-    if (!plan || plan->phase != 1) { set_error("rf_plan_finish before rf_plan_begin"); return RF_ERR_STATE; }
-    plan->phase = 0;
-    int rc = run_pending_interior(plan);
-    if (rc) return rc;
-    return run_steps(plan, plan->finish_steps);
+    rf_plan *inst = plan ? stepping_instance(plan) : nullptr;
+    if (!inst || inst->phase != 1) { set_error("rf_plan_finish before rf_plan_begin"); return RF_ERR_STATE; }
+    inst->phase = 0;
+    int rc = run_pending_interior(inst);
+    if (rc == RF_OK) rc = run_steps(inst, inst->finish_steps);
+    g_stepping.erase(plan);
+    release_instance(inst, true);
+    return rc;
 }
 
 int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t capacity, size_t *n_out) {

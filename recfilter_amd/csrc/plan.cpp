@@ -298,6 +298,17 @@ int build_cascade(const rf_filter_desc *desc, const std::vector<int> &stage_of, 
     return RF_OK;
 }
 
+// what a replica of this plan is built from (concurrent executions, capi.cpp)
+void save_desc(rf_plan *plan, const rf_filter_desc *desc) {
+    plan->saved.d = *desc;
+    plan->saved.scans.assign(desc->scans, desc->scans + desc->n_scans);
+    plan->saved.d.scans = nullptr;           // (re-pointed at the copies when a replica is built)
+    plan->saved.extents.clear();
+    if (desc->shard_extents != nullptr && desc->shard_world > 1)
+        plan->saved.extents.assign(desc->shard_extents, desc->shard_extents + desc->shard_world);
+    plan->saved.d.shard_extents = nullptr;
+}
+
 }  // namespace
 
 int build_plan(const rf_filter_desc *desc, rf_plan **out) {
@@ -469,7 +480,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
             for (int st : stage_of) n_stages = std::max(n_stages, st + 1);
             if (n_stages > 1) {
                 const int rc = build_cascade(desc, stage_of, plan.get());
-                if (rc == RF_OK) { *out = plan.release(); return RF_OK; }
+                if (rc == RF_OK) { save_desc(plan.get(), desc); *out = plan.release(); return RF_OK; }
                 if (desc->path == RF_PATH_TILED_FUSED) return rc;
                 plan->begin_steps.clear();          // (auto: the paths below run the scans as given)
                 plan->stages.clear();
@@ -552,6 +563,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     if (rc != RF_OK) return rc;
     add_pointwise_steps(plan.get());
     if (!host_only) RF_HIP_CHECK(hipDeviceSynchronize());   // uploads done before the first execute
+    save_desc(plan.get(), desc);
     *out = plan.release();
     return RF_OK;
 }
@@ -559,6 +571,10 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
 }  // namespace rf
 
 rf_plan::~rf_plan() {
+    replicas.clear();
+    stages.clear();
+    helpers.clear();
+    if (done) (void)hipEventDestroy(done);
     for (auto &b : buffers)
         if (b.ptr) (void)hipFree(b.ptr);
 }

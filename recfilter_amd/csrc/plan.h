@@ -4,6 +4,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -117,6 +118,23 @@ struct rf_plan {
 
     // host tables exposed through rf_plan_table
     std::map<std::string, std::vector<double>> tables;
+
+    // ---- concurrent executions (capi.cpp, acquire_instance) ------------------------------------------------------------
+    // A plan is a description plus tables; an EXECUTION needs a tail/carry workspace and a context (plane pointers, stream,
+    // stepping phase).  The plan object holds one of each.  An execute that arrives on another stream while the last one
+    // enqueued here may still be in flight runs on a REPLICA -- the same description built again: own workspace, own
+    // context -- created on first need and kept.  Executes on one stream share an instance (stream order separates them).
+    struct SavedDesc {
+        rf_filter_desc d{};
+        std::vector<rf_scan_desc> scans;
+        std::vector<int64_t> extents;
+    } saved;
+    std::mutex pool_mu;                                  // guards replicas and the fields below of every instance
+    std::vector<std::unique_ptr<rf_plan>> replicas;
+    std::mutex enqueue_mu;                               // one host thread enqueues on an instance at a time
+    hipStream_t last_stream = nullptr;                   // stream of the last execution enqueued on this instance
+    bool used = false;
+    hipEvent_t done = nullptr;                           // recorded behind it
 
     ~rf_plan();
     void *alloc(size_t bytes, bool zero, int *status);

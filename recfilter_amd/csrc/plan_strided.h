@@ -192,26 +192,27 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
             if (rc != RF_OK) return rc;
             plan->helpers.emplace_back(child);
             plan->workspace_bytes += child->workspace_bytes;
-            std::vector<Step> &apply = plan->exchange_apply_steps.back();
+            // ONE step: the helper has one workspace, so its launches for a plane run back to back (the steps of an execute
+            // run plane by plane inside every step)
             std::vector<const Step *> steps;
             for (const Step &s : child->begin_steps) steps.push_back(&s);
             for (const auto &ex : child->exchange_local_steps)
                 for (const Step &s : ex) steps.push_back(&s);
             for (const Step &s : child->finish_steps) steps.push_back(&s);
-            for (size_t i = 0; i < steps.size(); i++) {
-                const Step *sp = steps[i];
-                Step w;
-                w.name = "carry_planes." + sp->name;
-                w.run = [plan, child, sp, tails, chunk_pp](int pl) {
-                    // the helper's context: this plane's run of carry planes, filtered in place (set per step: the steps of
-                    // an execute run plane by plane inside every step)
-                    child->in[0] = child->orig_in[0] = tails + (size_t)pl * chunk_pp;
-                    child->out[0] = tails + (size_t)pl * chunk_pp;
-                    child->stream = plan->stream;
-                    return sp->run(0);
-                };
-                apply.push_back(w);
-            }
+            Step w;
+            w.name = "carry_planes_xy";
+            w.run = [plan, child, steps, tails, chunk_pp](int pl) {
+                // the helper's context: this plane's run of carry planes, filtered in place
+                child->in[0] = child->orig_in[0] = tails + (size_t)pl * chunk_pp;
+                child->out[0] = tails + (size_t)pl * chunk_pp;
+                child->stream = plan->stream;
+                for (const Step *sp : steps) {
+                    const int rc = sp->run(0);
+                    if (rc != RF_OK) return rc;
+                }
+                return (int)RF_OK;
+            };
+            plan->exchange_apply_steps.back().push_back(w);
         }
     } else {
         for (int s = 0; s < n; s++) {

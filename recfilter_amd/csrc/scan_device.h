@@ -59,11 +59,17 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
     for (int n = 0; n < NR; n++) {
         x_first[n] = v[n][m_first];
         if (!CAUSAL && entry_valid < kFusedSeg) {                    // partial entry segment: its last existing sample
-            // (three plain registers behind an opaque asm: left alone the compiler folds the select chain into
-            // v[n][entry_valid - 1], a run-time index that sends the whole register array to scratch)
-            Acc s3 = v[n][3], s7 = v[n][7], s11 = v[n][11];
-            asm volatile("" : "+v"(s3), "+v"(s7), "+v"(s11));
-            const Acc pick = entry_valid == 4 ? s3 : (entry_valid == 8 ? s7 : s11);
+            // (entry_valid is wave-uniform: a scalar switch over statically indexed registers, each case behind an opaque
+            // asm -- left alone the compiler folds the cases into v[n][entry_valid - 1], a run-time index that sends the
+            // whole register array to scratch)
+            Acc pick = v[n][0];
+#define RF_PICK(c) case c + 1: pick = v[n][c]; asm volatile("" : "+v"(pick)); break;
+            switch (entry_valid) {
+                RF_PICK(1) RF_PICK(2) RF_PICK(3) RF_PICK(4) RF_PICK(5) RF_PICK(6) RF_PICK(7) RF_PICK(8)
+                RF_PICK(9) RF_PICK(10) RF_PICK(11) RF_PICK(12) RF_PICK(13) RF_PICK(14)
+                default: break;
+            }
+#undef RF_PICK
             x_first[n] = first_lane ? pick : x_first[n];
         }
     }
@@ -84,7 +90,7 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
             for (int n = 0; n < NR; n++) v[n][m] = sc.b * v[n][m];
     }
     // An anticausal scan of a row's partial last tile enters inside the entry lane's segment when the width is not a
-    // multiple of 16: only its first entry_valid (4, 8 or 12; wave-uniform) samples exist.  The dead ones are cleared --
+    // multiple of 16: only its first entry_valid (1..15; wave-uniform) samples exist.  The dead ones are cleared --
     // an earlier causal scan ran on into them -- and the clamped prologue is positioned per lane; with a zero state
     // the dead positions then stay zero until the scan reaches the image.  Only those tiles take this path.
     if (!CAUSAL && entry_valid < kFusedSeg) {
@@ -105,6 +111,13 @@ __device__ __forceinline__ void scan_rows16(Acc (&v)[NR][kFusedSeg], const Fused
 #pragma unroll
                 for (int j = K - 1; j > 0; j--) h[n][j] = h[n][j - 1];
                 h[n][0] = acc;
+                // every position before the border reads the scan's first output from here on (lib/recfilter.cpp:330-336):
+                // as the state, so that a prologue longer than the entry segment (fewer than K samples exist in it, e.g. a
+                // width of 16 m + 1) carries over into the next lane
+                if (clamp_first && pr == 0) {
+#pragma unroll
+                    for (int j = 1; j < K; j++) h[n][j] = acc;
+                }
                 y0[n] = (pr == 0) ? acc : y0[n];
                 v[n][m] = acc;
             }

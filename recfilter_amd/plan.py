@@ -155,6 +155,11 @@ class Plan:
         return int(capi.lib().rf_plan_workspace_bytes(self._h))
 
     @property
+    def num_instances(self) -> int:
+        """execution instances the plan holds: 1 + the replicas concurrent executes on other streams made it build"""
+        return int(capi.lib().rf_plan_num_instances(self._h))
+
+    @property
     def num_kernels(self) -> int:
         return int(capi.lib().rf_plan_num_kernels(self._h))
 
@@ -202,9 +207,8 @@ class Plan:
         return ctypes.c_void_p(s.cuda_stream)
 
     def execute(self, inputs, outputs=None, stream=None):
-        """rf_plan_execute: asynchronous on `stream` (default: torch's current stream).  One execution in flight per
-        plan (it owns one workspace): overlapping executes must share the stream; use one Plan per stream otherwise
-        (include/recfilter_amd.h)."""
+        """rf_plan_execute: asynchronous on `stream` (default: torch's current stream).  Executes on distinct streams may
+        overlap: the plan runs them on replicas of itself with their own workspaces (include/recfilter_amd.h)."""
         import torch
         if outputs is None:
             outputs = self._new_outputs(inputs)

@@ -958,6 +958,63 @@ def test_batched_planes_match_the_per_plane_launches(planes, shape, dtype):
     _check(imgs, batched, scans, not integer)
 
 
+def test_one_plan_executes_concurrently_on_distinct_streams():
+    """a plan is immutable after create, executes on distinct streams with distinct workspaces may overlap.
+    Four images through ONE plan on four streams back to back (nothing waits in between), twice; then from four host
+    threads at once.  Every result against the oracle; the plan built replicas for the overlapping executions and reuses
+    an idle instance for a later execute on yet another stream."""
+    import threading
+    import torch
+    import recfilter_amd as rfa
+    scans = rc.xy_pm(rc.GAUSS2)
+    shape = (1024, 2048)
+    imgs = [rc.random_image(shape, np.float32, 700 + i) for i in range(4)]
+    wants = [oracle.apply_filter(im.astype(np.float64), scans, True) for im in imgs]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    with rfa.Plan(shape, scans, clamped=True) as plan:
+        assert plan.path == 3 and plan.num_instances == 1
+        outs = [torch.empty_like(d) for d in dev]
+        for rep in range(2):
+            for i in range(4):
+                plan.execute([dev[i]], [outs[i]], stream=streams[i])
+        torch.cuda.synchronize()
+        n_over = plan.num_instances
+        assert 2 <= n_over <= 4, n_over
+        for o, w in zip(outs, wants):
+            assert rc.rel_err(o.cpu().numpy(), w) < TOL
+        # everything has drained: an execute on a fifth stream takes an idle instance instead of building another
+        extra = torch.cuda.Stream()
+        out5 = plan.execute([dev[0]], stream=extra)[0]
+        torch.cuda.synchronize()
+        assert plan.num_instances == n_over and rc.rel_err(out5.cpu().numpy(), wants[0]) < TOL
+        # four host threads, one stream each, three executes each
+        outs2 = [torch.empty_like(d) for d in dev]
+        errors = []
+
+        def worker(i):
+            try:
+                for _ in range(3):
+                    plan.execute([dev[i]], [outs2[i]], stream=streams[i])
+            except Exception as exc:      # pragma: no cover
+                errors.append(exc)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for o, w in zip(outs2, wants):
+            assert rc.rel_err(o.cpu().numpy(), w) < TOL
+        # same stream: one instance however many executes are queued
+    with rfa.Plan(shape, scans, clamped=True) as plan:
+        for i in range(8):
+            plan.execute([dev[i % 4]], [outs[i % 4]])
+        torch.cuda.synchronize()
+        assert plan.num_instances == 1
+
+
 # ---- unsigned-byte input planes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8) -------------------------
 @pytest.mark.parametrize("shape,path", [((128, 512), 0), ((75, 464), 0), ((64, 250), 0), ((64, 256), 1), ((40, 16, 272), 0)],
                          ids=["fused", "fused_partial", "generic_auto", "untiled", "fused_3d"])
