@@ -123,6 +123,9 @@ typedef struct {
  *   RF_PLAN_LATE_EXCHANGE   a z-sharded volume exchanges the carries of the x/y-FILTERED data, after its x/y stage
  *                           (nothing runs beside the all-gather); default: the carries of the raw input first, the x/y
  *                           stage beside the all-gather (rf_plan_interior below).
+ *   RF_PLAN_SERIAL_UNTILED  RF_PATH_UNTILED as one serial recurrence per line for every filter (the literal operator of
+ *                           lib/recfilter.cpp:302-343; an independent on-device reference) instead of the line-parallel
+ *                           kernels it uses where they apply.
  *   RF_PLAN_TILE_ROWS(n) /  n = 32, 64 or 128: tile height of the fused x/y stage / tile width of the strided z stage,
  *   RF_PLAN_TILE_PLANES(n)  where the shape admits it (default: chosen from the image size; rf_plan_tiles reports it).
  *                           rf_filter_desc.tile[] stays what RecFilter::split passes: binding on the generic and
@@ -135,7 +138,8 @@ typedef struct {
 #define RF_PLAN_STREAM_PASS1    0x20u
 #define RF_PLAN_STAGED_PASS1    0x40u
 #define RF_PLAN_LATE_EXCHANGE   0x80u
-#define RF_PLAN_ALL_FLAGS       0xffu
+#define RF_PLAN_SERIAL_UNTILED  0x01000000u
+#define RF_PLAN_ALL_FLAGS       0x010000ffu
 #define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
 #define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
 

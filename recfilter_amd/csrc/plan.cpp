@@ -38,7 +38,7 @@ double cast_coeff(double c, int dtype) {
 // lines of a strided dimension are moved 16 at a time).
 bool line_scans_applicable(const rf_plan *plan) {
     if (plan->sharded() || plan->scans.empty()) return false;
-    if (RF_KNOB("RF_NO_LINE_SCANS") != nullptr) return false;          // A/B runs against the one-thread-per-line kernel
+    if ((plan->flags & RF_PLAN_SERIAL_UNTILED) || RF_KNOB("RF_NO_LINE_SCANS") != nullptr) return false;     // the one-thread-per-line kernel
     bool strided = false;
     for (int d = 0; d < plan->ndim; d++) {
         const DimInfo &di = plan->dims[d];

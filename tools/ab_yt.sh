@@ -1,3 +1,5 @@
+# (developer switches exist only in the A/B build of the library: make -C recfilter_amd/csrc ab)
+make -s -C recfilter_amd/csrc ab -j8 && export RECFILTER_AMD_LIB=$PWD/recfilter_amd/librecfilter_amd_ab.so || exit 1
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_ytm.log 2>&1 || { tail -30 gpurun_out/gpu_tests_ytm.log; exit 1; }
 tail -3 gpurun_out/gpu_tests_ytm.log

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Orders 4..6 (zero border, f32): the plan's split into sections on the fused kernels against the scans as given
-(RF_NO_SECTIONS=1: generic path), 4096^2 and 16384^2."""
+(`python tools/order_probe.py given`: RF_PLAN_NO_SECTIONS, generic path), 4096^2 and 16384^2."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,7 +18,7 @@ for n in (4096, 16384):
     for name, poles in cases.items():
         co = from_poles(poles)
         scans = [(0, True, co), (0, False, co), (1, True, co), (1, False, co)]
-        plan = rfa.Plan((n, n), scans, clamped=False)
+        plan = rfa.Plan((n, n), scans, clamped=False, flags=rfa.capi.RF_PLAN_NO_SECTIONS if "given" in sys.argv[1:] else 0)
         for _ in range(3): plan.execute([img], [out])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

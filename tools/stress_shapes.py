@@ -31,7 +31,7 @@ for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "
     else:
         img = torch.rand(shape, device="cuda")
     npdt = np.int32 if dtype == torch.int32 else np.float32
-    with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped) as pf, rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1) as pu:
+    with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped) as pf, rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
         of, ou = pf.execute([img])[0], pu.execute([img])[0]
         torch.cuda.synchronize()
         if dtype == torch.int32:
@@ -67,7 +67,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "overlap":
         else:
             img = torch.rand(shape, device="cuda", dtype=torch.float64 if npdt == np.float64 else torch.float32)
         with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=4, tile=tiles) as po, \
-                rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1) as pu:
+                rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
             oo, ou = po.execute([img])[0], pu.execute([img])[0]
             torch.cuda.synchronize()
             if npdt == np.int32:
@@ -94,7 +94,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "big":
                 scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
         clamped = bool(rng.integers(0, 2))
         img = torch.rand((rows, cols), device="cuda")
-        with rfa.Plan((rows, cols), scans, clamped=clamped) as pf, rfa.Plan((rows, cols), scans, clamped=clamped, path=1) as pu:
+        with rfa.Plan((rows, cols), scans, clamped=clamped) as pf, rfa.Plan((rows, cols), scans, clamped=clamped, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
             of, ou = pf.execute([img])[0], pu.execute([img])[0]
             torch.cuda.synchronize()
             peak = float(ou.abs().max().item())
@@ -125,8 +125,9 @@ if len(sys.argv) > 3 and sys.argv[3] in ("f64", "1d"):
         tdt = torch.float64 if mode == "f64" else torch.float32
         npdt = np.float64 if mode == "f64" else np.float32
         img = torch.rand(shape, device="cuda", dtype=tdt)
-        os.environ["RF_NO_LINE_SCANS"] = "1"            # the literal recurrence as the reference
-        with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped) as pf, rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1) as pu:
+        # (the reference: the literal recurrence, one thread per line)
+        with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped) as pf, \
+             rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
             of, ou = pf.execute([img])[0], pu.execute([img])[0]
             torch.cuda.synchronize()
             peak = float(ou.abs().max().item())
@@ -154,8 +155,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "shard":
                 a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
                 scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
         clamped = bool(rng.integers(0, 2))
-        if rng.integers(0, 2): os.environ["RF_FUSED_TY"] = "128"
-        else: os.environ.pop("RF_FUSED_TY", None)
+        import recfilter_amd.plan as _rp
+        _rp.DEFAULT_FLAGS = rfa.capi.RF_PLAN_TILE_ROWS(128) if rng.integers(0, 2) else 0
         img = torch.rand(shape, device="cuda")
         with rfa.Plan(shape, scans, clamped=clamped) as p1:
             want = p1.execute([img])[0]
@@ -183,7 +184,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "shard":
 # ---- Tuple planes, pixel types, uint8 input and pointwise stages on random shapes, against the untiled path ----
 if len(sys.argv) > 3 and sys.argv[3] == "planes":
     worst = 0.0
-    os.environ["RF_NO_LINE_SCANS"] = "1"
+    import recfilter_amd.plan as _rp
+    SERIAL = rfa.capi.RF_PLAN_SERIAL_UNTILED        # (path=1 plans below: the literal recurrence as the reference)
     for case in range(n_cases):
         shape = (int(rng.integers(1, 1500)), 4 * int(rng.integers(1, 700)))
         planes = int(rng.integers(1, 6))
@@ -211,7 +213,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "planes":
             if kind == "f32pw":
                 kw = dict(prologue=(0.5, 0.25), epilogue=(float(np.float32(-0.75)), float(np.float32(1.75)) if case % 2 else 0.0, 0.125))
         with rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, planes=planes, **kw) as pf, \
-                rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, planes=planes, path=1, **kw) as pu:
+                rfa.Plan(shape, scans, dtype=npdt, clamped=clamped, planes=planes, path=1, flags=SERIAL, **kw) as pu:
             of, ou = pf.execute(imgs), pu.execute(imgs)
             torch.cuda.synchronize()
             err = 0.0
