@@ -8,15 +8,24 @@ import numpy as np, torch
 import recfilter_amd as rfa
 import ref_cases as rc
 
+ODD = "--odd" in sys.argv          # widths that are not multiples of 4 as well (4- and 8-byte pixels on the fused kernels)
+if ODD:
+    sys.argv.remove("--odd")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+
+
+def width(q):
+    return 4 * q + (int(rng.integers(0, 4)) if ODD else 0)
+
+
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
 for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
-        shape = (int(rng.integers(1, 9000)), 4 * int(rng.integers(1, 2400)))
+        shape = (int(rng.integers(1, 9000)), width(int(rng.integers(1, 2400))))
     else:
-        shape = (int(rng.choice([32, 64, 96])), int(rng.integers(1, 700)), 4 * int(rng.integers(1, 320)))
+        shape = (int(rng.choice([32, 64, 96])), int(rng.integers(1, 700)), width(int(rng.integers(1, 320))))
     scans = []
     for d in range(ndim):
         for _ in range(int(rng.integers(0, 3 if d < 2 else 2)) + (1 if d == 0 else 0)):
@@ -110,7 +119,7 @@ if len(sys.argv) > 3 and sys.argv[3] in ("f64", "1d"):
     worst = 0.0
     for case in range(n_cases):
         if mode == "f64":
-            shape = (int(rng.integers(1, 3000)), 4 * int(rng.integers(1, 900)))
+            shape = (int(rng.integers(1, 3000)), width(int(rng.integers(1, 900))))
             dims = 2
         else:
             shape = (int(rng.integers(8192, 3000000)),)
@@ -146,7 +155,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "shard":
         gran = int(rng.choice([32, 64, 128]))
         ext = [gran * int(rng.integers(1, 5)) for _ in range(world)]
         three = case % 3 == 0
-        shape = (sum(ext), int(rng.integers(1, 6)) * 32, 4 * int(rng.integers(16, 200))) if three else (sum(ext), 4 * int(rng.integers(16, 500)))
+        shape = (sum(ext), int(rng.integers(1, 6)) * 32, width(int(rng.integers(16, 200)))) if three else (sum(ext), width(int(rng.integers(16, 500))))
         nd = len(shape)
         scans = []
         for d in range(nd):
