@@ -41,7 +41,9 @@ namespace {
 // YPAT: the directions of the y scans when they are the usual ones -- 1: one causal scan, 2: causal then anticausal; 0: any.
 // With a run-time direction inside the loop over the scans every sample of the column is a phi of two register
 // assignments: ~TY register copies per scan (and spills on the 128-row tiles of kernels_fused_tall.hip).
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false>
+// LIN: a folded 1-D signal whose end falls inside the image (FusedArgs::lin_limit) -- its masked loads and stores are a
+// variant of the plain kernel (no epilogue operand, whole tiles, no y scans), so that no other kernel carries them
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false, bool LIN = false>
 __global__ void __launch_bounds__(kFusedThreads, (EPI || PixelTraits<P>::is_integer) ? 2 : 1)
 fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -169,7 +171,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
         // a folded 1-D signal that ends inside or before this tile (FusedArgs::lin_limit): zeros from its end on
         const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;
-        if (a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit) {       // (tile-uniform)
+        if (LIN && a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit) {       // (tile-uniform)
 #pragma unroll
             for (int i = 0; i < TY / 4; i++) {
                 const int64_t idx = lin0 + (int64_t)(rg + 4 * i) * a.NX + 4 * cc;
@@ -357,7 +359,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
             const uint32_t row_bytes = a.row_bytes;
             // rows of this column that exist: all of the tile's, or (folded 1-D signal) those before the signal's end
             int my_rows = rows_here;
-            if (a.lin_limit > 0) {
+            if (LIN && a.lin_limit > 0) {
                 const int64_t first = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX + t;
                 const int64_t left = a.lin_limit > first ? (a.lin_limit - first + a.NX - 1) / a.NX : 0;
                 my_rows = left < (int64_t)rows_here ? (int)left : rows_here;
@@ -378,7 +380,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     }
 }
 
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false>
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false, bool LIN = false>
 int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
@@ -390,12 +392,12 @@ int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename Pixe
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::atomic<bool> &done = attr_set[dev & 63];
     if (!done.load(std::memory_order_acquire)) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX, LIN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX, LIN>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -420,6 +422,9 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
     if constexpr (!PixelTraits<P>::is_integer) early = (a.pw_flags & 2) == 0 || a.post_i == typename PixelTraits<P>::Acc(0);
 #define RF_CASE(KK, TT)                                                                                         \
     if (K == KK && TY == TT) {                                                                                  \
+        if constexpr (std::is_same<P, PI>::value) {                                                             \
+            if (a.lin_limit > 0) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 0, false, true>(src, dst, a, stream); \
+        }                                                                                                       \
         if constexpr (!PixelTraits<P>::is_integer) {                                                            \
             if (epi && edge) return launch_fused_pass2_impl<P, KK, TT, true, true, PI>(src, dst, a, stream);    \
             if constexpr (TT == 64 && std::is_same<P, PI>::value) {                                             \

@@ -32,7 +32,13 @@ namespace {
 
 typedef float F2 __attribute__((ext_vector_type(2)));     // operands of the packed f32 instructions
 
-template <typename P, int K, int TY, typename PI>
+// MODE: what the loads of a tile have to mask.  0: nothing but whole chunks beyond the image (every 2-D / 3-D image whose
+// width is a multiple of 4); 1: the end of a folded 1-D signal (FusedArgs::lin_limit); 2: a width that is not a multiple
+// of 4 (a row's last chunk is partial).  Variants of their own, so that the kernel every other image runs stays small: with
+// the sample-by-sample loads of modes 1 and 2 in the common kernel it grew from 115 / 121 to 127 / 132 registers at order
+// 2 / 3 -- above 128 a SIMD holds three waves instead of four -- and pass 1 of an order-3 filter on 3 x 16384^2 took 0.89
+// instead of 0.69 ms (order 2, one plane: 0.237 against 0.205 ms; same box).
+template <typename P, int K, int TY, typename PI, int MODE = 0>
 __global__ void __launch_bounds__(kFusedThreads)
 fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>::Acc> a,
                    const typename PixelTraits<P>::Acc *__restrict__ Hx,     // [vx][s][r][256]
@@ -73,7 +79,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     // the row's last tile may be partial: 16-byte chunks beyond the image are taken as zeros
     const bool chunk_in = (tx != a.MX - 1) || (4 * cc < a.last_cols);
     // ... and when the width is not a multiple of 4 the last of them is partial (tile-uniform flag; scan_device.h)
-    const bool odd_cols = tx == a.MX - 1 && (a.last_cols & 3) != 0;
+    const bool odd_cols = MODE == 2 && tx == a.MX - 1;
     const int cols_valid = a.last_cols - 4 * cc;
     auto ld_cols = [&](int row) { return load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), cols_valid); };
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
@@ -87,7 +93,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const int rows_here = (ty == a.MY - 1) ? a.last_rows : TY;
     // a folded 1-D signal that ends inside or before this tile (FusedArgs::lin_limit): samples from the end on are zeros
     const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;         // linear index of the tile's first sample
-    const bool lin_cut = a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit;      // (tile-uniform)
+    const bool lin_cut = MODE == 1 && a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit;      // (tile-uniform)
     auto load_half = [&](int half) {
         const int r0 = kTailRows * half + rg;
         if (lin_cut) {
@@ -100,7 +106,12 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
             }
             return;
         }
-        if (odd_cols) {
+        // (whole tiles -- all but the last of a row and the last tile row -- load without a condition: a per-lane select
+        // between a load and zeros costs a branch per load and a wait for the load before the zeros may be written)
+        if ((tx != a.MX - 1 || a.last_cols == kFusedTX) && rows_here == TY) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) pre[i] = ld(kTailRows * half + 4 * i);
+        } else if (odd_cols) {
 #pragma unroll
             for (int i = 0; i < NL; i++) pre[i] = r0 + 4 * i < rows_here ? ld_cols(kTailRows * half + 4 * i) : zero4;
         } else if (rows_here == TY) {
@@ -591,6 +602,20 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
             if (src_u8) {                                                                                            \
                 hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, uint8_t>), grid, dim3(kFusedThreads), hx_bytes, stream, \
                                    (const uint8_t *)src, a, Hx, Hy);                                                 \
+                RF_HIP_CHECK(hipGetLastError());                                                                     \
+                return RF_OK;                                                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (a.lin_limit > 0) {                  /* folded 1-D signal whose end is masked */                             \
+            hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P, 1>), grid, dim3(kFusedThreads), hx_bytes, stream,       \
+                               (const P *)src, a, Hx, Hy);                                                           \
+            RF_HIP_CHECK(hipGetLastError());                                                                         \
+            return RF_OK;                                                                                            \
+        }                                                                                                            \
+        if constexpr (sizeof(P) >= 4) {                                                                              \
+            if ((a.last_cols & 3) != 0) {       /* width not a multiple of 4: the variant with partial-chunk loads */    \
+                hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P, 2>), grid, dim3(kFusedThreads), hx_bytes, stream,   \
+                                   (const P *)src, a, Hx, Hy);                                                       \
                 RF_HIP_CHECK(hipGetLastError());                                                                     \
                 return RF_OK;                                                                                        \
             }                                                                                                        \
