@@ -196,9 +196,10 @@ if len(sys.argv) > 3 and sys.argv[3] == "planes":
     import recfilter_amd.plan as _rp
     SERIAL = rfa.capi.RF_PLAN_SERIAL_UNTILED        # (path=1 plans below: the literal recurrence as the reference)
     for case in range(n_cases):
-        shape = (int(rng.integers(1, 1500)), 4 * int(rng.integers(1, 700)))
-        planes = int(rng.integers(1, 6))
         kind = ["f32", "i32", "i16", "u8", "f32pw"][case % 5]
+        q = int(rng.integers(1, 700))
+        shape = (int(rng.integers(1, 1500)), 4 * q if kind in ("i16", "u8") else width(q))       # (2-byte pixels / byte inputs: multiples of 4)
+        planes = int(rng.integers(1, 6))
         scans = []
         for d in range(2):
             for _ in range(int(rng.integers(0, 3)) + (1 if d == 0 else 0)):
@@ -236,3 +237,42 @@ if len(sys.argv) > 3 and sys.argv[3] == "planes":
             print(f"{case:3d} {pf.path_name:13s} {kind:6s} planes={planes} {str(shape):14s} scans={len(scans)} clamped={int(clamped)} err={err:.3e}",
                   "" if err < (1 if kind in ("i32", "i16") else 2e-4) else "  <-- CHECK", flush=True)
     print("worst (planes)", worst)
+
+# ---- one plan, many streams and host threads (execution instances, capi.cpp acquire_instance) against a serial run ----
+if len(sys.argv) > 3 and sys.argv[3] == "streams":
+    import threading
+    worst = 0.0
+    for case in range(n_cases):
+        shape = (int(rng.integers(64, 3000)), width(int(rng.integers(16, 900))))
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(1, 4))
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        n_streams, n_threads, reps = int(rng.integers(2, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        imgs = [torch.rand(shape, device="cuda") for _ in range(n_streams)]
+        with rfa.Plan(shape, scans, clamped=clamped) as plan:
+            want = [plan.execute([im])[0].clone() for im in imgs]
+            torch.cuda.synchronize()
+            streams = [torch.cuda.Stream() for _ in range(n_streams)]
+            outs = [torch.zeros_like(im) for im in imgs]
+            errors = []
+
+            def worker(tid):
+                try:
+                    for _ in range(reps):
+                        for i in range(tid, n_streams, n_threads):
+                            plan.execute([imgs[i]], [outs[i]], stream=streams[i])
+                except Exception as exc:
+                    errors.append(repr(exc))
+            threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+            for th in threads: th.start()
+            for th in threads: th.join()
+            torch.cuda.synchronize()
+            bad = sum(int((o != w).sum().item()) for o, w in zip(outs, want))
+            worst = max(worst, bad)
+            print(f"{case:3d} {plan.path_name:13s} {str(shape):14s} streams={n_streams} threads={n_threads} reps={reps} instances={plan.num_instances} "
+                  f"differing samples={bad} errors={errors}", "" if bad == 0 and not errors else "  <-- CHECK", flush=True)
+    print("worst (streams)", worst)
