@@ -94,6 +94,11 @@ def pmc_traffic(kernel_name, workload, shape):
                 if doc.get("kernel_sources_sha16") != info["running_sources_sha16"]:
                     info["traffic_note"] = "stale: collected on other kernel sources than the ones running"
                     return None, info
+                # HBM bytes of one whole step: every kernel's bytes per launch x its launches per step (the dominant
+                # kernel launches once per step)
+                per_step = entry["launches"]
+                info["step_traffic"] = int(sum((e["fetch_bytes_corrected"] + e["write_bytes"]) * e["launches"] / per_step
+                                               for e in table.values()))
                 return entry["fetch_bytes_corrected"] + entry["write_bytes"], info
         break          # the newest summary has no such kernel: older rounds' bytes are not this code's
     return None, info
@@ -166,7 +171,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     import torch
-    have = torch.cuda.device_count()                 # does not initialise the GPU
+    have = torch.cuda.device_count()                 # (a count; the ranks are child processes either way, see main)
     if args.device < 0 and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible devices, found {have}", file=sys.stderr)
         return 2
@@ -215,9 +220,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # Not launched by torch.distributed.run: become the launcher.  Nothing in this process has touched the GPU yet
-        # (torch.cuda.device_count() does not initialise it) and it never will: the ranks are CHILD processes, this one
-        # only waits and passes their exit code on.
+        # Not launched by torch.distributed.run: become the launcher.  This process only counts the devices, starts the
+        # ranks as CHILD processes (nothing is exec'ed over it), waits and passes their exit code on.
         sys.exit(spawn_ranks(args))
 
     import numpy as np

@@ -109,6 +109,25 @@ def test_bench_two_ranks_over_gloo(launcher):
     assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] in ("fused_pass2", "fused_tails")     # (the dominant one; a toss-up at this size)
 
 
+def test_bench_strong_scaling_volume_two_ranks_over_gloo():
+    """`bench.py --gpus 2 --workload cfg5 --strong`: the z-sharded volume with the early exchange (x/y stage beside the
+    all-gather) in the bench's own flow, two ranks on this box's one GPU over gloo."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--device", "0",
+           "--workload", "cfg5", "--size", "256", "--strong"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and c["path"] == "tiled_fused"
+    assert c["exchange"] == "stepping" and c["collectives_per_step"] == 1 and c["interior_beside_collective"] is True
+    assert "128x256x256" in c["workload"]
+
+
 def test_bench_refuses_more_ranks_than_devices():
     """`--gpus N` on a box with fewer than N devices must fail loudly, not benchmark one GPU and print n_gpus = 1."""
     import subprocess
