@@ -77,14 +77,25 @@ std::vector<const Step *> flat_steps(const rf_plan *plan) {
 rf_plan *acquire_instance(rf_plan *plan, hipStream_t stream) {
     if (plan->host_only) { plan->enqueue_mu.lock(); return plan; }
     std::unique_lock<std::mutex> pool(plan->pool_mu);
+    for (;;) {
+        std::vector<rf_plan *> all{plan};
+        for (auto &r : plan->replicas) all.push_back(r.get());
+        rf_plan *busy = nullptr;
+        for (rf_plan *inst : all)
+            if (inst->used && inst->last_stream == stream) {
+                if (inst->enqueue_mu.try_lock()) return inst;
+                busy = inst;                     // another host thread is enqueueing on it (or stepping through it)
+                break;
+            }
+        if (busy == nullptr) break;
+        // wait for that thread WITHOUT the pool lock, then look again: the instance may have moved to another stream
+        pool.unlock();
+        busy->enqueue_mu.lock();
+        busy->enqueue_mu.unlock();
+        pool.lock();
+    }
     std::vector<rf_plan *> all{plan};
     for (auto &r : plan->replicas) all.push_back(r.get());
-    for (rf_plan *inst : all)
-        if (inst->used && inst->last_stream == stream) {
-            pool.unlock();
-            inst->enqueue_mu.lock();             // (another host thread may be enqueueing on it: behind that one)
-            return inst;
-        }
     for (rf_plan *inst : all) {
         const bool idle = !inst->used || inst->done == nullptr || hipEventQuery(inst->done) == hipSuccess;
         if (idle && inst->enqueue_mu.try_lock()) { inst->used = true; inst->last_stream = stream; return inst; }
@@ -117,6 +128,15 @@ thread_local std::map<const rf_plan *, rf_plan *> g_stepping;
 rf_plan *stepping_instance(rf_plan *plan) {
     auto it = g_stepping.find(plan);
     return it == g_stepping.end() ? nullptr : it->second;
+}
+
+// a stepping call failed: the execute is over (the instance goes back to the pool; the next rf_plan_begin starts afresh)
+int abort_stepping(rf_plan *plan, rf_plan *inst, int rc) {
+    inst->phase = 0;
+    inst->interior_pending = false;
+    g_stepping.erase(plan);
+    release_instance(inst, true);        // (what was enqueued so far still runs: the completion event covers it)
+    return rc;
 }
 
 // the exchange-independent work of this execute, if the caller has not asked for it yet
@@ -163,6 +183,7 @@ int rf_plan_num_exchanges(const rf_plan *plan) { return plan ? (int)plan->exchan
 int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
     if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
     if (plan->sharded()) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
+    if (stepping_instance(plan) != nullptr) { set_error("rf_plan_execute between this thread's rf_plan_begin and rf_plan_finish"); return RF_ERR_STATE; }
     rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
     if (!inst) return RF_ERR_NOMEM;
     int rc = set_context(inst, in_planes, out_planes, stream);
@@ -181,6 +202,7 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
                           float *ms_out, const char **names_out, int capacity) {
     if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
     if (plan->sharded()) { set_error("a sharded plan must be driven through rf_plan_begin/exchange/finish"); return RF_ERR_STATE; }
+    if (stepping_instance(plan) != nullptr) { set_error("rf_plan_execute between this thread's rf_plan_begin and rf_plan_finish"); return RF_ERR_STATE; }
     rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
     if (!inst) return RF_ERR_NOMEM;
     struct Release {
@@ -241,7 +263,8 @@ int rf_plan_has_interior(const rf_plan *plan) { return plan && !plan->interior_s
 int rf_plan_interior(rf_plan *plan) {
     rf_plan *inst = plan ? stepping_instance(plan) : nullptr;
     if (!inst || inst->phase != 1) { set_error("rf_plan_interior before rf_plan_begin"); return RF_ERR_STATE; }
-    return run_pending_interior(inst);
+    const int rc = run_pending_interior(inst);
+    return rc == RF_OK ? rc : abort_stepping(plan, inst, rc);
 }
 
 size_t rf_plan_exchange_bytes(const rf_plan *plan, int exchange) {
@@ -255,7 +278,8 @@ int rf_plan_exchange_local(rf_plan *plan, int exchange, void *send) {
     if (exchange < 0 || exchange >= (int)inst->exchanges.size()) { set_error("exchange index out of range"); return RF_ERR_INVALID_ARG; }
     if (!send && inst->sharded()) { set_error("null send buffer"); return RF_ERR_INVALID_ARG; }
     inst->exchanges[exchange].send = send ? send : inst->exchanges[exchange].scratch;
-    return run_steps(inst, inst->exchange_local_steps[exchange]);
+    const int rc = run_steps(inst, inst->exchange_local_steps[exchange]);
+    return rc == RF_OK ? rc : abort_stepping(plan, inst, rc);
 }
 
 int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
@@ -265,10 +289,9 @@ int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
     if (!inst->sharded()) return RF_OK;   // nothing comes in from a neighbour
     if (!gathered) { set_error("null gathered buffer"); return RF_ERR_INVALID_ARG; }
     int rc = run_pending_interior(inst);      // (a caller that never called rf_plan_interior: nothing overlaps, same result)
-    if (rc) return rc;
-    rc = inst->exchanges[exchange].form_incoming(gathered);
-    if (rc) return rc;
-    return run_steps(inst, inst->exchange_apply_steps[exchange]);
+    if (rc == RF_OK) rc = inst->exchanges[exchange].form_incoming(gathered);
+    if (rc == RF_OK) rc = run_steps(inst, inst->exchange_apply_steps[exchange]);
+    return rc == RF_OK ? rc : abort_stepping(plan, inst, rc);
 }
 
 int rf_plan_finish(rf_plan *plan) {

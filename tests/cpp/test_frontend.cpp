@@ -423,6 +423,80 @@ int main() {
             if (exchanges[0] != 1) { failures++; std::printf("expected ONE all-gather per execution, saw %d\n", exchanges[0]); }
         }
     }
+    {   // a z-sharded volume from C++: two ranks as two threads; the plan exchanges the z carries of the RAW input and has
+        // exchange-independent work (the x/y stage), so the front-end hands the collective a SIDE stream and runs
+        // rf_plan_interior beside it.  Then ONE slab driven through the same calls (RF_PLAN_FORCE_EXCHANGE).
+        const int nx = 256, ny = 48, world = 2;
+        const std::vector<int64_t> extents = {64, 32};
+        const int nz = 96;
+        std::vector<float> image = random_image((size_t)nx * ny * nz, 17);
+        const std::vector<float> W = {0.40f, 0.70f, -0.20f};
+        struct Barrier {
+            std::mutex m; std::condition_variable cv; int count = 0, generation = 0, n;
+            explicit Barrier(int n_) : n(n_) {}
+            void wait() {
+                std::unique_lock<std::mutex> lk(m);
+                const int g = generation;
+                if (++count == n) { count = 0; generation++; cv.notify_all(); }
+                else cv.wait(lk, [&] { return g != generation; });
+            }
+        };
+        std::vector<float> ref = image;
+        for (int dim = 0; dim < 3; dim++) { loop_scan(ref, nx, ny, nz, dim, true, W); loop_scan(ref, nx, ny, nz, dim, false, W); }
+        for (int mode = 0; mode < 2; mode++) {          // 0: two slabs; 1: one slab with the exchange structure forced
+            const int ranks = mode == 0 ? world : 1;
+            Barrier barrier(ranks);
+            std::vector<const void *> sends(ranks, nullptr);
+            std::vector<std::vector<float>> outs(ranks);
+            std::vector<std::string> errors(ranks);
+            std::vector<int> side_stream_calls(ranks, 0);
+            auto rank_main = [&](int rank) {
+                try {
+                    hipStream_t st;
+                    if (hipStreamCreate(&st) != hipSuccess) throw RecFilterError("hipStreamCreate failed");
+                    const int64_t lo = mode == 0 ? (rank == 0 ? 0 : extents[0]) : 0;
+                    const int64_t mine = mode == 0 ? extents[rank] : nz;
+                    std::vector<float> slab(image.begin() + lo * nx * ny, image.begin() + (lo + mine) * nx * ny);
+                    float *d = upload(slab);
+                    RecFilterDim x("x", nx), y("y", ny), z("z", (int)mine);
+                    RecFilter F;
+                    F(x, y, z) = RecFilterImage(d);
+                    F.add_filter(+x, W); F.add_filter(-x, W); F.add_filter(+y, W); F.add_filter(-y, W);
+                    F.add_filter(+z, W); F.add_filter(-z, W);
+                    F.split(x, 32, y, 16, z, 32);
+                    if (mode == 0) F.shard(rank, world, extents);
+                    else F.plan_options(RF_PLAN_FORCE_EXCHANGE | RF_PLAN_TILED_ONLY);
+                    F.set_stream(st);
+                    RecFilter::AllGather gather = [&](const void *send, void *gathered, size_t bytes, void *stream) {
+                        if ((hipStream_t)stream != st) side_stream_calls[rank]++;
+                        sends[rank] = send;
+                        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) throw RecFilterError("sync failed");
+                        barrier.wait();
+                        for (int r = 0; r < ranks; r++)
+                            if (hipMemcpyAsync((char *)gathered + (size_t)r * bytes, sends[r], bytes, hipMemcpyDeviceToDevice,
+                                               (hipStream_t)stream) != hipSuccess) throw RecFilterError("copy failed");
+                        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) throw RecFilterError("sync failed");
+                        barrier.wait();
+                    };
+                    outs[rank] = F.realize_sharded(gather).to_host<float>();
+                    (void)hipFree(d);
+                    (void)hipStreamDestroy(st);
+                } catch (const std::exception &e) { errors[rank] = e.what(); }
+            };
+            std::vector<std::thread> threads;
+            for (int r = 0; r < ranks; r++) threads.emplace_back(rank_main, r);
+            for (auto &t : threads) t.join();
+            const char *label = mode == 0 ? "z-sharded volume, 2 ranks" : "one slab, exchange forced";
+            bool ok = true;
+            for (int r = 0; r < ranks; r++)
+                if (!errors[r].empty()) { std::fprintf(stderr, "rank %d: %s\n", r, errors[r].c_str()); ok = false; }
+            if (!ok) { failures++; std::printf("%-34s FAILED (exception)\n", label); continue; }
+            std::vector<float> got;
+            for (int r = 0; r < ranks; r++) got.insert(got.end(), outs[r].begin(), outs[r].end());
+            report(label, rel_err(ref, got));
+            if (side_stream_calls[0] != 1) { failures++; std::printf("%s: expected the collective on a side stream (interior beside it), saw %d\n", label, side_stream_calls[0]); }
+        }
+    }
     std::printf("%s\n", failures ? "SOME TESTS FAILED" : "all front-end tests passed");
     return failures ? 1 : 0;
 }
