@@ -75,6 +75,10 @@ struct FusedArgs {
     // Tuple planes of a 2-D filter batched into one launch: plane z of the "volume" is its own buffer (the kernels'
     // src/dst arguments are unused); the tails treat the planes exactly like the z planes of a 3-D image
     int32_t plane_batch;
+    // The final pass of an image with partial tiles runs as up to three launches: the whole tiles on the lean kernel, the
+    // last tile column and the last tile row on the EDGE variant (kernels_fused.hip, launch_fused_pass2).  tx0 / ty0: the
+    // tile this launch's block (0, 0) stands for; gx / gy: its grid (0 = MX / MY).  Read by the final-pass kernels only.
+    int32_t tx0, ty0, gx, gy;
     const void *in_planes[kFusedMaxPlanes];
     void *out_planes[kFusedMaxPlanes];
     // Layout of the y tails.  0: [j][ty][r][column] -- a tile's rows are 1-KiB pieces a whole image row apart; 1: tile-major,
@@ -159,6 +163,9 @@ int launch_fused_pass2(int K, int TY, const void *src, bool src_u8, P *dst, cons
 template <typename P>
 int launch_fused_pass2_tall(int K, const void *src, bool src_u8, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                             hipStream_t stream);
+// whether a final pass with partial tiles is worth three launches: enough whole tiles for the lean kernel to pay for two
+// more launches (a few microseconds each)
+inline bool split_final_pass(int64_t whole_tiles) { return whole_tiles >= 1024; }
 // pass 1 as a contraction with precomputed impulse responses (kernels_tails.hip)
 template <typename P>
 int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedArgs<typename PixelTraits<P>::Acc> &a,

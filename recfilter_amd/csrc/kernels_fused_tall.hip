@@ -38,7 +38,7 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     constexpr int TY = kTallTY, TL = kHalfRows, NR = TL / 16;
 
     const int t = threadIdx.x;
-    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int tx = (int)blockIdx.x + a.tx0, ty = (int)blockIdx.y + a.ty0;
     const int64_t z = blockIdx.z;
     if (a.plane_batch) {
         src = reinterpret_cast<const PI *>(a.in_planes[z]);
@@ -347,7 +347,7 @@ int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         done.store(true, std::memory_order_release);
     }
-    dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
+    dim3 grid((unsigned)(a.gx > 0 ? a.gx : a.MX), (unsigned)(a.gy > 0 ? a.gy : a.MY), (unsigned)a.NZ);
     hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY, XFIX>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
@@ -378,19 +378,35 @@ int launch_fused_pass2_tall(int K, const void *src, bool src_u8, P *dst, const F
     if (a.MX <= 0 || a.MY <= 0 || a.NZ <= 0) return RF_OK;
     if (a.NZ > 65535 || a.MY > 65535) { set_error("fused path: grid too large"); return RF_ERR_UNSUPPORTED; }
     const bool edge = a.last_cols != kFusedTX || a.last_rows != kTallTY;
+    // one launch of `aa`'s tiles on the lean (edge = false) or the EDGE variant
+    auto one = [&](const FusedArgs<typename PixelTraits<P>::Acc> &aa, bool e) -> int {
 #define RF_CASE(KK)                                                                                                     \
     if (K == KK) {                                                                                                      \
         if constexpr (std::is_same<P, float>::value) {                                                                  \
-            if (src_u8) return edge ? launch_tall_impl<P, KK, true, uint8_t>((const uint8_t *)src, dst, a, stream)       \
-                                    : launch_tall_impl<P, KK, false, uint8_t>((const uint8_t *)src, dst, a, stream);     \
+            if (src_u8) return e ? launch_tall_impl<P, KK, true, uint8_t>((const uint8_t *)src, dst, aa, stream)         \
+                                 : launch_tall_impl<P, KK, false, uint8_t>((const uint8_t *)src, dst, aa, stream);       \
         }                                                                                                               \
-        return edge ? launch_tall_impl<P, KK, true, P>((const P *)src, dst, a, stream)                                  \
-                    : launch_tall_impl<P, KK, false, P>((const P *)src, dst, a, stream);                                \
+        return e ? launch_tall_impl<P, KK, true, P>((const P *)src, dst, aa, stream)                                    \
+                 : launch_tall_impl<P, KK, false, P>((const P *)src, dst, aa, stream);                                  \
     }
-    RF_CASE(1) RF_CASE(2) RF_CASE(3)
+        RF_CASE(1) RF_CASE(2) RF_CASE(3)
 #undef RF_CASE
-    set_error("fused path: unsupported order %d", K);
-    return RF_ERR_UNSUPPORTED;
+        set_error("fused path: unsupported order %d", K);
+        return (int)RF_ERR_UNSUPPORTED;
+    };
+    // Partial tiles: the EDGE variant costs the final pass twice its time (no rows leave from inside the last scan, a
+    // bound and a select per access: 16384 x 16380, 0.704 against 0.366 ms), and only the last tile column / row needs it.
+    // Whole tiles run on the lean kernel, the two strips on the EDGE one (FusedArgs::tx0 ..).
+    const int MXf = a.MX - (a.last_cols != kFusedTX ? 1 : 0), MYf = a.MY - (a.last_rows != kTallTY ? 1 : 0);
+    if (edge && split_final_pass((int64_t)MXf * MYf * a.NZ)) {
+        FusedArgs<typename PixelTraits<P>::Acc> part = a;
+        part.gx = MXf; part.gy = MYf;
+        int rc = one(part, false);
+        if (rc == RF_OK && MXf < a.MX) { part = a; part.tx0 = a.MX - 1; part.gx = 1; part.gy = a.MY; rc = one(part, true); }
+        if (rc == RF_OK && MYf < a.MY) { part = a; part.ty0 = a.MY - 1; part.gy = 1; part.gx = MXf; rc = one(part, true); }
+        return rc;
+    }
+    return one(a, edge);
 }
 
 template int launch_fused_pass2_tall<float>(int, const void *, bool, float *, const FusedArgs<float> &, hipStream_t);

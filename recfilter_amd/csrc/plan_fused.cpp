@@ -88,16 +88,19 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         TY = 32;
     // Large images: 128-row tiles halve the y tails and the kernels that walk them between the passes; the final pass
     // takes such a tile through the LDS in two halves and keeps its columns in registers (kernels_fused_tall.hip).
-    // Needs whole 128-row tiles in y... and enough of them to fill the chip several times over.
+    // Needs enough of them to fill the chip several times over (row shards: whole 128-row tiles per slab).  A height that is
+    // not a multiple of 128 leaves a partial last tile row, which the final pass runs as a strip of its own on the EDGE
+    // variant (kernels_fused_tall.hip): 16380 x 16384, 0.70 ms on 64-row tiles with the EDGE kernel everywhere.
     const int nx_early = (int)dx.scan_ids.size(), ny_early = (int)dy.scan_ids.size();
     // (end of round 2, same box, 64 against 128 rows: order 1, cfg4a 1.660 -> 1.636 ms, one bicubic plane 0.593 -> 0.575; order 2,
     // cfg3 0.624 -> 0.601; order 3, cfg4b 2.25 -> 1.87 ms; below ~4096 tiles -- cfg2, 8192^2 -- the 64-row tiles stay ahead)
     // (integer pixels keep 64 rows: their final pass needs more registers than the 128-sample column leaves)
-    if (TY == 64 && !chained && ny_early > 0 && nx_early > 0 && !PixelTraits<P>::is_integer && NYB % 128 == 0 &&
+    if ((TY == 64 || (TY == 32 && NY >= 4096)) && !chained && ny_early > 0 && nx_early > 0 && !PixelTraits<P>::is_integer &&
+        (NYB % 128 == 0 || !rows_sharded) &&
         !(plan->pw.post && plan->pw.post_i != 0.0 && K <= 2) &&     // (orders 1, 2: an epilogue with an input operand keeps the input
                                                                     // column in registers, which a 128-sample column leaves no room for)
         RF_KNOB("RF_NO_TALL_TILES") == nullptr &&
-        ((NX + kFusedTX - 1) / kFusedTX) * (NY / 128) * NZ >= 4096)
+        ((NX + kFusedTX - 1) / kFusedTX) * ((NY + 127) / 128) * NZ >= 4096)
         TY = 128;
     if (const int want = plan->fused_tile_rows() ? plan->fused_tile_rows() : RF_KNOB("RF_FUSED_TY") ? atoi(RF_KNOB("RF_FUSED_TY")) : 0) {
         // RF_PLAN_TILE_ROWS(n): the caller's tile height, where the shape admits it

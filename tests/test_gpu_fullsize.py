@@ -272,3 +272,38 @@ def test_streaming_pass1_3d_and_planes():
         torch.cuda.synchronize()
     for im, o in zip(imgs, outs):
         assert rc.rel_err(o.cpu().numpy(), oracle.apply_filter(im.astype(np.float64), c["scans"], True)) < TOL
+
+
+@pytest.mark.parametrize("case", ["rows64_both", "tall_both", "odd_width", "planes_int32", "volume"])
+def test_final_pass_split_into_whole_tiles_and_edge_strips(case):
+    """An image with partial tiles and at least 1024 whole ones runs its final pass as up to three launches: the whole
+    tiles on the lean kernel, the last tile column and the last tile row on the EDGE variant (FusedArgs::tx0 ..;
+    kernels_fused.hip / kernels_fused_tall.hip).  Every sample against the oracle; the launch names say what ran."""
+    import torch
+    import recfilter_amd as rfa
+    if case == "rows64_both":
+        shape, scans, clamped, planes, dtype, ty = (8292, 8228), rc.xy_pm(rc.GAUSS2), True, 1, np.float32, 64
+    elif case == "tall_both":
+        shape, scans, clamped, planes, dtype, ty = (16380, 8188), rc.xy_pm(rc.GAUSS3), True, 1, np.float32, 128
+    elif case == "odd_width":
+        shape, scans, clamped, planes, dtype, ty = (4200, 8193), rc.REFERENCE_TESTS["test_generic_xy"]["scans"], False, 1, np.float32, 64
+    elif case == "planes_int32":
+        shape, scans, clamped, planes, dtype, ty = (2100, 4200), [(0, True, [1.0, 1.0]), (0, False, [1.0, 1.0, -1.0]), (1, True, [1.0, 2.0, -1.0])], False, 3, np.int32, 64
+    else:
+        shape, scans, clamped, planes, dtype, ty = (40, 1030, 1040), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1, np.float32, 64
+    rng = np.random.default_rng(5)
+    if dtype == np.int32:
+        imgs = [rng.integers(0, 4, size=shape).astype(np.int32) for _ in range(planes)]
+    else:
+        imgs = [rc.random_image(shape, np.float32, 50 + p) for p in range(planes)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes) as plan:
+        assert plan.path == 3 and list(plan.tiles)[1] == ty, plan.tiles
+        outs = [o.cpu().numpy() for o in plan.execute(dev)]
+        torch.cuda.synchronize()
+    for im, out in zip(imgs, outs):
+        if dtype == np.int32:
+            np.testing.assert_array_equal(out, oracle.apply_filter(im, scans, clamped, threads=_threads()))
+        else:
+            want = oracle.apply_filter(im.astype(np.float64), scans, clamped, threads=_threads())
+            assert _floor_err(out, want) < TOL

@@ -1216,7 +1216,7 @@ def test_tall_tiles_other_features(plan_flags):
     assert np.abs(out - want).max() < 2e-5
     plan_flags(TILED)
     for shape, sc, want_ty in (((16384, 8192), scans, 128), ((16384, 8192), rc.xy_pm([1.3, -0.3]), 128), ((2048, 2048), scans, 32),
-                               ((8192, 8192), scans, 64), ((16384 + 64, 8192), scans, 64)):
+                               ((8192, 8192), scans, 64), ((16384 + 64, 8192), scans, 128), ((16380, 8188), scans, 128)):      # (partial last tile row / column: strips of their own)
         with rfa.Plan(shape, sc, clamped=True) as plan:
             assert list(plan.tiles)[:2] == [256, want_ty], (shape, plan.tiles)
 
