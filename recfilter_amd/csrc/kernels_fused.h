@@ -163,9 +163,6 @@ int launch_fused_pass2(int K, int TY, const void *src, bool src_u8, P *dst, cons
 template <typename P>
 int launch_fused_pass2_tall(int K, const void *src, bool src_u8, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
                             hipStream_t stream);
-// whether a final pass with partial tiles is worth three launches: enough whole tiles for the lean kernel to pay for two
-// more launches (a few microseconds each)
-inline bool split_final_pass(int64_t whole_tiles) { return whole_tiles >= 1024; }
 // pass 1 as a contraction with precomputed impulse responses (kernels_tails.hip)
 template <typename P>
 int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedArgs<typename PixelTraits<P>::Acc> &a,

@@ -406,25 +406,12 @@ int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename Pixe
 
 template <typename P, typename PI>
 static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a,
-                                    hipStream_t stream, int edge_mode = -1) {
+                                    hipStream_t stream) {
     // the epilogue variant that keeps the input column in registers exists for float pixels only
     bool epi = false;
-    const bool has_partial = a.last_cols != kFusedTX || a.last_rows != TY;
-    // (edge_mode: the tiles of this launch are all whole (0) / include partial ones (1); -1: decide here, and run a large
-    // image with partial tiles as three launches -- whole tiles on the lean kernel, last tile column and last tile row on
-    // the EDGE variant, which costs 20-35 % more per tile: 8192 x 8188, 0.134 against 0.101 ms)
-    if (edge_mode < 0 && has_partial && a.lin_limit == 0) {
-        const int MXf = a.MX - (a.last_cols != kFusedTX ? 1 : 0), MYf = a.MY - (a.last_rows != TY ? 1 : 0);
-        if (split_final_pass((int64_t)MXf * MYf * a.NZ)) {
-            FusedArgs<typename PixelTraits<P>::Acc> part = a;
-            part.gx = MXf; part.gy = MYf;
-            int rc = launch_fused_pass2_typed<P, PI>(K, TY, src, dst, part, stream, 0);
-            if (rc == RF_OK && MXf < a.MX) { part = a; part.tx0 = a.MX - 1; part.gx = 1; part.gy = a.MY; rc = launch_fused_pass2_typed<P, PI>(K, TY, src, dst, part, stream, 1); }
-            if (rc == RF_OK && MYf < a.MY) { part = a; part.ty0 = a.MY - 1; part.gy = 1; part.gx = MXf; rc = launch_fused_pass2_typed<P, PI>(K, TY, src, dst, part, stream, 1); }
-            return rc;
-        }
-    }
-    const bool edge = edge_mode < 0 ? has_partial : edge_mode != 0;
+    const bool edge = a.last_cols != kFusedTX || a.last_rows != TY;
+    // (three launches like the 128-row final pass's -- whole tiles lean, edge strips on the EDGE variant -- gain nothing here:
+    // the 64-row EDGE variant costs 20-35 % per tile, what the two extra strips cost: 8192 x 8188, 0.134 / 0.135 ms)
     if constexpr (!PixelTraits<P>::is_integer) epi = (a.pw_flags & 2) && a.post_i != typename PixelTraits<P>::Acc(0) && K <= 2;
     if (a.lin_limit > 0 && (a.ny != 0 || a.NZ != 1 || a.plane_batch || epi || edge)) {
         set_error("fused pass 2: a signal that ends inside the image needs a 1-D plan of whole tiles without an input-operand epilogue");

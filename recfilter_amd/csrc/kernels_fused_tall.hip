@@ -394,16 +394,19 @@ int launch_fused_pass2_tall(int K, const void *src, bool src_u8, P *dst, const F
         set_error("fused path: unsupported order %d", K);
         return (int)RF_ERR_UNSUPPORTED;
     };
-    // Partial tiles: the EDGE variant costs the final pass twice its time (no rows leave from inside the last scan, a
-    // bound and a select per access: 16384 x 16380, 0.704 against 0.366 ms), and only the last tile column / row needs it.
-    // Whole tiles run on the lean kernel, the two strips on the EDGE one (FusedArgs::tx0 ..).
-    const int MXf = a.MX - (a.last_cols != kFusedTX ? 1 : 0), MYf = a.MY - (a.last_rows != kTallTY ? 1 : 0);
-    if (edge && split_final_pass((int64_t)MXf * MYf * a.NZ)) {
+    // Partial tiles.  The EDGE variant costs the final pass almost twice its time per tile (no rows leave from inside the last
+    // scan, a bound and a select per access, 24-144 bytes of scratch: 16384 x 16256, 0.662 ms against 0.366 ms for 16384^2),
+    // and only the last tile column / row needs it: the whole tiles run on the lean kernel, the two strips as launches of
+    // their own on the EDGE variant (FusedArgs::tx0 ..): 0.386 + 0.042 ms.  (One launch with a per-workgroup branch between
+    // the two bodies was slower than the three launches: 0.531 ms.)
+    static const bool edge_everywhere = RF_KNOB("RF_TALL_EDGE_EVERYWHERE") != nullptr;      // A/B runs
+    if (edge && !edge_everywhere) {
+        const int MXf = a.MX - (a.last_cols != kFusedTX ? 1 : 0), MYf = a.MY - (a.last_rows != kTallTY ? 1 : 0);
         FusedArgs<typename PixelTraits<P>::Acc> part = a;
         part.gx = MXf; part.gy = MYf;
-        int rc = one(part, false);
+        int rc = (MXf > 0 && MYf > 0) ? one(part, false) : (int)RF_OK;
         if (rc == RF_OK && MXf < a.MX) { part = a; part.tx0 = a.MX - 1; part.gx = 1; part.gy = a.MY; rc = one(part, true); }
-        if (rc == RF_OK && MYf < a.MY) { part = a; part.ty0 = a.MY - 1; part.gy = 1; part.gx = MXf; rc = one(part, true); }
+        if (rc == RF_OK && MYf < a.MY && MXf > 0) { part = a; part.ty0 = a.MY - 1; part.gy = 1; part.gx = MXf; rc = one(part, true); }
         return rc;
     }
     return one(a, edge);
