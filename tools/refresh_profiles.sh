@@ -1,13 +1,12 @@
 #!/bin/bash
 # Collect the round's evidence on a GPU box: bench line, rocprofv3 kernel-trace stats and the two PMC passes
 # (FETCH_SIZE, WRITE_SIZE -- separate runs, never combined with a sys trace) of the same command.
-#   bash tools/refresh_profiles.sh <tag>        -> gpurun_out/prof_<tag>/{bench.json,kernel_stats.csv,pmc_traffic.json}
+#   bash tools/refresh_profiles.sh <round, e.g. r3>   -> gpurun_out/prof_<round>/{bench.json,kernel_stats.csv,pmc_traffic.json}
 set -u
 tag=${1:-latest}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
-python3 $root/bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline > $out/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -16,4 +15,8 @@ cd $root
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 python3 tools/pmc_summary.py $(ls $out/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $out/pmc_write/*/*counter_collection.csv | head -1) $out/pmc_traffic.json
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+# the bench line LAST, with the fresh PMC summary in place: bench.py reports `traffic` only from a summary collected on the
+# kernel sources that are running (git_head is stamped afterwards, where .git exists: tools/stamp_head.py)
+mkdir -p $root/profiles/$tag && cp $out/pmc_traffic.json $root/profiles/$tag/pmc_traffic.json
+python3 $root/bench.py > $out/bench.json 2> $out/bench.err
 cut -c1-1500 $out/bench.json; head -8 $out/kernel_stats.csv; cat $out/pmc_traffic.json | head -30
