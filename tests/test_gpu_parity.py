@@ -1015,6 +1015,40 @@ def test_one_plan_executes_concurrently_on_distinct_streams():
         assert plan.num_instances == 1
 
 
+def test_plans_release_their_device_memory():
+    """rf_plan_destroy frees everything a plan allocated -- workspace, tables, the replicas concurrent executes made it build,
+    the stages of a cascade, the helper plan of an early exchange: free device memory returns to where it was."""
+    import torch
+    import recfilter_amd as rfa
+    torch.cuda.synchronize()
+    x = torch.rand((1024, 2048), device="cuda")
+    vol = torch.rand((64, 64, 256), device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+
+    def cycle():
+        with rfa.Plan((1024, 2048), rc.xy_pm(rc.GAUSS2), clamped=True) as p:
+            for st in streams:
+                p.execute([x], stream=st)
+            torch.cuda.synchronize()
+            assert p.num_instances >= 2
+        with rfa.Plan((1024, 2048), [(0, True, [0.5, 0.5])] * 6 + [(1, False, [0.6, 0.4])]) as p:      # in-plan cascade
+            p.execute([x])
+        with rfa.Plan((64, 64, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], shard_rank=0, shard_world=2) as p:   # helper plan
+            assert p.has_interior
+        with rfa.Plan((1024, 2048), rc.xy_pm(rc.GAUSS2), clamped=True, path=4, tile=[32, 32]) as p:
+            p.execute([x])
+        torch.cuda.synchronize()
+    cycle()                                   # (first use: code objects, torch's allocator pools)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"device memory leaked: {(free0 - free1) / 2 ** 20:.1f} MiB over 5 cycles"
+    del vol
+
+
 # ---- unsigned-byte input planes converted on load (rf_pointwise_desc.in_dtype = RF_IN_U8) -------------------------
 @pytest.mark.parametrize("shape,path", [((128, 512), 0), ((75, 464), 0), ((64, 250), 0), ((64, 256), 1), ((40, 16, 272), 0)],
                          ids=["fused", "fused_partial", "generic_auto", "untiled", "fused_3d"])
