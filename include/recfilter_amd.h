@@ -191,7 +191,7 @@ int rf_plan_num_kernels(const rf_plan *plan);
  * executes; an execute finds the instance that last ran on its stream (stream order separates the two), else one whose
  * last execution has finished (hipEventQuery), else builds a replica.  So rf_plan_execute may be called on distinct
  * streams, and from distinct host threads, without the executions waiting for one another (the call that builds a replica
- * synchronises the device once).  rf_plan_workspace_bytes reports one instance.  The stepping calls below belong to the
+ * takes the host time of a plan creation once; it does not wait for the device).  rf_plan_workspace_bytes reports one instance.  The stepping calls below belong to the
  * host thread that called rf_plan_begin, until its rf_plan_finish.
  *
  * in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan whose kernels

@@ -562,7 +562,10 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     }
     if (rc != RF_OK) return rc;
     add_pointwise_steps(plan.get());
-    if (!host_only) RF_HIP_CHECK(hipDeviceSynchronize());   // uploads done before the first execute
+    // The tables are uploaded with blocking copies; the zero fills (hipMemset) are work of the null stream: wait for THAT
+    // stream, not for the device -- a replica is built while other streams are busy with executions of this very plan
+    // (capi.cpp, acquire_instance), and a device-wide wait would serialise what the replica exists to overlap.
+    if (!host_only) RF_HIP_CHECK(hipStreamSynchronize(nullptr));
     save_desc(plan.get(), desc);
     *out = plan.release();
     return RF_OK;
