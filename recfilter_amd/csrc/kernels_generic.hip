@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "plan_clamp1d.h"
 
 namespace rf {
 
@@ -679,6 +680,64 @@ int launch_merged_apply(GenericDimArgs<Acc> a, const Acc *Y, hipStream_t stream)
     set_error("merged exchange: order %d with %d scans not instantiated", a.k, a.n_scans);
     return RF_ERR_UNSUPPORTED;
 }
+
+// ---- clamped 1-D signals on the fused kernels (plan_clamp1d.h): the two small launches around the zero-border plan ----
+// dots[s] = sum_i w[s][i] * in[window of scan s][i], one workgroup per scan, double accumulation
+template <typename P>
+__global__ void __launch_bounds__(kBlock)
+clamp1d_dots_kernel(const P *__restrict__ in, int64_t N, int L, const int32_t *__restrict__ side, const double *__restrict__ w,
+                    double *__restrict__ dots) {
+    const int s = blockIdx.x;
+    const P *win = side[s] == 0 ? in : in + (N - L);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < L; i += kBlock) acc += w[(int64_t)s * L + i] * (double)win[i];
+    __shared__ double red[kBlock];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int step = kBlock / 2; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step) red[threadIdx.x] += red[threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dots[s] = red[0];
+}
+
+// beta_s = dots[s] + sum_{q<s} beta_q H[q][s] (every thread: n <= RF_MAX_SCANS), then out[window] += sum_s beta_s G_s
+template <typename P>
+__global__ void __launch_bounds__(kBlock)
+clamp1d_fix_kernel(P *__restrict__ out, int64_t N, int L, int n, const int32_t *__restrict__ side, const double *__restrict__ H,
+                   const double *__restrict__ G, const double *__restrict__ dots) {
+    double beta[RF_MAX_SCANS];
+    for (int s = 0; s < n; s++) {
+        double b = dots[s];
+        for (int q = 0; q < s; q++) b += beta[q] * H[q * n + s];
+        beta[s] = b;
+    }
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);       // [0, 2L): the start window, then the end window
+    if (i >= 2 * L) return;
+    const int which = i / L, k = i % L;
+    double add = 0.0;
+    for (int s = 0; s < n; s++)
+        if (side[s] == which) add += beta[s] * G[(int64_t)s * L + k];
+    P *p = which == 0 ? out + k : out + (N - L) + k;
+    *p = (P)((double)*p + add);
+}
+
+template <typename P>
+int launch_clamp1d_dots(const P *in, int64_t N, int L, int n, const int32_t *side, const double *w, double *dots, hipStream_t stream) {
+    hipLaunchKernelGGL(clamp1d_dots_kernel<P>, dim3((unsigned)n), dim3(kBlock), 0, stream, in, N, L, side, w, dots);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+template <typename P>
+int launch_clamp1d_fix(P *out, int64_t N, int L, int n, const int32_t *side, const double *H, const double *G, const double *dots,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(clamp1d_fix_kernel<P>, dim3((unsigned)((2 * L + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, out, N, L, n, side,
+                       H, G, dots);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+template int launch_clamp1d_dots<float>(const float *, int64_t, int, int, const int32_t *, const double *, double *, hipStream_t);
+template int launch_clamp1d_fix<float>(float *, int64_t, int, int, const int32_t *, const double *, const double *, const double *, hipStream_t);
 
 template <typename P>
 int launch_pointwise(const P *f, const P *x, P *dst, int64_t n, double c0, double c1, double c2, hipStream_t stream) {

@@ -8,6 +8,7 @@
 #include "plan.h"
 #include "sections.h"
 #include "plan_generic.h"
+#include "plan_clamp1d.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -298,6 +299,81 @@ int build_cascade(const rf_filter_desc *desc, const std::vector<int> &stage_of, 
     return RF_OK;
 }
 
+// ---- clamped 1-D signals (plan_clamp1d.h) ----------------------------------------------------------------------------
+// The zero-border fused plan of the same scans as a child, a launch of n dot products in front of it and the corrections of
+// the two ends of the output behind it.  RF_ERR_UNSUPPORTED (the caller goes on to the other paths) when the filter does not
+// decay inside a quarter of the signal or its zero-border form does not run on the fused kernels.
+int build_clamped_1d(const rf_filter_desc *desc, rf_plan *parent) {
+    Clamp1DTables t;
+    if (!build_clamp1d_tables(parent->scans, parent->dims[0].N, t)) {
+        set_error("clamped 1-D: the filter does not decay inside a quarter of the signal");
+        return RF_ERR_UNSUPPORTED;
+    }
+    rf_filter_desc cd = *desc;
+    cd.border = RF_BORDER_ZERO;
+    cd.path = RF_PATH_TILED_FUSED;
+    rf_plan *child = nullptr;
+    int rc = build_plan(&cd, &child);
+    if (rc != RF_OK) return RF_ERR_UNSUPPORTED;
+    std::unique_ptr<rf_plan> holder(child);
+    if (child->path != RF_PATH_TILED_FUSED) return RF_ERR_UNSUPPORTED;
+    int status = RF_OK;
+    const int n = t.n, L = t.L;
+    const int32_t *d_side = (const int32_t *)parent->upload(t.side.data(), t.side.size() * sizeof(int32_t), &status);
+    const double *d_w = (const double *)parent->upload(t.w.data(), t.w.size() * sizeof(double), &status);
+    const double *d_G = (const double *)parent->upload(t.G.data(), t.G.size() * sizeof(double), &status);
+    const double *d_H = (const double *)parent->upload(t.H.data(), t.H.size() * sizeof(double), &status);
+    double *d_dots = (double *)parent->alloc((size_t)n * parent->n_planes * sizeof(double), true, &status);
+    if (status != RF_OK) return status;
+    const int64_t N = parent->dims[0].N;
+    Step dots;
+    dots.name = "clamp1d_dots";
+    dots.run = [parent, N, L, n, d_side, d_w, d_dots](int pl) {
+        return launch_clamp1d_dots<float>((const float *)parent->orig_in[pl], N, L, n, d_side, d_w, d_dots + (size_t)pl * n, parent->stream);
+    };
+    parent->begin_steps.push_back(dots);
+    std::vector<const Step *> steps;
+    for (const Step &s : child->begin_steps) steps.push_back(&s);
+    for (const auto &ex : child->exchange_local_steps)
+        for (const Step &s : ex) steps.push_back(&s);
+    for (const Step &s : child->finish_steps) steps.push_back(&s);
+    for (size_t k = 0; k < steps.size(); k++) {
+        const Step *sp = steps[k];
+        Step w;
+        w.name = sp->name;
+        const bool first = k == 0;
+        w.run = [parent, child, sp, first](int pl) {
+            if (first && pl == 0) {          // the child's context, all planes
+                for (int q = 0; q < parent->n_planes; q++) {
+                    child->in[q] = child->orig_in[q] = parent->orig_in[q];
+                    child->out[q] = parent->out[q];
+                }
+                child->stream = parent->stream;
+            }
+            return sp->run(pl);
+        };
+        parent->begin_steps.push_back(w);
+    }
+    Step fix;
+    fix.name = "clamp1d_fix";
+    fix.run = [parent, N, L, n, d_side, d_H, d_G, d_dots](int pl) {
+        return launch_clamp1d_fix<float>((float *)parent->out[pl], N, L, n, d_side, d_H, d_G, d_dots + (size_t)pl * n, parent->stream);
+    };
+    parent->begin_steps.push_back(fix);
+    for (auto &ex : child->exchanges) ex.send = ex.scratch;
+    parent->path = RF_PATH_TILED_FUSED;
+    parent->vector_access = true;
+    parent->workspace_bytes += child->workspace_bytes;
+    for (int d = 0; d < RF_MAX_DIMS; d++) { parent->dims[d].T = child->dims[d].T; parent->dims[d].M = child->dims[d].M; }
+    parent->tables = child->tables;
+    parent->tables["clamp1d_w"] = t.w;
+    parent->tables["clamp1d_G"] = t.G;
+    parent->tables["clamp1d_H"] = t.H;
+    parent->tables["clamp1d_L"] = {(double)L};
+    parent->stages.push_back(std::move(holder));
+    return RF_OK;
+}
+
 // what a replica of this plan is built from (concurrent executions, capi.cpp)
 void save_desc(rf_plan *plan, const rf_filter_desc *desc) {
     plan->saved.d = *desc;
@@ -466,6 +542,16 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
                 }
             }
         }
+    }
+
+    // A clamped 1-D signal: the zero-border fused plan plus the border corrections (plan_clamp1d.h).
+    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && desc->ndim == 1 && plan->clamped && plan->dtype == RF_F32 &&
+        !plan->sharded() && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && desc->n_scans >= 1) {
+        const int rc = build_clamped_1d(desc, plan.get());
+        if (rc == RF_OK) { save_desc(plan.get(), desc); if (!host_only) RF_HIP_CHECK(hipStreamSynchronize(nullptr)); *out = plan.release(); return RF_OK; }
+        if (rc != RF_ERR_UNSUPPORTED) return rc;
+        plan->begin_steps.clear();
+        plan->stages.clear();
     }
 
     // What the fused kernels cannot take in one piece because of the NUMBER or the ORDER of its scans runs as a cascade of

@@ -1529,3 +1529,37 @@ def test_1d_integer_signals_any_length(n, dtype):
         torch.cuda.synchronize()
     assert torch.equal(fused, plain)
     np.testing.assert_array_equal(fused[:n].cpu().numpy(), oracle.apply_filter(big_in[:n].cpu().numpy(), scans, False))
+
+
+# ---- clamped 1-D signals: the zero-border fused plan plus the border corrections (plan_clamp1d.h) ----------------------
+@pytest.mark.parametrize("n", [10_000, 65_536, 100_001, 1_000_003])
+@pytest.mark.parametrize("pattern", ["c", "ca", "acca", "ccccc"])
+def test_clamped_1d_signals_on_the_fused_kernels(n, pattern):
+    rng = np.random.default_rng(len(pattern) * 1000 + n % 997)
+    scans = []
+    for ch in pattern:
+        k = int(rng.integers(1, 4))
+        co = [float(rng.uniform(0.3, 1.2))] + [float(-c) for c in np.poly(rng.uniform(-0.85, 0.85, size=k))[1:]]
+        scans.append((0, ch == "c", co))
+    planes = 2 if n < 200_000 else 1
+    imgs, outs, (path, _) = _run((n,), scans, clamped=True, planes=planes, seed=n % 13)
+    assert path == 3
+    _check(imgs, outs, scans, True)
+    imgs, outs, (path, _) = _run((n,), scans, clamped=True, planes=1, seed=3, inplace=True)
+    assert path == 3
+    _check(imgs, outs, scans, True)
+
+
+def test_clamped_1d_fallbacks():
+    """What the border corrections do not cover stays where it was: filters that do not decay (a running sum), integer
+    pixels, signals below 8192 samples, a prologue."""
+    import recfilter_amd as rfa
+    for kw in (dict(scans=[(0, True, [1.0, 1.0])]), dict(scans=[(0, True, [0.5, 0.4])], dtype=np.int32), dict(scans=[(0, True, [0.5, 0.4])], prologue=(0.5, 0.1))):
+        scans = kw.pop("scans")
+        with rfa.Plan((100_000,), scans, clamped=True, **kw) as plan:
+            assert plan.path != 3
+    imgs, outs, (path, _) = _run((5000,), [(0, True, [0.5, 0.4]), (0, False, [0.5, 0.4])], clamped=True)
+    assert path != 3
+    _check(imgs, outs, [(0, True, [0.5, 0.4]), (0, False, [0.5, 0.4])], True)
+    imgs, outs, (path, _) = _run((100_000,), [(0, True, [1.0, 1.0])], clamped=True)
+    _check(imgs, outs, [(0, True, [1.0, 1.0])], True)

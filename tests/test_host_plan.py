@@ -413,8 +413,46 @@ def test_in_plan_cascade_decisions():
     # an epilogue that reads the input cannot be cascaded (the last stage no longer sees it): as before
     with plan_of((256, 512), [(0, True, [0.5, 0.5])] * 5, epilogue=(1.0, 1.0, 0.0)) as p:
         assert p.path_name != "tiled_fused"
-    # clamped 1-D signals stay off the fused kernels whatever the split
-    with plan_of((100_000,), [(0, True, bq)] * 5, clamped=True) as p:
+    # clamped 1-D signals: the zero-border fused plan (here a cascade of two stages) plus the border corrections
+    # (plan_clamp1d.h) -- unless the filter does not decay (a running sum), which keeps the generic path
+    with plan_of((100_000,), [(0, True, bq)] * 5, clamped=True) as p, plan_of((100_000,), [(0, True, bq)] * 5) as z:
+        assert p.path_name == "tiled_fused" and p.num_kernels == z.num_kernels + 2
+        assert p.table("clamp1d_L")[0] % 256 == 0 and p.table("clamp1d_H").size == 25
+    with plan_of((100_000,), [(0, True, [1.0, 1.0])], clamped=True) as p:
         assert p.path_name != "tiled_fused"
     with plan_of((1_000_000,), [(0, True, bq)] * 5, flags=T | capi.RF_PLAN_NO_CASCADE) as p:
         assert p.path_name != "tiled_fused"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_clamped_1d_border_correction_tables(seed):
+    """plan_clamp1d.h on the host: a clamped scan is the zero-border scan plus (the border sample) x (a fixed decaying
+    sequence), so a clamped 1-D filter is its zero-border form plus rank-one corrections of the two ends whose weights
+    (w: what the border samples were before each scan, as dot products with the input's ends; H: how earlier corrections
+    move later border samples; G: what each correction adds to the output) depend on the filter alone.  Replayed here in
+    numpy from the plan's tables against the oracle's clamped filter."""
+    rng = np.random.default_rng(4400 + seed)
+    n = int(rng.integers(1, 6))
+    scans = []
+    for _ in range(n):
+        k = int(rng.integers(1, 4))
+        co = [float(rng.uniform(0.3, 1.2))] + [float(-c) for c in np.poly(rng.uniform(-0.8, 0.8, size=k))[1:]]
+        scans.append((0, bool(rng.integers(0, 2)), [float(np.float32(v)) for v in co]))
+    N = 40_000
+    p = _host_plan((N,), scans, clamped=True)
+    assert p.path == capi.RF_PATH_TILED_FUSED
+    L = int(p.table("clamp1d_L")[0])
+    w, G, H = p.table("clamp1d_w").reshape(n, L), p.table("clamp1d_G").reshape(n, L), p.table("clamp1d_H").reshape(n, n)
+    x = rng.standard_normal(N)
+    out = oracle.apply_filter(x, scans, clamped=False)
+    beta = np.zeros(n)
+    for s in range(n):
+        win = x[:L] if scans[s][1] else x[N - L:]
+        beta[s] = w[s] @ win + sum(beta[q] * H[q, s] for q in range(s))
+    for s in range(n):
+        if scans[s][1]:
+            out[:L] += beta[s] * G[s]
+        else:
+            out[N - L:] += beta[s] * G[s]
+    want = oracle.apply_filter(x, scans, clamped=True)
+    assert np.max(np.abs(out - want)) <= 1e-11 * np.max(np.abs(want))
