@@ -673,8 +673,9 @@ def test_long_1d_signal_int32_prefix_sum_bit_exact_and_fallbacks():
     imgs, outs, (path, _) = _run((8000,), scans)
     assert path == 2
     _check(imgs, outs, scans, False)
+    # (a clamped 1-D signal: fused since round 3 -- the zero-border plan plus the border corrections, plan_clamp1d.h)
     imgs, outs, (path, _) = _run((8192,), [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], clamped=True)
-    assert path == 2
+    assert path == 3
     _check(imgs, outs, [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)], True)
 
 

@@ -130,7 +130,7 @@ if len(sys.argv) > 3 and sys.argv[3] in ("f64", "1d"):
                 k = int(rng.integers(1, 4))
                 a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
                 scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
-        clamped = bool(rng.integers(0, 2)) if mode == "f64" else False
+        clamped = bool(rng.integers(0, 2))        # (1-D: clamped signals run the zero-border plan plus border corrections)
         tdt = torch.float64 if mode == "f64" else torch.float32
         npdt = np.float64 if mode == "f64" else np.float32
         img = torch.rand(shape, device="cuda", dtype=tdt)
