@@ -1564,3 +1564,14 @@ def test_clamped_1d_fallbacks():
     _check(imgs, outs, [(0, True, [0.5, 0.4]), (0, False, [0.5, 0.4])], True)
     imgs, outs, (path, _) = _run((100_000,), [(0, True, [1.0, 1.0])], clamped=True)
     _check(imgs, outs, [(0, True, [1.0, 1.0])], True)
+
+
+def test_clamped_1d_high_order_scans():
+    """Orders above 3 under a clamped border: the border corrections are built from the scans as given (any order), the
+    zero-border plan underneath runs them as sections on the fused kernels."""
+    o5 = _from_poles([0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j])
+    o8 = _from_poles([0.7, -0.6, 0.5 + 0.4j, 0.5 - 0.4j, -0.3 + 0.5j, -0.3 - 0.5j, 0.2 + 0.7j, 0.2 - 0.7j])
+    for scans in ([(0, True, o5), (0, False, o5)], [(0, False, o8)], [(0, True, o8), (0, True, rc.GAUSS3), (0, False, o5)]):
+        imgs, outs, (path, _) = _run((300_000,), scans, clamped=True)
+        assert path == 3
+        _check(imgs, outs, scans, True)
