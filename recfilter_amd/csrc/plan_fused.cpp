@@ -86,6 +86,13 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (TY == 64 && NY % 32 == 0 && !rows_sharded && ((NX + kFusedTX - 1) / kFusedTX) * (NY / 64) * NZ <= 384 &&
         !(K >= 3 && NY / 32 > 64))
         TY = 32;
+    // ... and a mid-size image whose height is not a multiple of 64 runs the EDGE variants of its kernels either way: 32-row
+    // tiles then waste less of the partial last tile row and cost the EDGE final pass less (tools/ty_probe.py, 64 -> 32 rows:
+    // 5000^2 order 2 0.127 -> 0.123 ms, order 3 0.175 -> 0.156; 6000 x 8000 0.181 -> 0.172 / 0.234 -> 0.224; from ~4000 tiles
+    // on the 64-row tiles are ahead again: 9000 x 12000 0.330 against 0.358)
+    if (TY == 64 && NY % 64 != 0 && NY >= 32 && !rows_sharded && !chained &&
+        ((NX + kFusedTX - 1) / kFusedTX) * ((NY + 63) / 64) * NZ <= 3200)
+        TY = 32;
     // Large images: 128-row tiles halve the y tails and the kernels that walk them between the passes; the final pass
     // takes such a tile through the LDS in two halves and keeps its columns in registers (kernels_fused_tall.hip).
     // Needs enough of them to fill the chip several times over (row shards: whole 128-row tiles per slab).  A height that is

@@ -276,9 +276,10 @@ def test_streaming_pass1_3d_and_planes():
 
 @pytest.mark.parametrize("case", ["rows64_both", "tall_both", "odd_width", "planes_int32", "volume"])
 def test_final_pass_split_into_whole_tiles_and_edge_strips(case):
-    """An image with partial tiles and at least 1024 whole ones runs its final pass as up to three launches: the whole
-    tiles on the lean kernel, the last tile column and the last tile row on the EDGE variant (FusedArgs::tx0 ..;
-    kernels_fused.hip / kernels_fused_tall.hip).  Every sample against the oracle; the launch names say what ran."""
+    """Large images with partial tiles, every sample against the oracle: on 128-row tiles the final pass is up to three
+    launches -- the whole tiles on the lean kernel, the last tile column and the last tile row on the EDGE variant
+    (FusedArgs::tx0 ..; kernels_fused_tall.hip) --, on 64- and 32-row tiles one launch of the EDGE variant (mid-size images
+    whose height is not a multiple of 64 take 32-row tiles)."""
     import torch
     import recfilter_amd as rfa
     if case == "rows64_both":
@@ -286,9 +287,9 @@ def test_final_pass_split_into_whole_tiles_and_edge_strips(case):
     elif case == "tall_both":
         shape, scans, clamped, planes, dtype, ty = (16380, 8188), rc.xy_pm(rc.GAUSS3), True, 1, np.float32, 128
     elif case == "odd_width":
-        shape, scans, clamped, planes, dtype, ty = (4200, 8193), rc.REFERENCE_TESTS["test_generic_xy"]["scans"], False, 1, np.float32, 64
+        shape, scans, clamped, planes, dtype, ty = (4200, 8193), rc.REFERENCE_TESTS["test_generic_xy"]["scans"], False, 1, np.float32, 32
     elif case == "planes_int32":
-        shape, scans, clamped, planes, dtype, ty = (2100, 4200), [(0, True, [1.0, 1.0]), (0, False, [1.0, 1.0, -1.0]), (1, True, [1.0, 2.0, -1.0])], False, 3, np.int32, 64
+        shape, scans, clamped, planes, dtype, ty = (2100, 4200), [(0, True, [1.0, 1.0]), (0, False, [1.0, 1.0, -1.0]), (1, True, [1.0, 2.0, -1.0])], False, 3, np.int32, 32
     else:
         shape, scans, clamped, planes, dtype, ty = (40, 1030, 1040), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1, np.float32, 64
     rng = np.random.default_rng(5)
