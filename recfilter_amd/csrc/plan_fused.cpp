@@ -93,6 +93,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (TY == 64 && NY % 64 != 0 && NY >= 32 && !rows_sharded && !chained &&
         ((NX + kFusedTX - 1) / kFusedTX) * ((NY + 63) / 64) * NZ <= 3200)
         TY = 32;
+    // ... except at order 3 with 65..128 32-row tiles per column, where the y carry scan leaves its register-resident form
+    // (kernels_carry.hip): 64-row tiles with a partial last row are ahead there (2160 x 3840: 74 against 85 us, 3000 x 4000:
+    // 98 / 110, 4000^2: 112 / 123; above 128 tiles per column the 32-row tiles win again, 5000^2: 157 / 175 us)
+    if (TY == 32 && K >= 3 && !rows_sharded && !chained && NY >= 64 && (NY + 31) / 32 > 64 && (NY + 31) / 32 <= 128)
+        TY = 64;
     // Large images: 128-row tiles halve the y tails and the kernels that walk them between the passes; the final pass
     // takes such a tile through the LDS in two halves and keeps its columns in registers (kernels_fused_tall.hip).
     // Needs enough of them to fill the chip several times over (row shards: whole 128-row tiles per slab).  A height that is
