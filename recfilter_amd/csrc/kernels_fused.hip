@@ -284,7 +284,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
         if constexpr (YPAT >= 1) {
             // YPAT 3 / 4: pattern 1 / 2 without an epilogue -- the rows are stored from inside the last scan, each as soon
             // as it is final, instead of TY stores in one burst behind the recurrence
-            static_assert(!EDGE || YPAT == 0, "the fixed patterns are instantiated for whole tiles");
+            static_assert(!EDGE || YPAT <= 2, "rows leave from inside the last scan on whole tiles only");
             constexpr int PAT = YPAT > 2 ? YPAT - 2 : YPAT;
             constexpr bool EARLY = YPAT > 2;
             char *dpb_early = reinterpret_cast<char *>(dst + tile_off);
@@ -305,6 +305,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
             if constexpr (PAT == 2) {
                 const bool clamp_first = a.clamped && ty == a.MY - 1 && a.y_last_border;
                 if constexpr (EARLY) { scan_col<Acc, false, K, TY>(col, a.ys[1], clamp_first, CY[1], row_out); return; }
+                else if (EDGE && rows_here != TY) scan_col_partial_up<Acc, K, TY>(col, a.ys[1], clamp_first, rows_here);     // partial last tile row
                 else scan_col<Acc, false, K, TY>(col, a.ys[1], clamp_first, CY[1]);
             }
         } else {
@@ -435,8 +436,12 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
             }                                                                                                   \
             if (epi) return launch_fused_pass2_impl<P, KK, TT, true, false, PI>(src, dst, a, stream);           \
         }                                                                                                       \
+        if constexpr (std::is_same<P, float>::value && std::is_same<P, PI>::value) {   /* partial tiles, the usual y scans */ \
+            if (edge && ypat == 1) return launch_fused_pass2_impl<P, KK, TT, false, true, PI, 1>(src, dst, a, stream); \
+            if (edge && ypat == 2) return launch_fused_pass2_impl<P, KK, TT, false, true, PI, 2>(src, dst, a, stream); \
+        }                                                                                                       \
         if (edge) return launch_fused_pass2_impl<P, KK, TT, false, true, PI>(src, dst, a, stream);              \
-        if constexpr (TT == 64 && std::is_same<P, PI>::value) {        /* the usual y scans, directions fixed at compile time */ \
+        if constexpr ((TT == 64 || std::is_same<P, float>::value) && std::is_same<P, PI>::value) {   /* the usual y scans, directions fixed at compile time */ \
             if (ypat == 1 && early && xpat == 1) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 3, true>(src, dst, a, stream); \
             if (ypat == 2 && early && xpat == 2) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 4, true>(src, dst, a, stream); \
             if (ypat == 1 && early) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 3>(src, dst, a, stream); \
