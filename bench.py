@@ -17,6 +17,11 @@ GPU (strictly one after the other on one stream: what `kernels_ms` adds up to an
 profiles/ show), two in flight on N > 1 GPUs, where the second step keeps the all-gather's latency off the critical
 path (`config.steps_in_flight` says which; on one GPU two in flight are worth 2 %).
 
+After the timed region of a sharded run the result is CHECKED: every rank gathers all input slabs, runs the unsharded plan
+on the whole image and compares its slab of that with what the sharded protocol produced (`sharded_parity`, max over ranks;
+above 1e-4 the bench exits non-zero).  A default run (no --workload / --size) also measures BASELINE config 5 -- 2048^3, six
+order-2 scans, sharded along z over the N GPUs, strong scaling -- and carries its line, same keys, as `configs[0]`.
+
 Prints ONE JSON line (rank 0).  `value` = Mpixels/s over all GPUs; `roofline` prices the dominant
 kernel against the 8 TB/s HBM peak with HIP-event timing of that kernel; `cpu_baseline` is the CPU
 oracle (a port of the reference's scan operator, OpenMP over all host cores) on a bounded sample.
@@ -195,65 +200,33 @@ def metric_name(workload_name, shape, planes):
     return f"Mpixels/s + achieved HBM GB/s, {'x'.join(map(str, shape))} x{planes} {what}"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
-    ap.add_argument("--path", type=int, default=0, help="rf_path override (debug)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
-                    "multi-rank path on a box with one GPU)")
-    ap.add_argument("--device", type=int, default=-1, help="device ordinal for every rank (debug; default LOCAL_RANK)")
-    ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's shape is the GLOBAL image, every rank "
-                    "owns 1/N of its outermost dimension (BASELINE config 5: 2048^3 z-sharded over 8 GPUs); default is weak "
-                    "scaling, every rank owns a full-size slab")
-    ap.add_argument("--force-stepping", action="store_true", help="one rank: drive the sharded protocol anyway (begin, exit carries, "
-                    "all-gather over the process group, interior, entering carries, finish) on a plan built with "
-                    "RF_PLAN_FORCE_EXCHANGE -- what every rank of an N-GPU run executes, on a box with one GPU")
-    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU, each on its own HIP stream with its own "
-                    "plan and output planes (1 = strictly one after the other on one stream; 0 = auto: 1 on one GPU, so "
-                    "that per-kernel durations under rocprofv3 are those of kernels running alone, 2 on several GPUs, "
-                    "where the second step hides the all-gather)")
-    args = ap.parse_args()
+def strict_rel_err(got, want):
+    """SURVEY 8d's pointwise metric on device tensors: max |got - want| / max(|want|, 1e-6)."""
+    import torch
+    worst = 0.0
+    rows = max(1, (1 << 26) // max(1, got[0].numel()))             # in pieces of 256 MiB: no slab-sized temporaries pile up
+    for g, w in zip(got.split(rows), want.split(rows)):
+        worst = max(worst, float(((g - w).abs() / w.abs().clamp_min(1e-6)).max().item()))
+    return worst
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # Not launched by torch.distributed.run: become the launcher.  This process only counts the devices, starts the
-        # ranks as CHILD processes (nothing is exec'ed over it), waits and passes their exit code on.
-        sys.exit(spawn_ranks(args))
 
+def run_workload(args, dist, rank, world, name, size, strong, primary):
+    """One bench line (a dict; meaningful on rank 0) for one workload: cold region, per-kernel pass, timed region, and -- for a
+    sharded run -- the parity of the sharded result against the unsharded plan on the gathered image."""
     import numpy as np
     import torch
     import recfilter_amd as rfa
+    from recfilter_amd.dist import ShardedFilter
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.device < 0 and torch.cuda.device_count() < world:
-        raise SystemExit(f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()}")
-    device = local_rank if args.device < 0 else args.device
-    torch.cuda.set_device(device)
-    dist = None
-    if world > 1 or "WORLD_SIZE" in os.environ:      # (a launcher with one rank still gets its process group: the
-        import torch.distributed as dist            #  barrier and the reduction of the step time then run over RCCL)
-        os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(args.backend)
-
-    cfg = workload(args.workload, args.size)
+    cfg = workload(name, size)
     shape, planes = cfg["shape"], cfg["planes"]
-    if args.strong and world > 1:
+    global_shape = tuple(shape)
+    if strong and world > 1:
         if shape[0] % (world * 64) != 0:
             raise SystemExit(f"--strong: outermost extent {shape[0]} is not a multiple of {world} slabs of whole tiles")
         shape = (shape[0] // world,) + tuple(shape[1:])
+    else:
+        global_shape = (shape[0] * world,) + tuple(shape[1:])       # weak scaling: every rank owns a full-size slab
     dtype = torch.float32
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     inputs = [torch.rand(shape, generator=gen, device="cuda", dtype=dtype) for _ in range(planes)]
@@ -263,7 +236,6 @@ def main():
     outputs = output_sets[0]
     samples_local = int(np.prod(shape)) * planes
 
-    from recfilter_amd.dist import ShardedFilter
     stepping = world > 1 or (args.force_stepping and dist is not None)
     if args.force_stepping and dist is None:
         raise SystemExit("--force-stepping needs a process group: launch with torch.distributed.run --nproc-per-node=1")
@@ -315,11 +287,11 @@ def main():
             _, times = plan.execute_timed(inputs, outputs)
             if i < 2 * reps:          # not recorded: the GPU is still on its way up (see above)
                 continue
-            for name, ms in times:
-                if name not in acc:
-                    acc[name] = []
-                    order.append(name)
-                acc[name].append(ms)
+            for kname, ms in times:
+                if kname not in acc:
+                    acc[kname] = []
+                    order.append(kname)
+                acc[kname].append(ms)
         kernels = {n: float(np.mean(acc[n])) for n in order}        # ms per step, all planes
         # the dominant kernel among those that move image bytes (at toy sizes a launch-bound carry kernel can take longer)
         passes = [n for n in order if algorithmic_bytes_per_launch(n, 1, 4) > 0] or order
@@ -330,7 +302,7 @@ def main():
         alg = algorithmic_bytes_per_launch(dom, samples_local // launches, 4)
         avg_ms = kernels[dom] / launches
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_info = pmc_traffic(dom, args.workload, shape)
+        traffic, traffic_info = pmc_traffic(dom, name, shape)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, **traffic_info,
@@ -359,37 +331,168 @@ def main():
     total_px = samples_local * joined
     value = total_px / (ms_per_step * 1e-3) / 1e6
 
+    # --- sharded parity (outside the timed region): the result of the path that was just timed, against the UNSHARDED plan
+    # on the whole image.  Every rank gathers all slabs of the input (rank-major along the outermost dimension = the global
+    # image), filters it with an unsharded plan on the same path, and compares its own slab of that with what the sharded
+    # protocol -- exit carries, all-gather, entering carries -- leaves in its output planes, after one more execute into
+    # cleared planes.  MAX over ranks; above 1e-4 the bench fails (a wrong exchange must not print as a speed-up).
+    parity = None
+    if stepping and not args.no_sharded_parity:
+        if args.corrupt_exchange:
+            # (test hook) what a broken exchange looks like: every rank receives carries that are not the ones that were sent
+            def corrupted(gathered, send):
+                dist.all_gather_into_tensor(gathered, send)
+                gathered.view(torch.float32).mul_(1.25)
+                return None
+            filt.collective = corrupted
+        for o in outputs:
+            o.zero_()
+        filt.execute(inputs, outputs)
+        torch.cuda.synchronize()
+        worst = 0.0
+        lo = rank * shape[0]
+        whole_in, whole_out = [], []
+        for p in range(planes):
+            w = torch.empty(global_shape, device="cuda", dtype=dtype)
+            if joined > 1:
+                dist.all_gather_into_tensor(w, inputs[p])
+            else:
+                w.copy_(inputs[p])
+            whole_in.append(w)
+            whole_out.append(torch.empty_like(w))
+        with rfa.Plan(global_shape, cfg["scans"], clamped=cfg["clamped"], planes=planes, path=filt.plan.path) as whole_plan:
+            whole_plan.execute(whole_in, whole_out)
+            torch.cuda.synchronize()
+        for p in range(planes):
+            worst = max(worst, strict_rel_err(outputs[p], whole_out[p][lo:lo + shape[0]]))
+        del whole_in, whole_out
+        t = torch.tensor([worst], device="cuda", dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parity = float(t.item())
+        if not (parity <= SHARDED_PARITY_BAR):           # (also catches NaN)
+            raise SystemExit(f"bench.py: sharded result differs from the unsharded plan on the gathered image: "
+                             f"max rel err {parity:.3e} > {SHARDED_PARITY_BAR:g} ({name}, {joined} rank(s))")
+
+    whole = 8.0 * total_px / (ms_per_step * 1e-3) / 1e9      # 8 B per f32 sample per filter
+    line = {
+        "metric": metric_name(name, cfg["shape"], planes),
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": joined, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        # what ran before the W warm-up steps of the timed region: one cold region of W + K steps (its per-step time is
+        # ms_per_step_cold: the driver's arguments on a GPU straight from idle) and the per-kernel HIP-event pass
+        "ms_per_step_cold": round(elapsed_cold * 1000.0 / args.steps, 4),
+        "preheat_executions": preheat + args.warmup + args.steps, "preheat_copies": 6,
+        "higher_is_better": True,
+        "scaling": "strong" if (strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
+                               f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
+                   "global_shape": list(global_shape),
+                   "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
+                   "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else
+                               ("none (one rank driven through the sharded protocol: exit carries, all-gather, entering carries)"
+                                if stepping else "none"),
+                   "exchange": ("stepping" if stepping else "none"),
+                   "collectives_per_step": (filt.plan.num_exchanges if stepping else 0),
+                   "interior_beside_collective": bool(stepping and filt.plan.has_interior),
+                   "steps_in_flight": inflight,
+                   "backend": (args.backend if dist is not None else "none"),
+                   "rccl_ranks": (joined if (dist is not None and args.backend == "nccl") else 0)},
+        # max over ranks and samples of |sharded - unsharded| / max(|unsharded|, 1e-6), the unsharded plan run on the gathered
+        # image; null when nothing was sharded (one rank, plain execute)
+        "sharded_parity": parity, "sharded_parity_bar": SHARDED_PARITY_BAR,
+        "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / joined, 4),
+        "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
+        "roofline": roofline,
+        "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
+    }
+    if primary and rank == 0 and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(cfg)
+    # leave the GPU as it was found: the next workload of this process needs the memory
+    for pl in filt.plans:
+        pl.close()
+    del filt, inputs, output_sets, outputs
+    torch.cuda.empty_cache()
+    return line
+
+
+SHARDED_PARITY_BAR = 1e-4       # north_star's float tolerance
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4a | cfg4b | cfg5 (default: cfg3, the configuration the "
+                    "metric is quoted on, followed by BASELINE config 5 -- 2048^3 sharded along z, strong scaling -- whose line "
+                    "rides in the same JSON object under \"configs\")")
+    ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
+    ap.add_argument("--path", type=int, default=0, help="rf_path override (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="default run: only the headline workload, not config 5 behind it")
+    ap.add_argument("--extra-size", type=int, default=0, help="override every extent of the config-5 line of a default run (debug)")
+    ap.add_argument("--no-sharded-parity", action="store_true", help="skip the check of the sharded result against the unsharded "
+                    "plan on the gathered image (it runs outside the timed region)")
+    ap.add_argument("--corrupt-exchange", action="store_true", help="(test hook) scale the gathered carries of the parity execute: "
+                    "the bench must then fail")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
+                    "multi-rank path on a box with one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="device ordinal for every rank (debug; default LOCAL_RANK)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's shape is the GLOBAL image, every rank "
+                    "owns 1/N of its outermost dimension (BASELINE config 5: 2048^3 z-sharded over 8 GPUs); default is weak "
+                    "scaling, every rank owns a full-size slab")
+    ap.add_argument("--force-stepping", action="store_true", help="one rank: drive the sharded protocol anyway (begin, exit carries, "
+                    "all-gather over the process group, interior, entering carries, finish) on a plan built with "
+                    "RF_PLAN_FORCE_EXCHANGE -- what every rank of an N-GPU run executes, on a box with one GPU")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU, each on its own HIP stream with its own "
+                    "plan and output planes (1 = strictly one after the other on one stream; 0 = auto: 1 on one GPU, so "
+                    "that per-kernel durations under rocprofv3 are those of kernels running alone, 2 on several GPUs, "
+                    "where the second step hides the all-gather)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not launched by torch.distributed.run: become the launcher.  This process only counts the devices, starts the
+        # ranks as CHILD processes (nothing is exec'ed over it), waits and passes their exit code on.
+        sys.exit(spawn_ranks(args))
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.device < 0 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()}")
+    device = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1 or "WORLD_SIZE" in os.environ:      # (a launcher with one rank still gets its process group: the
+        import torch.distributed as dist            #  barrier and the reduction of the step time then run over RCCL)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
+
+    # The default run -- what a driver that only varies --gpus gets -- is the headline workload (cfg3; weak scaling on N
+    # GPUs) AND north_star's config 5: 2048^3, six scans of order 2, sharded along z over the N GPUs (strong scaling, the
+    # early exchange); its line, same keys, is the one entry of "configs".  Any explicit --workload / --size / --path /
+    # --force-stepping runs exactly what it names.
+    default_run = args.workload is None and not args.size and not args.path and not args.force_stepping and not args.strong
+    name = args.workload or "cfg3"
+    line = run_workload(args, dist, rank, world, name, args.size, args.strong, primary=True)
+    if default_run and not args.no_extra_configs:
+        if (args.extra_size or 2048) % (world * 64) == 0:
+            extra = run_workload(args, dist, rank, world, "cfg5", args.extra_size, True, primary=False)
+            extra["scaling"] = "strong"                  # (one GPU holds the whole volume: the N = 1 point of the strong curve)
+            line["configs"] = [extra]
+        else:
+            line["configs_skipped"] = f"cfg5 --strong: 2048 planes do not split into {world} slabs of whole 64-plane tiles"
     if rank == 0:
-        whole = 8.0 * total_px / (ms_per_step * 1e-3) / 1e9      # 8 B per f32 sample per filter
-        line = {
-            "metric": metric_name(args.workload, cfg["shape"], planes),
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": joined, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            # what ran before the W warm-up steps of the timed region: one cold region of W + K steps (its per-step time is
-            # ms_per_step_cold: the driver's arguments on a GPU straight from idle) and the per-kernel HIP-event pass
-            "ms_per_step_cold": round(elapsed_cold * 1000.0 / args.steps, 4),
-            "preheat_executions": preheat + args.warmup + args.steps, "preheat_copies": 6,
-            "higher_is_better": True,
-            "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {'x'.join(map(str, shape))} f32 x{planes} plane(s) per GPU, "
-                                   f"{len(cfg['scans'])} scans, {'clamped' if cfg['clamped'] else 'zero'} border",
-                       "path": filt.plan.path_name, "tiles": list(filt.plan.tiles),
-                       "sharding": "rows (outermost dim), one all-gather per step" if world > 1 else
-                                   ("none (one rank driven through the sharded protocol: exit carries, all-gather, entering carries)"
-                                    if stepping else "none"),
-                       "exchange": ("stepping" if stepping else "none"),
-                       "collectives_per_step": (filt.plan.num_exchanges if stepping else 0),
-                       "interior_beside_collective": bool(stepping and filt.plan.has_interior),
-                       "steps_in_flight": inflight,
-                       "backend": (args.backend if dist is not None else "none"),
-                       "rccl_ranks": (joined if (dist is not None and args.backend == "nccl") else 0)},
-            "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / joined, 4),
-            "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
-            "roofline": roofline,
-            "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()                  # rank 0 was still timing single kernels: leave the group together

@@ -492,6 +492,12 @@ public:
             if (rf_plan_execute(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
         } else {
             if (rf_plan_begin(c->plan, in.data(), c->out.data(), c->stream) != RF_OK) fail(rf_last_error_string());
+            // whatever throws between here and rf_plan_finish (fail(), the caller's collective) hands the execution instance
+            // back to the plan, so that the next realize starts afresh
+            struct AbortUnlessFinished {
+                rf_plan *plan; bool finished = false;
+                ~AbortUnlessFinished() { if (!finished) (void)rf_plan_abort(plan); }
+            } stepping_guard{c->plan};
             const int nex = rf_plan_num_exchanges(c->plan);
             if ((int)c->xsend.size() != nex) {
                 for (void *p : c->xsend) (void)hipFree(p);
@@ -526,6 +532,7 @@ public:
                 }
                 if (rf_plan_exchange_apply(c->plan, e, c->xgathered[(size_t)e]) != RF_OK) fail(rf_last_error_string());
             }
+            stepping_guard.finished = true;      // (rf_plan_finish ends the execute whether it succeeds or not)
             if (rf_plan_finish(c->plan) != RF_OK) fail(rf_last_error_string());
         }
         RecFilterRealization r;

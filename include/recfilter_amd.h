@@ -192,7 +192,7 @@ int rf_plan_num_kernels(const rf_plan *plan);
  * last execution has finished (hipEventQuery), else builds a replica.  So rf_plan_execute may be called on distinct
  * streams, and from distinct host threads, without the executions waiting for one another (the call that builds a replica
  * takes the host time of a plan creation once; it does not wait for the device).  rf_plan_workspace_bytes reports one instance.  The stepping calls below belong to the
- * host thread that called rf_plan_begin, until its rf_plan_finish.
+ * host thread that called rf_plan_begin, until its rf_plan_finish (or rf_plan_abort).
  *
  * in_planes/out_planes: n_planes device pointers each.  in == out (same pointers) is allowed.  A plan whose kernels
  * move 16 bytes per lane -- the fused path (rf_plan_path() == RF_PATH_TILED_FUSED) and the line-parallel untiled
@@ -242,6 +242,11 @@ int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered);
 int rf_plan_has_interior(const rf_plan *plan);
 int rf_plan_interior(rf_plan *plan);
 int rf_plan_finish(rf_plan *plan);
+/* Abandons the execute this host thread began with rf_plan_begin and did not finish (the caller's collective failed, an
+ * exception unwound between the calls): the execution instance goes back to the plan's pool; kernels already enqueued still
+ * run, the output planes are undefined.  A no-op without such an execute.  rf_plan_begin does the same to an unfinished
+ * execute of the calling thread before it starts a new one, and rf_plan_destroy may be called in any state. */
+int rf_plan_abort(rf_plan *plan);
 
 /* ---- plan tables (host side of the tiling algebra; also what the CPU tests inspect) ------- */
 /* Copies a named table into out (as doubles) and returns its element count through n_out;

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "rf_plan_create", "rf_plan_destroy", "rf_plan_workspace_bytes", "rf_plan_num_instances", "rf_plan_path", "rf_plan_tiles",
     "rf_plan_num_kernels", "rf_plan_execute", "rf_plan_execute_timed", "rf_plan_num_exchanges",
     "rf_plan_exchange_bytes",
-    "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_has_interior", "rf_plan_interior", "rf_plan_finish",
+    "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_has_interior", "rf_plan_interior", "rf_plan_finish", "rf_plan_abort",
     "rf_plan_table", "rf_plan_debug_buffer", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
     "rf_gaussian_box_filter", "rf_box_difference", "rf_tap_filter", "rf_last_error_string", "rf_version", "rf_device_count",
 ]
@@ -133,6 +133,7 @@ def lib() -> ctypes.CDLL:
     L.rf_plan_exchange_local.argtypes = [vp, ctypes.c_int, vp]
     L.rf_plan_exchange_apply.argtypes = [vp, ctypes.c_int, vp]
     L.rf_plan_finish.argtypes = [vp]
+    L.rf_plan_abort.argtypes = [vp]
     L.rf_plan_has_interior.argtypes = [vp]
     L.rf_plan_interior.argtypes = [vp]
     L.rf_plan_table.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,

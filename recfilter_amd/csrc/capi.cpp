@@ -71,73 +71,91 @@ std::vector<const Step *> flat_steps(const rf_plan *plan) {
 }
 
 // ---- concurrent executions -------------------------------------------------------------------------------------------
-// The instance of `plan` an execution on `stream` runs on, with its enqueue lock held (plan.h): the instance that last ran
+// The instance of `plan` an execution on `stream` runs on, OWNED by the calling thread (plan.h): the instance that last ran
 // on this stream (stream order separates the two executions); else one whose last execution has finished; else a new
-// replica.  release_instance() records the completion event and drops the lock.
-rf_plan *acquire_instance(rf_plan *plan, hipStream_t stream) {
-    if (plan->host_only) { plan->enqueue_mu.lock(); return plan; }
-    std::unique_lock<std::mutex> pool(plan->pool_mu);
-    for (;;) {
-        std::vector<rf_plan *> all{plan};
-        for (auto &r : plan->replicas) all.push_back(r.get());
-        rf_plan *busy = nullptr;
-        for (rf_plan *inst : all)
-            if (inst->used && inst->last_stream == stream) {
-                if (inst->enqueue_mu.try_lock()) return inst;
-                busy = inst;                     // another host thread is enqueueing on it (or stepping through it)
-                break;
-            }
-        if (busy == nullptr) break;
-        // wait for that thread WITHOUT the pool lock, then look again: the instance may have moved to another stream
-        pool.unlock();
-        busy->enqueue_mu.lock();
-        busy->enqueue_mu.unlock();
-        pool.lock();
-    }
+// replica.  All pool state -- the `owned` flags included -- lives under the primary's pool_mu; an instance's completion
+// event is looked at only while nobody owns the instance, so no thread can be about to re-record it.
+// release_instance() records the completion event and hands the instance back.
+std::vector<rf_plan *> instances(rf_plan *plan) {
     std::vector<rf_plan *> all{plan};
     for (auto &r : plan->replicas) all.push_back(r.get());
-    for (rf_plan *inst : all) {
-        const bool idle = !inst->used || inst->done == nullptr || hipEventQuery(inst->done) == hipSuccess;
-        if (idle && inst->enqueue_mu.try_lock()) { inst->used = true; inst->last_stream = stream; return inst; }
+    return all;
+}
+
+rf_plan *acquire_instance(rf_plan *plan, hipStream_t stream) {
+    std::unique_lock<std::mutex> pool(plan->pool_mu);
+    if (plan->host_only) {
+        plan->pool_cv.wait(pool, [&] { return !plan->owned; });
+        plan->owned = true;
+        return plan;
     }
-    (void)hipGetLastError();                     // (hipEventQuery reports "not ready" as an error code)
+    for (;;) {
+        rf_plan *same = nullptr;
+        for (rf_plan *inst : instances(plan))
+            if (inst->used && inst->last_stream == stream) { same = inst; break; }
+        if (same != nullptr) {
+            if (!same->owned) { same->owned = true; return same; }
+            // another host thread is enqueueing on it (or stepping through it): wait for a release, then look again --
+            // the instance may have moved to another stream meanwhile
+            plan->pool_cv.wait(pool);
+            continue;
+        }
+        for (rf_plan *inst : instances(plan)) {
+            if (inst->owned) continue;
+            const bool idle = !inst->used || hipEventQuery(inst->done) == hipSuccess;
+            if (idle) { inst->owned = true; inst->used = true; inst->last_stream = stream; return inst; }
+        }
+        (void)hipGetLastError();                 // (hipEventQuery reports "not ready" as an error code)
+        break;
+    }
+    // every instance is busy on another stream: build a replica, without the pool lock (a plan build takes host time)
     rf_filter_desc d = plan->saved.d;
     d.scans = plan->saved.scans.data();
     d.shard_extents = plan->saved.extents.empty() ? nullptr : plan->saved.extents.data();
     d.device = plan->device;
+    pool.unlock();
     rf_plan *fresh = nullptr;
     if (build_plan(&d, &fresh) != RF_OK) return nullptr;
     fresh->used = true;
+    fresh->owned = true;
     fresh->last_stream = stream;
-    fresh->enqueue_mu.lock();
+    pool.lock();
     plan->replicas.emplace_back(fresh);
     return fresh;
 }
 
-void release_instance(rf_plan *inst, bool ran) {
-    if (ran && !inst->host_only) {
-        if (inst->done == nullptr && hipEventCreateWithFlags(&inst->done, hipEventDisableTiming) != hipSuccess) inst->done = nullptr;
-        if (inst->done != nullptr) (void)hipEventRecord(inst->done, inst->stream);
+// `enqueued`: at least one launch of this execution may have been attempted on inst->stream -- also when the execution
+// then failed: what was enqueued still runs on the instance's workspace, and the completion event must cover it.
+void release_instance(rf_plan *plan, rf_plan *inst, bool enqueued) {
+    if (enqueued && !inst->host_only && inst->done != nullptr) (void)hipEventRecord(inst->done, inst->stream);
+    {
+        std::lock_guard<std::mutex> pool(plan->pool_mu);
+        inst->owned = false;
     }
-    inst->enqueue_mu.unlock();
+    plan->pool_cv.notify_all();
 }
 
-// stepping API: the instance rf_plan_begin acquired on this host thread, until rf_plan_finish
-thread_local std::map<const rf_plan *, rf_plan *> g_stepping;
-
+// stepping API: the instance rf_plan_begin acquired for this host thread, until rf_plan_finish / rf_plan_abort.  The map
+// lives in the plan (not in thread-local storage), so it goes away with the plan and never outlives it.
 rf_plan *stepping_instance(rf_plan *plan) {
-    auto it = g_stepping.find(plan);
-    return it == g_stepping.end() ? nullptr : it->second;
+    std::lock_guard<std::mutex> pool(plan->pool_mu);
+    auto it = plan->stepping.find(std::this_thread::get_id());
+    return it == plan->stepping.end() ? nullptr : it->second;
 }
 
-// a stepping call failed: the execute is over (the instance goes back to the pool; the next rf_plan_begin starts afresh)
-int abort_stepping(rf_plan *plan, rf_plan *inst, int rc) {
+// the execute this thread began is over, finished or not: the instance goes back to the pool (what was enqueued so far
+// still runs: the completion event covers it) and the next rf_plan_begin starts afresh
+int end_stepping(rf_plan *plan, rf_plan *inst, int rc) {
     inst->phase = 0;
     inst->interior_pending = false;
-    g_stepping.erase(plan);
-    release_instance(inst, true);        // (what was enqueued so far still runs: the completion event covers it)
+    {
+        std::lock_guard<std::mutex> pool(plan->pool_mu);
+        plan->stepping.erase(std::this_thread::get_id());
+    }
+    release_instance(plan, inst, true);
     return rc;
 }
+int abort_stepping(rf_plan *plan, rf_plan *inst, int rc) { return end_stepping(plan, inst, rc); }
 
 // the exchange-independent work of this execute, if the caller has not asked for it yet
 int run_pending_interior(rf_plan *plan) {
@@ -156,6 +174,9 @@ extern "C" {
 int rf_plan_create(const rf_filter_desc *desc, rf_plan **plan_out) { return build_plan(desc, plan_out); }
 
 int rf_plan_destroy(rf_plan *plan) {
+    // (ownership of instances is a flag inside the plan and the stepping map lives in the plan: an execute abandoned between
+    // rf_plan_begin and rf_plan_finish leaves nothing behind that outlives the plan.  The caller must not destroy a plan
+    // while another host thread is inside one of its calls, as for any object.)
     if (plan) {
         if (!plan->host_only) (void)hipSetDevice(plan->device);
         delete plan;
@@ -187,6 +208,7 @@ int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *ou
     rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
     if (!inst) return RF_ERR_NOMEM;
     int rc = set_context(inst, in_planes, out_planes, stream);
+    const bool context_set = rc == RF_OK;        // from here on launches are attempted on inst->stream
     if (rc == RF_OK) {
         for (auto &ex : inst->exchanges) ex.send = ex.scratch;
         for (const Step *st : flat_steps(inst)) {
@@ -194,7 +216,7 @@ int rf_plan_execute(rf_plan *plan, const void *const *in_planes, void *const *ou
             if (rc != RF_OK) break;
         }
     }
-    release_instance(inst, rc == RF_OK);
+    release_instance(plan, inst, context_set);
     return rc;
 }
 
@@ -206,9 +228,9 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
     rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
     if (!inst) return RF_ERR_NOMEM;
     struct Release {
-        rf_plan *inst; bool ran = false;
-        ~Release() { release_instance(inst, ran); }
-    } guard{inst};
+        rf_plan *plan, *inst; bool ran = false;
+        ~Release() { release_instance(plan, inst, ran); }
+    } guard{plan, inst};
     int rc = set_context(inst, in_planes, out_planes, stream);
     if (rc) return rc;
     for (auto &ex : inst->exchanges) ex.send = ex.scratch;
@@ -246,15 +268,27 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
 
 int rf_plan_begin(rf_plan *plan, const void *const *in_planes, void *const *out_planes, void *stream) {
     if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
-    if (stepping_instance(plan) != nullptr) { set_error("rf_plan_begin: the previous execute of this thread was not finished"); return RF_ERR_STATE; }
+    // An execute this thread began and never finished (its caller failed between the calls -- a collective that raised, an
+    // exception on the way) is abandoned here: begin always starts afresh.
+    if (rf_plan *stale = stepping_instance(plan)) (void)abort_stepping(plan, stale, RF_OK);
     rf_plan *inst = acquire_instance(plan, (hipStream_t)stream);
     if (!inst) return RF_ERR_NOMEM;
     int rc = set_context(inst, in_planes, out_planes, stream);
+    const bool context_set = rc == RF_OK;
     if (rc == RF_OK) rc = run_steps(inst, inst->begin_steps);
-    if (rc != RF_OK) { release_instance(inst, false); return rc; }
+    if (rc != RF_OK) { release_instance(plan, inst, context_set); return rc; }
     inst->phase = 1;
     inst->interior_pending = !inst->interior_steps.empty();
-    g_stepping[plan] = inst;            // held (enqueue lock included) until rf_plan_finish on this thread
+    {
+        std::lock_guard<std::mutex> pool(plan->pool_mu);
+        plan->stepping[std::this_thread::get_id()] = inst;      // owned by this thread until rf_plan_finish / rf_plan_abort
+    }
+    return RF_OK;
+}
+
+int rf_plan_abort(rf_plan *plan) {
+    if (!plan) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
+    if (rf_plan *inst = stepping_instance(plan)) (void)abort_stepping(plan, inst, RF_OK);
     return RF_OK;
 }
 
@@ -297,12 +331,9 @@ int rf_plan_exchange_apply(rf_plan *plan, int exchange, const void *gathered) {
 int rf_plan_finish(rf_plan *plan) {
     rf_plan *inst = plan ? stepping_instance(plan) : nullptr;
     if (!inst || inst->phase != 1) { set_error("rf_plan_finish before rf_plan_begin"); return RF_ERR_STATE; }
-    inst->phase = 0;
     int rc = run_pending_interior(inst);
     if (rc == RF_OK) rc = run_steps(inst, inst->finish_steps);
-    g_stepping.erase(plan);
-    release_instance(inst, true);
-    return rc;
+    return end_stepping(plan, inst, rc);
 }
 
 int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t capacity, size_t *n_out) {

@@ -548,7 +548,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && desc->ndim == 1 && plan->clamped && plan->dtype == RF_F32 &&
         !plan->sharded() && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && desc->n_scans >= 1) {
         const int rc = build_clamped_1d(desc, plan.get());
-        if (rc == RF_OK) { save_desc(plan.get(), desc); if (!host_only) RF_HIP_CHECK(hipStreamSynchronize(nullptr)); *out = plan.release(); return RF_OK; }
+        if (rc == RF_OK) { save_desc(plan.get(), desc); if (int fb = plan->finish_build()) return fb; *out = plan.release(); return RF_OK; }
         if (rc != RF_ERR_UNSUPPORTED) return rc;
         plan->begin_steps.clear();
         plan->stages.clear();
@@ -566,7 +566,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
             for (int st : stage_of) n_stages = std::max(n_stages, st + 1);
             if (n_stages > 1) {
                 const int rc = build_cascade(desc, stage_of, plan.get());
-                if (rc == RF_OK) { save_desc(plan.get(), desc); *out = plan.release(); return RF_OK; }
+                if (rc == RF_OK) { save_desc(plan.get(), desc); if (int fb = plan->finish_build()) return fb; *out = plan.release(); return RF_OK; }
                 if (desc->path == RF_PATH_TILED_FUSED) return rc;
                 plan->begin_steps.clear();          // (auto: the paths below run the scans as given)
                 plan->stages.clear();
@@ -648,10 +648,11 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     }
     if (rc != RF_OK) return rc;
     add_pointwise_steps(plan.get());
-    // The tables are uploaded with blocking copies; the zero fills (hipMemset) are work of the null stream: wait for THAT
-    // stream, not for the device -- a replica is built while other streams are busy with executions of this very plan
-    // (capi.cpp, acquire_instance), and a device-wide wait would serialise what the replica exists to overlap.
-    if (!host_only) RF_HIP_CHECK(hipStreamSynchronize(nullptr));
+    // Table uploads and zero fills are work of a private NON-BLOCKING stream (build_stream below): waiting for it waits
+    // neither for the device nor -- as the legacy null stream would -- for every blocking stream of the process.  A replica
+    // is built while other streams are busy with executions of this very plan (capi.cpp, acquire_instance), and such a
+    // wait would serialise what the replica exists to overlap.
+    if (int fb = plan->finish_build()) return fb;
     save_desc(plan.get(), desc);
     *out = plan.release();
     return RF_OK;
@@ -668,6 +669,27 @@ rf_plan::~rf_plan() {
         if (b.ptr) (void)hipFree(b.ptr);
 }
 
+namespace {
+// One stream per device for everything a plan build puts on the GPU (zero fills, table uploads): created once with
+// hipStreamNonBlocking, so that it neither waits for nor is waited for by the null stream, and kept for the life of the
+// process.  HIP streams may be used from several host threads.
+hipStream_t build_stream(int device, int *status) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        rf::set_error("hipStreamCreateWithFlags (plan build stream) failed");
+        *status = RF_ERR_HIP;
+        return nullptr;
+    }
+    streams[device] = s;
+    return s;
+}
+}  // namespace
+
 void *rf_plan::alloc(size_t bytes, bool zero, int *status) {
     if (*status != RF_OK) return nullptr;
     if (bytes == 0) bytes = 16;
@@ -678,21 +700,38 @@ void *rf_plan::alloc(size_t bytes, bool zero, int *status) {
         *status = RF_ERR_NOMEM;
         return nullptr;
     }
-    if (zero && hipMemset(p, 0, bytes) != hipSuccess) {
-        rf::set_error("hipMemset failed");
-        *status = RF_ERR_HIP;
-    }
     buffers.push_back({p, bytes});
     workspace_bytes += bytes;
+    if (zero) {
+        hipStream_t bs = build_stream(device, status);
+        if (*status == RF_OK && hipMemsetAsync(p, 0, bytes, bs) != hipSuccess) {
+            rf::set_error("hipMemsetAsync failed");
+            *status = RF_ERR_HIP;
+        }
+    }
     return p;
 }
 
 void *rf_plan::upload(const void *host, size_t bytes, int *status) {
     void *p = alloc(bytes, false, status);
     if (!p) return nullptr;
-    if (bytes && hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-        rf::set_error("hipMemcpy (table upload) failed");
-        *status = RF_ERR_HIP;
+    if (bytes) {
+        // the host tables are temporaries of the build: the copy has left them when this returns
+        hipStream_t bs = build_stream(device, status);
+        if (*status == RF_OK && (hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, bs) != hipSuccess || hipStreamSynchronize(bs) != hipSuccess)) {
+            rf::set_error("hipMemcpyAsync (table upload) failed");
+            *status = RF_ERR_HIP;
+        }
     }
     return p;
+}
+
+int rf_plan::finish_build() {
+    if (host_only) return RF_OK;
+    int status = RF_OK;
+    hipStream_t bs = build_stream(device, &status);
+    if (status != RF_OK) return status;
+    RF_HIP_CHECK(hipStreamSynchronize(bs));
+    if (done == nullptr) RF_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    return RF_OK;
 }

@@ -4,7 +4,9 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -129,16 +131,25 @@ struct rf_plan {
         std::vector<rf_scan_desc> scans;
         std::vector<int64_t> extents;
     } saved;
-    std::mutex pool_mu;                                  // guards replicas and the fields below of every instance
+    // Everything below is guarded by the PRIMARY plan's pool_mu (a replica's own pool_mu / pool_cv / stepping are unused).
+    // An instance is OWNED by the host thread that is enqueueing an execution on it (rf_plan_execute: for the duration of
+    // the call; the stepping calls: from rf_plan_begin to rf_plan_finish / rf_plan_abort).  Ownership is a flag, not a
+    // mutex held across API calls: a plan may be destroyed, and a stepping execute abandoned, from any state.
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;                     // signalled whenever an instance is released
     std::vector<std::unique_ptr<rf_plan>> replicas;
-    std::mutex enqueue_mu;                               // one host thread enqueues on an instance at a time
+    std::map<std::thread::id, rf_plan *> stepping;       // the instance a host thread's rf_plan_begin acquired
+    bool owned = false;                                  // a host thread is enqueueing on this instance
     hipStream_t last_stream = nullptr;                   // stream of the last execution enqueued on this instance
     bool used = false;
-    hipEvent_t done = nullptr;                           // recorded behind it
+    // recorded behind every execution; created once when the plan is built (never rewritten), queried only while the
+    // instance is not owned -- i.e. never while another thread may be about to record it
+    hipEvent_t done = nullptr;
 
     ~rf_plan();
     void *alloc(size_t bytes, bool zero, int *status);
     void *upload(const void *host, size_t bytes, int *status);
+    int finish_build();      // waits for the uploads and zero fills (the build stream), creates `done`
 };
 
 namespace rf {

@@ -108,10 +108,31 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
         d_Apow = (const Acc *)plan->upload(hApow.data(), hApow.size() * sizeof(Acc), &status);
     }
     const size_t tails_pp = (size_t)n * M * K * di.lines, inc_pp = (size_t)n * K * di.lines;
-    const bool early = sharded && !from_input && desc != nullptr && xy_begin != (size_t)-1 && d == 2 &&
-                       merged_exchange_applies(n, K, plan->shard_world) && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 &&
-                       !(plan->flags & RF_PLAN_LATE_EXCHANGE) && di.lines == plan->dims[0].N * plan->dims[1].N &&
-                       sizeof(P) == sizeof(Acc);      // (the carry planes are filtered as pixels: f32 / i32)
+    bool early = sharded && !from_input && desc != nullptr && xy_begin != (size_t)-1 && d == 2 &&
+                 merged_exchange_applies(n, K, plan->shard_world) && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 &&
+                 !(plan->flags & RF_PLAN_LATE_EXCHANGE) && di.lines == plan->dims[0].N * plan->dims[1].N &&
+                 sizeof(P) == sizeof(Acc);      // (the carry planes are filtered as pixels: f32 / i32)
+    // The early exchange needs a helper plan: F over the carry planes = the x/y scans of this filter on a volume of
+    // (tiles + 1) * scans * k planes, in place.  It is built BEFORE anything of the early layout is committed: a helper that
+    // cannot be built (unsupported shape, out of memory) leaves the plan on the late exchange instead of failing it.
+    rf_plan *child = nullptr;
+    if (early) {
+        std::vector<rf_scan_desc> xy;
+        for (int i = 0; i < desc->n_scans; i++)
+            if (desc->scans[i].dim != d) xy.push_back(desc->scans[i]);
+        rf_filter_desc cd = *desc;
+        cd.scans = xy.data();
+        cd.n_scans = (int32_t)xy.size();
+        cd.extent[2] = (int64_t)n * K * (M + 1);
+        cd.n_planes = 1;
+        cd.tile[2] = 0;
+        cd.path = RF_PATH_TILED_FUSED;
+        cd.device = plan->host_only ? RF_DEVICE_HOST_ONLY : plan->device;
+        cd.shard_rank = 0; cd.shard_world = 1; cd.shard_extents = nullptr;
+        cd.flags = (desc->flags & (RF_PLAN_STREAM_PASS1 | RF_PLAN_STAGED_PASS1 | 0x0000ff00u)) | RF_PLAN_TILED_ONLY | RF_PLAN_NO_CASCADE;
+        if (build_plan(&cd, &child) != RF_OK) { child = nullptr; early = false; }
+    }
+    std::unique_ptr<rf_plan> child_owner(child);
     // early exchange: the tails and the entering carries of a plane are ONE run of (tiles + 1) * scans * k carry planes,
     // which the x/y filter then takes as a volume of that many z planes
     const size_t chunk_pp = early ? tails_pp + inc_pp : 0;
@@ -173,24 +194,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
         int rc = add_merged_exchange<S, Acc>(plan, tab, dn, M, TZ, di.lines, mask, gargs, incoming, inc_pp, d_AC, C, "carry_" + dn);
         if (rc != RF_OK) return rc;
         if (early) {
-            // F over the carry planes: the x/y scans of this filter on a volume of (tiles + 1) * scans * k planes, in place
-            std::vector<rf_scan_desc> xy;
-            for (int i = 0; i < desc->n_scans; i++)
-                if (desc->scans[i].dim != d) xy.push_back(desc->scans[i]);
-            rf_filter_desc cd = *desc;
-            cd.scans = xy.data();
-            cd.n_scans = (int32_t)xy.size();
-            cd.extent[2] = (int64_t)n * K * (M + 1);
-            cd.n_planes = 1;
-            cd.tile[2] = 0;
-            cd.path = RF_PATH_TILED_FUSED;
-            cd.device = plan->host_only ? RF_DEVICE_HOST_ONLY : plan->device;
-            cd.shard_rank = 0; cd.shard_world = 1; cd.shard_extents = nullptr;
-            cd.flags = (desc->flags & (RF_PLAN_STREAM_PASS1 | RF_PLAN_STAGED_PASS1 | 0x0000ff00u)) | RF_PLAN_TILED_ONLY | RF_PLAN_NO_CASCADE;
-            rf_plan *child = nullptr;
-            rc = build_plan(&cd, &child);
-            if (rc != RF_OK) return rc;
-            plan->helpers.emplace_back(child);
+            plan->helpers.emplace_back(child_owner.release());
             plan->workspace_bytes += child->workspace_bytes;
             // ONE step: the helper has one workspace, so its launches for a plane run back to back (the steps of an execute
             // run plane by plane inside every step)

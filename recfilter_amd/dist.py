@@ -85,22 +85,30 @@ class ShardedFilter:
         if self.world == 1 and not self.force_exchange:
             return plan.execute(inputs, outputs, **kw)
         plan.begin(inputs, outputs, **kw)
-        n_ex = plan.num_exchanges
-        for i in range(n_ex):
-            send, gathered = self._buffers((slot, i), plan, inputs[0])
-            plan.exchange_local(i, send.data_ptr())
-            # issued after what the current stream holds (the exit carries); asynchronous to what follows on it
-            if self.collective is not None:
-                work = self.collective(gathered, send)
-            else:
-                import torch.distributed as dist
-                work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
-            if i == n_ex - 1 and getattr(plan, "has_interior", False):
-                plan.interior()          # exchange-independent work (a z-sharded volume's x/y stage) beside the collective
-            if work is not None:
-                work.wait()              # the current stream waits for the gathered carries
-            plan.exchange_apply(i, gathered.data_ptr())
-        plan.finish()
+        try:
+            n_ex = plan.num_exchanges
+            for i in range(n_ex):
+                send, gathered = self._buffers((slot, i), plan, inputs[0])
+                plan.exchange_local(i, send.data_ptr())
+                # issued after what the current stream holds (the exit carries); asynchronous to what follows on it
+                if self.collective is not None:
+                    work = self.collective(gathered, send)
+                else:
+                    import torch.distributed as dist
+                    work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
+                if i == n_ex - 1 and getattr(plan, "has_interior", False):
+                    plan.interior()          # exchange-independent work (a z-sharded volume's x/y stage) beside the collective
+                if work is not None:
+                    work.wait()              # the current stream waits for the gathered carries
+                plan.exchange_apply(i, gathered.data_ptr())
+            plan.finish()
+        except BaseException:
+            # a collective that raised, a stepping call that failed: hand the execution instance back (rf_plan_abort), so
+            # that the next execute of this thread starts afresh instead of finding the plan "begun"
+            abort = getattr(plan, "abort", None)
+            if abort is not None:
+                abort()
+            raise
         return outputs
 
     def execute(self, inputs, outputs):

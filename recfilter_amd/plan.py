@@ -255,6 +255,11 @@ class Plan:
     def finish(self):
         capi.check(capi.lib().rf_plan_finish(self._h))
 
+    def abort(self) -> None:
+        """rf_plan_abort: abandon the execute this thread began and did not finish (a collective that raised)."""
+        if self._h:
+            capi.lib().rf_plan_abort(self._h)
+
 
 # ---- coefficient design (lib/iir_coeff.cpp) ---------------------------------------------------
 def gaussian_weights(sigma: float, order: int) -> List[float]:

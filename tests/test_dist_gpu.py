@@ -107,6 +107,43 @@ def test_bench_two_ranks_over_gloo(launcher):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["path"] == "tiled_fused"
     assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0
     assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] in ("fused_pass2", "fused_tails")     # (the dominant one; a toss-up at this size)
+    # the sharded result was checked against the unsharded plan on the gathered 2048 x 1024 image
+    assert d["config"]["global_shape"] == [2048, 1024] and 0 <= d["sharded_parity"] < 1e-4 and "configs" not in d
+
+
+def test_bench_fails_on_a_corrupted_exchange():
+    """A wrong exchange must not print as a speed-up: with the gathered carries of the parity execute scaled by 1.25 the bench
+    exits non-zero and prints no JSON line, for row shards (the correction inside pass 2) and for z slabs (early exchange)."""
+    import subprocess
+    for extra in (["--size", "1024"], ["--workload", "cfg5", "--size", "256", "--strong"]):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--device", "0",
+               "--corrupt-exchange"] + extra
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode != 0, out.stdout[-2000:]
+        assert "differs from the unsharded plan" in out.stderr
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_default_run_carries_config5_strong():
+    """What a driver that only varies --gpus gets: the headline line (cfg3, weak) with north_star's config 5 -- the volume
+    sharded along z, strong scaling, early exchange -- as configs[0], both checked against the unsharded plan.  Two ranks on
+    this box's one GPU over gloo; config 5 shrunk to 256^3 (two ranks of the full volume do not fit one device)."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--device", "0",
+           "--extra-size", "256"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_shape"] == [32768, 16384]
+    assert d["metric"].startswith("Mpixels/s + achieved HBM GB/s, 16384^2 order-2") and 0 <= d["sharded_parity"] < 1e-4
+    (e,) = d["configs"]
+    assert e["scaling"] == "strong" and e["n_gpus"] == 2 and e["config"]["global_shape"] == [256, 256, 256]
+    assert e["config"]["interior_beside_collective"] is True and 0 <= e["sharded_parity"] < 1e-4 and e["value"] > 0
 
 
 def test_bench_strong_scaling_volume_two_ranks_over_gloo():
@@ -125,7 +162,7 @@ def test_bench_strong_scaling_volume_two_ranks_over_gloo():
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and c["path"] == "tiled_fused"
     assert c["exchange"] == "stepping" and c["collectives_per_step"] == 1 and c["interior_beside_collective"] is True
-    assert "128x256x256" in c["workload"]
+    assert "128x256x256" in c["workload"] and c["global_shape"] == [256, 256, 256] and 0 <= d["sharded_parity"] < 1e-4
 
 
 def test_bench_refuses_more_ranks_than_devices():
@@ -265,6 +302,7 @@ def test_bench_forced_stepping_one_rank_over_rccl():
         assert d["n_gpus"] == 1 and c["backend"] == "nccl" and c["rccl_ranks"] == 1 and d["value"] > 0
         assert c["exchange"] == "stepping" and c["collectives_per_step"] == 1 and c["path"] == "tiled_fused"
         assert c["interior_beside_collective"] == ("cfg5" in extra)
+        assert 0 <= d["sharded_parity"] < 1e-4          # one rank through the protocol against the plain plan
         assert d["ms_per_step_cold"] > 0 and d["preheat_executions"] >= 3 * 5
 
 

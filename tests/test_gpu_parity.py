@@ -1019,6 +1019,121 @@ def test_one_plan_executes_concurrently_on_distinct_streams():
         assert plan.num_instances == 1
 
 
+def test_abandoned_stepping_execute_is_recovered():
+    """a caller that fails between rf_plan_begin and rf_plan_finish (a collective that raised) must not leave
+    the plan unusable.  begin() again on the same thread restarts; rf_plan_abort hands the instance back; another thread is
+    not blocked by the abandoned execute; a plan may be destroyed while an execute is begun; ShardedFilter aborts when its
+    collective raises."""
+    import threading
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    from recfilter_amd.dist import ShardedFilter
+    scans = rc.xy_pm(rc.GAUSS2)
+    shape = (512, 1024)
+    img = rc.random_image(shape, np.float32, 811)
+    want = oracle.apply_filter(img.astype(np.float64), scans, True)
+    dev = torch.from_numpy(img).cuda()
+    out = torch.empty_like(dev)
+    flags = capi.RF_PLAN_FORCE_EXCHANGE | capi.RF_PLAN_TILED_ONLY
+
+    def whole(plan, o):
+        plan.begin([dev], [o])
+        for i in range(plan.num_exchanges):
+            send = torch.empty(plan.exchange_bytes(i), dtype=torch.uint8, device="cuda")
+            plan.exchange_local(i, send.data_ptr())
+            plan.exchange_apply(i, send.data_ptr())           # one rank: gathered == send
+        plan.finish()
+        torch.cuda.synchronize()
+        assert rc.rel_err(o.cpu().numpy(), want) < TOL
+
+    with rfa.Plan(shape, scans, clamped=True, flags=flags) as plan:
+        plan.begin([dev], [out])                              # ... and the caller "fails" here
+        whole(plan, out)                                      # begin on the same thread starts afresh
+        plan.begin([dev], [out])
+        plan.abort()
+        plan.abort()                                          # a no-op without a begun execute
+        with pytest.raises(RuntimeError):
+            plan.finish()                                     # nothing to finish after the abort
+        whole(plan, out)
+        # an execute begun and abandoned on THIS thread does not block another thread on the same (null) stream
+        plan.begin([dev], [out])
+        plan.abort()
+        errors = []
+
+        def other():
+            try:
+                whole(plan, torch.empty_like(dev))
+            except Exception as exc:          # pragma: no cover
+                errors.append(exc)
+        th = threading.Thread(target=other)
+        th.start()
+        th.join(timeout=120)
+        assert not th.is_alive() and not errors, errors
+        assert plan.num_instances == 1
+        plan.begin([dev], [out])                              # destroyed while begun: nothing dangles (the `with` closes it)
+    # a new plan -- possibly at the same address -- starts clean
+    with rfa.Plan(shape, scans, clamped=True, flags=flags) as plan:
+        with pytest.raises(RuntimeError):
+            plan.finish()
+        whole(plan, out)
+
+    # the Python driver: a collective that raises leaves the plan ready for the next execute
+    calls = [0]
+
+    def flaky(gathered, send):
+        calls[0] += 1
+        if calls[0] == 1:
+            raise RuntimeError("collective failed")
+        gathered.copy_(send)
+        return None
+    filt = ShardedFilter(shape, scans, clamped=True, rank=0, world=1, force_exchange=True, flags=capi.RF_PLAN_TILED_ONLY,
+                         collective=flaky)
+    with pytest.raises(RuntimeError, match="collective failed"):
+        filt.execute([dev], [out])
+    out.zero_()
+    filt.execute([dev], [out])
+    torch.cuda.synchronize()
+    assert rc.rel_err(out.cpu().numpy(), want) < TOL
+
+
+def test_instance_pool_under_contention():
+    """an instance is judged idle only while nobody owns it.  Eight host threads hammer ONE plan, two threads per
+    stream (so that same-stream executes contend for one instance while other streams look for idle ones); every output is
+    checked after every execute against the oracle, which a shared workspace between two executions in flight would break."""
+    import threading
+    import torch
+    import recfilter_amd as rfa
+    scans = rc.xy_pm(rc.GAUSS2)
+    shape = (512, 1024)
+    imgs = [rc.random_image(shape, np.float32, 820 + i) for i in range(8)]
+    wants = [oracle.apply_filter(im.astype(np.float64), scans, True) for im in imgs]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    errors = []
+    with rfa.Plan(shape, scans, clamped=True) as plan:
+        def worker(i):
+            try:
+                st = streams[i % 4]
+                out = torch.empty_like(dev[i])
+                for rep in range(12):
+                    plan.execute([dev[i]], [out], stream=st)
+                    if rep % 4 == 3:
+                        st.synchronize()
+                        err = rc.rel_err(out.cpu().numpy(), wants[i])
+                        assert err < TOL, (i, rep, err)
+            except BaseException as exc:      # pragma: no cover
+                errors.append(exc)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        assert 1 <= plan.num_instances <= 8
+
+
 def test_plans_release_their_device_memory():
     """rf_plan_destroy frees everything a plan allocated -- workspace, tables, the replicas concurrent executes made it build,
     the stages of a cascade, the helper plan of an early exchange: free device memory returns to where it was."""

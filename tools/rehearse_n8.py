@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Rehearsal of `bench.py --gpus 8`'s sharded-parity leg on ONE GPU (the pool has no multi-GPU box).
+
+    python tools/rehearse_n8.py [--world 8] [--slab 16384] [--cfg5 2048]
+
+cfg3, weak scaling: `world` slabs of slab x 16384 rows go through the stepping protocol (emulated ranks: one plan per rank
+on this device, the all-gather a rank-major device buffer), and the concatenated result is compared with the UNSHARDED plan
+on the whole (world * slab) x 16384 image -- the plan bench.py builds on every rank of an 8-GPU run (8 GiB in, 8 GiB out,
+1024 tiles per column), which no other test builds at that size.  Then cfg5 --strong: 2048^3 in `world` z slabs against the
+unsharded volume.  Prints one line per workload with bench.py's metric (max |a - b| / max(|b|, 1e-6))."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def emulate(name, local_shape, world, cfg):
+    import torch
+    import recfilter_amd as rfa
+    from bench import strict_rel_err
+    planes = cfg.get("planes", 1)
+    assert planes == 1
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    global_shape = (local_shape[0] * world,) + tuple(local_shape[1:])
+    whole_in = torch.rand(global_shape, generator=gen, device="cuda", dtype=torch.float32)
+    sharded_out = torch.empty_like(whole_in)
+    ins = list(whole_in.split(local_shape[0]))
+    outs = list(sharded_out.split(local_shape[0]))
+    t0 = time.perf_counter()
+    plans = [rfa.Plan(local_shape, cfg["scans"], clamped=cfg["clamped"], shard_rank=r, shard_world=world) for r in range(world)]
+    for r in range(world):
+        plans[r].begin([ins[r]], [outs[r]])
+    nex = plans[0].num_exchanges
+    for e in range(nex):
+        nbytes = plans[0].exchange_bytes(e)
+        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            plans[r].exchange_local(e, gathered.data_ptr() + r * nbytes)
+        if e == nex - 1:
+            for r in range(world):
+                plans[r].interior()
+        for r in range(world):
+            plans[r].exchange_apply(e, gathered.data_ptr())
+    for r in range(world):
+        plans[r].finish()
+    torch.cuda.synchronize()
+    path, tiles = plans[0].path_name, list(plans[0].tiles)
+    for p in plans:
+        p.close()
+    whole_out = torch.empty_like(whole_in)
+    with rfa.Plan(global_shape, cfg["scans"], clamped=cfg["clamped"]) as plan:
+        plan.execute([whole_in], [whole_out])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plan.execute([whole_in], [whole_out])
+        e1.record()
+        torch.cuda.synchronize()
+        whole_ms = e0.elapsed_time(e1)
+        whole_path, whole_tiles = plan.path_name, list(plan.tiles)
+    err = max(strict_rel_err(outs[r], whole_out.split(local_shape[0])[r]) for r in range(world))
+    print(f"{name}: world {world}, slab {'x'.join(map(str, local_shape))} ({path}, tiles {tiles}), {nex} exchange(s); unsharded "
+          f"{'x'.join(map(str, global_shape))} ({whole_path}, tiles {whole_tiles}) {whole_ms:.3f} ms; "
+          f"sharded_parity {err:.3e}  [{time.perf_counter() - t0:.1f} s]", flush=True)
+    assert err < 1e-4
+    del whole_in, whole_out, sharded_out
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--slab", type=int, default=16384)
+    ap.add_argument("--cfg5", type=int, default=2048)
+    args = ap.parse_args()
+    import ref_cases as rc
+    cfg3 = dict(rc.BASELINE_CONFIGS["cfg3_gaussian2_xy"])
+    emulate("cfg3 weak", (args.slab, 16384), args.world, cfg3)
+    if args.cfg5:
+        cfg5 = dict(rc.BASELINE_CONFIGS["cfg5_generic_xyz"])
+        emulate("cfg5 strong", (args.cfg5 // args.world, args.cfg5, args.cfg5), args.world, cfg5)
+
+
+if __name__ == "__main__":
+    main()
