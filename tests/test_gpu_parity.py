@@ -481,6 +481,27 @@ def test_cpp_front_end_runs_the_reference_tests():
     assert "all front-end tests passed" in res.stdout
 
 
+def test_cpp_front_end_over_real_rccl():
+    """a C++ caller whose all-gather is ncclAllGather on a communicator it initialised itself
+    (ncclCommInitRank, one rank: the pool's boxes have one GPU), handed to RecFilter::realize_sharded as
+    include/recfilter.hpp documents.  Row shards (collective on the filter's stream) and z slabs (collective on the side
+    stream, rf_plan_interior beside it) on plans with RF_PLAN_FORCE_EXCHANGE, against realize() and raster loops.  A fresh
+    child process linked against librccl: nothing of this (torch-initialised) process is involved."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "test_frontend_rccl")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(here, "cpp"), "test_frontend_rccl"])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RCCL_ID_FILE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "all rccl front-end tests passed" in res.stdout and "RCCL communicator: 1 rank(s)" in res.stdout
+    assert "(3 ncclAllGather calls on 1 rank(s))" in res.stdout
+
+
 # ---- randomized filters: every path against the oracle ------------------------------------------------------
 def _random_filter(rng, ndim, max_order=3, max_per_dim=4, stable=True):
     scans = []
