@@ -31,6 +31,7 @@ namespace {
 
 
 typedef float F2 __attribute__((ext_vector_type(2)));     // operands of the packed f32 instructions
+typedef float F4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f32_4x4x1_16b_f32
 
 // MODE: what the loads of a tile have to mask.  0: nothing but whole chunks beyond the image (every 2-D / 3-D image whose
 // width is a multiple of 4); 1: the end of a folded 1-D signal (FusedArgs::lin_limit); 2: a width that is not a multiple
@@ -38,7 +39,15 @@ typedef float F2 __attribute__((ext_vector_type(2)));     // operands of the pac
 // the sample-by-sample loads of modes 1 and 2 in the common kernel it grew from 115 / 121 to 127 / 132 registers at order
 // 2 / 3 -- above 128 a SIMD holds three waves instead of four -- and pass 1 of an order-3 filter on 3 x 16384^2 took 0.89
 // instead of 0.69 ms (order 2, one plane: 0.237 against 0.205 ms; same box).
-template <typename P, int K, int TY, typename PI, int MODE = 0>
+//
+// YM (f32 pixels): the y part -- 2 * ny * K multiply-adds per sample on the vector ALU otherwise -- runs on the matrix cores,
+// v_mfma_f32_4x4x1_16b_f32 (sixteen independent 4 x 4 outer products per issue, exact f32 fma chains; lane map:
+// profiles/r2/mfma_4x4x1_16b_lane_map.txt): block b = four adjacent columns, A[b][i] = this step's pixel of column 4b + i
+// (the lane's own column: the operand is the register the VALU form multiplies), B[b][j] = Hy[tail 4g + j][row] (the step's
+// 32-row slice of Hy staged in LDS next to the tile, 16 bytes per lane and four rows), accumulator D[b][i][j] = combined row
+// 4g + j at column 4b + i, alive across the tile's steps: lane 4b + j ends up with four adjacent columns of ONE tail and
+// stores them as 16 bytes.  At order 3 with two y scans the vector ALU loses 96 of its ~330 instructions per step and wave.
+template <typename P, int K, int TY, typename PI, int MODE = 0, bool YM = false>
 __global__ void __launch_bounds__(kFusedThreads)
 fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>::Acc> a,
                    const typename PixelTraits<P>::Acc *__restrict__ Hx,     // [vx][s][r][256]
@@ -53,6 +62,10 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     Acc *hx_lds = reinterpret_cast<Acc *>(hx_raw);
     A4 *tile4 = reinterpret_cast<A4 *>(tile);
     A4 *hx4 = reinterpret_cast<A4 *>(hx_lds);
+    static_assert(!YM || (std::is_same<Acc, float>::value && kTailRows == 32), "the matrix-core y part is f32");
+    constexpr int kHyPitch4 = 9;                  // YM: 32 rows + 4 floats of padding per tail, in 16-byte units (the four
+                                                  // tails of a group are read side by side: no two on the same banks)
+    constexpr int NGY = (kFusedMaxScans * K + 3) / 4;     // YM: groups of four y tails
     constexpr int NH = TY / kTailRows;            // steps per tile (2 for TY = 64)
     constexpr int NL = kTailRows / 4;             // float4 loads per thread per step
     constexpr int NR = kTailRows / 16;            // rows per thread in the x part
@@ -84,9 +97,18 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     auto ld_cols = [&](int row) { return load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), cols_valid); };
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
 
-    Acc comb[kFusedMaxScans * K];
+    Acc comb[YM ? 1 : kFusedMaxScans * K];
 #pragma unroll
-    for (int jr = 0; jr < kFusedMaxScans * K; jr++) comb[jr] = Acc(0);
+    for (int jr = 0; jr < (YM ? 1 : kFusedMaxScans * K); jr++) comb[jr] = Acc(0);
+    // YM: the step's slice of Hy behind Hx in the dynamic LDS, [tail (padded to groups of four)][kHyPitch4 * 4]; threads
+    // (tail, chunk of four rows) fetch it with the step's pixels
+    A4 *hy4 = hx4 + (a.nx > 0 ? a.nx : 1) * K * (kFusedTX / 4);
+    const int nyk4 = (nyk + 3) & ~3;
+    const int hy_jr = t >> 3, hy_m = t & 7;
+    A4 hy_pre = zero4;
+    F4 yacc[YM ? NGY : 1];
+#pragma unroll
+    for (int g = 0; g < (YM ? NGY : 1); g++) yacc[g] = F4{0.0f, 0.0f, 0.0f, 0.0f};
 
     A4 pre[NL];
     // rows of this half that exist (the last tile row may be partial): the fast path when all of them do
@@ -95,6 +117,9 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;         // linear index of the tile's first sample
     const bool lin_cut = MODE == 1 && a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit;      // (tile-uniform)
     auto load_half = [&](int half) {
+        if constexpr (YM) {
+            if (hy_jr < nyk) hy_pre = *reinterpret_cast<const A4 *>(Hy + (size_t)(vy * nyk + hy_jr) * TY + kTailRows * half + 4 * hy_m);
+        }
         const int r0 = kTailRows * half + rg;
         if (lin_cut) {
 #pragma unroll
@@ -149,6 +174,9 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
         }
 #pragma unroll
         for (int i = 0; i < NL; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = pre[i];
+        if constexpr (YM) {
+            if (hy_jr < nyk4) hy4[hy_jr * kHyPitch4 + hy_m] = hy_pre;       // (tails beyond nyk: zeros)
+        }
         __syncthreads();
         if (half + 1 < NH) load_half(half + 1);                 // next half in flight during this one's math
 
@@ -220,7 +248,21 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
             Acc col[kTailRows];
 #pragma unroll
             for (int i = 0; i < kTailRows; i++) col[i] = tile[i * kFusedTX + e];
-            if constexpr (std::is_same<Acc, float>::value) {
+            if constexpr (YM) {
+#pragma unroll
+                for (int m = 0; m < kTailRows / 4; m++) {
+#pragma unroll
+                    for (int g = 0; g < NGY; g++) {
+                        if (4 * g < nyk) {                                   // (uniform)
+                            const A4 h = hy4[(4 * g + (t & 3)) * kHyPitch4 + m];
+                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 0], h.x, yacc[g], 0, 0, 0);
+                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 1], h.y, yacc[g], 0, 0, 0);
+                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 2], h.z, yacc[g], 0, 0, 0);
+                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 3], h.w, yacc[g], 0, 0, 0);
+                        }
+                    }
+                }
+            } else if constexpr (std::is_same<Acc, float>::value) {
                 // two rows per instruction (v_pk_fma_f32), two tails at a time so that consecutive packed FMAs are
                 // independent (a dependent pair costs a wait state); an odd last tail is paired with itself
 #pragma unroll
@@ -253,7 +295,18 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
         }
     }
     // combined rows -> yt; with x scans in the filter xscan_rows_kernel finishes them in place
-    if (nyk > 0) {
+    if constexpr (YM) {
+        if (nyk > 0) {
+            // lane 4b + j, register i: combined row 4g + j at the tile's column (t & ~3) + i (thread t reads column t: `e` is
+            // where the swizzle put it)
+            const int64_t line = (int64_t)tx * kFusedTX + (t & ~3) + a.NXP * z;
+#pragma unroll
+            for (int g = 0; g < NGY; g++) {
+                const int jr = 4 * g + (t & 3);
+                if (jr < nyk) *reinterpret_cast<F4 *>(a.yt + a.yt_index(jr / K, ty, jr % K, K, line)) = yacc[g];
+            }
+        }
+    } else if (nyk > 0) {
         const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;
 #pragma unroll
         for (int jr = 0; jr < kFusedMaxScans * K; jr++)
@@ -596,6 +649,10 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
     dim3 grid((unsigned)a.MX, (unsigned)a.MY, (unsigned)a.NZ);
     static const size_t pad_bytes = RF_KNOB("RF_TAILS_PAD_LDS") ? (size_t)atoi(RF_KNOB("RF_TAILS_PAD_LDS")) : 0;     // A/B: bounds the residency
     const size_t hx_bytes = (size_t)(a.nx > 0 ? a.nx : 1) * K * kFusedTX * sizeof(typename PixelTraits<P>::Acc) + pad_bytes;
+    // the y part on the matrix cores (f32 pixels, whole-chunk loads): order 3 by default -- its vector ALU is the loaded pipe
+    const size_t hy_bytes = (size_t)((a.ny * K + 3) & ~3) * 9 * 16;
+    static const char *ym_knob = RF_KNOB("RF_TAILS_YMFMA");                  // A/B: 0 = never, 1 = every order
+    const bool ymfma = a.ny > 0 && (ym_knob ? atoi(ym_knob) != 0 : K == 3);
 #define RF_CASE(KK, TT)                                                                                             \
     if (K == KK && TY == TT) {                                                                                       \
         if constexpr (std::is_same<P, float>::value) {                                                               \
@@ -616,6 +673,14 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
             if ((a.last_cols & 3) != 0) {       /* width not a multiple of 4: the variant with partial-chunk loads */    \
                 hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P, 2>), grid, dim3(kFusedThreads), hx_bytes, stream,   \
                                    (const P *)src, a, Hx, Hy);                                                       \
+                RF_HIP_CHECK(hipGetLastError());                                                                     \
+                return RF_OK;                                                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+        if constexpr (std::is_same<P, float>::value && TT >= 32) {                                                   \
+            if (ymfma) {        /* y tails on the matrix cores; the step's Hy slice behind Hx in the dynamic LDS */         \
+                hipLaunchKernelGGL((fused_tails_kernel<P, KK, TT, P, 0, true>), grid, dim3(kFusedThreads), hx_bytes + hy_bytes, \
+                                   stream, (const P *)src, a, Hx, Hy);                                               \
                 RF_HIP_CHECK(hipGetLastError());                                                                     \
                 return RF_OK;                                                                                        \
             }                                                                                                        \
