@@ -120,6 +120,10 @@ typedef struct {
  *   RF_PLAN_NO_PLANE_BATCH  the planes of a 2-D Tuple run as separate launches instead of one batched launch per step.
  *   RF_PLAN_STREAM_PASS1 /  pass 1 of the fused path as the LDS-DMA streaming kernel wherever its shape rules allow,
  *   RF_PLAN_STAGED_PASS1    whatever the image size / never (default: single planes of at least 2048 tiles).
+ *                           STAGED also keeps the vector-ALU contraction (fused_tails_kernel) for every order.
+ *   RF_PLAN_MFMA_PASS1      pass 1 with its x-tail contraction on the matrix cores (kernels_tails_mfma.hip) wherever its
+ *                           shape rules allow -- f32 images of whole tiles, at most two scans per dimension -- whatever
+ *                           the order (default: orders 2 and 3).  The streaming kernel keeps what it takes.
  *   RF_PLAN_LATE_EXCHANGE   a z-sharded volume exchanges the carries of the x/y-FILTERED data, after its x/y stage
  *                           (nothing runs beside the all-gather); default: the carries of the raw input first, the x/y
  *                           stage beside the all-gather (rf_plan_interior below).
@@ -139,7 +143,8 @@ typedef struct {
 #define RF_PLAN_STAGED_PASS1    0x40u
 #define RF_PLAN_LATE_EXCHANGE   0x80u
 #define RF_PLAN_SERIAL_UNTILED  0x01000000u
-#define RF_PLAN_ALL_FLAGS       0x010000ffu
+#define RF_PLAN_MFMA_PASS1      0x02000000u
+#define RF_PLAN_ALL_FLAGS       0x030000ffu
 #define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
 #define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
 

@@ -31,6 +31,7 @@ RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED, RF_PA
 RF_PLAN_FORCE_EXCHANGE, RF_PLAN_TILED_ONLY, RF_PLAN_NO_CASCADE, RF_PLAN_NO_SECTIONS = 0x01, 0x02, 0x04, 0x08
 RF_PLAN_NO_PLANE_BATCH, RF_PLAN_STREAM_PASS1, RF_PLAN_STAGED_PASS1, RF_PLAN_LATE_EXCHANGE = 0x10, 0x20, 0x40, 0x80
 RF_PLAN_SERIAL_UNTILED = 0x01000000
+RF_PLAN_MFMA_PASS1 = 0x02000000
 
 
 def RF_PLAN_TILE_ROWS(n: int) -> int:

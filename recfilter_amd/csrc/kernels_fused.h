@@ -172,6 +172,10 @@ int launch_fused_tails(int K, int TY, const void *src, bool src_u8, const FusedA
 bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t n_tiles, int MX,
                              int64_t NZ, int nxk, int nyk, int mode /* +1 RF_PLAN_STREAM_PASS1, -1 RF_PLAN_STAGED_PASS1 */);
 int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, const float *Hx, const float *Hy, hipStream_t stream);
+// pass 1 with the x-tail contraction on the matrix cores, one tile per workgroup (kernels_tails_mfma.hip)
+bool mfma_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t lin_limit, int nx, int ny,
+                           int mode);
+int launch_mfma_tails(int K, int TY, const float *src, const FusedArgs<float> &a, const float *Hx, const float *Hy, hipStream_t stream);
 // tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)
 template <typename Acc>
 int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream,

@@ -97,221 +97,233 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
     auto ld_cols = [&](int row) { return load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)row * in_row_bytes), cols_valid); };
     const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
 
-    Acc comb[YM ? 1 : kFusedMaxScans * K];
-#pragma unroll
-    for (int jr = 0; jr < (YM ? 1 : kFusedMaxScans * K); jr++) comb[jr] = Acc(0);
-    // YM: the step's slice of Hy behind Hx in the dynamic LDS, [tail (padded to groups of four)][kHyPitch4 * 4]; threads
-    // (tail, chunk of four rows) fetch it with the step's pixels
-    A4 *hy4 = hx4 + (a.nx > 0 ? a.nx : 1) * K * (kFusedTX / 4);
-    const int nyk4 = (nyk + 3) & ~3;
-    const int hy_jr = t >> 3, hy_m = t & 7;
-    A4 hy_pre = zero4;
-    F4 yacc[YM ? NGY : 1];
-#pragma unroll
-    for (int g = 0; g < (YM ? NGY : 1); g++) yacc[g] = F4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    A4 pre[NL];
     // rows of this half that exist (the last tile row may be partial): the fast path when all of them do
     const int rows_here = (ty == a.MY - 1) ? a.last_rows : TY;
     // a folded 1-D signal that ends inside or before this tile (FusedArgs::lin_limit): samples from the end on are zeros
     const int64_t lin0 = ((int64_t)ty * TY) * a.NX + (int64_t)tx * kFusedTX;         // linear index of the tile's first sample
     const bool lin_cut = MODE == 1 && a.lin_limit > 0 && lin0 + (int64_t)(TY - 1) * a.NX + kFusedTX > a.lin_limit;      // (tile-uniform)
-    auto load_half = [&](int half) {
-        if constexpr (YM) {
-            if (hy_jr < nyk) hy_pre = *reinterpret_cast<const A4 *>(Hy + (size_t)(vy * nyk + hy_jr) * TY + kTailRows * half + 4 * hy_m);
-        }
-        const int r0 = kTailRows * half + rg;
-        if (lin_cut) {
+    // Whole tiles -- all but the last tile of a row, the last tile row and the tile a folded signal ends in -- run a body of
+    // their own (WHOLE), instantiated apart from the one that masks: with the load variants joined in ONE body the compiler
+    // merged their registers through copies behind the loads (`global_load v[22:25]; s_waitcnt vmcnt(0); v_mov v26, v25`), i.e.
+    // every step WAITED for the pixels it had just requested for the next step -- the memory latency was exposed once per
+    // step instead of hidden behind the step's arithmetic (ISA of round 3's kernel; pass 1 at order 3 paid its whole VALU
+    // time on top of the loads for it).
+    const bool whole_tile = !lin_cut && (tx != a.MX - 1 || a.last_cols == kFusedTX) && rows_here == TY && !odd_cols;
+    auto body = [&](auto whole_tag) {
+        constexpr bool WHOLE = decltype(whole_tag)::value;
+        Acc comb[YM ? 1 : kFusedMaxScans * K];
 #pragma unroll
-            for (int i = 0; i < NL; i++) {
-                const int64_t idx = lin0 + (int64_t)(r0 + 4 * i) * a.NX + 4 * cc;
-                // (the one chunk the end falls into is loaded sample by sample: nothing behind the end is read)
-                pre[i] = idx + 3 < a.lin_limit ? ld(kTailRows * half + 4 * i)
-                         : idx < a.lin_limit   ? ld_head(kTailRows * half + 4 * i, (int)(a.lin_limit - idx)) : zero4;
-            }
-            return;
-        }
-        // (whole tiles -- all but the last of a row and the last tile row -- load without a condition: a per-lane select
-        // between a load and zeros costs a branch per load and a wait for the load before the zeros may be written)
-        if ((tx != a.MX - 1 || a.last_cols == kFusedTX) && rows_here == TY) {
+        for (int jr = 0; jr < (YM ? 1 : kFusedMaxScans * K); jr++) comb[jr] = Acc(0);
+        // YM: the step's slice of Hy behind Hx in the dynamic LDS, [tail (padded to groups of four)][kHyPitch4 * 4]; threads
+        // (tail, chunk of four rows) fetch it with the step's pixels
+        A4 *hy4 = hx4 + (a.nx > 0 ? a.nx : 1) * K * (kFusedTX / 4);
+        const int nyk4 = (nyk + 3) & ~3;
+        const int hy_jr = t >> 3, hy_m = t & 7;
+        A4 hy_pre = zero4;
+        F4 yacc[YM ? NGY : 1];
 #pragma unroll
-            for (int i = 0; i < NL; i++) pre[i] = ld(kTailRows * half + 4 * i);
-        } else if (odd_cols) {
-#pragma unroll
-            for (int i = 0; i < NL; i++) pre[i] = r0 + 4 * i < rows_here ? ld_cols(kTailRows * half + 4 * i) : zero4;
-        } else if (rows_here == TY) {
-#pragma unroll
-            for (int i = 0; i < NL; i++) pre[i] = chunk_in ? ld(kTailRows * half + 4 * i) : zero4;
-        } else {
-#pragma unroll
-            for (int i = 0; i < NL; i++)
-                pre[i] = (chunk_in && r0 + 4 * i < rows_here) ? ld(kTailRows * half + 4 * i) : zero4;
-        }
-    };
-    load_half(0);
-    // impulse responses of the x tails for this tile's border variant -> LDS (read back per segment below);
-    // 16-byte chunk c of a row is stored at chunk c ^ ((c >> 4) & 3), the same swizzle as the pixels
-    if (nxk > 0) {
-        const A4 *hsrc = reinterpret_cast<const A4 *>(Hx + (size_t)vx * nxk * kFusedTX);
-        for (int c = t; c < nxk * 64; c += kFusedThreads) hx4[(c & ~63) | swz_chunk(c & 63)] = hsrc[c];
-    }
+        for (int g = 0; g < (YM ? NGY : 1); g++) yacc[g] = F4{0.0f, 0.0f, 0.0f, 0.0f};
 
-#pragma unroll
-    for (int half = 0; half < NH; half++) {
-        if (half > 0) __syncthreads();                          // previous step's readers are done
-        if constexpr (!PixelTraits<P>::is_integer) {
-            if (a.pw_flags & 1) {                                   // fused prologue x' = pre_s * in + pre_b
+        A4 pre[NL];
+        auto load_half = [&](int half) {
+            if constexpr (YM) {
+                if (hy_jr < nyk) hy_pre = *reinterpret_cast<const A4 *>(Hy + (size_t)(vy * nyk + hy_jr) * TY + kTailRows * half + 4 * hy_m);
+            }
+            const int r0 = kTailRows * half + rg;
+            if (!WHOLE && lin_cut) {
 #pragma unroll
                 for (int i = 0; i < NL; i++) {
-                    // samples beyond the image stay zero: they do not exist
-                    const bool in = chunk_in && kTailRows * half + rg + 4 * i < rows_here;
-                    const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
-                    pre[i].x = s * pre[i].x + b; pre[i].y = s * pre[i].y + b;
-                    pre[i].z = s * pre[i].z + b; pre[i].w = s * pre[i].w + b;
-                    if (odd_cols) clear_dead_cols<A4, Acc>(pre[i], cols_valid);
+                    const int64_t idx = lin0 + (int64_t)(r0 + 4 * i) * a.NX + 4 * cc;
+                    // (the one chunk the end falls into is loaded sample by sample: nothing behind the end is read)
+                    pre[i] = idx + 3 < a.lin_limit ? ld(kTailRows * half + 4 * i)
+                             : idx < a.lin_limit   ? ld_head(kTailRows * half + 4 * i, (int)(a.lin_limit - idx)) : zero4;
                 }
+                return;
             }
-        }
+            // (whole tiles -- all but the last of a row and the last tile row -- load without a condition: a per-lane select
+            // between a load and zeros costs a branch per load and a wait for the load before the zeros may be written)
+            if constexpr (WHOLE) {
 #pragma unroll
-        for (int i = 0; i < NL; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = pre[i];
-        if constexpr (YM) {
-            if (hy_jr < nyk4) hy4[hy_jr * kHyPitch4 + hy_m] = hy_pre;       // (tails beyond nyk: zeros)
-        }
-        __syncthreads();
-        if (half + 1 < NH) load_half(half + 1);                 // next half in flight during this one's math
-
-        // ---- x tails of this half's rows: dot products + reduction over the 16 lanes of a row ----
+                for (int i = 0; i < NL; i++) pre[i] = ld(kTailRows * half + 4 * i);
+            } else if (odd_cols) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) pre[i] = r0 + 4 * i < rows_here ? ld_cols(kTailRows * half + 4 * i) : zero4;
+            } else if (rows_here == TY) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) pre[i] = chunk_in ? ld(kTailRows * half + 4 * i) : zero4;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NL; i++)
+                    pre[i] = (chunk_in && r0 + 4 * i < rows_here) ? ld(kTailRows * half + 4 * i) : zero4;
+            }
+        };
+        load_half(0);
+        // impulse responses of the x tails for this tile's border variant -> LDS (read back per segment below);
+        // 16-byte chunk c of a row is stored at chunk c ^ ((c >> 4) & 3), the same swizzle as the pixels
         if (nxk > 0) {
-            Acc v[NR][kFusedSeg];
+            const A4 *hsrc = reinterpret_cast<const A4 *>(Hx + (size_t)vx * nxk * kFusedTX);
+            for (int c = t; c < nxk * 64; c += kFusedThreads) hx4[(c & ~63) | swz_chunk(c & 63)] = hsrc[c];
+        }
+
 #pragma unroll
-            for (int n = 0; n < NR; n++) {
+        for (int half = 0; half < NH; half++) {
+            if (half > 0) __syncthreads();                          // previous step's readers are done
+            if constexpr (!PixelTraits<P>::is_integer) {
+                if (a.pw_flags & 1) {                                   // fused prologue x' = pre_s * in + pre_b
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    A4 q = tile4[(slot + 16 * n) * 64 + 4 * l + (j ^ sw)];
-                    v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
+                    for (int i = 0; i < NL; i++) {
+                        // samples beyond the image stay zero: they do not exist
+                        const bool in = WHOLE || (chunk_in && kTailRows * half + rg + 4 * i < rows_here);
+                        const Acc s = in ? a.pre_s : Acc(0), b = in ? a.pre_b : Acc(0);
+                        pre[i].x = s * pre[i].x + b; pre[i].y = s * pre[i].y + b;
+                        pre[i].z = s * pre[i].z + b; pre[i].w = s * pre[i].w + b;
+                        if (!WHOLE && odd_cols) clear_dead_cols<A4, Acc>(pre[i], cols_valid);
+                    }
                 }
             }
-            const int64_t line0 = (int64_t)ty * TY + kTailRows * half + slot + a.NYP * z;
-#pragma unroll 1
-            for (int sr = 0; sr < nxk; sr++) {
-                Acc h[kFusedSeg];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    A4 q = hx4[sr * 64 + 4 * l + (j ^ sw)];
-                    h[4 * j + 0] = q.x; h[4 * j + 1] = q.y; h[4 * j + 2] = q.z; h[4 * j + 3] = q.w;
+            for (int i = 0; i < NL; i++) tile4[(rg + 4 * i) * 64 + swz_chunk(cc)] = pre[i];
+            if constexpr (YM) {
+                if (hy_jr < nyk4) hy4[hy_jr * kHyPitch4 + hy_m] = hy_pre;       // (tails beyond nyk: zeros)
+            }
+            __syncthreads();
+            if (half + 1 < NH) load_half(half + 1);                 // next half in flight during this one's math
+
+            // ---- x tails of this half's rows: dot products + reduction over the 16 lanes of a row ----
+            if (nxk > 0) {
+                Acc v[NR][kFusedSeg];
+#pragma unroll
+                for (int n = 0; n < NR; n++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        A4 q = tile4[(slot + 16 * n) * 64 + 4 * l + (j ^ sw)];
+                        v[n][4 * j + 0] = q.x; v[n][4 * j + 1] = q.y; v[n][4 * j + 2] = q.z; v[n][4 * j + 3] = q.w;
+                    }
                 }
-                Acc acc[NR];
-                if constexpr (std::is_same<Acc, float>::value) {
-                    // two samples per instruction (v_pk_fma_f32): neighbours along the row sit in adjacent registers
-                    // (two accumulators per row: consecutive packed FMAs are independent, a dependent pair costs a wait state)
-                    F2 acc2[NR][2];
+                const int64_t line0 = (int64_t)ty * TY + kTailRows * half + slot + a.NYP * z;
+#pragma unroll 1
+                for (int sr = 0; sr < nxk; sr++) {
+                    Acc h[kFusedSeg];
 #pragma unroll
-                    for (int n = 0; n < NR; n++) acc2[n][0] = acc2[n][1] = F2{0.0f, 0.0f};
+                    for (int j = 0; j < 4; j++) {
+                        A4 q = hx4[sr * 64 + 4 * l + (j ^ sw)];
+                        h[4 * j + 0] = q.x; h[4 * j + 1] = q.y; h[4 * j + 2] = q.z; h[4 * j + 3] = q.w;
+                    }
+                    Acc acc[NR];
+                    if constexpr (std::is_same<Acc, float>::value) {
+                        // two samples per instruction (v_pk_fma_f32): neighbours along the row sit in adjacent registers
+                        // (two accumulators per row: consecutive packed FMAs are independent, a dependent pair costs a wait state)
+                        F2 acc2[NR][2];
 #pragma unroll
-                    for (int m = 0; m < kFusedSeg; m += 2) {
-                        const F2 hh = F2{h[m], h[m + 1]};
+                        for (int n = 0; n < NR; n++) acc2[n][0] = acc2[n][1] = F2{0.0f, 0.0f};
 #pragma unroll
-                        for (int n = 0; n < NR; n++)
-                            acc2[n][(m >> 1) & 1] = hh * F2{v[n][m], v[n][m + 1]} + acc2[n][(m >> 1) & 1];
+                        for (int m = 0; m < kFusedSeg; m += 2) {
+                            const F2 hh = F2{h[m], h[m + 1]};
+#pragma unroll
+                            for (int n = 0; n < NR; n++)
+                                acc2[n][(m >> 1) & 1] = hh * F2{v[n][m], v[n][m + 1]} + acc2[n][(m >> 1) & 1];
+                        }
+#pragma unroll
+                        for (int n = 0; n < NR; n++) {
+                            const F2 s2 = acc2[n][0] + acc2[n][1];
+                            acc[n] = s2.x + s2.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NR; n++) {
+                            acc[n] = Acc(0);
+#pragma unroll
+                            for (int m = 0; m < kFusedSeg; m++) acc[n] = acc[n] + h[m] * v[n][m];
+                        }
                     }
 #pragma unroll
-                    for (int n = 0; n < NR; n++) {
-                        const F2 s2 = acc2[n][0] + acc2[n][1];
-                        acc[n] = s2.x + s2.y;
+                    for (int n = 0; n < NR; n++) {          // sum over the row's 16 lanes; total lands in lane 15
+                        acc[n] = acc[n] + row_shift<true, 8>(acc[n]);
+                        acc[n] = acc[n] + row_shift<true, 4>(acc[n]);
+                        acc[n] = acc[n] + row_shift<true, 2>(acc[n]);
+                        acc[n] = acc[n] + row_shift<true, 1>(acc[n]);
+                    }
+                    if (l == 15) {
+                        const int s = sr / K, r = sr % K;
+#pragma unroll
+                        for (int n = 0; n < NR; n++)
+                            a.xt[(((int64_t)s * a.MX + tx) * K + r) * Lx + line0 + 16 * n] = acc[n];
+                    }
+                }
+            }
+
+            // ---- y: contract this half's rows with Hy (thread = column) ----
+            if (nyk > 0) {
+                Acc col[kTailRows];
+#pragma unroll
+                for (int i = 0; i < kTailRows; i++) col[i] = tile[i * kFusedTX + e];
+                if constexpr (YM) {
+#pragma unroll
+                    for (int m = 0; m < kTailRows / 4; m++) {
+#pragma unroll
+                        for (int g = 0; g < NGY; g++) {
+                            if (4 * g < nyk) {                                   // (uniform)
+                                const A4 h = hy4[(4 * g + (t & 3)) * kHyPitch4 + m];
+                                yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 0], h.x, yacc[g], 0, 0, 0);
+                                yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 1], h.y, yacc[g], 0, 0, 0);
+                                yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 2], h.z, yacc[g], 0, 0, 0);
+                                yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 3], h.w, yacc[g], 0, 0, 0);
+                            }
+                        }
+                    }
+                } else if constexpr (std::is_same<Acc, float>::value) {
+                    // two rows per instruction (v_pk_fma_f32), two tails at a time so that consecutive packed FMAs are
+                    // independent (a dependent pair costs a wait state); an odd last tail is paired with itself
+#pragma unroll
+                    for (int g = 0; g < (kFusedMaxScans * K + 1) / 2; g++) {
+                        if (2 * g < nyk) {
+                            const int j0 = 2 * g, j1 = (2 * g + 1 < nyk) ? 2 * g + 1 : 2 * g;
+                            const Acc *h0 = Hy + (size_t)(vy * nyk + j0) * TY + kTailRows * half;     // wave-uniform
+                            const Acc *h1 = Hy + (size_t)(vy * nyk + j1) * TY + kTailRows * half;
+                            F2 c0 = F2{0.0f, 0.0f}, c1 = F2{0.0f, 0.0f};
+#pragma unroll
+                            for (int i = 0; i < kTailRows; i += 2) {
+                                const F2 cc = F2{col[i], col[i + 1]};
+                                c0 = F2{h0[i], h0[i + 1]} * cc + c0;
+                                c1 = F2{h1[i], h1[i + 1]} * cc + c1;
+                            }
+                            comb[2 * g] = comb[2 * g] + (c0.x + c0.y);
+                            if (2 * g + 1 < kFusedMaxScans * K) comb[2 * g + 1] = comb[2 * g + 1] + (c1.x + c1.y);
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int n = 0; n < NR; n++) {
-                        acc[n] = Acc(0);
+                    for (int jr = 0; jr < kFusedMaxScans * K; jr++) {
+                        if (jr < nyk) {
+                            const Acc *hy = Hy + (size_t)(vy * nyk + jr) * TY + kTailRows * half;     // wave-uniform
 #pragma unroll
-                        for (int m = 0; m < kFusedSeg; m++) acc[n] = acc[n] + h[m] * v[n][m];
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < NR; n++) {          // sum over the row's 16 lanes; total lands in lane 15
-                    acc[n] = acc[n] + row_shift<true, 8>(acc[n]);
-                    acc[n] = acc[n] + row_shift<true, 4>(acc[n]);
-                    acc[n] = acc[n] + row_shift<true, 2>(acc[n]);
-                    acc[n] = acc[n] + row_shift<true, 1>(acc[n]);
-                }
-                if (l == 15) {
-                    const int s = sr / K, r = sr % K;
-#pragma unroll
-                    for (int n = 0; n < NR; n++)
-                        a.xt[(((int64_t)s * a.MX + tx) * K + r) * Lx + line0 + 16 * n] = acc[n];
-                }
-            }
-        }
-
-        // ---- y: contract this half's rows with Hy (thread = column) ----
-        if (nyk > 0) {
-            Acc col[kTailRows];
-#pragma unroll
-            for (int i = 0; i < kTailRows; i++) col[i] = tile[i * kFusedTX + e];
-            if constexpr (YM) {
-#pragma unroll
-                for (int m = 0; m < kTailRows / 4; m++) {
-#pragma unroll
-                    for (int g = 0; g < NGY; g++) {
-                        if (4 * g < nyk) {                                   // (uniform)
-                            const A4 h = hy4[(4 * g + (t & 3)) * kHyPitch4 + m];
-                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 0], h.x, yacc[g], 0, 0, 0);
-                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 1], h.y, yacc[g], 0, 0, 0);
-                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 2], h.z, yacc[g], 0, 0, 0);
-                            yacc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 * m + 3], h.w, yacc[g], 0, 0, 0);
+                            for (int i = 0; i < kTailRows; i++) comb[jr] = comb[jr] + hy[i] * col[i];
                         }
                     }
                 }
-            } else if constexpr (std::is_same<Acc, float>::value) {
-                // two rows per instruction (v_pk_fma_f32), two tails at a time so that consecutive packed FMAs are
-                // independent (a dependent pair costs a wait state); an odd last tail is paired with itself
-#pragma unroll
-                for (int g = 0; g < (kFusedMaxScans * K + 1) / 2; g++) {
-                    if (2 * g < nyk) {
-                        const int j0 = 2 * g, j1 = (2 * g + 1 < nyk) ? 2 * g + 1 : 2 * g;
-                        const Acc *h0 = Hy + (size_t)(vy * nyk + j0) * TY + kTailRows * half;     // wave-uniform
-                        const Acc *h1 = Hy + (size_t)(vy * nyk + j1) * TY + kTailRows * half;
-                        F2 c0 = F2{0.0f, 0.0f}, c1 = F2{0.0f, 0.0f};
-#pragma unroll
-                        for (int i = 0; i < kTailRows; i += 2) {
-                            const F2 cc = F2{col[i], col[i + 1]};
-                            c0 = F2{h0[i], h0[i + 1]} * cc + c0;
-                            c1 = F2{h1[i], h1[i + 1]} * cc + c1;
-                        }
-                        comb[2 * g] = comb[2 * g] + (c0.x + c0.y);
-                        if (2 * g + 1 < kFusedMaxScans * K) comb[2 * g + 1] = comb[2 * g + 1] + (c1.x + c1.y);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int jr = 0; jr < kFusedMaxScans * K; jr++) {
-                    if (jr < nyk) {
-                        const Acc *hy = Hy + (size_t)(vy * nyk + jr) * TY + kTailRows * half;     // wave-uniform
-#pragma unroll
-                        for (int i = 0; i < kTailRows; i++) comb[jr] = comb[jr] + hy[i] * col[i];
-                    }
-                }
             }
         }
-    }
-    // combined rows -> yt; with x scans in the filter xscan_rows_kernel finishes them in place
-    if constexpr (YM) {
-        if (nyk > 0) {
-            // lane 4b + j, register i: combined row 4g + j at the tile's column (t & ~3) + i (thread t reads column t: `e` is
-            // where the swizzle put it)
-            const int64_t line = (int64_t)tx * kFusedTX + (t & ~3) + a.NXP * z;
+        // combined rows -> yt; with x scans in the filter xscan_rows_kernel finishes them in place
+        if constexpr (YM) {
+            if (nyk > 0) {
+                // lane 4b + j, register i: combined row 4g + j at the tile's column (t & ~3) + i (thread t reads column t: `e` is
+                // where the swizzle put it)
+                const int64_t line = (int64_t)tx * kFusedTX + (t & ~3) + a.NXP * z;
 #pragma unroll
-            for (int g = 0; g < NGY; g++) {
-                const int jr = 4 * g + (t & 3);
-                if (jr < nyk) *reinterpret_cast<F4 *>(a.yt + a.yt_index(jr / K, ty, jr % K, K, line)) = yacc[g];
+                for (int g = 0; g < NGY; g++) {
+                    const int jr = 4 * g + (t & 3);
+                    if (jr < nyk) *reinterpret_cast<F4 *>(a.yt + a.yt_index(jr / K, ty, jr % K, K, line)) = yacc[g];
+                }
             }
-        }
-    } else if (nyk > 0) {
-        const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;
+        } else if (nyk > 0) {
+            const int64_t line = (int64_t)tx * kFusedTX + t + a.NXP * z;
 #pragma unroll
-        for (int jr = 0; jr < kFusedMaxScans * K; jr++)
-            if (jr < nyk) a.yt[a.yt_index(jr / K, ty, jr % K, K, line)] = comb[jr];
-    }
+            for (int jr = 0; jr < kFusedMaxScans * K; jr++)
+                if (jr < nyk) a.yt[a.yt_index(jr / K, ty, jr % K, K, line)] = comb[jr];
+        }
+    };
+    if (whole_tile) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 // tile-local x scans (all of them, zero carries) of the combined rows, in place in yt, plus the

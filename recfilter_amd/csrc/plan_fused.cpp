@@ -364,14 +364,19 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Step p1;
     p1.name = "fused_tails";
     const int stream_mode = (plan->flags & RF_PLAN_STREAM_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
-    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode](int pl) {
+    const int mfma_mode = (plan->flags & RF_PLAN_MFMA_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
+    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode, mfma_mode](int pl) {
         const FusedArgs<Acc> a = fargs(pl);
         (void)stream_mode;
+        (void)mfma_mode;
         // images of whole 256 x 64 tiles stream through the LDS-DMA ring (kernels_stream.hip)
         if constexpr (std::is_same<P, float>::value) {
             if (a.lin_limit == 0 && stream_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, (int64_t)a.MX * a.MY * a.NZ, a.MX,
                                         a.NZ, a.nx * K, a.ny * K, stream_mode))
                 return launch_stream_tails(K, (const float *)(padded ? plan->pad_in[pl] : plan->in[pl]), a, d_Hx, d_Hy, plan->stream);
+            // ... other f32 images of whole tiles contract their x tails on the matrix cores (kernels_tails_mfma.hip)
+            if (mfma_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, a.lin_limit, a.nx, a.ny, mfma_mode))
+                return launch_mfma_tails(K, TY, (const float *)(padded ? plan->pad_in[pl] : plan->in[pl]), a, d_Hx, d_Hy, plan->stream);
         }
         return launch_fused_tails<P>(K, TY, padded ? plan->pad_in[pl] : plan->in[pl], plan->pw.in_u8, a, d_Hx, d_Hy, plan->stream);
     };

@@ -274,6 +274,40 @@ def test_streaming_pass1_3d_and_planes():
         assert rc.rel_err(o.cpu().numpy(), oracle.apply_filter(im.astype(np.float64), c["scans"], True)) < TOL
 
 
+@pytest.mark.parametrize("mode", ["mfma", "staged"])
+@pytest.mark.parametrize("name", ["gauss2_clamped", "gauss3_clamped", "generic_xy_zero", "sat", "x_only", "y_only", "single_tile"])
+def test_both_staged_pass1_kernels_on_whole_tiles(name, mode):
+    """Pass 1 of f32 images made of whole tiles has two register-staged kernels: mfma_tails_kernel (x tails on the matrix
+    cores, per-row LDS swizzle; default for orders 2 and 3) and fused_tails_kernel (vector ALU; order 1 and everything the
+    other one does not take).  RF_PLAN_MFMA_PASS1 / RF_PLAN_STAGED_PASS1 send every order to one or the other: all three
+    tile heights, every scan mix of the fused cases, border variants (one tile, a tile row, a tile column), 3 planes."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    pick = capi.RF_PLAN_MFMA_PASS1 if mode == "mfma" else capi.RF_PLAN_STAGED_PASS1
+    case = rc.FUSED_CASES[name]
+    for ty in (32, 64, 128):
+        flags = capi.RF_PLAN_TILED_ONLY | pick | capi.RF_PLAN_TILE_ROWS(ty)
+        for shape in ((ty, 256), (ty * 3, 256), (ty, 1024), (ty * 2, 768)):
+            img = rc.random_image(shape, np.float32, 23)
+            got = _gpu(shape, case["scans"], case["clamped"], img, flags=flags)
+            want = oracle.apply_filter(img.astype(np.float64), case["scans"], case["clamped"])
+            assert rc.rel_err(got, want) < TOL, (name, mode, ty, shape)
+    # Tuple planes in one launch, and a volume (z = the grid's batch dimension)
+    c = rc.BASELINE_CONFIGS["cfg4b_gaussian3_rgb"]
+    flags = capi.RF_PLAN_TILED_ONLY | pick | capi.RF_PLAN_TILE_ROWS(128)
+    imgs = [rc.random_image((256, 768), np.float32, 40 + p) for p in range(3)]
+    with rfa.Plan((256, 768), c["scans"], clamped=True, planes=3, flags=flags) as plan:
+        outs = plan.execute([torch.from_numpy(i).cuda() for i in imgs])
+        torch.cuda.synchronize()
+    for im, o in zip(imgs, outs):
+        assert rc.rel_err(o.cpu().numpy(), oracle.apply_filter(im.astype(np.float64), c["scans"], True)) < TOL
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    vol = rc.random_image((24, 128, 512), np.float32, 24)
+    got = _gpu((24, 128, 512), scans, False, vol, flags=capi.RF_PLAN_TILED_ONLY | pick | capi.RF_PLAN_TILE_ROWS(64))
+    assert rc.rel_err(got, oracle.apply_filter(vol.astype(np.float64), scans, False)) < TOL
+
+
 @pytest.mark.parametrize("case", ["rows64_both", "tall_both", "odd_width", "planes_int32", "volume"])
 def test_final_pass_split_into_whole_tiles_and_edge_strips(case):
     """Large images with partial tiles, every sample against the oracle: on 128-row tiles the final pass is up to three

@@ -14,7 +14,7 @@ f=glob.glob(sys.argv[1]+'/*/*kernel_stats.csv')[0]
 out=[]
 for r in csv.DictReader(open(f)):
     n=r['Name']
-    for k in ('fused_tails_kernel','fused_pass2','carry_pair','carry_block','xscan_rows','stream_tails','strided_pass'):
+    for k in ('fused_tails_kernel','fused_pass2','carry_pair','carry_block','xscan_rows','stream_tails','strided_pass','mfma_tails'):
         if k in n: out.append(f"{k}={float(r['AverageNs'])/1e3:.1f}")
 print(sys.argv[2], sys.argv[3], ' '.join(out))
 PY

@@ -8,8 +8,8 @@ for path in sys.argv[1:-1]:
         name = r["Kernel_Name"]
         if "rf::" not in name:
             continue
-        m = re.search(r"(\w+_kernel)", name)
-        short = m.group(1) if m else name[:40]
+        m = re.search(r"(\w+_kernel)(<[^,>]*,\s*\d+)?", name)
+        short = (m.group(1) + (m.group(2) or "")) if m else name[:40]
         per_dispatch[(r["Dispatch_Id"], short)][r["Counter_Name"]] = per_dispatch[(r["Dispatch_Id"], short)].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     for (_, short), counters in per_dispatch.items():
         for c, v in counters.items():
@@ -18,7 +18,8 @@ res = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
 for k, cs in res.items():
     wc = cs.get("SQ_WAVE_CYCLES")
     if wc:
-        for c in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY"):
+        for c in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY",
+                  "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INST_CYCLES_VMEM"):
             if c in cs:
                 cs[c + "_per_wave_cycle"] = round(cs[c] / wc, 4)
     if cs.get("SQ_LDS_IDX_ACTIVE"):
