@@ -79,6 +79,13 @@ struct FusedArgs {
     // last tile column and the last tile row on the EDGE variant (kernels_fused.hip, launch_fused_pass2).  tx0 / ty0: the
     // tile this launch's block (0, 0) stands for; gx / gy: its grid (0 = MX / MY).  Read by the final-pass kernels only.
     int32_t tx0, ty0, gx, gy;
+    // Final pass on 128-row tiles: workgroup b of the launch takes tile (b mod 8) * (tiles / 8) + b / 8 instead of tile b, i.e.
+    // every XCD (workgroups are dealt to the eight XCDs round robin) walks a contiguous eighth of the tiles.  Set by the
+    // launcher for images whose row pitch is not a multiple of 128 bytes: their rows start anywhere inside a 128-byte line,
+    // so the line at every tile boundary is written in two parts by two workgroups -- in the same L2 when they are
+    // neighbours inside an XCD (tools/microbench/hbm_read_patterns pitch 16380: tile-shaped copy 0.438 -> 0.413 ms; an
+    // aligned pitch copies in 0.324 ms and prefers the plain order, 0.337 ms with this one).
+    int32_t xcd_contig;
     const void *in_planes[kFusedMaxPlanes];
     void *out_planes[kFusedMaxPlanes];
     // Layout of the y tails.  0: [j][ty][r][column] -- a tile's rows are 1-KiB pieces a whole image row apart; 1: tile-major,

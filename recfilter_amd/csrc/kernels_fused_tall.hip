@@ -38,7 +38,14 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     constexpr int TY = kTallTY, TL = kHalfRows, NR = TL / 16;
 
     const int t = threadIdx.x;
-    const int tx = (int)blockIdx.x + a.tx0, ty = (int)blockIdx.y + a.ty0;
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (a.xcd_contig) {                                        // (uniform; FusedArgs::xcd_contig)
+        const unsigned gxn = gridDim.x, total = gxn * gridDim.y;
+        unsigned b = (unsigned)by * gxn + (unsigned)bx;
+        b = (b & 7u) * (total >> 3) + (b >> 3);
+        bx = (int)(b % gxn); by = (int)(b / gxn);
+    }
+    const int tx = bx + a.tx0, ty = by + a.ty0;
     const int64_t z = blockIdx.z;
     if (a.plane_batch) {
         src = reinterpret_cast<const PI *>(a.in_planes[z]);
@@ -348,7 +355,9 @@ int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)(a.gx > 0 ? a.gx : a.MX), (unsigned)(a.gy > 0 ? a.gy : a.MY), (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY, XFIX>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    FusedArgs<Acc> aa = a;
+    aa.xcd_contig = (a.row_bytes % 128u != 0 && (grid.x * grid.y) % 8u == 0 && grid.x * grid.y >= 2048u) ? 1 : 0;
+    hipLaunchKernelGGL((fused_pass2_tall_kernel<P, K, EDGE, PI, YPAT, EARLY, XFIX>), grid, dim3(kFusedThreads), lds, stream, src, dst, aa);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }

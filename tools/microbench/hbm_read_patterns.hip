@@ -8,9 +8,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __global__ void __launch_bounds__(256) linear_kernel(const f4 *src, float *out) {
     const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
@@ -131,9 +134,47 @@ __global__ void __launch_bounds__(256) linear_copy_kernel(const f4 *src, f4 *dst
     }
 }
 
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+// `hbm_read_patterns pitch <width>`: the tile-shaped copy on an image of 16384 rows whose width (a multiple of 4) is not a
+// multiple of 32 samples -- rows are 16-byte aligned but start anywhere inside a 128-byte line; whole tiles only.
+int pitch_main(int width) {
+    const int n = 16384;
+    const int nx4 = width / 4, mx = width / 256, tiles = mx * (n / 64);
+    const size_t bytes = (size_t)n * width * 4, moved = (size_t)n * mx * 256 * 4;
+    f4 *src; float *dst;
+    CK(hipMalloc(&src, bytes + 4096));
+    CK(hipMalloc(&dst, bytes + 4096));
+    CK(hipMemset(src, 0, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time2 = [&](const char *name, auto launch) {
+        for (int i = 0; i < 3; i++) launch();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 20; i++) launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= 20;
+        std::printf("width %5d  %-34s %.4f ms  %.2f TB/s\n", width, name, ms, 2.0 * moved / (ms * 1e-3) / 1e12);
+    };
+    float *out;
+    CK(hipMalloc(&out, (size_t)tiles * 256 * 4));
+    time2("tile read only (x2 for the rate)", [&] { hipLaunchKernelGGL(tile_kernel<64>, dim3(tiles), dim3(256), 0, 0, src, out, nx4, mx); });
+    time2("tile copy", [&] { hipLaunchKernelGGL((tile_copy_kernel<false, false>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy, nt loads", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, false>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    time2("tile copy, nt both", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    if (tiles % 8 == 0) {
+        time2("tile copy nt, XCD-contiguous", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, true, 1>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+        time2("tile copy nt loads, XCD-contig", [&] { hipLaunchKernelGGL((tile_copy_kernel<true, false, 1>), dim3(tiles), dim3(256), 0, 0, src, dst, nx4, mx); });
+    }
+    return 0;
+}
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc >= 3 && std::string(argv[1]) == "pitch") {
+        for (int i = 2; i < argc; i++)
+            if (int rc = pitch_main(atoi(argv[i]))) return rc;
+        return 0;
+    }
     const int n = 16384;
     const size_t bytes = (size_t)n * n * 4;
     f4 *src; float *out;
