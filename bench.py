@@ -271,7 +271,7 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
 
     # --- per-kernel timing with HIP events on the launch stream (single-device plan) -----------------
     # Runs BEFORE the warm-up and the timed steps, on every rank (rank 0 reports): a GPU that starts from idle needs
-    # some 25 ms of load before its kernels run at their steady durations (tools/region_probe.py: cfg3 0.66 ms for the
+    # some 25 ms of load before its kernels run at their steady durations (tools/probes/region_probe.py: cfg3 0.66 ms for the
     # first execution, 0.63 over the first five, 0.59 after about forty), and the driver's 5 + 20 steps are 15 ms.
     # Every rank runs it (the clocks of every GPU have to come up); a rank whose own plan is sharded (or forced into the
     # stepping protocol) times an unsharded plan of the same slab, which has the same kernels.

@@ -32,8 +32,16 @@ def test_every_app_runs_and_checks(app, tmp_path, capsys):
     row = capsys.readouterr().out.strip().splitlines()[-1].split("\t")
     assert int(row[0]) == int(w) and float(row[1]) > 0
     err = float(row[3].split()[-1])
-    # the unsharp mask cancels O(1) terms, see test_unsharp_mask_front_end
-    assert err < (5e-3 if app.startswith("box") or app == "diff_gauss" else 1e-3 if app.startswith("usm") else 1e-4)
+    if len(row) > 4:
+        # An app whose expression cancels -- the unsharp mask (1 + w) I - w Blur(I), differences of summed-area tables whose
+        # entries grow with the image area -- is not held to a bare loosened bar: profile_app evaluates the SAME expression
+        # with the f32 oracle (the reference's own arithmetic: its apps are float pipelines) against the f64 evaluation,
+        # and ours may carry at most four times that error (or the 1e-4 of every other app, whichever is larger).
+        err_f32 = float(row[4].split()[-1])
+        assert err < max(1e-4, 4.0 * err_f32), (app, err, err_f32)
+        assert err < 5e-3                                     # ... and never beyond what round 3 accepted bare
+    else:
+        assert err < 1e-4, (app, err)
 
 
 @pytest.mark.gpu

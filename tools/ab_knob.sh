@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do for rep in $(seq $REPS); do for v in $settings; do
   d=/tmp/rp_ab_$rep; rm -rf $d
   if [ "$v" != "-" ]; then export "$v"; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $root/tools/p1_probe.py $c > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $root/tools/probes/p1_probe.py $c > /dev/null 2>&1
   if [ "$v" != "-" ]; then unset "${v%%=*}"; fi
   python3 - $d "$v" $c <<'PY'
 import csv,glob,sys

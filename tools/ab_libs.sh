@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do for rep in 1 2 3; do for v in $libs; do
   d=/tmp/rp_${v}_${c}_$rep; rm -rf $d
   export RECFILTER_AMD_LIB=$root/recfilter_amd/librecfilter_$v.so
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $root/tools/p1_probe.py $c > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $root/tools/probes/p1_probe.py $c > /dev/null 2>&1
   python3 - $d $v $c <<'PY'
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+'/*/*kernel_stats.csv')[0]

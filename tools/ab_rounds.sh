@@ -8,8 +8,8 @@ REPS=${REPS:-4}
 cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do for rep in $(seq $REPS); do for v in r2 r3 new; do
   d=/tmp/rp_${v}_$rep; rm -rf $d
-  if [ $v = new ]; then cd $root; else cd $root/old_$v; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 tools/p1_probe.py $c > /tmp/p1_$v.json 2>/dev/null
+  if [ $v = new ]; then cd $root; probe=tools/probes/p1_probe.py; else cd $root/old_$v; probe=tools/p1_probe.py; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $probe $c > /tmp/p1_$v.json 2>/dev/null
   python3 - $d $v $c /tmp/p1_$v.json <<'PY'
 import csv,glob,json,sys
 f=glob.glob(sys.argv[1]+'/*/*kernel_stats.csv')[0]

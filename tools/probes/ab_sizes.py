@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times a spread of sizes/configs with the library RECFILTER_AMD_LIB points at (A/B runs of kernel variants)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import recfilter_amd as rfa

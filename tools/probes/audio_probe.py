@@ -2,7 +2,7 @@
 """Per-kernel times of a 1-D signal through n causal biquads (apps/audio): where a long signal's time goes (tuning aid).
 usage: audio_probe.py [samples] [n ...]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

@@ -2,7 +2,7 @@
 """Clamped 1-D signals: the fused plan with border corrections against the generic path (what they ran on before round 3)."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import recfilter_amd as rfa, ref_cases as rc
 

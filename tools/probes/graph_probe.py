@@ -2,7 +2,7 @@
 """Does capturing one execute in a HIP graph lower the fixed cost of a small image?  (plan.execute is capturable:
 no allocation, no host synchronisation, every launch on the stream it is given.)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import recfilter_amd as rfa

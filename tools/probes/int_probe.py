@@ -2,7 +2,7 @@
 """Fused path per pixel type (tuning aid): step time and per-kernel times of a summed-area table and of an order-2
 4-scan integer filter, f32 against int32 / int16."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import recfilter_amd as rfa

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Order-3 filters on the fused path (tuning aid): cfg4b and the single-plane gaussian_3xy of the reference, per kernel."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

@@ -2,7 +2,7 @@
 """Per-kernel times of the order-3 Gaussian (gaussian_3xy of the reference's sweep) at mid sizes (tuning aid).
 usage: mid_probe.py [order] sizes..."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

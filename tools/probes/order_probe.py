@@ -2,7 +2,7 @@
 """Orders 4..6 (zero border, f32): the plan's split into sections on the fused kernels against the scans as given
 (`python tools/order_probe.py given`: RF_PLAN_NO_SECTIONS, generic path), 4096^2 and 16384^2."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import recfilter_amd as rfa

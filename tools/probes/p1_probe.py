@@ -2,7 +2,7 @@
 """Times pass 1 (and the whole cfg3 step) under the current environment knobs; one line of JSON (tuning aid).
 The knobs exist only in the A/B build: make -C recfilter_amd/csrc ab; RECFILTER_AMD_LIB=recfilter_amd/librecfilter_amd_ab.so RF_...=1 python tools/p1_probe.py"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

@@ -2,7 +2,7 @@
 """Is a sharded result bit-identical to the unsharded one?  (rehearse_n8.py printed sharded_parity 0 for cfg3.)  Counts the
 samples that differ, per slab row range, on a small row-sharded image; compares both with the f64 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

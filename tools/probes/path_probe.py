@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time of every execution path on one image (tuning aid): which path serves which pixel type / size how fast."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

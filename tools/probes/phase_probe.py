@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timing of filter variants on one GPU (tuning aid): which phase of the fused pass costs what."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

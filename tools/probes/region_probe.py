@@ -2,7 +2,7 @@
 """Where a short timed region's fixed cost sits: wall clock between synchronize() calls against HIP events around the
 same K executions (cfg3).  usage: region_probe.py [size]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import recfilter_amd as rfa

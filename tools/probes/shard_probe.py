@@ -2,7 +2,7 @@
 """Times the pieces of a sharded step on ONE GPU: `world` slab plans of cfg3 size emulate the ranks, the all-gather is a
 device copy.  Shows what the exchange costs each rank besides the collective itself (tuning aid)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import recfilter_amd as rfa

@@ -2,7 +2,7 @@
 """Where the fixed cost of a small image goes: CPU enqueue time per execute against the GPU's steady rate, and the
 per-kernel times (tuning aid)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import recfilter_amd as rfa

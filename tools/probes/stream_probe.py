@@ -2,7 +2,7 @@
 """Would running independent planes on two streams hide the latency-bound carry kernels behind the other plane's
 HBM-bound passes?  Two one-plane plans, same stream vs two streams."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import recfilter_amd as rfa

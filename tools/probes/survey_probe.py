@@ -4,7 +4,7 @@ and the per-kernel times -- to spot cliffs away from the headline shape.  python
 import os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import recfilter_amd as rfa, ref_cases as rc
 

@@ -3,7 +3,7 @@
 python tools/ty_probe.py"""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import recfilter_amd as rfa, ref_cases as rc
 from recfilter_amd import capi

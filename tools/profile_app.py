@@ -331,6 +331,14 @@ def run_one(rfa, build, w, args, *extra):
         if expect is not None:
             want = expect(want, im.astype(np.float64))
         err = rc.rel_err(out, want)
+        run_one.err_f32 = None
+        if expect is not None:
+            # Apps whose expression cancels (unsharp mask, differences of summed-area tables): the SAME expression evaluated
+            # in f32 -- the reference's arithmetic: its apps are Halide float pipelines -- by the f32 oracle, against the
+            # f64 evaluation.  That is the error the reference's own result carries; the tests bar ours against it.
+            im32 = im.astype(np.float32)
+            want32 = expect(oracle.apply_filter(im32, scans, clamped), im32)
+            run_one.err_f32 = rc.rel_err(np.asarray(want32, dtype=np.float64), want)
     return ms, err
 
 
@@ -360,7 +368,9 @@ def main(argv=None):
         row = f"{w}\t{ms:.6f}\t{throughput(ms, w * w):.3f}"
         if log:
             log.write(row + "\n"); log.flush()
-        print(row + ("" if err is None else f"\tmax rel err {err:.3e}"), flush=True)
+        e32 = getattr(run_one, "err_f32", None)
+        print(row + ("" if err is None else f"\tmax rel err {err:.3e}") +
+              ("" if err is None or e32 is None else f"\tf32 evaluation of the same expression {e32:.3e}"), flush=True)
     return 0
 
 
