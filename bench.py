@@ -55,7 +55,7 @@ def algorithmic_bytes_per_launch(kernel_name, samples, itemsize):
     every sample once and writes it once; pass 1 only reads; carry kernels touch no image bytes."""
     if "pass2" in kernel_name:
         return 2 * itemsize * samples
-    if "pass1" in kernel_name or "tails" in kernel_name:
+    if "pass1" in kernel_name or "tails" in kernel_name:      # (fused_tails: whichever pass-1 kernel the plan launches)
         return itemsize * samples
     return 0
 
@@ -86,7 +86,7 @@ def pmc_traffic(kernel_name, workload, shape):
     info = {"traffic_source": None, "traffic_head": None, "traffic_sources_sha16": None, "running_sources_sha16": kernel_sources_sha16()}
     if workload != "cfg3" or tuple(shape) != (16384, 16384):
         return None, info
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         rel = os.path.join("profiles", rnd, "pmc_traffic.json")
         try:
             doc = json.load(open(os.path.join(ROOT, rel)))
