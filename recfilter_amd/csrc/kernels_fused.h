@@ -15,6 +15,7 @@ constexpr int kFusedTX = 256;       // tile width: 16 lanes x 16 samples = one D
 constexpr int kFusedSeg = 16;       // samples per lane in the x phase
 constexpr int kFusedThreads = 256;  // 4 waves
 constexpr int kFusedMaxK = 3;       // max feedback order on the fused path
+constexpr int kFusedMaxMod = 8;     // == RF_MAX_ORDER: samples a border modification touches
 constexpr int kFusedMaxScans = 4;   // max scans per dimension on the fused path
 
 // One scan as the fused kernels read it (device memory, uniform -> scalar loads).
@@ -27,6 +28,9 @@ struct FusedScan {
     Acc R[kFusedMaxK][kFusedSeg];           // R[j][m]: effect on the segment's sample m (MEMORY order, so that
                                             // neighbours pair up for packed FMAs) of component j of the entering state
     Acc P[4][kFusedMaxK][kFusedMaxK];       // segment exit-state transfer over 1, 2, 4, 8 segments
+    // border modification of a scan in zero-border form (Scan::mod_n, rf_internal.h); read only when FusedArgs::mod_form
+    int32_t mod_n;
+    Acc mod_g[kFusedMaxMod];
 };
 
 // y scans only need their coefficients
@@ -35,6 +39,8 @@ struct FusedScanY {
     int32_t causal;
     Acc b;
     Acc a[kFusedMaxK];
+    int32_t mod_n;                          // as FusedScan::mod_n
+    Acc mod_g[kFusedMaxMod];
 };
 
 // Passed to the kernels BY VALUE: the scan tables then live in the kernarg segment (constant address
@@ -86,6 +92,10 @@ struct FusedArgs {
     // neighbours inside an XCD (tools/microbench/hbm_read_patterns pitch 16380: tile-shaped copy 0.438 -> 0.413 ms; an
     // aligned pitch copies in 0.324 ms and prefers the plain order, 0.337 ms with this one).
     int32_t xcd_contig;
+    // The plan's scans are in zero-border form behind border modifications (clamped filters whose high-order scans were split
+    // into sections, plan.cpp): `clamped` then only says WHERE the modifications apply; the kernels that run recurrences take
+    // their general-pattern code and call border_mod_* (scan_device.h) instead of the native clamped prologue.
+    int32_t mod_form;
     const void *in_planes[kFusedMaxPlanes];
     void *out_planes[kFusedMaxPlanes];
     // Layout of the y tails.  0: [j][ty][r][column] -- a tile's rows are 1-KiB pieces a whole image row apart; 1: tile-major,
@@ -111,6 +121,7 @@ struct StridedArgs {
     int32_t M;                   // tiles of TZ samples
     int32_t n_scans;
     int32_t clamped, first_is_border, last_is_border;
+    int32_t mod_form;            // as FusedArgs::mod_form
     FusedScanY<Acc> scans[kFusedMaxScans];
     Acc *tails;                  // [s][t][r][line]
     const Acc *incoming;         // [s][r][line]

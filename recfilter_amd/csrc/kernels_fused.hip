@@ -43,7 +43,10 @@ namespace {
 // assignments: ~TY register copies per scan (and spills on the 128-row tiles of kernels_fused_tall.hip).
 // LIN: a folded 1-D signal whose end falls inside the image (FusedArgs::lin_limit) -- its masked loads and stores are a
 // variant of the plain kernel (no epilogue operand, whole tiles, no y scans), so that no other kernel carries them
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false, bool LIN = false>
+// MOD: the plan's scans are in zero-border form behind border modifications (FusedArgs::mod_form) -- an instance of its own of
+// the general-pattern code (inside the common EDGE instance the eight modification factors per scan exhausted its scalar
+// registers: 173 / 203 / 236 vector registers became 233 / 265 / 297 at orders 1 / 2 / 3, for every image with partial tiles)
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false, bool LIN = false, bool MOD = false>
 __global__ void __launch_bounds__(kFusedThreads, (EPI || PixelTraits<P>::is_integer) ? 2 : 1)
 fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<typename PixelTraits<P>::Acc> a) {
     using Acc = typename PixelTraits<P>::Acc;
@@ -259,8 +262,16 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
 #pragma unroll
                         for (int q = 1; q < kFusedMaxScans; q++) cx[n][j] = (s == q) ? CX[q][n][j] : cx[n][j];
                     }
-                if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
-                else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
+                bool cf = clamp_first;
+                if constexpr (MOD) {                               // zero-border form behind a border modification
+                    if (a.clamped && tile_first) {
+                        if (causal) border_mod_rows16<Acc, true, NR>(v, sc, clamp_first);
+                        else        border_mod_rows16<Acc, false, NR>(v, sc, clamp_first);
+                    }
+                    cf = false;
+                }
+                if (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, cf, cx);
+                else        scan_rows16<Acc, false, K, NR>(v, sc, first_lane, cf, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
             }
         }
 #pragma unroll
@@ -322,9 +333,17 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
 #pragma unroll
                     for (int q = 1; q < kFusedMaxScans; q++) c[r] = (j == q) ? CY[q][r] : c[r];
                 }
-                if (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
-                else if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
-                else scan_col_partial_up<Acc, K, TY>(col, sc, clamp_first, rows_here);     // partial last tile row
+                bool cf = clamp_first;
+                if constexpr (MOD) {
+                    if (clamp_first) {
+                        if (causal) border_mod_col<Acc, true, TY>(col, sc);
+                        else        border_mod_col<Acc, false, TY>(col, sc);
+                    }
+                    cf = false;
+                }
+                if (causal) scan_col<Acc, true, K, TY>(col, sc, cf, c);
+                else if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, cf, c);
+                else scan_col_partial_up<Acc, K, TY>(col, sc, cf, rows_here);     // partial last tile row
             }
         }
         if constexpr (!PixelTraits<P>::is_integer) {
@@ -381,7 +400,7 @@ fused_pass2_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedArgs<ty
     }
 }
 
-template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false, bool LIN = false>
+template <typename P, int K, int TY, bool EPI, bool EDGE, typename PI, int YPAT = 0, bool XFIX = false, bool LIN = false, bool MOD = false>
 int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
     using Acc = typename PixelTraits<P>::Acc;
     const size_t lds = (size_t)TY * kFusedTX * sizeof(Acc);
@@ -393,12 +412,12 @@ int launch_fused_pass2_impl(const PI *src, P *dst, const FusedArgs<typename Pixe
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::atomic<bool> &done = attr_set[dev & 63];
     if (!done.load(std::memory_order_acquire)) {
-        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX, LIN>),
+        RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX, LIN, MOD>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)(a.gx > 0 ? a.gx : a.MX), (unsigned)(a.gy > 0 ? a.gy : a.MY), (unsigned)a.NZ);
-    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX, LIN>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
+    hipLaunchKernelGGL((fused_pass2_kernel<P, K, TY, EPI, EDGE, PI, YPAT, XFIX, LIN, MOD>), grid, dim3(kFusedThreads), lds, stream, src, dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -418,13 +437,21 @@ static int launch_fused_pass2_typed(int K, int TY, const PI *src, P *dst, const 
         set_error("fused pass 2: a signal that ends inside the image needs a 1-D plan of whole tiles without an input-operand epilogue");
         return RF_ERR_INVALID_ARG;
     }
-    const int ypat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
-    const int xpat = (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
+    // (a plan in mod form -- FusedArgs::mod_form -- takes the general-pattern code, which applies its border modifications)
+    const int ypat = a.mod_form ? 0 : (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
+    const int xpat = a.mod_form ? 0 : (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
     bool early = true;        // rows can leave from inside the last scan (an affine epilogue is applied on the way out; one with
                               // an input operand only where the column is in registers, i.e. the EPI variants)
     if constexpr (!PixelTraits<P>::is_integer) early = (a.pw_flags & 2) == 0 || a.post_i == typename PixelTraits<P>::Acc(0);
 #define RF_CASE(KK, TT)                                                                                         \
     if (K == KK && TY == TT) {                                                                                  \
+        if constexpr (std::is_same<P, float>::value && std::is_same<P, PI>::value) {                            \
+            if (a.mod_form) {                                                                                   \
+                if (epi) { set_error("fused pass 2: clamped sections cannot take an epilogue with an input operand"); return RF_ERR_UNSUPPORTED; } \
+                return edge ? launch_fused_pass2_impl<P, KK, TT, false, true, PI, 0, false, false, true>(src, dst, a, stream)   \
+                            : launch_fused_pass2_impl<P, KK, TT, false, false, PI, 0, false, false, true>(src, dst, a, stream); \
+            }                                                                                                   \
+        }                                                                                                       \
         if constexpr (std::is_same<P, PI>::value) {                                                             \
             if (a.lin_limit > 0) return launch_fused_pass2_impl<P, KK, TT, false, false, PI, 0, false, true>(src, dst, a, stream); \
         }                                                                                                       \

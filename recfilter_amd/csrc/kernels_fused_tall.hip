@@ -231,8 +231,15 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                 for (int n = 0; n < NR; n++)
 #pragma unroll
                     for (int j = 0; j < K; j++) cx[n][j] = cx_lds[(((h * kFusedMaxScans + s) * NR + n) * K + j) * 16 + slot];
-                if constexpr (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, clamp_first, cx);
-                else scan_rows16<Acc, false, K, NR>(v, sc, first_lane, clamp_first, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
+                bool cf = clamp_first;
+                if constexpr (!(XFIX && YPAT >= 1)) {              // (the general-pattern variants: what a mod-form plan launches)
+                    if (a.mod_form) {
+                        if (a.clamped && tile_first) border_mod_rows16<Acc, causal, NR>(v, sc, clamp_first);
+                        cf = false;
+                    }
+                }
+                if constexpr (causal) scan_rows16<Acc, true, K, NR>(v, sc, first_lane, cf, cx);
+                else scan_rows16<Acc, false, K, NR>(v, sc, first_lane, cf, cx, l > last_lane, EDGE ? entry_valid : kFusedSeg);
             };
             // (the x scans' directions are compile-time too where they follow the y pattern: every row of the tile would
             // otherwise be a phi of two register assignments per scan, as the column is in the y phase)
@@ -272,10 +279,17 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
         Acc c[K];
 #pragma unroll
         for (int r = 0; r < K; r++) c[r] = cy_lds[(j * K + r) * kFusedTX + t];      // (written by this thread)
-        if constexpr (causal) scan_col<Acc, true, K, TY>(col, sc, clamp_first, c);
+        bool cf = clamp_first;
+        if constexpr (YPAT == 0) {
+            if (a.mod_form) {
+                if (clamp_first) border_mod_col<Acc, causal, TY>(col, sc);
+                cf = false;
+            }
+        }
+        if constexpr (causal) scan_col<Acc, true, K, TY>(col, sc, cf, c);
         else {
-            if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, clamp_first, c);
-            else scan_col_partial_up<Acc, K, TY>(col, sc, clamp_first, rows_here);
+            if (rows_here == TY) scan_col<Acc, false, K, TY>(col, sc, cf, c);
+            else scan_col_partial_up<Acc, K, TY>(col, sc, cf, rows_here);
         }
     };
     // whole tiles without an epilogue: the rows are stored from inside the last scan, each as soon as it is final
@@ -364,10 +378,11 @@ int launch_tall_pat(const PI *src, P *dst, const FusedArgs<typename PixelTraits<
 
 template <typename P, int K, bool EDGE, typename PI>
 int launch_tall_impl(const PI *src, P *dst, const FusedArgs<typename PixelTraits<P>::Acc> &a, hipStream_t stream) {
-    const int pat = (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
+    // (a plan in mod form -- FusedArgs::mod_form -- takes the general-pattern code, which applies its border modifications)
+    const int pat = a.mod_form ? 0 : (a.ny == 1 && a.ys[0].causal != 0) ? 1 : (a.ny == 2 && a.ys[0].causal != 0 && a.ys[1].causal == 0) ? 2 : 0;
     bool early = !EDGE && pat > 0;
     if constexpr (!PixelTraits<P>::is_integer) early = early && (a.pw_flags & 2) == 0;
-    const int xpat = (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
+    const int xpat = a.mod_form ? 0 : (a.nx == 1 && a.xs[0].causal != 0) ? 1 : (a.nx == 2 && a.xs[0].causal != 0 && a.xs[1].causal == 0) ? 2 : 0;
     if constexpr (!EDGE) {
         if (early && pat == 1 && xpat == 1) return launch_tall_pat<P, K, EDGE, PI, 1, true, true>(src, dst, a, stream);
         if (early && pat == 2 && xpat == 2) return launch_tall_pat<P, K, EDGE, PI, 2, true, true>(src, dst, a, stream);

@@ -12,6 +12,7 @@
 
 #include "kernels.h"
 #include "kernels_fused.h"
+#include "scan_device.h"
 
 namespace rf {
 
@@ -83,7 +84,13 @@ strided_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, StridedArgs<
                 for (int r = 0; r < K; r++) carry[r] = a.tails[(((int64_t)s * a.M + tp) * K + r) * a.lines + line];
             }
         }
-        const bool clamp_first = a.clamped && border;
+        bool clamp_first = a.clamped && border;
+        if constexpr (PAT == 0) {
+            if (a.mod_form) {                       // zero-border form behind a border modification (scan_device.h)
+                if (clamp_first) border_mod_col<Acc, causal, TZ>(col, sc);
+                clamp_first = false;
+            }
+        }
         scan_regs<Acc, causal, K, TZ>(col, sc, clamp_first, carry);
         if (!FINAL) {
 #pragma unroll
@@ -122,7 +129,7 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
     dim3 grid((unsigned)((a.lines + 255) / 256), (unsigned)a.M);
     // the fast variants: whole runs of 256 lines per workgroup, the usual scan patterns (else the general one)
     const bool uni = a.inner % 256 == 0 && a.lines % 256 == 0;
-    const int pat = (a.n_scans == 1 && a.scans[0].causal != 0) ? 1
+    const int pat = a.mod_form ? 0 : (a.n_scans == 1 && a.scans[0].causal != 0) ? 1
                   : (a.n_scans == 2 && a.scans[0].causal != 0 && a.scans[1].causal == 0) ? 2 : 0;
     // Workgroups per CU: these kernels stream 64 or 128 rows per wave that lie a whole plane apart; beyond three waves
     // per SIMD more rows in flight make the memory system slower, not faster (2048^3, 64 samples per thread: 5.7 ms at

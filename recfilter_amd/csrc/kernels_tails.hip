@@ -347,7 +347,7 @@ fused_tails_kernel(const PI *__restrict__ src, FusedArgs<typename PixelTraits<P>
 constexpr int kXcMaxTiles = 32;   // XC = tiles per wave (four waves): 4 up to 16 tiles per row, 8 up to 32 (order 1)
 
 
-template <typename Acc, int K, bool EDGE, bool TALL, int XC = 0>
+template <typename Acc, int K, bool EDGE, bool TALL, int XC = 0, bool MOD = false>
 __global__ void __launch_bounds__(256, XC ? (sizeof(Acc) == 8 ? 2 : 3) : (sizeof(Acc) == 8 ? 3 : 6))
 xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, const Acc *__restrict__ G,
                   const Acc *__restrict__ Wx = nullptr, const Acc *__restrict__ Ax = nullptr, Acc *__restrict__ xt_done = nullptr) {
@@ -608,8 +608,14 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
             const int last_lane = (EDGE && tx == a.MX - 1) ? a.last_lane : 15;       // a row's last tile may be partial
             const bool first_lane = causal ? (l == 0) : (l == last_lane);
             const bool clamp_first = a.clamped && tile_first && first_lane;
-            if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, clamp_first, zero);
-            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, clamp_first, zero, l > last_lane,
+            bool cf = clamp_first;
+            if constexpr (MOD) {        // FusedArgs::mod_form: zero-border scans behind border modifications (scan_device.h)
+                if (causal) border_mod_rows16<Acc, true, 1>(v, sc, clamp_first);
+                else        border_mod_rows16<Acc, false, 1>(v, sc, clamp_first);
+                cf = false;
+            }
+            if (causal) scan_rows16<Acc, true, K, 1>(v, sc, first_lane, cf, zero);
+            else        scan_rows16<Acc, false, K, 1>(v, sc, first_lane, cf, zero, l > last_lane,
                                                           (EDGE && tx == a.MX - 1) ? a.last_cols - 16 * a.last_lane : kFusedSeg);
         }
         if (residual) {
@@ -733,6 +739,17 @@ bool xscan_completes_x_tails(int K, int TY, int MX, int nx, int ny, size_t acc_b
     return true;
 }
 
+// one launch of xscan_rows_kernel: the MOD instance (float accumulators only) for plans in mod form
+#define RF_XSCAN_LAUNCH(PLAIN, MODDED, ...)                                                                          \
+    do {                                                                                                            \
+        bool launched_ = false;                                                                                     \
+        if constexpr (std::is_same<Acc, float>::value) {                                                            \
+            if (a.mod_form) { hipLaunchKernelGGL((xscan_rows_kernel<RF_UNPAREN MODDED>), __VA_ARGS__); launched_ = true; } \
+        }                                                                                                           \
+        if (!launched_) hipLaunchKernelGGL((xscan_rows_kernel<RF_UNPAREN PLAIN>), __VA_ARGS__);                     \
+    } while (0)
+#define RF_UNPAREN(...) __VA_ARGS__
+
 template <typename Acc>
 int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream,
                       const Acc *Wx, const Acc *Ax, Acc *xt_done) {
@@ -754,8 +771,8 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
         const size_t xc_bytes = g_bytes + (size_t)a.nx * a.MX * K * TY * sizeof(Acc);
 #define RF_CASE(KK, CH)                                                                                                    \
         if (K == KK && (a.MX + 3) / 4 <= CH) {                                                                             \
-            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, false, CH>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done);  \
-            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, false, CH>), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done); \
+            if (edge) RF_XSCAN_LAUNCH((Acc, KK, true, false, CH), (Acc, KK, true, false, CH, true), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done);  \
+            else      RF_XSCAN_LAUNCH((Acc, KK, false, false, CH), (Acc, KK, false, false, CH, true), dim3(grid), dim3(256), xc_bytes, stream, a, gj, TY, Hy, G, Wx, Ax, xt_done); \
             RF_HIP_CHECK(hipGetLastError());                                                                               \
             return RF_OK;                                                                                                  \
         }
@@ -767,11 +784,11 @@ int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, con
 #define RF_CASE(KK)                                                                                                        \
     if (K == KK) {                                                                                                         \
         if (TY > 64) {      /* 128-row tiles: two 64-row blocks of the carry strips per lane */                            \
-            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, true>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
-            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, true>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
+            if (edge) RF_XSCAN_LAUNCH((Acc, KK, true, true), (Acc, KK, true, true, 0, true), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
+            else      RF_XSCAN_LAUNCH((Acc, KK, false, true), (Acc, KK, false, true, 0, true), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
         } else {                                                                                                           \
-            if (edge) hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, true, false>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
-            else      hipLaunchKernelGGL((xscan_rows_kernel<Acc, KK, false, false>), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
+            if (edge) RF_XSCAN_LAUNCH((Acc, KK, true, false), (Acc, KK, true, false, 0, true), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G);  \
+            else      RF_XSCAN_LAUNCH((Acc, KK, false, false), (Acc, KK, false, false, 0, true), dim3(grid), dim3(256), g_bytes, stream, a, gj, TY, Hy, G); \
         }                                                                                                                  \
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \

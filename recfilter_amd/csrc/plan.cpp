@@ -508,20 +508,41 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     // Orders above 3 (lib/split.cpp:575-578 pads any order; the fused kernels stop at 3): with a zero border and float
     // pixels a scan of order 4..RF_MAX_ORDER is the same filter as its first/second/third-order sections applied one after
     // the other (sections.h), and those the fused kernels take -- as long as no dimension ends up with more than four scans.
+    // With a CLAMPED border (2-D / 3-D, f32) the same rewrite works on scans in "mod form": a clamped scan IS the zero-border
+    // scan of an input whose first k samples in scan direction are x_r + g_r x_0 (tables.h, scan_tile) --
+    //     y_r = b x_r + sum_{j<r} a_j y_{r-1-j} + (sum_{j>=r} a_j) c_r,   c_0 = x_0,  c_r = y_0 = (b + sum a) x_0
+    // (lib/recfilter.cpp:330-336), so  g_0 = (sum_j a_j) / b,  g_r = (sum_{j>=r} a_j)(b + sum a) / b -- and the zero-border
+    // scan factors into sections exactly.  The first section of every scan carries the modification of the ORIGINAL scan;
+    // every scan of the plan (the low-order ones too) is put into that form, and the kernels that run recurrences apply the
+    // modification on the tile where the scan enters the image (scan_device.h, border_mod_*).
     // The rewrite is kept only if it makes the fused path applicable; every other path runs the scans as given.
-    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && !plan->clamped &&
+    if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) &&
         (plan->dtype == RF_F32 || plan->dtype == RF_F64) && !(desc->flags & RF_PLAN_NO_SECTIONS)) {
         bool high = false;
         for (const Scan &sc : plan->scans) high = high || sc.order > kFusedMaxK;
+        const bool mod = plan->clamped;
+        if (mod && (plan->dtype != RF_F32 || desc->ndim < 2 || plan->sharded())) high = false;
         if (high) {
             std::vector<Scan> rewritten;
             bool ok = true;
             const int dtype = plan->dtype;
             for (const Scan &sc : plan->scans) {
-                if (sc.order <= kFusedMaxK) { rewritten.push_back(sc); continue; }
                 std::vector<Scan> sec;
-                ok = ok && split_into_sections(sc, kFusedMaxK, [dtype](double v) { return cast_coeff(v, dtype); }, sec);
+                if (sc.order <= kFusedMaxK) sec.push_back(sc);
+                else ok = ok && split_into_sections(sc, kFusedMaxK, [dtype](double v) { return cast_coeff(v, dtype); }, sec);
                 if (!ok) break;
+                if (mod) {
+                    // the modification of the scan as given, carried by its first section
+                    if (sc.b == 0.0) { ok = false; break; }
+                    double suffix[RF_MAX_ORDER + 1] = {0};
+                    for (int j = sc.order - 1; j >= 0; j--) suffix[j] = suffix[j + 1] + sc.a[j];
+                    const double total = sc.b + suffix[0];
+                    for (size_t i = 0; i < sec.size(); i++) {
+                        sec[i].mod_n = i == 0 ? sc.order : 0;
+                        for (int r = 0; r < RF_MAX_ORDER; r++)
+                            sec[i].mod_g[r] = (i == 0 && r < sc.order) ? (r == 0 ? suffix[0] / sc.b : suffix[r] * total / sc.b) : 0.0;
+                    }
+                }
                 rewritten.insert(rewritten.end(), sec.begin(), sec.end());
             }
             if (ok) {
@@ -529,6 +550,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
                 DimInfo saved[RF_MAX_DIMS];
                 for (int d = 0; d < RF_MAX_DIMS; d++) saved[d] = plan->dims[d];
                 plan->scans = rewritten;
+                plan->mod_form = mod;
                 for (int d = 0; d < desc->ndim; d++) { plan->dims[d].scan_ids.clear(); plan->dims[d].k = 0; }
                 for (size_t i = 0; i < plan->scans.size(); i++) {
                     DimInfo &di = plan->dims[plan->scans[i].dim];
@@ -538,6 +560,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
                 std::string unused;
                 if (!fused_plan_applicable(plan.get(), desc, &unused)) {
                     plan->scans = original;
+                    plan->mod_form = false;
                     for (int d = 0; d < RF_MAX_DIMS; d++) plan->dims[d] = saved[d];
                 }
             }
@@ -596,7 +619,8 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         const bool fused_ok = fused_plan_applicable(plan.get(), desc, &why);
         // (where the fused kernels apply, split() widths are hints -- the tile size never changes the result -- so a small
         // split() filter takes the line kernels too: the reference's own sweep, scripts/profile_app.sh, tiles at 32)
-        if (fused_ok && !plan->sharded() && max_extent <= long_limit && plan->total * plan->n_planes <= long_limit * long_limit * 4 &&
+        // (scans in mod form -- clamped sections, above -- exist for the fused kernels only)
+        if (fused_ok && !plan->mod_form && !plan->sharded() && max_extent <= long_limit && plan->total * plan->n_planes <= long_limit * long_limit * 4 &&
             plan->pw.pre == false && plan->pw.post == false && line_scans_applicable(plan.get()))
             path = RF_PATH_UNTILED;
         else if (fused_ok) path = RF_PATH_TILED_FUSED;
@@ -632,7 +656,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         return RF_ERR_INVALID_ARG;
     };
     int rc = build(path);
-    if (rc == RF_ERR_UNSUPPORTED && desc->path == RF_PATH_AUTO && path != RF_PATH_UNTILED && !plan->sharded()) {
+    if (rc == RF_ERR_UNSUPPORTED && desc->path == RF_PATH_AUTO && path != RF_PATH_UNTILED && !plan->sharded() && !plan->mod_form) {
         // auto mode: a shape no tile fits falls back to the untiled recurrence (still on the GPU)
         std::unique_ptr<rf_plan> fresh(new rf_plan);
         // rebuild the description part

@@ -54,6 +54,9 @@ struct rf_plan {
     int dtype = RF_F32;
     int n_planes = 1;
     bool clamped = false;
+    // the scans are in zero-border form behind border modifications (Scan::mod_n >= 0 for every scan; plan.cpp, "clamped
+    // sections"): a clamped filter whose scans of order 4..8 were split into sections of order <= 3
+    bool mod_form = false;
     int path = RF_PATH_UNTILED;
     int device = 0;
     bool host_only = false;               // tables only, no device memory, cannot execute

@@ -118,6 +118,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         // RF_PLAN_TILE_ROWS(n): the caller's tile height, where the shape admits it
         if (want == 32 || want == 64 || (want == 128 && !chained && (!rows_sharded || NYB % 128 == 0))) TY = want;
     }
+    // scans in mod form (plan.cpp, "clamped sections"): whole tile rows, so that a modification sits at compile-time rows of
+    // the column (fused_plan_applicable has checked that 32 divides the height)
+    if (plan->mod_form && ny_early > 0)
+        while (TY > 32 && NY % TY != 0) TY /= 2;
     // f64 pixels: a 256 x 32 tile is the 64 KiB of LDS a 256 x 64 tile of f32 takes (any height: partial last tile row)
     if (sizeof(Acc) == 8) {
         if (rows_sharded && NYB % 32 != 0) { set_error("row-sharded f64 slabs must be multiples of 32 rows"); return RF_ERR_UNSUPPORTED; }
@@ -291,6 +295,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     fbase.NYP = NYP; fbase.last_rows = TVy;
     fbase.row_bytes = (uint32_t)(NX * (int64_t)sizeof(P));
     fbase.clamped = plan->clamped ? 1 : 0;
+    fbase.mod_form = plan->mod_form ? 1 : 0;
     fbase.y_first_border = (!y_sharded || plan->shard_rank == 0) ? 1 : 0;
     fbase.y_last_border = (!y_sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
     if constexpr (!PixelTraits<P>::is_integer) {
@@ -319,6 +324,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         fbase.ys[j].causal = hys[j].causal;
         fbase.ys[j].b = hys[j].b;
         for (int e = 0; e < kFusedMaxK; e++) fbase.ys[j].a[e] = hys[j].a[e];
+        fbase.ys[j].mod_n = hys[j].mod_n;
+        for (int e = 0; e < kFusedMaxMod; e++) fbase.ys[j].mod_g[e] = hys[j].mod_g[e];
     }
     auto fargs = [=](int pl) {
         FusedArgs<Acc> a = fbase;
@@ -608,6 +615,16 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
         return true;
     }
     if (plan->dims[0].scan_ids.empty() && plan->dims[1].scan_ids.empty()) return no("no scans along x or y");
+    if (plan->mod_form) {
+        // scans in zero-border form behind border modifications (plan.cpp, "clamped sections"): the kernels position a
+        // modification at compile-time indices of the entry segment / the tile's first or last rows
+        if (plan->dtype != RF_F32 || plan->sharded()) return no("clamped sections: unsharded f32 images");
+        if (plan->dims[0].N % 16 != 0) return no("clamped sections: width must be a multiple of 16");
+        if (!plan->dims[1].scan_ids.empty() && plan->dims[1].N % 32 != 0) return no("clamped sections: height must be a multiple of 32");
+        if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty() && strided_tile(plan, 2) == 0) return no("clamped sections: the z stage needs the strided kernels");
+        for (int d = 0; d < plan->ndim; d++)
+            if ((int)plan->dims[d].scan_ids.size() > kFusedMaxScans) return no("clamped sections: more than 4 scans in a dimension");
+    }
     // rows of 4- and 8-byte pixels only have to be element-aligned: a width that is not a multiple of 4 ends every row in a
     // partial chunk, loaded sample by sample (scan_device.h, load_chunk_cols); 2-byte pixels and unsigned-byte inputs are
     // moved in 8- and 4-byte pieces and keep the rule

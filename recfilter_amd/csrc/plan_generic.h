@@ -37,6 +37,8 @@ ScanS<S> make_table_scan(const Scan &s) {
     } else {
         t.b = (S)s.b;
         for (int j = 0; j < RF_MAX_ORDER; j++) t.a[j] = (S)s.a[j];
+        t.mod_n = s.mod_n;
+        for (int j = 0; j < RF_MAX_ORDER; j++) t.mod_g[j] = (S)s.mod_g[j];
     }
     return t;
 }
@@ -64,6 +66,10 @@ FusedScan<Acc> make_fused_scan(const Scan &scan, int K, bool with_segment_tables
     f.causal = ts.causal ? 1 : 0;
     f.b = table_to_acc<S, Acc>(ts.b);
     for (int j = 0; j < K && j < kFusedMaxK; j++) f.a[j] = table_to_acc<S, Acc>(ts.a[j]);
+    f.mod_n = scan.mod_n;
+    if constexpr (!std::is_same<S, uint64_t>::value) {
+        for (int j = 0; j < kFusedMaxMod && j < RF_MAX_ORDER; j++) f.mod_g[j] = (Acc)ts.mod_g[j];
+    }
     if (with_segment_tables) {
         ScanS<S> twin = ts;
         twin.causal = true;

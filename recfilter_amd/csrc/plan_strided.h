@@ -71,6 +71,10 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
         base.scans[i].causal = t.causal ? 1 : 0;
         base.scans[i].b = table_to_acc<S, Acc>(t.b);
         for (int j = 0; j < kFusedMaxK; j++) base.scans[i].a[j] = j < K ? table_to_acc<S, Acc>(t.a[j]) : Acc(0);
+        base.scans[i].mod_n = sc.mod_n;
+        if constexpr (!std::is_same<S, uint64_t>::value) {
+            for (int j = 0; j < kFusedMaxMod && j < RF_MAX_ORDER; j++) base.scans[i].mod_g[j] = (Acc)t.mod_g[j];
+        }
         if (t.causal) mask |= 1u << i;
     }
     DimTables<S> tab = build_dim_tables<S>(ts, K, TZ, plan->clamped);
@@ -150,6 +154,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
 
     base.n = di.N; base.inner = di.stride; base.lines = di.lines; base.M = M; base.n_scans = n;
     base.clamped = plan->clamped ? 1 : 0;
+    base.mod_form = plan->mod_form ? 1 : 0;
     base.first_is_border = (!sharded || plan->shard_rank == 0) ? 1 : 0;
     base.last_is_border = (!sharded || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
     auto sargs = [=](int pl) {

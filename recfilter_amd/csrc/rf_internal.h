@@ -43,6 +43,11 @@ struct Scan {
     int order = 0;                    // feedback taps of this scan
     double b = 0.0;                   // feedforward, already cast through the pixel type
     double a[RF_MAX_ORDER] = {0};     // feedback, already cast through the pixel type
+    // Border modification (plan.cpp, "clamped sections"): mod_n < 0 -- the scan handles a clamped border natively (the
+    // prologue of lib/recfilter.cpp:330-336); mod_n >= 0 -- the scan is run with a ZERO border, and on the tile where it
+    // enters a clamped image its first mod_n samples x_r (in scan direction) are first replaced by x_r + mod_g[r] * x_0.
+    int mod_n = -1;
+    double mod_g[RF_MAX_ORDER] = {0};
 };
 
 // Coefficients as a kernel receives them, in the pixel's arithmetic type.

@@ -275,6 +275,36 @@ __device__ __forceinline__ void scan_col_partial_up(Acc (&col)[TY], const SC &sc
     }
 }
 
+// ---- border modification of scans in zero-border form (FusedArgs::mod_form; plan.cpp, "clamped sections") ----------------
+// A clamped scan is the zero-border scan of an input whose first k samples in scan direction are x_r + g_r * x_0
+// (tables.h, scan_tile).  These run on the tile where the scan enters a clamped image, in front of a scan called with
+// clamp_first = false.  The plan guarantees whole entry segments (width % 16 == 0) and whole tile rows.
+template <typename Acc, bool CAUSAL, int NR, typename SC>
+__device__ __forceinline__ void border_mod_rows16(Acc (&v)[NR][kFusedSeg], const SC &sc, bool entry_lane) {
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        const Acc x0 = v[n][CAUSAL ? 0 : kFusedSeg - 1];
+#pragma unroll
+        for (int r = 0; r < kFusedMaxMod; r++) {
+            const Acc g = (entry_lane && r < sc.mod_n) ? sc.mod_g[r] : Acc(0);
+            const int m = CAUSAL ? r : kFusedSeg - 1 - r;
+            v[n][m] = v[n][m] + g * x0;
+        }
+    }
+}
+
+// (whole tile rows only: a plan in mod form picks a tile height that divides the image's, plan_fused.cpp)
+template <typename Acc, bool CAUSAL, int TY, typename SC>
+__device__ __forceinline__ void border_mod_col(Acc (&col)[TY], const SC &sc) {
+    const Acc x0 = col[CAUSAL ? 0 : TY - 1];
+#pragma unroll
+    for (int r = 0; r < kFusedMaxMod && r < TY; r++) {
+        const Acc g = r < sc.mod_n ? sc.mod_g[r] : Acc(0);
+        const int m = CAUSAL ? r : TY - 1 - r;
+        col[m] = col[m] + g * x0;
+    }
+}
+
 template <typename Acc>
 struct Vec4 {
     typedef Acc type __attribute__((ext_vector_type(4)));

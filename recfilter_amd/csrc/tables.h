@@ -39,6 +39,8 @@ struct ScanS {
     bool causal;
     S b;
     S a[RF_MAX_ORDER];
+    int mod_n = -1;              // Scan::mod_n / mod_g (rf_internal.h): >= 0 -- zero-border recurrence behind a border modification
+    S mod_g[RF_MAX_ORDER] = {};
 };
 
 // In-place scan of one tile in memory order -- the operator of lib/recfilter.cpp:321-343
@@ -50,6 +52,19 @@ struct ScanS {
 template <typename S>
 inline void scan_tile(S *v, int T, int k, const ScanS<S> &sc, bool clamp_first, const S *carry, int T_valid = -1) {
     if (T_valid < 0 || T_valid > T) T_valid = T;
+    if (clamp_first && sc.mod_n >= 0) {
+        // A clamped scan IS the zero-border scan of a modified input: y_r = b x_r + sum_{j<r} a_j y_{r-1-j} + (sum_{j>=r} a_j) c_r
+        // with c_0 = x_0, c_r = y_0 = (b + sum a) x_0 (lib/recfilter.cpp:330-336), i.e. x~_r = x_r + g_r x_0 for the first
+        // samples in scan direction.  The plan uses this form for scans it has split into sections (plan.cpp).
+        if (T_valid >= 1) {
+            const S x0 = v[sc.causal ? 0 : T_valid - 1];
+            for (int r = 0; r < sc.mod_n && r < T_valid; r++) {
+                const int m = sc.causal ? r : T_valid - 1 - r;
+                v[m] = v[m] + sc.mod_g[r] * x0;
+            }
+        }
+        clamp_first = false;
+    }
     S hist[RF_MAX_ORDER];
     for (int j = 0; j < k; j++) hist[j] = carry ? carry[j] : S(0);
     S y0 = S(0);

@@ -1418,10 +1418,73 @@ def test_high_order_scans_run_as_sections_on_the_fused_path(name, poles):
     imgs, outs, (path, tiles) = _run((328, 1024), scans, clamped=False)
     assert path == 3, (name, path)
     _check(imgs, outs, scans, False)
-    # a clamped border keeps the scans as given (the prologue of a high-order scan is not its sections' prologues)
+    # a clamped border: the sections run in zero-border form behind border modifications (next test); shapes that form does
+    # not take (a width that is not a multiple of 16) keep the scans as given on another path
     imgs, outs, (path, _) = _run((128, 256), scans, clamped=True)
+    assert path == 3
+    _check(imgs, outs, scans, True)
+    imgs, outs, (path, _) = _run((128, 260), scans, clamped=True)
     assert path != 3
     _check(imgs, outs, scans, True)
+
+
+@pytest.mark.parametrize("name,poles", [
+    ("order4", [0.7, 0.6, 0.3 + 0.5j, 0.3 - 0.5j]),
+    ("order5", [0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j]),
+    ("order6", [0.85, 0.1, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j]),
+    ("order8", [0.8, -0.7, 0.5, -0.3, 0.3 + 0.6j, 0.3 - 0.6j, -0.1 + 0.7j, -0.1 - 0.7j]),
+])
+def test_clamped_high_order_scans_as_sections_behind_border_modifications(name, poles):
+    """orders 4..8 with a CLAMPED border on the fused kernels.  A clamped scan is the zero-border scan of
+    an input whose first k samples in scan direction are x_r + g_r x_0 (lib/recfilter.cpp:330-336 rearranged; plan.cpp), and the
+    zero-border scan factors into sections: pass 1 and the carries see the modification through their tables, the kernels that
+    run recurrences (both final passes, xscan_rows, the strided z pass) apply it on the tile where a scan enters the image.
+    Against the oracle run on the ORIGINAL coefficients with its clamped border: every tile height, one tile / partial last
+    tile column / many tiles, two scans per dimension and one, mixed with low-order scans, planes, a volume."""
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    co = _from_poles(poles, b=0.25)
+    pm = [(0, True, co), (0, False, co), (1, True, co), (1, False, co)]
+    shapes = [(128, 256), (320, 1024), (352, 1280), (64, 16), (96, 48)] if len(poles) <= 6 else [(128, 256), (352, 1280)]
+    for shape in shapes:
+        scans = pm if len(poles) <= 6 else [(0, True, co), (1, False, co)]      # (order 8: three sections per scan, four scans per dimension at most)
+        imgs, outs, (path, tiles) = _run(shape, scans, clamped=True)
+        assert path == 3, (name, shape, path)
+        _check(imgs, outs, scans, True)
+    if len(poles) > 6:
+        return
+    for ty in (32, 64, 128):
+        imgs, outs, (path, tiles) = _run((256, 768), pm, clamped=True, flags=capi.RF_PLAN_TILED_ONLY | capi.RF_PLAN_TILE_ROWS(ty))
+        assert path == 3 and list(tiles)[1] == ty
+        _check(imgs, outs, pm, True)
+    # high order along x only, the usual order-2 pair along y (every scan of the plan is put into the same form); anticausal first
+    mixed = [(0, False, co), (0, True, co), (1, True, rc.GAUSS2), (1, False, rc.GAUSS2)]
+    imgs, outs, (path, _) = _run((160, 512), mixed, clamped=True, planes=3)
+    assert path == 3
+    _check(imgs, outs, mixed, True)
+    # a volume: high order along z (the strided kernels), order 3 along x and y
+    vol = [(0, True, rc.GAUSS3), (0, False, rc.GAUSS3), (1, True, rc.GAUSS3), (2, True, co), (2, False, co)]
+    imgs, outs, (path, _) = _run((64, 96, 256), vol, clamped=True)
+    assert path == 3
+    _check(imgs, outs, vol, True)
+
+
+def test_clamped_sections_full_size_and_fallbacks():
+    """An order-5 clamped x/y filter at 4096^2 on path 3 (the 128-row final pass is forced on small shapes in the test above);
+    f64 pixels and heights that are not multiples of 32 keep the scans as given (another path), same result."""
+    import recfilter_amd as rfa
+    co = _from_poles([0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j], b=0.25)
+    pm = [(0, True, co), (0, False, co), (1, True, co), (1, False, co)]
+    imgs, outs, (path, tiles) = _run((4096, 4096), pm, clamped=True)
+    assert path == 3, (path, tiles)
+    _check(imgs, outs, pm, True)
+    imgs, outs, (path, _) = _run((72, 256), pm, clamped=True)                   # 72 rows: not a multiple of 32
+    assert path != 3
+    _check(imgs, outs, pm, True)
+    imgs, outs, (path, _) = _run((128, 256), pm, dtype=np.float64, clamped=True)
+    assert path != 3
+    for im, o in zip(imgs, outs):
+        assert rc.rel_err(o, oracle.apply_filter(im, pm, True)) < 1e-9
 
 
 def test_high_order_sections_other_cases():

@@ -377,7 +377,16 @@ def test_high_order_scans_are_split_into_sections_for_the_fused_path():
         with rfa.Plan((512, 512), scans, device=capi.RF_DEVICE_HOST_ONLY, **kw) as plan:
             return plan.path_name
     assert path_of(xy(o5), clamped=False) == "tiled_fused"                 # 5 = 3 + 2: four scans per dimension
-    assert path_of(xy(o5), clamped=True) != "tiled_fused"                  # clamped border: not the same filter
+    # clamped border (2-D / 3-D f32, width % 16 == 0, height % 32 == 0): the same sections in zero-border form behind border
+    # modifications (plan.cpp, "clamped sections"); other shapes and f64 keep the scans as given on another path
+    assert path_of(xy(o5), clamped=True) == "tiled_fused"
+    assert path_of(xy(o5), clamped=True, dtype=np.float64) != "tiled_fused"
+    with rfa.Plan((512, 520), xy(o5), clamped=True, device=capi.RF_DEVICE_HOST_ONLY, flags=T) as plan:
+        assert plan.path_name != "tiled_fused"                              # width not a multiple of 16
+    with rfa.Plan((520, 512), xy(o5), clamped=True, device=capi.RF_DEVICE_HOST_ONLY, flags=T) as plan:
+        assert plan.path_name != "tiled_fused"                              # height not a multiple of 32
+    with rfa.Plan((100_000,), [(0, True, o5)], clamped=True, device=capi.RF_DEVICE_HOST_ONLY, flags=T) as plan:
+        assert plan.path_name != "tiled_fused" or plan.num_kernels > 0       # 1-D: the clamped 1-D path (plan_clamp1d.h), not this rewrite
     assert path_of(xy(o5), clamped=False, dtype=np.float64) == "tiled_fused"     # f64 pixels: sections in f64
     assert path_of(xy([1.0, 1.0, 0.0, 0.0, 1.0]), clamped=False, dtype=np.int32) != "tiled_fused"     # integer pixels: as given
     assert path_of(xy(o6c), clamped=False) == "tiled_fused"                # three conjugate pairs, twice: six sections per
