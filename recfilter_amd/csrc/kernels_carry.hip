@@ -30,7 +30,9 @@ constexpr int kCarryLines = 64;    // lines per workgroup = one wave: 256-byte c
 constexpr int kCarryChunks = 16;   // chunks per line per block of tiles = waves per workgroup
 constexpr int kCarryMaxC = 16;     // tiles per chunk (orders <= 3; higher orders keep 4 tiles of k-vectors in registers)
 constexpr int kCarryMaxCHigh = 4;
-constexpr int kCarryPair3MaxC = 8;  // order-3 pair kernel: 8 tiles per thread
+constexpr int kCarryPair3MaxC = 8;  // order 3, two scans: more than 8 tiles per thread take the pair kernel ...
+constexpr int kCarryPair3Chunks = 8; // ... as 8 chunk-waves of up to 16 tiles: 158 registers and no scratch, where 16 waves of 8 tiles had 128
+                                     // registers and 168 bytes of scratch that its loads waited for (cfg4b y carries: 122 -> 90 us)
 constexpr int kCarryChunksHigh = 8; // and at most 8 chunk-waves, which bounds the LDS combine buffer (k = 8 in f64: 32 KiB)
 
 template <typename Acc, int K>
@@ -370,10 +372,11 @@ __device__ __forceinline__ void pair_run_scan(Acc (&t)[MAXC][KP], int s, const C
 // terms of the second scan (create_tail_residual_term, lib/split.cpp:912-1004) from its own registers plus one
 // halo tile from each neighbouring chunk (through LDS).  The general kernel above re-reads the first scan's
 // completed tails from memory behind a barrier instead.
-// MAXC: tiles a thread owns (16; 8 for order 3, whose two register-resident scans of 16 tiles do not fit the 128 registers
-// of a 16-wave workgroup -- lines of at most 128 tiles, i.e. every image on 128-row tiles, take it)
-template <typename Acc, int K, int MAXC>
-__global__ void __launch_bounds__(kCarryLines * kCarryChunks)
+// MAXC: tiles a thread owns (16).  Order 3: two register-resident scans of 16 tiles do not fit the 128 registers of a
+// 16-wave workgroup, so its launches have 8 chunk-waves (NCHB) -- lines of at most 128 tiles, i.e. every image on 128-row tiles
+// NCHB: most chunk-waves the launch may have (bounds the registers: 16 waves -> 128, 8 waves -> 256)
+template <typename Acc, int K, int MAXC, int NCHB = kCarryChunks>
+__global__ void __launch_bounds__(kCarryLines * NCHB)
 carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
                   const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
                   Acc *__restrict__ send) {
@@ -645,7 +648,7 @@ template int launch_row_chain<uint32_t>(int, const uint32_t *, uint32_t *, int, 
 template int launch_row_chain<double>(int, const double *, double *, int, bool, const double *, const double *, int, hipStream_t);
 
 int carry_chunk_count(int64_t M, int64_t lines, int C, int K) {
-    if (K == 3 && M > 64 && C <= kCarryPair3MaxC && (int64_t)kCarryChunks * C >= M) return (int)((M + C - 1) / C);      // the pair kernel's chunking
+    if (K == 3 && M > 64 && C > kCarryPair3MaxC && (int64_t)kCarryPair3Chunks * C >= M) return (int)((M + C - 1) / C);      // the order-3 pair kernel's chunking
     const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
     int64_t want = (4096 + line_groups - 1) / line_groups;
@@ -696,8 +699,10 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
             return RF_OK;
         }
         static const bool pair3_off = RF_KNOB("RF_CARRY_NO_PAIR3") != nullptr;
-        if (s_end - s_begin == 2 && K == 3 && a.M > 64 && C <= kCarryPair3MaxC && (int64_t)n_chunks * C >= a.M && !pair_off && !pair3_off) {
-            hipLaunchKernelGGL((carry_pair_kernel<Acc, 3, kCarryPair3MaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+        if (s_end - s_begin == 2 && K == 3 && a.M > 64 && C > kCarryPair3MaxC && C <= kCarryMaxC && n_chunks <= kCarryPair3Chunks &&
+            (int64_t)n_chunks * C >= a.M && !pair_off && !pair3_off) {
+            // order 3: eight waves of up to 16 tiles (158 registers, no scratch)
+            hipLaunchKernelGGL((carry_pair_kernel<Acc, 3, kCarryMaxC, kCarryPair3Chunks>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
                                (const Acc *)a.incoming, a.W, a.A, AC, C, send);
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
@@ -716,9 +721,9 @@ int carry_chunk_length(int64_t M, int64_t lines, int K) {
     // order 3: chunks of at most 8 tiles whenever 16 of them cover the line, so that two scans of a dimension fit the
     // register-chained pair kernel
     // (long lines only: at 64 tiles per line the general kernel is as fast)
-    if (K == 3 && M > 64 && M <= (int64_t)kCarryChunks * kCarryPair3MaxC && RF_KNOB("RF_CARRY_NO_PAIR3") == nullptr &&
+    if (K == 3 && M > 64 && M <= (int64_t)kCarryPair3Chunks * kCarryMaxC && RF_KNOB("RF_CARRY_NO_PAIR3") == nullptr &&
         RF_KNOB("RF_CARRY_NO_PAIR") == nullptr)
-        return (int)((M + kCarryChunks - 1) / kCarryChunks);
+        return (int)((M + kCarryPair3Chunks - 1) / kCarryPair3Chunks);
     const int max_c = K <= 3 ? kCarryMaxC : kCarryMaxCHigh;
     const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     // Chunks (waves) per line: enough to put ~4096 waves on the chip, no more -- with many lines a single
