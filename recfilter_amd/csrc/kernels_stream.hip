@@ -331,6 +331,10 @@ bool stream_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_
     if (off || src_u8 || (pw_flags & 1) || TY != kStreamTY || last_cols != kFusedTX || last_rows != TY) return false;
     if (K < 1 || K > 3) return false;
     if (!force && (NZ != 1 || nxk > 4 || nyk > 4)) return false;
+    // Round 4 (profiles/r4/ab_pass1_three_way.txt, 64-row tiles, same box): the register-staged kernels have caught up -- order
+    // 2 on 16384^2: this kernel 194 us, mfma_tails_kernel 192, fused_tails_kernel 202; order 1 on 8192^2: 48.9 / 48.5 / 47.9 -- so
+    // the automatic choice no longer takes this kernel; RF_PLAN_STREAM_PASS1 (and the A/B knob) still does.
+    if (!force) return false;
     const char *mt = RF_KNOB("RF_STREAM_MIN_TILES");              // (read per call: the tests lower it to cover small shapes)
     const int64_t min_tiles = mode > 0 ? 1 : mt ? atoll(mt) : 2048;
     if (n_tiles < min_tiles) return false;      // below that a walker has too few tiles to amortise its pipeline fill
