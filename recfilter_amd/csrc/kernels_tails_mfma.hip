@@ -103,15 +103,17 @@ mfma_tails_kernel(const float *__restrict__ src, FusedArgs<float> a,
     // where only the next step's pixels are ever pending -- needs no wait of its own for them.  (Requested behind the pixels,
     // the loop's first use of a fragment was a `s_waitcnt vmcnt(0)`: every step waited for the pixels it had just requested.)
     float Bx[NGX][16];
+    if constexpr (NX > 0) {
 #pragma unroll
-    for (int g = 0; g < NGX; g++) {
-        // (lanes of a tail that does not exist fetch tail 0: what they contribute lands in accumulator columns nobody
-        //  stores -- no select behind the load, which would make the kernel wait for the table before it requests a pixel)
-        const int sr = 4 * g + j4 < nxk ? 4 * g + j4 : 0;
+        for (int g = 0; g < NGX; g++) {
+            // (lanes of a tail that does not exist fetch tail 0: what they contribute lands in accumulator columns nobody
+            //  stores -- no select behind the load, which would make the kernel wait for the table before it requests a pixel)
+            const int sr = 4 * g + j4 < nxk ? 4 * g + j4 : 0;
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const F4 h = *reinterpret_cast<const F4 *>(Hx + ((size_t)vx * nxk + sr) * kFusedTX + 4 * (16 * w + 4 * m + cg));
-            Bx[g][4 * m + 0] = h.x; Bx[g][4 * m + 1] = h.y; Bx[g][4 * m + 2] = h.z; Bx[g][4 * m + 3] = h.w;
+            for (int m = 0; m < 4; m++) {
+                const F4 h = *reinterpret_cast<const F4 *>(Hx + ((size_t)vx * nxk + sr) * kFusedTX + 4 * (16 * w + 4 * m + cg));
+                Bx[g][4 * m + 0] = h.x; Bx[g][4 * m + 1] = h.y; Bx[g][4 * m + 2] = h.z; Bx[g][4 * m + 3] = h.w;
+            }
         }
     }
     load_step(0);

@@ -619,6 +619,7 @@ bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *, std::str
         // scans in zero-border form behind border modifications (plan.cpp, "clamped sections"): the kernels position a
         // modification at compile-time indices of the entry segment / the tile's first or last rows
         if (plan->dtype != RF_F32 || plan->sharded()) return no("clamped sections: unsharded f32 images");
+        if (plan->pw.post && plan->pw.post_i != 0.0) return no("clamped sections: no epilogue with an input operand");
         if (plan->dims[0].N % 16 != 0) return no("clamped sections: width must be a multiple of 16");
         if (!plan->dims[1].scan_ids.empty() && plan->dims[1].N % 32 != 0) return no("clamped sections: height must be a multiple of 32");
         if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty() && strided_tile(plan, 2) == 0) return no("clamped sections: the z stage needs the strided kernels");

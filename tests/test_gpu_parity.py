@@ -1481,6 +1481,21 @@ def test_clamped_sections_full_size_and_fallbacks():
     imgs, outs, (path, _) = _run((72, 256), pm, clamped=True)                   # 72 rows: not a multiple of 32
     assert path != 3
     _check(imgs, outs, pm, True)
+    # pointwise stages: an affine prologue and an affine epilogue ride along; an epilogue with an input operand keeps the scans
+    # as given (another path)
+    import torch
+    img = rc.random_image((128, 512), np.float32, 77)
+    dev = torch.from_numpy(img).cuda()
+    with rfa.Plan((128, 512), pm, clamped=True, prologue=(0.5, 0.25), epilogue=(2.0, 0.0, -1.0)) as plan:
+        assert plan.path == 3
+        got = plan.execute([dev])[0].cpu().numpy()
+    want = 2.0 * oracle.apply_filter(0.5 * img.astype(np.float64) + 0.25, pm, True) - 1.0
+    assert rc.rel_err(got, want) < TOL
+    with rfa.Plan((128, 512), pm, clamped=True, epilogue=(-0.7, 1.7, 0.0)) as plan:
+        assert plan.path != 3
+        got = plan.execute([dev])[0].cpu().numpy()
+    want = 1.7 * img.astype(np.float64) - 0.7 * oracle.apply_filter(img.astype(np.float64), pm, True)
+    assert np.abs(got - want).max() < 2e-5
     imgs, outs, (path, _) = _run((128, 256), pm, dtype=np.float64, clamped=True)
     assert path != 3
     for im, o in zip(imgs, outs):
