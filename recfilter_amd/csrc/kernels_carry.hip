@@ -651,10 +651,14 @@ int carry_chunk_count(int64_t M, int64_t lines, int C, int K) {
     if (K == 3 && M > 64 && C > kCarryPair3MaxC && (int64_t)kCarryPair3Chunks * C >= M) return (int)((M + C - 1) / C);      // the order-3 pair kernel's chunking
     const int max_chunks = K <= 3 ? kCarryChunks : kCarryChunksHigh;
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
-    int64_t want = (4096 + line_groups - 1) / line_groups;
+    static const int64_t target_waves_n = RF_KNOB("RF_CARRY_WAVES") ? atoll(RF_KNOB("RF_CARRY_WAVES")) : 4096;      // A/B
+    int64_t want = (target_waves_n + line_groups - 1) / line_groups;
     want = want < 1 ? 1 : (want > max_chunks ? max_chunks : want);
     int64_t need = (M + C - 1) / C;          // chunks that cover the line in one block
     int64_t n = need < want ? need : want;
+    // ... a line that a few more chunks cover in ONE block takes them: two scans then run in the register-chained pair kernel
+    // instead of block after block in the general one (cfg4a's y carries, 128 tiles per line at 6 wanted chunks: 48 -> 41 us)
+    if (need <= max_chunks && need <= 2 * want) n = need;
     return (int)(n < 1 ? 1 : n);
 }
 
@@ -729,7 +733,8 @@ int carry_chunk_length(int64_t M, int64_t lines, int K) {
     // Chunks (waves) per line: enough to put ~4096 waves on the chip, no more -- with many lines a single
     // wave walks all tiles of its 64 lines and the cross-chunk combine through LDS disappears.
     const int64_t line_groups = (lines + kCarryLines - 1) / kCarryLines;
-    int64_t want = (4096 + line_groups - 1) / line_groups;
+    static const int64_t target_waves_l = RF_KNOB("RF_CARRY_WAVES") ? atoll(RF_KNOB("RF_CARRY_WAVES")) : 4096;      // A/B
+    int64_t want = (target_waves_l + line_groups - 1) / line_groups;
     want = want < 1 ? 1 : (want > max_chunks ? max_chunks : want);
     if (want > M) want = M < 1 ? 1 : M;
     int64_t c = (M + want - 1) / want;
