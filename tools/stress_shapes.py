@@ -20,7 +20,7 @@ def width(q):
 
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes") else n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes", "streams", "sections", "whole") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), width(int(rng.integers(1, 2400))))
@@ -276,3 +276,74 @@ if len(sys.argv) > 3 and sys.argv[3] == "streams":
             print(f"{case:3d} {plan.path_name:13s} {str(shape):14s} streams={n_streams} threads={n_threads} reps={reps} instances={plan.num_instances} "
                   f"differing samples={bad} errors={errors}", "" if bad == 0 and not errors else "  <-- CHECK", flush=True)
     print("worst (streams)", worst)
+
+# ---- orders 4..8 as sections: random stable pole sets, both borders (clamped: zero-border form behind border modifications),
+# shapes the rewrite takes (width % 16 == 0, height % 32 == 0), 2-D and 3-D, against the serial untiled kernel on the SAME
+# high-order coefficients ----
+if len(sys.argv) > 3 and sys.argv[3] == "sections":
+    worst = 0.0
+    for case in range(n_cases):
+        def random_scan(dim):
+            k = int(rng.integers(4, 9))
+            poles = []
+            while len(poles) < k:
+                if k - len(poles) >= 2 and rng.random() < 0.6:
+                    r, th = rng.uniform(0.2, 0.85), rng.uniform(0.2, 2.9)
+                    poles += [r * np.exp(1j * th), r * np.exp(-1j * th)]
+                else:
+                    poles.append(rng.uniform(-0.8, 0.88))
+            p = np.poly(poles).real
+            return (dim, bool(rng.integers(0, 2)), [float(rng.uniform(0.1, 0.6))] + [float(-v) for v in p[1:]])
+        ndim = 2 if case % 3 else 3
+        if ndim == 2:
+            shape = (32 * int(rng.integers(1, 90)), 16 * int(rng.integers(1, 300)))
+        else:
+            shape = (int(rng.choice([32, 64, 128])), 32 * int(rng.integers(1, 12)), 16 * int(rng.integers(1, 40)))
+        scans = []
+        for d in range(ndim):
+            n_here = int(rng.integers(0, 2)) + (1 if d == 0 else 0)
+            for _ in range(n_here):
+                scans.append(random_scan(d) if rng.random() < 0.7 else (d, bool(rng.integers(0, 2)), [0.4, 0.5, -0.1]))
+        if all(len(co) - 1 <= 3 for _, _, co in scans):
+            scans[0] = random_scan(scans[0][0])
+        clamped = bool(rng.integers(0, 2))
+        img = torch.rand(shape, device="cuda")
+        with rfa.Plan(shape, scans, clamped=clamped, flags=rfa.capi.RF_PLAN_TILED_ONLY) as pf, \
+             rfa.Plan(shape, scans, clamped=clamped, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
+            of, ou = pf.execute([img])[0], pu.execute([img])[0]
+            torch.cuda.synchronize()
+            peak = float(ou.abs().max().item())
+            err = float(((of - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
+            worst = max(worst, err)
+            print(f"{case:3d} {pf.path_name:13s} {str(shape):22s} orders={[len(co) - 1 for _, _, co in scans]} clamped={int(clamped)} err={err:.3e}",
+                  "" if err < 2e-4 else "  <-- CHECK", flush=True)
+    print("worst (sections)", worst)
+
+# ---- images of whole tiles (what the matrix-core pass 1 takes), orders 1..3, one or two scans per dimension, planes ----
+if len(sys.argv) > 3 and sys.argv[3] == "whole":
+    worst = 0.0
+    for case in range(n_cases):
+        ty = int(rng.choice([32, 64, 128]))
+        shape = (ty * int(rng.integers(1, 40)), 256 * int(rng.integers(1, 24)))
+        planes = int(rng.choice([1, 1, 3]))
+        k = int(rng.integers(1, 4))
+        scans = []
+        for d in range(2):
+            for _ in range(int(rng.integers(0 if d else 1, 3))):
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        imgs = [torch.rand(shape, device="cuda") for _ in range(planes)]
+        flags = rfa.capi.RF_PLAN_TILED_ONLY | rfa.capi.RF_PLAN_TILE_ROWS(ty) | (rfa.capi.RF_PLAN_MFMA_PASS1 if case % 2 else 0)
+        with rfa.Plan(shape, scans, clamped=clamped, planes=planes, flags=flags) as pf, \
+             rfa.Plan(shape, scans, clamped=clamped, planes=planes, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
+            of, ou = pf.execute(imgs), pu.execute(imgs)
+            torch.cuda.synchronize()
+            err = 0.0
+            for a_, b_ in zip(of, ou):
+                peak = float(b_.abs().max().item())
+                err = max(err, float(((a_ - b_).abs() / torch.clamp(b_.abs(), min=1e-2 * peak)).max().item()))
+            worst = max(worst, err)
+            print(f"{case:3d} {pf.path_name:13s} {str(shape):16s} x{planes} tiles={list(pf.tiles)} order={k} scans={len(scans)} clamped={int(clamped)} err={err:.3e}",
+                  "" if err < 2e-4 else "  <-- CHECK", flush=True)
+    print("worst (whole)", worst)
