@@ -81,13 +81,19 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
             }
         }
     }
+    // row shard: tails completed with zero entering carries + Y * (true entering carries), as in fused_pass2_kernel.  The
+    // entering carries are requested here, with the other carries; the correction itself waits until the pixels have been
+    // requested (apply_entering_carries below) -- computed here it made every tile wait for its carry loads before it asked
+    // for a single pixel.
+    Acc yin[kFusedMaxScans][K];
     if (a.y_apply != nullptr) {
-        // row shard: tails completed with zero entering carries + Y * (true entering carries), as in fused_pass2_kernel
-        Acc yin[kFusedMaxScans][K];
 #pragma unroll
         for (int q = 0; q < kFusedMaxScans; q++)
 #pragma unroll
             for (int o = 0; o < K; o++) yin[q][o] = q < a.ny ? a.y_incoming[((int64_t)q * K + o) * Ly + line] : Acc(0);
+    }
+    auto apply_entering_carries = [&]() {
+        if (a.y_apply == nullptr) return;
 #pragma unroll
         for (int j = 0; j < kFusedMaxScans; j++) {
             if (j < a.ny) {
@@ -109,7 +115,7 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                 }
             }
         }
-    }
+    };
 
     const char *spb = reinterpret_cast<const char *>(src + tile_off);
     const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
@@ -182,6 +188,7 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     request_pixels(0);
     request_pixels(1);
     park_carries();
+    apply_entering_carries();
     // ... and wait in LDS meanwhile, [j][r][column] behind the x carries (registers are the scarce resource here)
     Acc *cy_lds = tile + kHalfRows * kFusedTX + 2 * kFusedMaxScans * (kHalfRows / 16) * K * 16;
 #pragma unroll
