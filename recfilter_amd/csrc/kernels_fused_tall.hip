@@ -62,6 +62,32 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
     const int entry_valid = last_cols - 16 * last_lane;
     const int rows_here = (EDGE && ty == a.MY - 1) ? a.last_rows : TY;
 
+    const char *spb = reinterpret_cast<const char *>(src + tile_off);
+    const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
+    const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
+    const bool chunk_in = 4 * cc < last_cols;
+    // ... and when the width is not a multiple of 4 the last of them is partial (tile-uniform flag; scan_device.h)
+    const bool odd_cols = EDGE && (last_cols & 3) != 0;
+    const int cols_valid = last_cols - 4 * cc;
+    const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+
+    Acc col[TY];              // this thread's column, all 128 rows
+    A4 tmp[2][TL / 4];       // both halves are requested up front
+    auto request_pixels = [&](int h) {
+        // wave w streams rows w, w+4, ... of the half
+#pragma unroll
+        for (int i = 0; i < TL / 4; i++) {
+            const int row = TL * h + rg + 4 * i;
+            const bool in = chunk_in && (!EDGE || row < rows_here);
+            if (odd_cols) tmp[h][i] = in ? load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes), cols_valid) : zero4;
+            else tmp[h][i] = in ? load_chunk<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes)) : zero4;
+        }
+    };
+
+    // Order of the requests: the first half's pixels, then every carry, then the second half's pixels.  (Carries first -- round
+    // 1's order -- delays the first pixel request by ~90 load instructions per tile; the x phase of the first half waits for
+    // "everything but the second half" either way.)
+    request_pixels(0);
     // ---- y carries: requested first, used last ----
     Acc CY[kFusedMaxScans][K];
 #pragma unroll
@@ -117,17 +143,6 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
         }
     };
 
-    const char *spb = reinterpret_cast<const char *>(src + tile_off);
-    const uint32_t in_row_bytes = a.row_bytes / (uint32_t)sizeof(P) * (uint32_t)sizeof(PI);
-    const uint32_t off0 = (uint32_t)rg * in_row_bytes + (uint32_t)cc * (uint32_t)(4 * sizeof(PI));
-    const bool chunk_in = 4 * cc < last_cols;
-    // ... and when the width is not a multiple of 4 the last of them is partial (tile-uniform flag; scan_device.h)
-    const bool odd_cols = EDGE && (last_cols & 3) != 0;
-    const int cols_valid = last_cols - 4 * cc;
-    const A4 zero4 = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
-
-    Acc col[TY];              // this thread's column, all 128 rows
-    A4 tmp[2][TL / 4];       // both halves are requested up front
     // The x carries entering the rows of both halves: requested before the pixels, parked in LDS behind the tile once they
     // have arrived ([half][s][n][j][row slot]; read by every lane of a row, used by its entry lane) -- a 128-sample column,
     // a prefetched half tile and the x phase leave no registers for them.
@@ -174,18 +189,6 @@ fused_pass2_tall_kernel(const PI *__restrict__ src, P *__restrict__ dst, FusedAr
                 }
             }
     };
-    auto request_pixels = [&](int h) {
-        // wave w streams rows w, w+4, ... of the half
-#pragma unroll
-        for (int i = 0; i < TL / 4; i++) {
-            const int row = TL * h + rg + 4 * i;
-            const bool in = chunk_in && (!EDGE || row < rows_here);
-            if (odd_cols) tmp[h][i] = in ? load_chunk_cols<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes), cols_valid) : zero4;
-            else tmp[h][i] = in ? load_chunk<PI, Acc>(spb + (off0 + (uint32_t)(TL * h + 4 * i) * in_row_bytes)) : zero4;
-        }
-    };
-
-    request_pixels(0);
     request_pixels(1);
     park_carries();
     apply_entering_carries();
