@@ -672,6 +672,17 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     }
     if (rc != RF_OK) return rc;
     add_pointwise_steps(plan.get());
+    {   // the scans as the plan runs them (after the rewrite into sections, grouped by dimension), for rf_plan_table("scans"):
+        // per scan [dim, causal, order, b, a[0..7], mod_n, mod_g[0..7]] -- what tests/fused_emulator.py replays
+        std::vector<double> flat;
+        for (const Scan &sc : plan->scans) {
+            flat.push_back(sc.dim); flat.push_back(sc.causal ? 1.0 : 0.0); flat.push_back(sc.order); flat.push_back(sc.b);
+            for (int j = 0; j < RF_MAX_ORDER; j++) flat.push_back(sc.a[j]);
+            flat.push_back(sc.mod_n);
+            for (int j = 0; j < RF_MAX_ORDER; j++) flat.push_back(sc.mod_g[j]);
+        }
+        plan->tables["scans"] = flat;
+    }
     // Table uploads and zero fills are work of a private NON-BLOCKING stream (build_stream below): waiting for it waits
     // neither for the device nor -- as the legacy null stream would -- for every blocking stream of the process.  A replica
     // is built while other streams are busy with executions of this very plan (capi.cpp, acquire_instance), and such a

@@ -23,11 +23,24 @@ def _f32(c):
     return float(np.float32(c))
 
 
+def plan_scans(plan):
+    """The scans as the plan runs them (rf_plan_table("scans"): after the rewrite of high orders into sections), as
+    (dim, causal, [b, a...]) plus, per scan, its border modification (mod_n, [g...]) -- mod_n < 0: native clamped prologue."""
+    t = plan.table("scans").reshape(-1, 21)
+    scans = [(int(r[0]), bool(r[1]), [float(r[3])] + [float(v) for v in r[4:4 + int(r[2])]]) for r in t]
+    mods = [(int(r[12]), [float(v) for v in r[13:21]]) for r in t]
+    return scans, mods
+
+
 class FusedEmu:
-    def __init__(self, plan, scans, clamped):
+    def __init__(self, plan, scans, clamped, mods=None):
+        """mods: per scan of `scans` (mod_n, [g...]) for plans in mod form (plan_scans); None: native clamped prologues."""
         self.plan, self.clamped = plan, clamped
+        mods = mods if mods is not None else [(-1, [])] * len(scans)
         self.xs = [(bool(c), [_f32(v) for v in co]) for d, c, co in scans if d == 0]
         self.ys = [(bool(c), [_f32(v) for v in co]) for d, c, co in scans if d == 1]
+        self.xmod = [m for (d, _, _), m in zip(scans, mods) if d == 0]
+        self.ymod = [m for (d, _, _), m in zip(scans, mods) if d == 1]
         self.K = max([len(co) - 1 for _, co in self.xs + self.ys])
         K, nx, ny = self.K, len(self.xs), len(self.ys)
         self.TY = plan.tiles[1]
@@ -71,7 +84,14 @@ class FusedEmu:
                 scan_tile(w, True, b, a, K, clamp_first, c)
                 v[:, off:] = w
             else:
-                scan_tile(v, True, b, a, K, clamp_first and l == first, c)
+                cf = clamp_first and l == first
+                mod_n, g = self.xmod[s]
+                if cf and mod_n >= 0:                     # zero-border form behind a border modification (plan.cpp)
+                    x0 = v[:, 0].copy()
+                    for r in range(mod_n):
+                        v[:, r] += _f32(g[r]) * x0
+                    cf = False
+                scan_tile(v, True, b, a, K, cf, c)
             seg[:, l, :] = v
             if not causal and l < first:
                 continue                              # dead lane: exit state stays zero
@@ -131,7 +151,15 @@ class FusedEmu:
             rows = rows_of(ty)
             v = np.ascontiguousarray(tile[:rows].T)
             b, a = self.yc[j]
-            scan_tile(v, self.ys[j][0], b, a, K, clamped and yfirst(j, ty),
+            cf = clamped and yfirst(j, ty)
+            mod_n, g = self.ymod[j]
+            if cf and mod_n >= 0:                         # zero-border form behind a border modification (plan.cpp)
+                idx = (lambda r: r) if self.ys[j][0] else (lambda r: rows - 1 - r)
+                x0 = v[:, idx(0)].copy()
+                for r in range(mod_n):
+                    v[:, idx(r)] += _f32(g[r]) * x0
+                cf = False
+            scan_tile(v, self.ys[j][0], b, a, K, cf,
                       None if carry is None else [carry[r] for r in range(K)])
             out = tile.copy()
             out[:rows] = v.T

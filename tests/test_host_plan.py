@@ -219,6 +219,32 @@ def test_fused_plan_tables_reproduce_oracle(name):
     assert rc.rel_err(got, want) < 2e-6      # tables are stored in f32, the emulation runs in f64
 
 
+@pytest.mark.parametrize("order", [4, 5, 6, 8])
+def test_clamped_sections_tables_reproduce_oracle(order):
+    """Orders 4..8 with a clamped border: the plan rewrites every scan into zero-border form behind a border
+    modification (rf_plan_table("scans"): sections + the gammas of the scan as given).  The numpy replay of the fused
+    pipeline from the plan's tables -- pass-1 contractions, carries, residual, final pass with the modification applied
+    where the kernels apply it -- must reproduce the oracle run on the ORIGINAL high-order coefficients with its clamped
+    border.  Checks the host side of the rewrite (gammas, tables built through them) without a GPU."""
+    import fused_emulator
+    poles = {4: [0.7, 0.6, 0.3 + 0.5j, 0.3 - 0.5j], 5: [0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j],
+             6: [0.85, 0.1, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j],
+             8: [0.8, -0.7, 0.5, -0.3, 0.3 + 0.6j, 0.3 - 0.6j, -0.1 + 0.7j, -0.1 - 0.7j]}[order]
+    co = [0.25] + [float(-v) for v in np.poly(poles).real[1:]]
+    scans = [(0, True, co), (0, False, co), (1, True, co), (1, False, co)] if order <= 6 else [(0, False, co), (1, True, co)]
+    shape = (96, 528)                                  # three 32-row tile rows; a partial last tile column of 16 columns
+    p = _host_plan(shape, scans, dtype=np.float32, clamped=True, path=capi.RF_PATH_TILED_FUSED)
+    assert p.path == capi.RF_PATH_TILED_FUSED
+    run_scans, mods = fused_emulator.plan_scans(p)
+    assert len(run_scans) > len(scans) and all(len(c) - 1 <= 3 for _, _, c in run_scans)      # sections of order <= 3
+    assert all(m[0] >= 0 for m in mods)                                                        # every scan in mod form
+    assert sorted(m[0] for m in mods if m[0] > 0) == [order] * len(scans)                      # one modification per scan as given
+    img = rc.random_image(shape).astype(np.float64)
+    want = oracle.apply_filter(img, scans, True)
+    got = fused_emulator.FusedEmu(p, run_scans, True, mods).run(img)
+    assert rc.rel_err(got, want) < 2e-5      # sections rounded to f32 recompose the denominator to 2e-6
+
+
 def test_fused_not_applicable_falls_back_in_auto_mode():
     # a width that is not a multiple of 4: fused for 4- and 8-byte pixels (rows end in a partial chunk); int16 pixels are
     # moved in 8-byte pieces and keep the rule
