@@ -169,7 +169,53 @@ int pitch_main(int width) {
     return 0;
 }
 
+// `hbm_read_patterns zcopy <n>`: what the strided z pass moves, as a bare copy of an n^3 volume: thread = one (x, y) line, TZ
+// samples a plane apart in registers, 256-byte runs per wave and plane -- with TZ = 64 / 128 and 4 or 8 bytes per lane.
+template <int TZ, typename V, bool NT>
+__global__ void __launch_bounds__(256) zcopy_kernel(const V *src, V *dst, size_t inner, size_t lines) {
+    const size_t line = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (line >= lines) return;
+    const size_t base = line + (size_t)blockIdx.y * TZ * inner;
+    V col[TZ];
+#pragma unroll
+    for (int i = 0; i < TZ; i++) col[i] = NT ? __builtin_nontemporal_load(src + base + (size_t)i * inner) : src[base + (size_t)i * inner];
+#pragma unroll
+    for (int i = 0; i < TZ; i++) {
+        if (NT) __builtin_nontemporal_store(col[i], dst + base + (size_t)i * inner);
+        else dst[base + (size_t)i * inner] = col[i];
+    }
+}
+
+int zcopy_main(int n) {
+    const size_t total = (size_t)n * n * n, bytes = total * 4;
+    float *src, *dst;
+    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes));
+    CK(hipMemset(src, 0, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time2 = [&](const char *name, auto launch) {
+        for (int i = 0; i < 2; i++) launch();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 5; i++) launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= 5;
+        std::printf("%d^3  %-40s %.3f ms  %.2f TB/s\n", n, name, ms, 2.0 * bytes / (ms * 1e-3) / 1e12);
+    };
+    const size_t inner = (size_t)n * n;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    time2("z copy, 128 planes, 4 B per lane, nt", [&] { hipLaunchKernelGGL((zcopy_kernel<128, float, true>), dim3(inner / 256, n / 128), dim3(256), 0, 0, src, dst, inner, inner); });
+    time2("z copy, 128 planes, 4 B per lane", [&] { hipLaunchKernelGGL((zcopy_kernel<128, float, false>), dim3(inner / 256, n / 128), dim3(256), 0, 0, src, dst, inner, inner); });
+    time2("z copy, 64 planes, 4 B per lane, nt", [&] { hipLaunchKernelGGL((zcopy_kernel<64, float, true>), dim3(inner / 256, n / 64), dim3(256), 0, 0, src, dst, inner, inner); });
+    time2("z copy, 64 planes, 8 B per lane, nt", [&] { hipLaunchKernelGGL((zcopy_kernel<64, f2, true>), dim3(inner / 512, n / 64), dim3(256), 0, 0, (const f2 *)src, (f2 *)dst, inner / 2, inner / 2); });
+    time2("z copy, 32 planes, 16 B per lane, nt", [&] { hipLaunchKernelGGL((zcopy_kernel<32, f4, true>), dim3(inner / 1024, n / 32), dim3(256), 0, 0, (const f4 *)src, (f4 *)dst, inner / 4, inner / 4); });
+    time2("linear copy, nt", [&] { hipLaunchKernelGGL(linear_copy_kernel<true>, dim3((unsigned)(total / 16384)), dim3(256), 0, 0, (const f4 *)src, (f4 *)dst); });
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 3 && std::string(argv[1]) == "zcopy") return zcopy_main(atoi(argv[2]));
     if (argc >= 3 && std::string(argv[1]) == "pitch") {
         for (int i = 2; i < argc; i++)
             if (int rc = pitch_main(atoi(argv[i]))) return rc;
