@@ -619,25 +619,35 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
                                                           (EDGE && tx == a.MX - 1) ? a.last_cols - 16 * a.last_lane : kFusedSeg);
         }
         if (residual) {
+            // v += sum G_q[.][o] * tau[q][o].  Interior tiles (variant 0) read G from the LDS copy, the few border tiles their
+            // variant from memory -- two loops, each with its own address space.  (As ONE select between the two pointers every
+            // chunk was a generic (flat) load with two selects on its address; flat loads count against the LDS and the memory
+            // counter.)
+            typedef __attribute__((address_space(3))) const A4 *LdsA4;
+            typedef __attribute__((address_space(1))) const A4 *GlobA4;
+            auto add_residual = [&](auto from_lds) __attribute__((always_inline)) {
+                constexpr bool LDS = decltype(from_lds)::value;
 #pragma unroll
-            for (int q = 0; q < kFusedMaxScans; q++) {
-                if (q < a.nx) {
+                for (int q = 0; q < kFusedMaxScans; q++) {
+                    if (q < a.nx) {
 #pragma unroll
-                    for (int o = 0; o < K; o++) {
-                        // this lane's 16 columns of G_q[.][o]
-                        Acc g[kFusedSeg];
+                        for (int o = 0; o < K; o++) {
+                            // this lane's 16 columns of G_q[.][o]
 #pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            A4 w = (vx == 0)
-                                ? reinterpret_cast<const A4 *>(g_lds)[(q * K + o) * 64 + 4 * l + (c ^ sw)]
-                                : reinterpret_cast<const A4 *>(G + (((size_t)vx * a.nx + q) * K + o) * kFusedTX)[4 * l + c];
-                            g[4 * c + 0] = w.x; g[4 * c + 1] = w.y; g[4 * c + 2] = w.z; g[4 * c + 3] = w.w;
+                            for (int c = 0; c < 4; c++) {
+                                A4 w;
+                                if constexpr (LDS) w = ((LdsA4)reinterpret_cast<const A4 *>(g_lds))[(q * K + o) * 64 + 4 * l + (c ^ sw)];
+                                else w = ((GlobA4)reinterpret_cast<const A4 *>(G + (((size_t)vx * a.nx + q) * K + o) * kFusedTX))[4 * l + c];
+                                const Acc tq = tv[q * K + o];
+                                v[0][4 * c + 0] = v[0][4 * c + 0] + w.x * tq; v[0][4 * c + 1] = v[0][4 * c + 1] + w.y * tq;
+                                v[0][4 * c + 2] = v[0][4 * c + 2] + w.z * tq; v[0][4 * c + 3] = v[0][4 * c + 3] + w.w * tq;
+                            }
                         }
-#pragma unroll
-                        for (int m = 0; m < kFusedSeg; m++) v[0][m] = v[0][m] + g[m] * tv[q * K + o];
                     }
                 }
-            }
+            };
+            if (vx == 0) add_residual(std::true_type{});
+            else add_residual(std::false_type{});
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
