@@ -194,6 +194,21 @@ int launch_stream_tails(int K, const float *src, const FusedArgs<float> &a, cons
 bool mfma_tails_applicable(int K, int TY, bool src_u8, int pw_flags, int last_cols, int last_rows, int64_t lin_limit, int nx, int ny,
                            int mode);
 int launch_mfma_tails(int K, int TY, const float *src, const FusedArgs<float> &a, const float *Hx, const float *Hy, hipStream_t stream);
+// pass 1 of a 3-D plan in one read of the volume: x tails, the parts of the y tails' combined rows and the z tails
+// (kernels_tails_walk.hip)
+struct WalkArgs {
+    float *ytp;              // parts of the combined rows, [part][layout of FusedArgs::yt]; == yt when the y tile is one patch
+    int64_t part_stride;     // elements between two parts
+    float *zt;               // z tails, [s][tz][r][y * NX + x] (StridedArgs::tails)
+    const float *HzT;        // impulse responses of the z tails, [variant][z][4]
+    int32_t TY, TZ, MZ;      // rows of a y tile (32 * parts), planes of a z tile, z tiles
+    int32_t parts_log2;      // log2(TY / 32)
+    int32_t nzk, KZ;         // z tails per sample (= scans along z * KZ), order of the z scans
+};
+bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows);
+int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const WalkArgs &wa, const float *Hx, const float *Hy,
+                      hipStream_t stream);
+int launch_sum_parts(const float *parts, float *yt, int64_t n, int64_t stride, int n_parts, hipStream_t stream);
 // tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)
 template <typename Acc>
 int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream,

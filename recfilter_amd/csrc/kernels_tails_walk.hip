@@ -1,0 +1,298 @@
+// kernels_tails_walk.hip -- pass 1 of a 3-D filter in ONE read of the volume: the x tails, the y tails' combined rows AND
+// the z tails.
+//
+// Why: a 3-D filter runs as the fused x/y stage per plane followed by the strided z stage (plan_fused.cpp): four reads and
+// two writes of the volume, 24 B per sample.  The z operators commute with the x/y filter (plan_strided.h, "early form"), so
+// the z tails may be taken from the RAW volume, which pass 1 of the x/y stage reads anyway.  A z tail is a sum over the TZ
+// planes of a z tile, sum_z Hz[tail][z] * v(x, y, z): whoever forms it keeps n_z * k partial sums per (x, y) sample while it
+// walks the planes.  Here a workgroup of 1024 threads owns a patch of 256 x 32 samples and walks the TZ planes of one z tile:
+// eight samples and 8 * n_z * k accumulators per thread, the whole register file of a CU for one patch.  Per plane the patch
+// goes through kernels_tails_mfma.hip's step: staged in LDS (XOR-swizzled rows), x tails on the matrix cores
+// (v_mfma_f32_4x4x1_16b_f32: wave = 64 columns x 16 rows x half of the column chunks), y tails by thread = (column, eight
+// rows).  A y tile of TY = 32 * parts rows is `parts` patches, i.e. workgroups: each stores its PART of the combined rows
+// (ytp[part]), sum_parts_kernel adds them up in front of xscan_rows.
+// One workgroup per CU (16 waves); D planes of a thread's loads in flight.  20 B per sample instead of 24.
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+#include "kernels_fused.h"
+#include "scan_device.h"
+
+namespace rf {
+
+namespace {
+
+typedef float F2 __attribute__((ext_vector_type(2)));
+typedef float F4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 32;                 // rows of a patch
+constexpr int kWalkThreads = 1024;
+
+// v[l] + v[l ^ 32] in every lane (v_permlane32_swap: kernels_tails_mfma.hip)
+__device__ __forceinline__ float sum_lanes_xor_32(float v) {
+    typedef unsigned U2 __attribute__((ext_vector_type(2)));
+    const U2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// The patch in LDS: rows padded to 65 chunks of 16 bytes.  The sixteen rows an A operand gathers at one column then sit on
+// sixteen different bank groups, and every access of the step is one address register plus an immediate (with the XOR swizzle of
+// kernels_tails_mfma.hip the eight rows of the y part alone took eight address registers; this kernel has 128 in all).
+constexpr int kPitch4 = kFusedTX / 4 + 1;
+
+// K: order of the x/y stage; NX, NY: scans along x / y; NZK: z tails per sample (scans along z * their order); D: planes in flight
+template <int K, int NX, int NY, int NZK, int D>
+__global__ void __launch_bounds__(kWalkThreads)
+walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa,
+                  const float *__restrict__ Hx,     // [vx][s][r][256]
+                  const float *__restrict__ Hy,     // [vy][j][r][TY]
+                  const float *__restrict__ HzT) {  // [vz][z][4]
+    __shared__ __attribute__((aligned(16))) float tile[kRows * kPitch4 * 4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_raw[];      // [x stage: 16 waves x nxk x 32][y stage: 4 x nyk x 256][Hz: TZ x 4]
+    constexpr int nxk = NX * K, nyk = NY * K;
+    constexpr int NGX = (nxk + 3) / 4, NGY = (nyk + 3) / 4;
+    F4 *tile4 = reinterpret_cast<F4 *>(tile);
+    F4 *stage4 = reinterpret_cast<F4 *>(dyn_raw);
+    F4 *ystage4 = stage4 + 16 * nxk * (kRows / 4);
+    float *hz_lds = reinterpret_cast<float *>(ystage4 + 4 * nyk * (kFusedTX / 4));
+
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x, tz = blockIdx.z;
+    const int ty = blockIdx.y >> wa.parts_log2, h = blockIdx.y & ((1 << wa.parts_log2) - 1);     // (tile row, patch of it)
+    const int TZ = wa.TZ;
+    const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
+    const int vy = (ty == 0 ? 1 : 0) | (ty == a.MY - 1 ? 2 : 0);
+    const int vz = (tz == 0 ? 1 : 0) | (tz == wa.MZ - 1 ? 2 : 0);
+    const int64_t Lx = a.NYP * a.NZ;
+
+    const int cc = t & 63, rg = t >> 6;                              // load: 16-byte chunk, row (and row + 16)
+    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int j4 = lane & 3;                                         // all three contractions: the tail this lane's B operand and results belong to
+    const int64_t plane = a.NX * a.NY;
+    // (a wave-uniform base advanced per plane + one 32-bit lane offset: no address registers per load)
+    const char *spb = reinterpret_cast<const char *>(src + ((int64_t)tz * TZ) * plane + ((int64_t)ty * wa.TY + kRows * h) * a.NX + (int64_t)tx * kFusedTX);
+    const uint32_t off0 = (uint32_t)rg * a.row_bytes + (uint32_t)cc * 16u, off1 = off0 + 16u * a.row_bytes;
+    const int64_t plane_bytes = plane * (int64_t)sizeof(float);
+    auto ld = [&](const char *pb, uint32_t off) { return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(pb + off)); };
+
+    // ---- operands that do not change from plane to plane, requested before the first pixels ----
+    // x: wave w owns columns 16 w .. 16 w + 15 of all 32 rows; block b = (rows 4 (b & 7) .., column half b >> 3)
+    const int xrow = 4 * ((lane >> 2) & 7) + (lane & 3), xhf = lane >> 5;
+    float Bx[NGX][8];
+#pragma unroll
+    for (int g = 0; g < NGX; g++) {
+        const int sr = 4 * g + j4 < nxk ? 4 * g + j4 : 0;           // (a tail that does not exist: its products land in columns nobody stores)
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+            const F4 hh = *reinterpret_cast<const F4 *>(Hx + ((size_t)vx * nxk + sr) * kFusedTX + 16 * w + 8 * xhf + 4 * mi);
+            Bx[g][4 * mi + 0] = hh.x; Bx[g][4 * mi + 1] = hh.y; Bx[g][4 * mi + 2] = hh.z; Bx[g][4 * mi + 3] = hh.w;
+        }
+    }
+    // y: thread = (column yc, rows 8 yq ..); block = four adjacent columns
+    const int yc = t & 255, yq = __builtin_amdgcn_readfirstlane(t >> 8);
+    float By[NGY][8];
+#pragma unroll
+    for (int g = 0; g < NGY; g++) {
+        const int jr = 4 * g + j4 < nyk ? 4 * g + j4 : 0;
+        const float *hr = Hy + ((size_t)vy * nyk + jr) * wa.TY + kRows * h + 8 * yq;
+        const F4 h0 = *reinterpret_cast<const F4 *>(hr), h1 = *reinterpret_cast<const F4 *>(hr + 4);
+        By[g][0] = h0.x; By[g][1] = h0.y; By[g][2] = h0.z; By[g][3] = h0.w;
+        By[g][4] = h1.x; By[g][5] = h1.y; By[g][6] = h1.z; By[g][7] = h1.w;
+    }
+    // z: the tile's impulse responses -> LDS (one 4-byte read per lane and plane)
+    if (t < TZ) reinterpret_cast<F4 *>(hz_lds)[t] = *reinterpret_cast<const F4 *>(HzT + ((size_t)vz * TZ + t) * 4);
+
+    F4 pre[D][2];
+#pragma unroll
+    for (int d = 0; d < D; d++) { pre[d][0] = ld(spb + d * plane_bytes, off0); pre[d][1] = ld(spb + d * plane_bytes, off1); }
+    const char *lp = spb + D * plane_bytes;                          // the next plane to request (wave-uniform)
+    // z accumulators: [row rg / rg + 16][element e of the lane's chunk]; lane 4 b + j, register i: tail j of column 16 b + 4 i + e
+    F4 zacc[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) zacc[k][e] = F4{0.f, 0.f, 0.f, 0.f};
+    const float *hzp = hz_lds + j4;
+
+    // Plane z of the tile complete in the two stages: x tails -> xt, this patch's part of the combined rows -> ytp.  Both
+    // destinations advance by a fixed number of elements per plane: one pointer and one stride per flushing thread.
+    float *fp = nullptr;
+    const int64_t ystride = a.yt_tile_major ? (int64_t)a.MX * a.ny * K * kFusedTX : a.NXP, xstride = a.NYP;
+    const bool y_flusher = t < nyk * 64, x_flusher = t >= 512 && t < 512 + 64 && (t & 31) < nxk * (kRows / 4);
+    const int64_t fstride = y_flusher ? ystride : xstride;
+    {
+        const int64_t zg0 = (int64_t)tz * TZ;
+        if (y_flusher) {
+            const int jr = t >> 6, c4 = t & 63;
+            const int64_t line = (int64_t)tx * kFusedTX + 4 * c4 + a.NXP * zg0;
+            fp = wa.ytp + (int64_t)h * wa.part_stride + a.yt_index(jr / K, ty, jr % K, K, line);
+        } else if (x_flusher) {
+            const int u = t & 31, sr = u >> 3, q = u & 7;
+            const int s = sr / K, r = sr % K;
+            fp = a.xt + (((int64_t)s * a.MX + tx) * K + r) * Lx + (int64_t)ty * wa.TY + kRows * h + a.NYP * zg0 + 4 * q;
+        }
+    }
+    auto flush = [&]() {
+        if (y_flusher) {
+            const int jr = t >> 6, c4 = t & 63;
+            F4 v = ystage4[(0 * nyk + jr) * 64 + c4];
+#pragma unroll
+            for (int q = 1; q < 4; q++) v = v + ystage4[(q * nyk + jr) * 64 + c4];
+            *reinterpret_cast<F4 *>(fp) = v;
+        } else if (t >= 512 && t < 512 + 64) {
+            // wave 8: lanes u and u + 32 each add up eight of the sixteen waves' partial sums, the halves meet across the wave
+            const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, half8 = (t >> 5) & 1;
+            F4 v = stage4[(8 * half8) * nxk * (kRows / 4) + u];
+#pragma unroll
+            for (int p = 1; p < 8; p++) v = v + stage4[(8 * half8 + p) * nxk * (kRows / 4) + u];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = sum_lanes_xor_32(v[i]);
+            if (x_flusher && half8 == 0) *reinterpret_cast<F4 *>(fp) = v;
+        }
+        fp += fstride;
+    };
+
+    auto step = [&](int z, F4 &p0, F4 &p1, auto load_tag) {
+        constexpr bool LOAD = decltype(load_tag)::value;
+        __syncthreads();                                             // plane z - 1: readers done, its stages complete
+        if (z > 0) flush();
+        const F4 v0 = p0, v1 = p1;
+        tile4[rg * kPitch4 + cc] = v0;
+        tile4[(rg + 16) * kPitch4 + cc] = v1;
+        {
+            // z tails: block = four adjacent chunks of the row; A = the lane's own sample, B = Hz[tail j4][z]
+            const float hz = j4 < NZK ? hzp[4 * z] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                zacc[0][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0[e], hz, zacc[0][e], 0, 0, 0);
+                zacc[1][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1[e], hz, zacc[1][e], 0, 0, 0);
+            }
+        }
+        if constexpr (LOAD) {
+            p0 = ld(lp, off0);
+            p1 = ld(lp, off1);
+            lp += plane_bytes;
+        }
+        __syncthreads();
+
+        // ---- x tails: 32 rows x this wave's 16 columns ----
+        {
+            F4 av[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) av[mi] = tile4[xrow * kPitch4 + 4 * w + 2 * xhf + mi];
+#pragma unroll
+            for (int g = 0; g < NGX; g++) {
+                F4 acc0 = F4{0.f, 0.f, 0.f, 0.f}, acc1 = F4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][e], Bx[g][e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1][e], Bx[g][4 + e], acc1, 0, 0, 0);
+                }
+                F4 dsum = acc0 + acc1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) dsum[i] = sum_lanes_xor_32(dsum[i]);       // the two column halves
+                // lane 4 rg' + j (lanes 0..31), register i: row 4 rg' + i of tail 4 g + j, this wave's sixteen columns
+                const int sr = 4 * g + j4;
+                if (xhf == 0 && sr < nxk) stage4[((w * nxk + sr) * kRows >> 2) + (lane >> 2)] = dsum;
+            }
+        }
+        // ---- y tails: eight rows of column yc; lane 4 b + j ends up with tail j of the block's four columns ----
+        {
+            float col[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) col[i] = tile[(8 * yq + i) * (kPitch4 * 4) + yc];
+#pragma unroll
+            for (int g = 0; g < NGY; g++) {
+                F4 acc0 = F4{0.f, 0.f, 0.f, 0.f}, acc1 = F4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[i], By[g][i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[i + 1], By[g][i + 1], acc1, 0, 0, 0);
+                }
+                const int jr = 4 * g + j4;
+                if (jr < nyk) ystage4[(yq * nyk + jr) * 64 + (yc >> 2)] = acc0 + acc1;
+            }
+        }
+    };
+
+    __syncthreads();                                                 // hz_lds
+#pragma unroll 1
+    for (int z0 = 0; z0 < TZ - D; z0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) step(z0 + d, pre[d][0], pre[d][1], std::true_type{});
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) step(TZ - D + d, pre[d][0], pre[d][1], std::false_type{});
+    __syncthreads();
+    flush();
+
+    // z tails of the patch: [s][tz][r][line], line = y * NX + x (StridedArgs::tails); lane 4 b + j stores tail j of the block's
+    // sixteen columns
+    if (j4 < NZK) {
+        const int64_t half = 16 * a.NX;
+        const int64_t line = ((int64_t)ty * wa.TY + kRows * h + rg) * a.NX + (int64_t)tx * kFusedTX + 16 * (lane >> 2);
+        float *q = wa.zt + ((((int64_t)(j4 / wa.KZ)) * wa.MZ + tz) * wa.KZ + j4 % wa.KZ) * plane + line;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                *reinterpret_cast<F4 *>(q + k * half + 4 * i) = F4{zacc[k][0][i], zacc[k][1][i], zacc[k][2][i], zacc[k][3][i]};
+    }
+}
+
+// yt = sum of the parts of the combined rows (16 bytes per thread)
+__global__ void __launch_bounds__(256) sum_parts_kernel(const F4 *__restrict__ parts, F4 *__restrict__ yt, int64_t n4, int64_t stride4, int n_parts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    F4 v = __builtin_nontemporal_load(parts + i);
+    for (int p = 1; p < n_parts; p++) v = v + __builtin_nontemporal_load(parts + p * stride4 + i);
+    yt[i] = v;
+}
+
+}  // namespace
+
+// When pass 1 of a 3-D plan walks: f32 volumes of whole tiles (width % 256, height % TY, depth % TZ), unsharded, no pointwise
+// stage, x, y and z scans all present, orders <= 2, at most two scans per dimension.
+bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows) {
+    if (K < 1 || K > 2 || KZ < 1 || KZ > 2) return false;
+    if (nx < 1 || nx > 2 || ny != nx || nz < 1 || nz > 2) return false;
+    if (TY != 32 && TY != 64 && TY != 128) return false;
+    if (TZ != 32 && TZ != 64 && TZ != 128) return false;
+    if (last_cols != kFusedTX || last_rows != TY) return false;
+    return true;
+}
+
+int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const WalkArgs &wa, const float *Hx, const float *Hy,
+                      hipStream_t stream) {
+    if (a.MX <= 0 || a.MY <= 0 || wa.MZ <= 0) return RF_OK;
+    const int parts = wa.TY / kRows;
+    if ((int64_t)a.MY * parts > 65535 || wa.MZ > 65535) { set_error("walk tails: grid too large"); return RF_ERR_UNSUPPORTED; }
+    dim3 grid((unsigned)a.MX, (unsigned)(a.MY * parts), (unsigned)wa.MZ);
+    const int nxk = a.nx * K, nyk = a.ny * K;
+    const size_t lds = ((size_t)16 * nxk * kRows + (size_t)4 * nyk * kFusedTX + (size_t)4 * wa.TZ) * sizeof(float);
+    static const int depth = RF_KNOB("RF_WALK_DEPTH") ? atoi(RF_KNOB("RF_WALK_DEPTH")) : 4;      // A/B: planes in flight
+#define RF_CASE(KK, XX, ZZ, DD)                                                                                            \
+    if (K == KK && a.nx == XX && wa.nzk == ZZ && depth == DD) {                                                            \
+        hipLaunchKernelGGL((walk_tails_kernel<KK, XX, XX, ZZ, DD>), grid, dim3(kWalkThreads), lds, stream, src, a, wa, Hx, Hy, wa.HzT); \
+        RF_HIP_CHECK(hipGetLastError());                                                                                   \
+        return RF_OK;                                                                                                      \
+    }
+#define RF_CASES(KK, XX) RF_CASE(KK, XX, 1, 4) RF_CASE(KK, XX, 2, 4) RF_CASE(KK, XX, 4, 4) RF_CASE(KK, XX, 4, 2)
+    RF_CASES(2, 2) RF_CASES(2, 1) RF_CASES(1, 2) RF_CASES(1, 1)
+#undef RF_CASES
+#undef RF_CASE
+    set_error("walk tails: unsupported order %d / %d scans / %d z tails", K, a.nx, wa.nzk);
+    return RF_ERR_UNSUPPORTED;
+}
+
+int launch_sum_parts(const float *parts, float *yt, int64_t n, int64_t stride, int n_parts, hipStream_t stream) {
+    if (n <= 0) return RF_OK;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const F4 *>(parts), reinterpret_cast<F4 *>(yt), n4, stride / 4, n_parts);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+}  // namespace rf

@@ -10,6 +10,7 @@
 //   carry_y          y carry recurrence, all y scans (one launch per scan around the exchanges when sharded)
 //   fused_pass2      final correction pass
 #include <cstring>
+#include <memory>
 
 #include "kernels_fused.h"
 #include "plan.h"
@@ -289,6 +290,49 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     Acc *row_exit = chained ? (Acc *)plan->alloc((size_t)2 * K * Lx * np * sizeof(Acc), true, &status) : nullptr;
     if (status != RF_OK) return status;
 
+    // ---- 3-D volumes: pass 1 in ONE read (kernels_tails_walk.hip) ------------------------------------
+    // The z tails are taken from the raw input by the pass that extracts the x/y tails (the z operators commute with the x/y
+    // filter: plan_strided.h); the z stage then has no first pass.  Unsharded f32 volumes of whole tiles without pointwise
+    // stages; RF_PLAN_STAGED_PASS1 keeps the two first passes.
+    WalkArgs walk_args{};
+    std::shared_ptr<WalkHook> walk_hook;
+    rf_plan *walk_child = nullptr;
+    if constexpr (std::is_same<P, float>::value) {
+        static const char *walk_knob = RF_KNOB("RF_WALK");                        // A/B: 0 = never
+        const bool wanted = !(plan->flags & RF_PLAN_STAGED_PASS1) && !(walk_knob && atoi(walk_knob) == 0);
+        if (wanted && plan->ndim == 3 && !plan->sharded() && plan->n_planes == 1 && !batch && !chained && !plan->mod_form &&
+            !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&
+            plan->dims[2].lines == NX * NY) {
+            const DimInfo &dz = plan->dims[2];
+            const int TZ = strided_tile(plan, 2), nz = (int)dz.scan_ids.size(), KZ = dz.k;
+            if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy)) {
+                const int MZ = (int)(dz.N / TZ);
+                walk_child = build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * MZ);
+                if (walk_child) {
+                    // impulse responses of the z tails, transposed: [variant][z][4]
+                    std::vector<S> H = build_tail_responses<S>(table_scans(dz.scan_ids), KZ, TZ, plan->clamped);
+                    std::vector<float> hHz((size_t)4 * TZ * 4, 0.0f);
+                    std::vector<double> dHz(H.size());
+                    for (size_t e = 0; e < H.size(); e++) dHz[e] = table_to_double<S>(H[e]);
+                    for (int v = 0; v < 4; v++)
+                        for (int j = 0; j < nz * KZ; j++)
+                            for (int z = 0; z < TZ; z++)
+                                hHz[((size_t)v * TZ + z) * 4 + j] = table_to_acc<S, Acc>(H[((size_t)v * nz * KZ + j) * TZ + z]);
+                    plan->tables["H_z"] = dHz;
+                    const int parts = TY / 32;
+                    walk_args.HzT = (const float *)plan->upload(hHz.data(), hHz.size() * sizeof(float), &status);
+                    walk_args.TY = TY; walk_args.TZ = TZ; walk_args.MZ = MZ; walk_args.nzk = nz * KZ; walk_args.KZ = KZ;
+                    walk_args.parts_log2 = parts == 4 ? 2 : parts == 2 ? 1 : 0;
+                    walk_args.part_stride = (int64_t)yt_pp;
+                    walk_args.ytp = parts > 1 ? (float *)plan->alloc(yt_pp * parts * sizeof(float), false, &status) : nullptr;
+                    walk_hook = std::make_shared<WalkHook>();
+                    if (status != RF_OK) return status;
+                }
+            }
+        }
+    }
+    const bool walk = (bool)walk_hook;
+
     FusedArgs<Acc> fbase{};
     fbase.NX = NX; fbase.NY = NY; fbase.NZ = NZ; fbase.MX = MX; fbase.MY = MY; fbase.nx = nx; fbase.ny = ny;
     fbase.NXP = NXP; fbase.last_lane = (TVx - 1) / kFusedSeg; fbase.last_cols = TVx;
@@ -372,10 +416,19 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     p1.name = "fused_tails";
     const int stream_mode = (plan->flags & RF_PLAN_STREAM_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
     const int mfma_mode = (plan->flags & RF_PLAN_MFMA_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
-    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode, mfma_mode](int pl) {
+    if (walk) p1.name = "walk_tails";
+    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode, mfma_mode, walk_args, walk_hook](int pl) {
         const FusedArgs<Acc> a = fargs(pl);
         (void)stream_mode;
         (void)mfma_mode;
+        if constexpr (std::is_same<P, float>::value) {
+            if (walk_hook) {
+                WalkArgs wa = walk_args;
+                wa.zt = walk_hook->zt;
+                if (!wa.ytp) wa.ytp = a.yt;                 // one patch per y tile: the combined rows go where they belong
+                return launch_walk_tails(K, (const float *)plan->in[pl], a, wa, d_Hx, d_Hy, plan->stream);
+            }
+        }
         // images of whole 256 x 64 tiles stream through the LDS-DMA ring (kernels_stream.hip)
         if constexpr (std::is_same<P, float>::value) {
             if (a.lin_limit == 0 && stream_tails_applicable(K, TY, plan->pw.in_u8, a.pw_flags, a.last_cols, a.last_rows, (int64_t)a.MX * a.MY * a.NZ, a.MX,
@@ -405,6 +458,16 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->begin_steps.push_back(ci);
     }
     plan->begin_steps.push_back(p1);
+    if (walk && walk_args.ytp) {
+        Step sp;
+        sp.name = "sum_parts";
+        sp.run = [plan, fargs, walk_args, yt_pp, TY](int pl) {
+            if constexpr (std::is_same<P, float>::value)
+                return launch_sum_parts(walk_args.ytp, (float *)fargs(pl).yt, (int64_t)yt_pp, (int64_t)yt_pp, TY / 32, plan->stream);
+            else return (int)RF_OK;
+        };
+        plan->begin_steps.push_back(sp);
+    }
     if (nx > 0 && !chained && !merged_cx) {
         Step cx;
         cx.name = "carry_x";
@@ -567,7 +630,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
         int rc;
         if constexpr (sizeof(Acc) == 4)
-            rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false, desc, first_begin_step)
+            rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false, desc, first_begin_step,
+                                                                         walk_hook.get(), walk_child)
                                            : add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
         else rc = add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);      // (f64: no strided kernels)
         if (rc != RF_OK) return rc;

@@ -28,6 +28,32 @@ inline int strided_tile(const rf_plan *plan, int d) {
     return 0;
 }
 
+// What pass 1 of the x/y stage needs to know when it also forms this dimension's tails (kernels_tails_walk.hip): the strided
+// dimension then has no first pass of its own.  Filled by add_strided_dimension.
+struct WalkHook {
+    float *zt = nullptr;          // the dimension's tails, [s][t][r][line]
+};
+
+// The x/y filter F over `planes` carry planes of dimension d, in place: a fused x/y plan of its own (null: cannot be built).
+inline rf_plan *build_carry_planes_plan(const rf_plan *plan, const rf_filter_desc *desc, int d, int64_t planes) {
+    std::vector<rf_scan_desc> xy;
+    for (int i = 0; i < desc->n_scans; i++)
+        if (desc->scans[i].dim != d) xy.push_back(desc->scans[i]);
+    rf_filter_desc cd = *desc;
+    cd.scans = xy.data();
+    cd.n_scans = (int32_t)xy.size();
+    cd.extent[2] = planes;
+    cd.n_planes = 1;
+    cd.tile[2] = 0;
+    cd.path = RF_PATH_TILED_FUSED;
+    cd.device = plan->host_only ? RF_DEVICE_HOST_ONLY : plan->device;
+    cd.shard_rank = 0; cd.shard_world = 1; cd.shard_extents = nullptr;
+    cd.flags = (desc->flags & (RF_PLAN_STREAM_PASS1 | RF_PLAN_STAGED_PASS1 | 0x0000ff00u)) | RF_PLAN_TILED_ONLY | RF_PLAN_NO_CASCADE;
+    rf_plan *child = nullptr;
+    if (build_plan(&cd, &child) != RF_OK) return nullptr;
+    return child;
+}
+
 // Early exchange (a z-sharded volume whose x/y stage precedes this dimension).  The operators of this dimension -- tail
 // extraction, carry recurrence, the correction by the entering carries -- act along z alone and identically on every
 // (x, y) line; the x/y filter F acts on every z plane alone and identically: they commute, borders included (everything
@@ -41,8 +67,12 @@ inline int strided_tile(const rf_plan *plan, int d) {
 // max(kernels, exchange) instead of their sum, for (tiles + 1) * scans * k / planes of extra x/y work (cfg5 on 8 GPUs:
 // 12 carry planes beside 256).  `xy_begin` .. end of plan->begin_steps are the x/y stage's steps at the time of the call.
 // Needs: the merged exchange, no pointwise stages (a prologue's bias is not linear), the x/y stage in front.
+// `walk` (unsharded volumes, kernels_tails_walk.hip): the same commutation without an exchange -- pass 1 of the x/y stage has
+// formed this dimension's tails from the raw input as it went, so the dimension is: carry scan, F over the scans * k * tiles
+// carry planes (`walk_child`, built by the caller), pass 2 on the x/y-filtered output.
 template <typename P, typename S>
-int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter_desc *desc = nullptr, size_t xy_begin = (size_t)-1) {
+int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter_desc *desc = nullptr, size_t xy_begin = (size_t)-1,
+                          WalkHook *walk = nullptr, rf_plan *walk_child = nullptr) {
     using Acc = typename PixelTraits<P>::Acc;
     int status = RF_OK;
     DimInfo &di = plan->dims[d];
@@ -119,22 +149,10 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
     // The early exchange needs a helper plan: F over the carry planes = the x/y scans of this filter on a volume of
     // (tiles + 1) * scans * k planes, in place.  It is built BEFORE anything of the early layout is committed: a helper that
     // cannot be built (unsupported shape, out of memory) leaves the plan on the late exchange instead of failing it.
-    rf_plan *child = nullptr;
+    rf_plan *child = walk ? walk_child : nullptr;
     if (early) {
-        std::vector<rf_scan_desc> xy;
-        for (int i = 0; i < desc->n_scans; i++)
-            if (desc->scans[i].dim != d) xy.push_back(desc->scans[i]);
-        rf_filter_desc cd = *desc;
-        cd.scans = xy.data();
-        cd.n_scans = (int32_t)xy.size();
-        cd.extent[2] = (int64_t)n * K * (M + 1);
-        cd.n_planes = 1;
-        cd.tile[2] = 0;
-        cd.path = RF_PATH_TILED_FUSED;
-        cd.device = plan->host_only ? RF_DEVICE_HOST_ONLY : plan->device;
-        cd.shard_rank = 0; cd.shard_world = 1; cd.shard_extents = nullptr;
-        cd.flags = (desc->flags & (RF_PLAN_STREAM_PASS1 | RF_PLAN_STAGED_PASS1 | 0x0000ff00u)) | RF_PLAN_TILED_ONLY | RF_PLAN_NO_CASCADE;
-        if (build_plan(&cd, &child) != RF_OK) { child = nullptr; early = false; }
+        child = build_carry_planes_plan(plan, desc, d, (int64_t)n * K * (M + 1));
+        if (!child) early = false;
     }
     std::unique_ptr<rf_plan> child_owner(child);
     // early exchange: the tails and the entering carries of a plane are ONE run of (tiles + 1) * scans * k carry planes,
@@ -177,6 +195,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
 
     Step p1;
     p1.name = "strided_pass1_" + dn;
+    if (walk) walk->zt = reinterpret_cast<float *>(tails);
     p1.run = [plan, sargs, K, TZ, from_input, early](int pl) {
         const P *src = (from_input || early) ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
         return launch_strided_pass<P>(false, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
@@ -186,7 +205,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
         plan->interior_steps.assign(plan->begin_steps.begin() + (std::ptrdiff_t)xy_begin, plan->begin_steps.end());
         plan->begin_steps.resize(xy_begin);
     }
-    plan->begin_steps.push_back(p1);
+    if (!walk) plan->begin_steps.push_back(p1);
 
     if (!sharded) {
         Step cs;
@@ -195,6 +214,26 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
             return launch_carry_block<Acc>(K, gargs(pl), mask, 0, n, (Acc *)nullptr, d_AC, C, plan->stream);
         };
         plan->begin_steps.push_back(cs);
+        if (walk) {
+            plan->helpers.emplace_back(child_owner.release());
+            plan->workspace_bytes += child->workspace_bytes;
+            std::vector<const Step *> steps;
+            for (const Step &st : child->begin_steps) steps.push_back(&st);
+            for (const Step &st : child->finish_steps) steps.push_back(&st);
+            Step w;
+            w.name = "carry_planes_xy";
+            w.run = [plan, child, steps, tails, tails_stride](int pl) {
+                child->in[0] = child->orig_in[0] = tails + (size_t)pl * tails_stride;
+                child->out[0] = tails + (size_t)pl * tails_stride;
+                child->stream = plan->stream;
+                for (const Step *sp : steps) {
+                    const int rc = sp->run(0);
+                    if (rc != RF_OK) return rc;
+                }
+                return (int)RF_OK;
+            };
+            plan->begin_steps.push_back(w);
+        }
     } else if (merged_exchange_applies(n, K, plan->shard_world)) {
         int rc = add_merged_exchange<S, Acc>(plan, tab, dn, M, TZ, di.lines, mask, gargs, incoming, inc_pp, d_AC, C, "carry_" + dn);
         if (rc != RF_OK) return rc;
