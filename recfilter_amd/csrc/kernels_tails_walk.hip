@@ -41,8 +41,8 @@ __device__ __forceinline__ float sum_lanes_xor_32(float v) {
 // kernels_tails_mfma.hip the eight rows of the y part alone took eight address registers; this kernel has 128 in all).
 constexpr int kPitch4 = kFusedTX / 4 + 1;
 
-// K: order of the x/y stage; NX, NY: scans along x / y; NZK: z tails per sample (scans along z * their order); D: planes in flight
-template <int K, int NX, int NY, int NZK, int D>
+// K: order of the x/y stage; NX, NY: scans along x / y; D: planes of loads in flight
+template <int K, int NX, int NY, int D>
 __global__ void __launch_bounds__(kWalkThreads)
 walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa,
                   const float *__restrict__ Hx,     // [vx][s][r][256]
@@ -56,6 +56,10 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     F4 *stage4 = reinterpret_cast<F4 *>(dyn_raw);
     F4 *ystage4 = stage4 + 16 * nxk * (kRows / 4);
     float *hz_lds = reinterpret_cast<float *>(ystage4 + 4 * nyk * (kFusedTX / 4));
+    // the B operands of the x and y parts (fixed for the whole walk): 32 bytes per lane, kept in LDS -- as registers they are the
+    // sixteen that decide between two and four planes of loads in flight
+    F4 *hx_b = reinterpret_cast<F4 *>(hz_lds + 4 * 128);             // [g][wave][half][j][2]
+    F4 *hy_b = hx_b + NGX * 16 * 2 * 4 * 2;                          // [g][yq][j][2]
 
     const int t = threadIdx.x;
     const int tx = blockIdx.x, tz = blockIdx.z;
@@ -79,34 +83,39 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     // ---- operands that do not change from plane to plane, requested before the first pixels ----
     // x: wave w owns columns 16 w .. 16 w + 15 of all 32 rows; block b = (rows 4 (b & 7) .., column half b >> 3)
     const int xrow = 4 * ((lane >> 2) & 7) + (lane & 3), xhf = lane >> 5;
-    float Bx[NGX][8];
+    // (filled by the lanes that would hold them: lane (b, j) of wave w writes what lanes (.., j) of its half read back)
 #pragma unroll
     for (int g = 0; g < NGX; g++) {
         const int sr = 4 * g + j4 < nxk ? 4 * g + j4 : 0;           // (a tail that does not exist: its products land in columns nobody stores)
+        if ((lane & 28) == 0) {
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++) {
-            const F4 hh = *reinterpret_cast<const F4 *>(Hx + ((size_t)vx * nxk + sr) * kFusedTX + 16 * w + 8 * xhf + 4 * mi);
-            Bx[g][4 * mi + 0] = hh.x; Bx[g][4 * mi + 1] = hh.y; Bx[g][4 * mi + 2] = hh.z; Bx[g][4 * mi + 3] = hh.w;
+            for (int mi = 0; mi < 2; mi++)
+                hx_b[(((g * 16 + w) * 2 + xhf) * 4 + j4) * 2 + mi] =
+                    *reinterpret_cast<const F4 *>(Hx + ((size_t)vx * nxk + sr) * kFusedTX + 16 * w + 8 * xhf + 4 * mi);
         }
     }
     // y: thread = (column yc, rows 8 yq ..); block = four adjacent columns
     const int yc = t & 255, yq = __builtin_amdgcn_readfirstlane(t >> 8);
-    float By[NGY][8];
-#pragma unroll
-    for (int g = 0; g < NGY; g++) {
-        const int jr = 4 * g + j4 < nyk ? 4 * g + j4 : 0;
-        const float *hr = Hy + ((size_t)vy * nyk + jr) * wa.TY + kRows * h + 8 * yq;
-        const F4 h0 = *reinterpret_cast<const F4 *>(hr), h1 = *reinterpret_cast<const F4 *>(hr + 4);
-        By[g][0] = h0.x; By[g][1] = h0.y; By[g][2] = h0.z; By[g][3] = h0.w;
-        By[g][4] = h1.x; By[g][5] = h1.y; By[g][6] = h1.z; By[g][7] = h1.w;
+    if (t < NGY * 16) {
+        const int g = t >> 4, q = (t >> 2) & 3, j = t & 3;
+        const int jr = 4 * g + j < nyk ? 4 * g + j : 0;
+        const float *hr = Hy + ((size_t)vy * nyk + jr) * wa.TY + kRows * h + 8 * q;
+        hy_b[((g * 4 + q) * 4 + j) * 2 + 0] = *reinterpret_cast<const F4 *>(hr);
+        hy_b[((g * 4 + q) * 4 + j) * 2 + 1] = *reinterpret_cast<const F4 *>(hr + 4);
     }
     // z: the tile's impulse responses -> LDS (one 4-byte read per lane and plane)
     if (t < TZ) reinterpret_cast<F4 *>(hz_lds)[t] = *reinterpret_cast<const F4 *>(HzT + ((size_t)vz * TZ + t) * 4);
 
     F4 pre[D][2];
 #pragma unroll
-    for (int d = 0; d < D; d++) { pre[d][0] = ld(spb + d * plane_bytes, off0); pre[d][1] = ld(spb + d * plane_bytes, off1); }
-    const char *lp = spb + D * plane_bytes;                          // the next plane to request (wave-uniform)
+    for (int d = 0; d < D; d++) {
+        // (plane by plane, as the loop requests them: requested row by row instead -- the compiler's order without the fence --
+        //  the first plane is complete only when three of the first four loads are, and the loop's wait for `its` plane became
+        //  `s_waitcnt vmcnt(1)`: half of the next plane as well, every step)
+        pre[d][0] = ld(spb + d * plane_bytes, off0);
+        pre[d][1] = ld(spb + d * plane_bytes, off1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // z accumulators: [row rg / rg + 16][element e of the lane's chunk]; lane 4 b + j, register i: tail j of column 16 b + 4 i + e
     F4 zacc[2][4];
 #pragma unroll
@@ -115,54 +124,50 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
         for (int e = 0; e < 4; e++) zacc[k][e] = F4{0.f, 0.f, 0.f, 0.f};
     const float *hzp = hz_lds + j4;
 
-    // Plane z of the tile complete in the two stages: x tails -> xt, this patch's part of the combined rows -> ytp.  Both
-    // destinations advance by a fixed number of elements per plane: one pointer and one stride per flushing thread.
-    float *fp = nullptr;
-    const int64_t ystride = a.yt_tile_major ? (int64_t)a.MX * a.ny * K * kFusedTX : a.NXP, xstride = a.NYP;
-    const bool y_flusher = t < nyk * 64, x_flusher = t >= 512 && t < 512 + 64 && (t & 31) < nxk * (kRows / 4);
-    const int64_t fstride = y_flusher ? ystride : xstride;
-    {
-        const int64_t zg0 = (int64_t)tz * TZ;
-        if (y_flusher) {
-            const int jr = t >> 6, c4 = t & 63;
-            const int64_t line = (int64_t)tx * kFusedTX + 4 * c4 + a.NXP * zg0;
-            fp = wa.ytp + (int64_t)h * wa.part_stride + a.yt_index(jr / K, ty, jr % K, K, line);
-        } else if (x_flusher) {
-            const int u = t & 31, sr = u >> 3, q = u & 7;
-            const int s = sr / K, r = sr % K;
-            fp = a.xt + (((int64_t)s * a.MX + tx) * K + r) * Lx + (int64_t)ty * wa.TY + kRows * h + a.NYP * zg0 + 4 * q;
-        }
+    // Plane z of the tile complete in the two stages: x tails -> xt (wave 8), this patch's part of the combined rows -> ytp
+    // (waves 0 .. nyk - 1).  Destinations: a wave-uniform base that advances by a fixed number of elements per plane + one
+    // 32-bit offset per flushing lane (the tails of a volume that fits the memory stay below 4 GiB; launch_walk_tails checks).
+    const int64_t ystride = (int64_t)a.MX * a.ny * K * kFusedTX, xstride = a.NYP;          // (y tails tile-major)
+    const int64_t zg0 = (int64_t)tz * TZ;
+    float *const ybase = wa.ytp + (int64_t)h * wa.part_stride + a.yt_index(0, ty, 0, K, (int64_t)tx * kFusedTX + a.NXP * zg0);
+    float *const xbase = a.xt + ((int64_t)tx * K) * Lx + (int64_t)ty * wa.TY + kRows * h + a.NYP * zg0;
+    uint32_t foff = 0;
+    if (w < nyk) foff = (uint32_t)(t * 4);                                                  // [jr][256]: jr = t >> 6, chunk t & 63
+    else if (w == 8) {
+        const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, sr = u >> 3, q = u & 7;
+        foff = (uint32_t)((((int64_t)(sr / K) * a.MX * K + sr % K) * Lx + 4 * q));
     }
-    auto flush = [&]() {
-        if (y_flusher) {
+    auto flush = [&](int zl) {                                      // zl: the plane, counted inside the z tile
+        if (w < nyk) {
             const int jr = t >> 6, c4 = t & 63;
             F4 v = ystage4[(0 * nyk + jr) * 64 + c4];
 #pragma unroll
             for (int q = 1; q < 4; q++) v = v + ystage4[(q * nyk + jr) * 64 + c4];
-            *reinterpret_cast<F4 *>(fp) = v;
-        } else if (t >= 512 && t < 512 + 64) {
-            // wave 8: lanes u and u + 32 each add up eight of the sixteen waves' partial sums, the halves meet across the wave
+            *reinterpret_cast<F4 *>(ybase + (int64_t)zl * ystride + foff) = v;
+        } else if (w == 8) {
+            // lanes u and u + 32 each add up eight of the sixteen waves' partial sums, the halves meet across the wave
             const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, half8 = (t >> 5) & 1;
             F4 v = stage4[(8 * half8) * nxk * (kRows / 4) + u];
 #pragma unroll
             for (int p = 1; p < 8; p++) v = v + stage4[(8 * half8 + p) * nxk * (kRows / 4) + u];
 #pragma unroll
             for (int i = 0; i < 4; i++) v[i] = sum_lanes_xor_32(v[i]);
-            if (x_flusher && half8 == 0) *reinterpret_cast<F4 *>(fp) = v;
+            if ((t & 63) < nxk * (kRows / 4)) *reinterpret_cast<F4 *>(xbase + (int64_t)zl * xstride + foff) = v;
         }
-        fp += fstride;
     };
 
     auto step = [&](int z, F4 &p0, F4 &p1, auto load_tag) {
         constexpr bool LOAD = decltype(load_tag)::value;
         __syncthreads();                                             // plane z - 1: readers done, its stages complete
-        if (z > 0) flush();
         const F4 v0 = p0, v1 = p1;
         tile4[rg * kPitch4 + cc] = v0;
         tile4[(rg + 16) * kPitch4 + cc] = v1;
+        // (behind the wait for this plane's pixels and in front of the next request: the flushing waves' store is then never
+        //  the youngest operation their next wait has to count)
+        if (z > 0) flush(z - 1);
         {
             // z tails: block = four adjacent chunks of the row; A = the lane's own sample, B = Hz[tail j4][z]
-            const float hz = j4 < NZK ? hzp[4 * z] : 0.0f;
+            const float hz = hzp[4 * z];                          // (zero for a tail that does not exist: the table is padded)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 zacc[0][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0[e], hz, zacc[0][e], 0, 0, 0);
@@ -170,9 +175,9 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
             }
         }
         if constexpr (LOAD) {
+            const char *lp = spb + (int64_t)(z + D) * plane_bytes;        // (wave-uniform: scalar base + lane offset)
             p0 = ld(lp, off0);
             p1 = ld(lp, off1);
-            lp += plane_bytes;
         }
         __syncthreads();
 
@@ -183,11 +188,12 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
             for (int mi = 0; mi < 2; mi++) av[mi] = tile4[xrow * kPitch4 + 4 * w + 2 * xhf + mi];
 #pragma unroll
             for (int g = 0; g < NGX; g++) {
+                const F4 b0 = hx_b[(((g * 16 + w) * 2 + xhf) * 4 + j4) * 2], b1 = hx_b[(((g * 16 + w) * 2 + xhf) * 4 + j4) * 2 + 1];
                 F4 acc0 = F4{0.f, 0.f, 0.f, 0.f}, acc1 = F4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][e], Bx[g][e], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1][e], Bx[g][4 + e], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][e], b0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1][e], b1[e], acc1, 0, 0, 0);
                 }
                 F4 dsum = acc0 + acc1;
 #pragma unroll
@@ -204,11 +210,12 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
             for (int i = 0; i < 8; i++) col[i] = tile[(8 * yq + i) * (kPitch4 * 4) + yc];
 #pragma unroll
             for (int g = 0; g < NGY; g++) {
+                const F4 b0 = hy_b[((g * 4 + yq) * 4 + j4) * 2], b1 = hy_b[((g * 4 + yq) * 4 + j4) * 2 + 1];
                 F4 acc0 = F4{0.f, 0.f, 0.f, 0.f}, acc1 = F4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[i], By[g][i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[i + 1], By[g][i + 1], acc1, 0, 0, 0);
+                for (int i = 0; i < 4; i++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[i], b0[i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 + i], b1[i], acc1, 0, 0, 0);
                 }
                 const int jr = 4 * g + j4;
                 if (jr < nyk) ystage4[(yq * nyk + jr) * 64 + (yc >> 2)] = acc0 + acc1;
@@ -225,11 +232,11 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
 #pragma unroll
     for (int d = 0; d < D; d++) step(TZ - D + d, pre[d][0], pre[d][1], std::false_type{});
     __syncthreads();
-    flush();
+    flush(TZ - 1);
 
     // z tails of the patch: [s][tz][r][line], line = y * NX + x (StridedArgs::tails); lane 4 b + j stores tail j of the block's
     // sixteen columns
-    if (j4 < NZK) {
+    if (j4 < wa.nzk) {
         const int64_t half = 16 * a.NX;
         const int64_t line = ((int64_t)ty * wa.TY + kRows * h + rg) * a.NX + (int64_t)tx * kFusedTX + 16 * (lane >> 2);
         float *q = wa.zt + ((((int64_t)(j4 / wa.KZ)) * wa.MZ + tz) * wa.KZ + j4 % wa.KZ) * plane + line;
@@ -270,15 +277,15 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
     if ((int64_t)a.MY * parts > 65535 || wa.MZ > 65535) { set_error("walk tails: grid too large"); return RF_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)a.MX, (unsigned)(a.MY * parts), (unsigned)wa.MZ);
     const int nxk = a.nx * K, nyk = a.ny * K;
-    const size_t lds = ((size_t)16 * nxk * kRows + (size_t)4 * nyk * kFusedTX + (size_t)4 * wa.TZ) * sizeof(float);
+    const size_t lds = ((size_t)16 * nxk * kRows + (size_t)4 * nyk * kFusedTX + (size_t)4 * 128 + (size_t)((nxk + 3) / 4) * 1024 + (size_t)((nyk + 3) / 4) * 128) * sizeof(float);
     static const int depth = RF_KNOB("RF_WALK_DEPTH") ? atoi(RF_KNOB("RF_WALK_DEPTH")) : 4;      // A/B: planes in flight
-#define RF_CASE(KK, XX, ZZ, DD)                                                                                            \
-    if (K == KK && a.nx == XX && wa.nzk == ZZ && depth == DD) {                                                            \
-        hipLaunchKernelGGL((walk_tails_kernel<KK, XX, XX, ZZ, DD>), grid, dim3(kWalkThreads), lds, stream, src, a, wa, Hx, Hy, wa.HzT); \
+#define RF_CASE(KK, XX, DD)                                                                                                \
+    if (K == KK && a.nx == XX && depth == DD) {                                                                            \
+        hipLaunchKernelGGL((walk_tails_kernel<KK, XX, XX, DD>), grid, dim3(kWalkThreads), lds, stream, src, a, wa, Hx, Hy, wa.HzT); \
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }
-#define RF_CASES(KK, XX) RF_CASE(KK, XX, 1, 4) RF_CASE(KK, XX, 2, 4) RF_CASE(KK, XX, 4, 4) RF_CASE(KK, XX, 4, 2)
+#define RF_CASES(KK, XX) RF_CASE(KK, XX, 4) RF_CASE(KK, XX, 2)
     RF_CASES(2, 2) RF_CASES(2, 1) RF_CASES(1, 2) RF_CASES(1, 1)
 #undef RF_CASES
 #undef RF_CASE
