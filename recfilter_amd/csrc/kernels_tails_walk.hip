@@ -12,6 +12,7 @@
 // rows).  A y tile of TY = 32 * parts rows is `parts` patches, i.e. workgroups: each stores its PART of the combined rows
 // (ytp[part]), sum_parts_kernel adds them up in front of xscan_rows.
 // One workgroup per CU (16 waves); D planes of a thread's loads in flight.  20 B per sample instead of 24.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -41,21 +42,23 @@ __device__ __forceinline__ float sum_lanes_xor_32(float v) {
 // kernels_tails_mfma.hip the eight rows of the y part alone took eight address registers; this kernel has 128 in all).
 constexpr int kPitch4 = kFusedTX / 4 + 1;
 
-// K: order of the x/y stage; NX, NY: scans along x / y; D: planes of loads in flight
-template <int K, int NX, int NY, int D>
+// K: order of the x/y stage; NX, NY: scans along x / y
+template <int K, int NX, int NY>
 __global__ void __launch_bounds__(kWalkThreads)
 walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa,
                   const float *__restrict__ Hx,     // [vx][s][r][256]
                   const float *__restrict__ Hy,     // [vy][j][r][TY]
                   const float *__restrict__ HzT) {  // [vz][z][4]
-    __shared__ __attribute__((aligned(16))) float tile[kRows * kPitch4 * 4];
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_raw[];      // [x stage: 16 waves x nxk x 32][y stage: 4 x nyk x 256][Hz: TZ x 4]
+    // [patch x 2][x stage: 16 waves x nxk x 32, x 2][y stage: 4 x nyk x 256, x 2][Hz: 128 x 4][B operands]: the patch and the two
+    // stages are double-buffered by the plane's parity, so that a step needs ONE workgroup barrier (below)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_raw[];
     constexpr int nxk = NX * K, nyk = NY * K;
     constexpr int NGX = (nxk + 3) / 4, NGY = (nyk + 3) / 4;
-    F4 *tile4 = reinterpret_cast<F4 *>(tile);
-    F4 *stage4 = reinterpret_cast<F4 *>(dyn_raw);
-    F4 *ystage4 = stage4 + 16 * nxk * (kRows / 4);
-    float *hz_lds = reinterpret_cast<float *>(ystage4 + 4 * nyk * (kFusedTX / 4));
+    constexpr int kTile4 = kRows * kPitch4, kXs4 = 16 * nxk * (kRows / 4), kYs4 = 4 * nyk * (kFusedTX / 4);
+    F4 *tile4 = reinterpret_cast<F4 *>(dyn_raw);
+    F4 *stage4 = tile4 + 2 * kTile4;
+    F4 *ystage4 = stage4 + 2 * kXs4;
+    float *hz_lds = reinterpret_cast<float *>(ystage4 + 2 * kYs4);
     // the B operands of the x and y parts (fixed for the whole walk): 32 bytes per lane, kept in LDS -- as registers they are the
     // sixteen that decide between two and four planes of loads in flight
     F4 *hx_b = reinterpret_cast<F4 *>(hz_lds + 4 * 128);             // [g][wave][half][j][2]
@@ -106,6 +109,7 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     // z: the tile's impulse responses -> LDS (one 4-byte read per lane and plane)
     if (t < TZ) reinterpret_cast<F4 *>(hz_lds)[t] = *reinterpret_cast<const F4 *>(HzT + ((size_t)vz * TZ + t) * 4);
 
+    constexpr int D = 2;                                             // planes of a thread's loads in flight (four: no faster)
     F4 pre[D][2];
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -137,55 +141,61 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
         const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, sr = u >> 3, q = u & 7;
         foff = (uint32_t)((((int64_t)(sr / K) * a.MX * K + sr % K) * Lx + 4 * q));
     }
-    auto flush = [&](int zl) {                                      // zl: the plane, counted inside the z tile
+    auto flush = [&](int zl, int par) {                             // zl: the plane, counted inside the z tile; par: its parity
         if (w < nyk) {
+            const F4 *ys = ystage4 + par * kYs4;
             const int jr = t >> 6, c4 = t & 63;
-            F4 v = ystage4[(0 * nyk + jr) * 64 + c4];
+            F4 v = ys[(0 * nyk + jr) * 64 + c4];
 #pragma unroll
-            for (int q = 1; q < 4; q++) v = v + ystage4[(q * nyk + jr) * 64 + c4];
+            for (int q = 1; q < 4; q++) v = v + ys[(q * nyk + jr) * 64 + c4];
             *reinterpret_cast<F4 *>(ybase + (int64_t)zl * ystride + foff) = v;
         } else if (w == 8) {
             // lanes u and u + 32 each add up eight of the sixteen waves' partial sums, the halves meet across the wave
+            const F4 *xs = stage4 + par * kXs4;
             const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, half8 = (t >> 5) & 1;
-            F4 v = stage4[(8 * half8) * nxk * (kRows / 4) + u];
+            F4 v = xs[(8 * half8) * nxk * (kRows / 4) + u];
 #pragma unroll
-            for (int p = 1; p < 8; p++) v = v + stage4[(8 * half8 + p) * nxk * (kRows / 4) + u];
+            for (int p = 1; p < 8; p++) v = v + xs[(8 * half8 + p) * nxk * (kRows / 4) + u];
 #pragma unroll
             for (int i = 0; i < 4; i++) v[i] = sum_lanes_xor_32(v[i]);
             if ((t & 63) < nxk * (kRows / 4)) *reinterpret_cast<F4 *>(xbase + (int64_t)zl * xstride + foff) = v;
         }
     };
 
-    auto step = [&](int z, F4 &p0, F4 &p1, auto load_tag) {
+    // plane zn (in the registers p0, p1) -> patch buffer `par` + its z products; `between`: what the caller wants issued behind
+    // the wait for the plane's pixels and in front of the next request (the flush: the flushing waves' store is then never the
+    // youngest operation their next wait has to count); LOAD: request plane zn + 2 into the same registers
+    auto put = [&](int zn, int par, F4 &p0, F4 &p1, auto load_tag, auto between) {
         constexpr bool LOAD = decltype(load_tag)::value;
-        __syncthreads();                                             // plane z - 1: readers done, its stages complete
         const F4 v0 = p0, v1 = p1;
-        tile4[rg * kPitch4 + cc] = v0;
-        tile4[(rg + 16) * kPitch4 + cc] = v1;
-        // (behind the wait for this plane's pixels and in front of the next request: the flushing waves' store is then never
-        //  the youngest operation their next wait has to count)
-        if (z > 0) flush(z - 1);
-        {
-            // z tails: block = four adjacent chunks of the row; A = the lane's own sample, B = Hz[tail j4][z]
-            const float hz = hzp[4 * z];                          // (zero for a tail that does not exist: the table is padded)
+        F4 *tl = tile4 + par * kTile4;
+        tl[rg * kPitch4 + cc] = v0;
+        tl[(rg + 16) * kPitch4 + cc] = v1;
+        between();
+        // z tails: block = four adjacent chunks of the row; A = the lane's own sample, B = Hz[tail j4][zn]
+        const float hz = hzp[4 * zn];                              // (zero for a tail that does not exist: the table is padded)
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                zacc[0][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0[e], hz, zacc[0][e], 0, 0, 0);
-                zacc[1][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1[e], hz, zacc[1][e], 0, 0, 0);
-            }
+        for (int e = 0; e < 4; e++) {
+            zacc[0][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v0[e], hz, zacc[0][e], 0, 0, 0);
+            zacc[1][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v1[e], hz, zacc[1][e], 0, 0, 0);
         }
         if constexpr (LOAD) {
-            const char *lp = spb + (int64_t)(z + D) * plane_bytes;        // (wave-uniform: scalar base + lane offset)
+            const char *lp = spb + (int64_t)(zn + 2) * plane_bytes;       // (wave-uniform: scalar base + lane offset)
             p0 = ld(lp, off0);
             p1 = ld(lp, off1);
         }
-        __syncthreads();
+    };
 
+    // the x and y tails of the plane in patch buffer `par` -> the stages of that parity
+    auto contract = [&](int par) {
+        const F4 *tl = tile4 + par * kTile4;
+        const float *tlf = reinterpret_cast<const float *>(tl);
         // ---- x tails: 32 rows x this wave's 16 columns ----
         {
+            F4 *xs = stage4 + par * kXs4;
             F4 av[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) av[mi] = tile4[xrow * kPitch4 + 4 * w + 2 * xhf + mi];
+            for (int mi = 0; mi < 2; mi++) av[mi] = tl[xrow * kPitch4 + 4 * w + 2 * xhf + mi];
 #pragma unroll
             for (int g = 0; g < NGX; g++) {
                 const F4 b0 = hx_b[(((g * 16 + w) * 2 + xhf) * 4 + j4) * 2], b1 = hx_b[(((g * 16 + w) * 2 + xhf) * 4 + j4) * 2 + 1];
@@ -200,14 +210,15 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
                 for (int i = 0; i < 4; i++) dsum[i] = sum_lanes_xor_32(dsum[i]);       // the two column halves
                 // lane 4 rg' + j (lanes 0..31), register i: row 4 rg' + i of tail 4 g + j, this wave's sixteen columns
                 const int sr = 4 * g + j4;
-                if (xhf == 0 && sr < nxk) stage4[((w * nxk + sr) * kRows >> 2) + (lane >> 2)] = dsum;
+                if (xhf == 0 && sr < nxk) xs[((w * nxk + sr) * kRows >> 2) + (lane >> 2)] = dsum;
             }
         }
         // ---- y tails: eight rows of column yc; lane 4 b + j ends up with tail j of the block's four columns ----
         {
+            F4 *ys = ystage4 + par * kYs4;
             float col[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) col[i] = tile[(8 * yq + i) * (kPitch4 * 4) + yc];
+            for (int i = 0; i < 8; i++) col[i] = tlf[(8 * yq + i) * (kPitch4 * 4) + yc];
 #pragma unroll
             for (int g = 0; g < NGY; g++) {
                 const F4 b0 = hy_b[((g * 4 + yq) * 4 + j4) * 2], b1 = hy_b[((g * 4 + yq) * 4 + j4) * 2 + 1];
@@ -218,21 +229,37 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
                     acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(col[4 + i], b1[i], acc1, 0, 0, 0);
                 }
                 const int jr = 4 * g + j4;
-                if (jr < nyk) ystage4[(yq * nyk + jr) * 64 + (yc >> 2)] = acc0 + acc1;
+                if (jr < nyk) ys[(yq * nyk + jr) * 64 + (yc >> 2)] = acc0 + acc1;
             }
         }
     };
 
-    __syncthreads();                                                 // hz_lds
+    // One step = one plane z (parity par): contract it out of its patch buffer into the stages of its parity; flush plane z - 1
+    // out of the other stages; put plane z + 1 into the other patch buffer.  Everything a step writes was last read in the
+    // step before: one barrier per step.
+    auto step = [&](int z, int par, F4 &p0, F4 &p1, auto write_tag, auto load_tag) {
+        contract(par);
+        if constexpr (decltype(write_tag)::value) put(z + 1, par ^ 1, p0, p1, load_tag, [&] { if (z > 0) flush(z - 1, par ^ 1); });
+        else if (z > 0) flush(z - 1, par ^ 1);
+        __syncthreads();
+    };
+    const std::true_type yes{};
+    const std::false_type no{};
+
+    __syncthreads();                                                 // Hz and the B operands are in LDS
+    put(0, 0, pre[0][0], pre[0][1], yes, [] {});
+    __syncthreads();                                                 // plane 0
+    // planes 0 .. TZ - 5 request a further plane; TZ is a multiple of 32
 #pragma unroll 1
-    for (int z0 = 0; z0 < TZ - D; z0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; d++) step(z0 + d, pre[d][0], pre[d][1], std::true_type{});
+    for (int z0 = 0; z0 < TZ - 4; z0 += 2) {
+        step(z0, 0, pre[1][0], pre[1][1], yes, yes);
+        step(z0 + 1, 1, pre[0][0], pre[0][1], yes, yes);
     }
-#pragma unroll
-    for (int d = 0; d < D; d++) step(TZ - D + d, pre[d][0], pre[d][1], std::false_type{});
-    __syncthreads();
-    flush(TZ - 1);
+    step(TZ - 4, 0, pre[1][0], pre[1][1], yes, yes);                 // puts plane TZ - 3, requests plane TZ - 1
+    step(TZ - 3, 1, pre[0][0], pre[0][1], yes, no);                  // puts plane TZ - 2
+    step(TZ - 2, 0, pre[1][0], pre[1][1], yes, no);                  // puts plane TZ - 1
+    step(TZ - 1, 1, pre[0][0], pre[0][1], no, no);
+    flush(TZ - 1, 1);
 
     // z tails of the patch: [s][tz][r][line], line = y * NX + x (StridedArgs::tails); lane 4 b + j stores tail j of the block's
     // sixteen columns
@@ -277,17 +304,24 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
     if ((int64_t)a.MY * parts > 65535 || wa.MZ > 65535) { set_error("walk tails: grid too large"); return RF_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)a.MX, (unsigned)(a.MY * parts), (unsigned)wa.MZ);
     const int nxk = a.nx * K, nyk = a.ny * K;
-    const size_t lds = ((size_t)16 * nxk * kRows + (size_t)4 * nyk * kFusedTX + (size_t)4 * 128 + (size_t)((nxk + 3) / 4) * 1024 + (size_t)((nyk + 3) / 4) * 128) * sizeof(float);
-    static const int depth = RF_KNOB("RF_WALK_DEPTH") ? atoi(RF_KNOB("RF_WALK_DEPTH")) : 4;      // A/B: planes in flight
-#define RF_CASE(KK, XX, DD)                                                                                                \
-    if (K == KK && a.nx == XX && depth == DD) {                                                                            \
-        hipLaunchKernelGGL((walk_tails_kernel<KK, XX, XX, DD>), grid, dim3(kWalkThreads), lds, stream, src, a, wa, Hx, Hy, wa.HzT); \
+    const size_t lds = ((size_t)2 * kRows * kPitch4 * 4 + (size_t)2 * 16 * nxk * kRows + (size_t)2 * 4 * nyk * kFusedTX + (size_t)4 * 128 +
+                        (size_t)((nxk + 3) / 4) * 1024 + (size_t)((nyk + 3) / 4) * 128) * sizeof(float);
+    int dev = 0;
+    RF_HIP_CHECK(hipGetDevice(&dev));
+#define RF_CASE(KK, XX)                                                                                                    \
+    if (K == KK && a.nx == XX) {                                                                                           \
+        auto kern = walk_tails_kernel<KK, XX, XX>;                                                                         \
+        static std::atomic<bool> opted[64];                                                                                \
+        std::atomic<bool> &done = opted[dev & 63];                                                                         \
+        if (!done.load(std::memory_order_acquire)) {        /* more than 64 KiB of dynamic LDS: opt in, once per kernel and device */ \
+            RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            done.store(true, std::memory_order_release);                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, dim3(kWalkThreads), lds, stream, src, a, wa, Hx, Hy, wa.HzT);                        \
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }
-#define RF_CASES(KK, XX) RF_CASE(KK, XX, 4) RF_CASE(KK, XX, 2)
-    RF_CASES(2, 2) RF_CASES(2, 1) RF_CASES(1, 2) RF_CASES(1, 1)
-#undef RF_CASES
+    RF_CASE(2, 2) RF_CASE(2, 1) RF_CASE(1, 2) RF_CASE(1, 1)
 #undef RF_CASE
     set_error("walk tails: unsupported order %d / %d scans / %d z tails", K, a.nx, wa.nzk);
     return RF_ERR_UNSUPPORTED;
