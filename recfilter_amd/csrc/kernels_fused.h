@@ -102,6 +102,12 @@ struct FusedArgs {
     // [ty][z*MX + tx][j][r][256] -- every tile owns one contiguous block of ny*K KiB (what pass 1 writes and pass 2 reads in
     // one piece; pass 1 is sensitive to how its tail stores reach memory).  Row shards keep layout 0.
     int32_t yt_tile_major;
+    // The combined rows of pass 1 arrive in `yt_parts` parts (kernels_tails_walk.hip: a y tile is several 32-row patches, each
+    // the work of its own workgroup): part p of element e is ytp[p * yt_part_stride + e] in the layout of yt, and
+    // xscan_rows_kernel adds the parts up as it loads a row (it stores to yt).  0 / 1: the rows are in yt.
+    int32_t yt_parts;
+    int64_t yt_part_stride;
+    const Acc *ytp;
     // A long 1-D signal folded into rows whose length is not a whole number of rows (plan_fused.cpp, "chained rows"): the
     // image the kernels see is the signal followed by zeros, but only its first lin_limit samples exist in the caller's
     // buffers -- loads beyond them yield zeros, stores beyond them are dropped.  0: every sample of the image exists.
@@ -208,7 +214,6 @@ struct WalkArgs {
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows);
 int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const WalkArgs &wa, const float *Hx, const float *Hy,
                       hipStream_t stream);
-int launch_sum_parts(const float *parts, float *yt, int64_t n, int64_t stride, int n_parts, hipStream_t stream);
 // tile-local x scans of the combined rows + cross-dimension residual, in place in yt (G == nullptr: no residual)
 template <typename Acc>
 int launch_xscan_rows(int K, int TY, const FusedArgs<Acc> &a, const Acc *Hy, const Acc *G, hipStream_t stream,

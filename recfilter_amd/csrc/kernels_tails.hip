@@ -378,11 +378,30 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
     };
     A4 *yt4 = reinterpret_cast<A4 *>(a.yt);
     A4 tmp[4];
+    if (a.yt_parts <= 1) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int jr_i, tx_i;
-        tile_of(rg + 4 * i, jr_i, tx_i);
-        tmp[i] = (tx_i < a.MX) ? yt4[row_tile_index(jr_i, tx_i) * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+        for (int i = 0; i < 4; i++) {
+            int jr_i, tx_i;
+            tile_of(rg + 4 * i, jr_i, tx_i);
+            tmp[i] = (tx_i < a.MX) ? yt4[row_tile_index(jr_i, tx_i) * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+        }
+    } else {
+        // the combined rows come in parts (FusedArgs::yt_parts; whole tiles only): add them up
+        const A4 *p4 = reinterpret_cast<const A4 *>(a.ytp);
+        const int64_t stride4 = a.yt_part_stride >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int jr_i, tx_i;
+            tile_of(rg + 4 * i, jr_i, tx_i);
+            A4 v = A4{Acc(0), Acc(0), Acc(0), Acc(0)};
+            if (tx_i < a.MX) {
+                const int64_t e = row_tile_index(jr_i, tx_i) * 64 + cc;
+                v = p4[e];
+#pragma unroll 1
+                for (int p = 1; p < a.yt_parts; p++) v = v + p4[p * stride4 + e];
+            }
+            tmp[i] = v;
+        }
     }
     if constexpr (XC > 0) {
         const int64_t Lx = a.NYP * a.NZ;

@@ -10,7 +10,7 @@
 // goes through kernels_tails_mfma.hip's step: staged in LDS (XOR-swizzled rows), x tails on the matrix cores
 // (v_mfma_f32_4x4x1_16b_f32: wave = 64 columns x 16 rows x half of the column chunks), y tails by thread = (column, eight
 // rows).  A y tile of TY = 32 * parts rows is `parts` patches, i.e. workgroups: each stores its PART of the combined rows
-// (ytp[part]), sum_parts_kernel adds them up in front of xscan_rows.
+// (ytp[part]); xscan_rows_kernel, the next reader of the rows, adds the parts up as it loads them (FusedArgs::yt_parts).
 // One workgroup per CU (16 waves); D planes of a thread's loads in flight.  20 B per sample instead of 24.
 #include <atomic>
 #include <cstdlib>
@@ -275,15 +275,6 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     }
 }
 
-// yt = sum of the parts of the combined rows (16 bytes per thread)
-__global__ void __launch_bounds__(256) sum_parts_kernel(const F4 *__restrict__ parts, F4 *__restrict__ yt, int64_t n4, int64_t stride4, int n_parts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    F4 v = __builtin_nontemporal_load(parts + i);
-    for (int p = 1; p < n_parts; p++) v = v + __builtin_nontemporal_load(parts + p * stride4 + i);
-    yt[i] = v;
-}
-
 }  // namespace
 
 // When pass 1 of a 3-D plan walks: f32 volumes of whole tiles (width % 256, height % TY, depth % TZ), unsharded, no pointwise
@@ -325,15 +316,6 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
 #undef RF_CASE
     set_error("walk tails: unsupported order %d / %d scans / %d z tails", K, a.nx, wa.nzk);
     return RF_ERR_UNSUPPORTED;
-}
-
-int launch_sum_parts(const float *parts, float *yt, int64_t n, int64_t stride, int n_parts, hipStream_t stream) {
-    if (n <= 0) return RF_OK;
-    const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const F4 *>(parts), reinterpret_cast<F4 *>(yt), n4, stride / 4, n_parts);
-    RF_HIP_CHECK(hipGetLastError());
-    return RF_OK;
 }
 
 }  // namespace rf

@@ -361,6 +361,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                                Ly == NXP * (int64_t)NZ;
     fbase.yt_tile_major = yt_tile_major ? 1 : 0;
     fbase.lin_limit = in_place_tail ? dx.N : 0;
+    if constexpr (std::is_same<P, float>::value) {
+        // (pass 1 left the combined rows in parts: xscan_rows adds them up)
+        if (walk && walk_args.ytp) { fbase.yt_parts = TY / 32; fbase.yt_part_stride = walk_args.part_stride; fbase.ytp = walk_args.ytp; }
+    }
     std::memset(fbase.xs, 0, sizeof(fbase.xs));
     std::memset(fbase.ys, 0, sizeof(fbase.ys));
     for (int s = 0; s < nx; s++) fbase.xs[s] = hxs[s];
@@ -458,16 +462,6 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         plan->begin_steps.push_back(ci);
     }
     plan->begin_steps.push_back(p1);
-    if (walk && walk_args.ytp) {
-        Step sp;
-        sp.name = "sum_parts";
-        sp.run = [plan, fargs, walk_args, yt_pp, TY](int pl) {
-            if constexpr (std::is_same<P, float>::value)
-                return launch_sum_parts(walk_args.ytp, (float *)fargs(pl).yt, (int64_t)yt_pp, (int64_t)yt_pp, TY / 32, plan->stream);
-            else return (int)RF_OK;
-        };
-        plan->begin_steps.push_back(sp);
-    }
     if (nx > 0 && !chained && !merged_cx) {
         Step cx;
         cx.name = "carry_x";

@@ -1,0 +1,122 @@
+"""GPU parity of pass 1 in one read of a 3-D volume (recfilter_amd/csrc/kernels_tails_walk.hip): the plan whose first pass
+forms the x, y AND z tails (the z operators commuted in front of the x/y filter) against the CPU oracle and against the
+plan that keeps the two first passes (RF_PLAN_STAGED_PASS1), through the C ABI.  Reference semantics: the scan loops of
+lib/recfilter.cpp:302-343 (the oracle), tiling algebra lib/split.cpp:256-499, 1008-1130."""
+import numpy as np
+import pytest
+
+import oracle
+import ref_cases as rc
+
+pytestmark = pytest.mark.gpu
+
+XYZ = rc.REFERENCE_TESTS["test_generic_xyz"]["scans"]
+ORDER1 = [(0, True, [0.4, 0.6]), (0, False, [0.5, 0.5]), (1, True, [0.3, 0.7]), (1, False, [0.45, 0.55]),
+          (2, True, [0.5, 0.5]), (2, False, [0.6, 0.4])]
+ONE_EACH = [(0, True, [1.0, 0.5, 0.25]), (1, False, [1.0, 0.5, 0.125]), (2, True, [1.0, 0.5, 0.0625])]
+Z_MIXED = XYZ[:4] + [(2, True, [1.0, 0.5, 0.25]), (2, False, [0.7, 0.3])]
+Z_ORDER1 = XYZ[:4] + [(2, True, [0.5, 0.5]), (2, False, [0.7, 0.3])]
+XY_ORDER1_Z2 = ORDER1[:4] + XYZ[4:]
+
+
+def _cases():
+    from recfilter_amd import capi
+    return {
+        "xyz_zero": ((64, 64, 256), XYZ, False, 0),
+        "xyz_clamped_two_tile_columns": ((64, 96, 512), XYZ, True, 0),
+        "two_patches_per_y_tile": ((64, 128, 256), XYZ, False, capi.RF_PLAN_TILE_ROWS(64)),
+        "four_patches_per_y_tile_clamped": ((32, 256, 512), XYZ, True, capi.RF_PLAN_TILE_ROWS(128)),
+        "two_z_tiles_clamped": ((128, 64, 256), XYZ, True, capi.RF_PLAN_TILE_PLANES(64)),
+        "three_z_tiles_of_32": ((96, 64, 256), ORDER1, True, 0),
+        "z_tile_128": ((256, 32, 256), XYZ, True, capi.RF_PLAN_TILE_PLANES(128)),
+        "one_scan_per_dimension": ((64, 64, 512), ONE_EACH, False, 0),
+        "z_orders_2_and_1": ((64, 64, 256), Z_MIXED, True, 0),
+        "z_order_1_under_xy_order_2": ((64, 64, 256), Z_ORDER1, True, 0),
+        "z_order_2_over_xy_order_1": ((64, 64, 256), XY_ORDER1_Z2, False, 0),
+    }
+
+
+CASE_NAMES = ["xyz_zero", "xyz_clamped_two_tile_columns", "two_patches_per_y_tile", "four_patches_per_y_tile_clamped",
+              "two_z_tiles_clamped", "three_z_tiles_of_32", "z_tile_128", "one_scan_per_dimension", "z_orders_2_and_1",
+              "z_order_1_under_xy_order_2", "z_order_2_over_xy_order_1"]
+
+
+def _run(shape, scans, clamped, flags, img, in_place=False):
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    x = torch.from_numpy(img).cuda()
+    out = x if in_place else torch.empty_like(x)
+    with rfa.Plan(shape, scans, clamped=clamped, flags=flags, path=capi.RF_PATH_TILED_FUSED) as plan:
+        _, timed = plan.execute_timed([x], [out])
+        torch.cuda.synchronize()
+        if in_place:
+            x = torch.from_numpy(img).cuda()
+            out = x
+        plan.execute([x], [out])
+        torch.cuda.synchronize()
+    return out.cpu().numpy(), [k for k, _ in timed]
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_one_read_pass1_against_oracle_and_staged_plan(name):
+    from recfilter_amd import capi
+    shape, scans, clamped, flags = _cases()[name]
+    img = np.random.default_rng(11).random(shape, dtype=np.float32)
+    want = oracle.apply_filter(img.astype(np.float64), scans, clamped)
+    got, steps = _run(shape, scans, clamped, flags, img)
+    assert "walk_tails" in steps and "carry_planes_xy" in steps and "strided_pass1_z" not in steps, steps
+    staged, steps_staged = _run(shape, scans, clamped, flags | capi.RF_PLAN_STAGED_PASS1, img)
+    assert "walk_tails" not in steps_staged and "strided_pass1_z" in steps_staged, steps_staged
+    # tolerance: f32 arithmetic in a different summation order than the oracle's f64 loops (1e-4 strict; here the
+    # looser-to-fail max-norm bar at 2e-6, what the staged plan itself reaches)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() / scale < 2e-6
+    assert np.abs(staged - want).max() / scale < 2e-6
+    assert rc.rel_err_strict(got, want) < 1e-4
+
+
+def test_one_read_pass1_in_place():
+    shape, scans, clamped, flags = _cases()["four_patches_per_y_tile_clamped"]
+    img = np.random.default_rng(12).random(shape, dtype=np.float32)
+    want = oracle.apply_filter(img.astype(np.float64), scans, clamped)
+    got, steps = _run(shape, scans, clamped, flags, img, in_place=True)
+    assert "walk_tails" in steps
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
+
+
+@pytest.mark.parametrize("what", ["int32", "partial_tile_rows", "prologue", "planes"])
+def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
+    """Integer pixels, a height that is not whole tiles, a pointwise stage, Tuple planes: the z stage runs its own first pass."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    kw = dict(clamped=False, path=capi.RF_PATH_TILED_FUSED)
+    shape, dtype, planes = (64, 64, 256), np.float32, 1
+    if what == "int32":
+        dtype = np.int32
+        scans = [(0, True, [1, 1]), (1, True, [1, 1]), (2, True, [1, 1])]
+    else:
+        scans = XYZ
+    if what == "partial_tile_rows":
+        shape = (64, 80, 256)
+    if what == "prologue":
+        kw["prologue"] = (0.5, 0.25)
+    if what == "planes":
+        planes = 2
+    rng = np.random.default_rng(13)
+    imgs = [(rng.integers(0, 5, shape).astype(dtype) if dtype == np.int32 else rng.random(shape, dtype=np.float32)) for _ in range(planes)]
+    xs = [torch.from_numpy(im).cuda() for im in imgs]
+    outs = [torch.empty_like(x) for x in xs]
+    with rfa.Plan(shape, scans, dtype=dtype, planes=planes, **kw) as plan:
+        _, timed = plan.execute_timed(xs, outs)
+        torch.cuda.synchronize()
+    steps = [k for k, _ in timed]
+    assert "walk_tails" not in steps and "strided_pass1_z" in steps, steps
+    for im, out in zip(imgs, outs):
+        src = im.astype(np.float64) * 0.5 + 0.25 if what == "prologue" else im
+        if dtype == np.int32:
+            np.testing.assert_array_equal(out.cpu().numpy(), oracle.apply_filter(src, scans, False))
+        else:
+            want = oracle.apply_filter(src.astype(np.float64), scans, False)
+            assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6

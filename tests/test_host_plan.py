@@ -491,3 +491,27 @@ def test_clamped_1d_border_correction_tables(seed):
             out[N - L:] += beta[s] * G[s]
     want = oracle.apply_filter(x, scans, clamped=True)
     assert np.max(np.abs(out - want)) <= 1e-11 * np.max(np.abs(want))
+
+
+def test_one_read_pass1_z_tail_responses_reproduce_the_tile_local_scans():
+    """kernels_tails_walk.hip contracts the planes of a z tile with the table H_z: for a one-tile extent it must give the
+    tails of the dimension's scans run on the column (the oracle's loops), clamped border included; a plan that keeps the
+    two first passes (RF_PLAN_STAGED_PASS1) or cannot take the kernel (integer pixels) has no such table."""
+    scans = rc.REFERENCE_TESTS["test_generic_xyz"]["scans"]
+    zs = [(0, c, co) for d, c, co in scans if d == 2]
+    rng = np.random.default_rng(3)
+    for clamped in (False, True):
+        p = _host_plan((64, 64, 256), scans, clamped=clamped, path=capi.RF_PATH_TILED_FUSED)
+        H = p.table("H_z").reshape(4, len(zs) * 2, 64)
+        col = rng.random(64)
+        y1 = oracle.apply_filter(col, zs[:1], clamped)
+        y2 = oracle.apply_filter(col, zs, clamped)
+        want = [y1[63], y1[62], y2[0], y2[1]]           # causal: the last samples; anticausal: the first
+        np.testing.assert_allclose(H[3] @ col, want, rtol=1e-12, atol=1e-12)
+        if not clamped:                                 # zero border: every variant is the interior one
+            np.testing.assert_allclose(H[0] @ col, want, rtol=1e-12, atol=1e-12)
+    with pytest.raises(Exception):
+        _host_plan((64, 64, 256), scans, path=capi.RF_PATH_TILED_FUSED, flags=capi.RF_PLAN_STAGED_PASS1).table("H_z")
+    with pytest.raises(Exception):
+        _host_plan((64, 64, 256), [(0, True, [1, 1]), (1, True, [1, 1]), (2, True, [1, 1])], dtype=np.int32,
+                   path=capi.RF_PATH_TILED_FUSED).table("H_z")
