@@ -124,6 +124,12 @@ typedef struct {
  *   RF_PLAN_MFMA_PASS1      pass 1 with its x-tail contraction on the matrix cores (kernels_tails_mfma.hip) wherever its
  *                           shape rules allow -- f32 images of whole tiles, at most two scans per dimension -- whatever
  *                           the order (default: orders 2 and 3).  The streaming kernel keeps what it takes.
+ *   RF_PLAN_WALK_PASS1      3-D: pass 1 reads the volume ONCE and forms the x, y and z tails together (the z operators commuted
+ *                           in front of the x/y filter, kernels_tails_walk.hip; 20 instead of 24 bytes per sample) wherever
+ *                           its shape rules allow -- unsharded f32 volumes of whole tiles, no pointwise stage, orders <= 2,
+ *                           one or two scans in each of the three dimensions -- whatever the size (default: volumes of at
+ *                           least 256 patches of 256 x 32 samples x one z tile, one per compute unit);
+ *                           RF_PLAN_STAGED_PASS1 keeps the two first passes of the x/y and z stages.
  *   RF_PLAN_LATE_EXCHANGE   a z-sharded volume exchanges the carries of the x/y-FILTERED data, after its x/y stage
  *                           (nothing runs beside the all-gather); default: the carries of the raw input first, the x/y
  *                           stage beside the all-gather (rf_plan_interior below).
@@ -144,7 +150,8 @@ typedef struct {
 #define RF_PLAN_LATE_EXCHANGE   0x80u
 #define RF_PLAN_SERIAL_UNTILED  0x01000000u
 #define RF_PLAN_MFMA_PASS1      0x02000000u
-#define RF_PLAN_ALL_FLAGS       0x030000ffu
+#define RF_PLAN_WALK_PASS1      0x04000000u
+#define RF_PLAN_ALL_FLAGS       0x070000ffu
 #define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
 #define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
 

@@ -32,6 +32,7 @@ RF_PLAN_FORCE_EXCHANGE, RF_PLAN_TILED_ONLY, RF_PLAN_NO_CASCADE, RF_PLAN_NO_SECTI
 RF_PLAN_NO_PLANE_BATCH, RF_PLAN_STREAM_PASS1, RF_PLAN_STAGED_PASS1, RF_PLAN_LATE_EXCHANGE = 0x10, 0x20, 0x40, 0x80
 RF_PLAN_SERIAL_UNTILED = 0x01000000
 RF_PLAN_MFMA_PASS1 = 0x02000000
+RF_PLAN_WALK_PASS1 = 0x04000000
 
 
 def RF_PLAN_TILE_ROWS(n: int) -> int:

@@ -293,7 +293,10 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // ---- 3-D volumes: pass 1 in ONE read (kernels_tails_walk.hip) ------------------------------------
     // The z tails are taken from the raw input by the pass that extracts the x/y tails (the z operators commute with the x/y
     // filter: plan_strided.h); the z stage then has no first pass.  Unsharded f32 volumes of whole tiles without pointwise
-    // stages; RF_PLAN_STAGED_PASS1 keeps the two first passes.
+    // stages, of at least one patch column (256 x 32 samples x one z tile: a workgroup of 1024 threads) per compute unit --
+    // measured, one read against two: 256^3 (32 patch columns) 0.214 against 0.124 ms, 512^3 (256) 0.645 against 0.680,
+    // 768^3 1.97 / 2.05, 1024^3 4.5 / 4.95, 2048^3 34.0 / 37.0 (profiles/r4/walk_tails_sizes.txt); RF_PLAN_WALK_PASS1: whatever
+    // the size; RF_PLAN_STAGED_PASS1 keeps the two first passes.
     WalkArgs walk_args{};
     std::shared_ptr<WalkHook> walk_hook;
     rf_plan *walk_child = nullptr;
@@ -305,7 +308,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             plan->dims[2].lines == NX * NY) {
             const DimInfo &dz = plan->dims[2];
             const int TZ = strided_tile(plan, 2), nz = (int)dz.scan_ids.size(), KZ = dz.k;
-            if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy)) {
+            const int64_t patch_columns = TZ > 0 ? (int64_t)MX * (NY / 32) * (dz.N / TZ) : 0;
+            if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy) &&
+                (patch_columns >= 256 || (plan->flags & RF_PLAN_WALK_PASS1))) {
                 const int MZ = (int)(dz.N / TZ);
                 walk_child = build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * MZ);
                 if (walk_child) {

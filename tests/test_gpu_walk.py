@@ -47,7 +47,8 @@ def _run(shape, scans, clamped, flags, img, in_place=False):
     from recfilter_amd import capi
     x = torch.from_numpy(img).cuda()
     out = x if in_place else torch.empty_like(x)
-    with rfa.Plan(shape, scans, clamped=clamped, flags=flags, path=capi.RF_PATH_TILED_FUSED) as plan:
+    with rfa.Plan(shape, scans, clamped=clamped, flags=flags | (0 if flags & capi.RF_PLAN_STAGED_PASS1 else capi.RF_PLAN_WALK_PASS1),
+                  path=capi.RF_PATH_TILED_FUSED) as plan:
         _, timed = plan.execute_timed([x], [out])
         torch.cuda.synchronize()
         if in_place:
@@ -85,7 +86,7 @@ def test_one_read_pass1_in_place():
     assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
 
 
-@pytest.mark.parametrize("what", ["int32", "partial_tile_rows", "prologue", "planes"])
+@pytest.mark.parametrize("what", ["int32", "partial_tile_rows", "prologue", "planes"])   # (asked for, refused by the shape rules)
 def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
     """Integer pixels, a height that is not whole tiles, a pointwise stage, Tuple planes: the z stage runs its own first pass."""
     import torch
@@ -108,7 +109,7 @@ def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
     imgs = [(rng.integers(0, 5, shape).astype(dtype) if dtype == np.int32 else rng.random(shape, dtype=np.float32)) for _ in range(planes)]
     xs = [torch.from_numpy(im).cuda() for im in imgs]
     outs = [torch.empty_like(x) for x in xs]
-    with rfa.Plan(shape, scans, dtype=dtype, planes=planes, **kw) as plan:
+    with rfa.Plan(shape, scans, dtype=dtype, planes=planes, flags=capi.RF_PLAN_WALK_PASS1, **kw) as plan:
         _, timed = plan.execute_timed(xs, outs)
         torch.cuda.synchronize()
     steps = [k for k, _ in timed]
@@ -120,3 +121,25 @@ def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
         else:
             want = oracle.apply_filter(src.astype(np.float64), scans, False)
             assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6
+
+
+def test_one_read_pass1_is_the_default_from_256_patch_columns_on():
+    """Default choice (no flag): 512^3 / 4 = 128 x 512 x 512 has 2 x 16 x 2 = 64 patch columns -> two first passes; 512 x 512 x
+    512 has 256 -> one read.  Both against the oracle on a z slab (the whole volume's f64 reference is not needed twice)."""
+    import torch
+    import recfilter_amd as rfa
+    rng = np.random.default_rng(14)
+    for shape, expect in (((128, 512, 512), False), ((512, 512, 512), True)):
+        x = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
+        with rfa.Plan(shape, XYZ) as plan:
+            out, timed = plan.execute_timed([x])
+            torch.cuda.synchronize()
+        steps = [k for k, _ in timed]
+        assert ("walk_tails" in steps) == expect, (shape, steps)
+        if not expect:
+            want = oracle.apply_filter(x.cpu().numpy().astype(np.float64), XYZ, False)
+            assert rc.rel_err_strict(out[0].cpu().numpy(), want) < 1e-4
+        else:
+            import os
+            want = oracle.apply_filter(x.cpu().numpy().astype(np.float64), XYZ, False, threads=min(16, os.cpu_count() or 1))
+            assert rc.rel_err_strict(out[0].cpu().numpy(), want) < 1e-4

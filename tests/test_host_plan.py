@@ -501,7 +501,7 @@ def test_one_read_pass1_z_tail_responses_reproduce_the_tile_local_scans():
     zs = [(0, c, co) for d, c, co in scans if d == 2]
     rng = np.random.default_rng(3)
     for clamped in (False, True):
-        p = _host_plan((64, 64, 256), scans, clamped=clamped, path=capi.RF_PATH_TILED_FUSED)
+        p = _host_plan((64, 64, 256), scans, clamped=clamped, path=capi.RF_PATH_TILED_FUSED, flags=capi.RF_PLAN_WALK_PASS1)
         H = p.table("H_z").reshape(4, len(zs) * 2, 64)
         col = rng.random(64)
         y1 = oracle.apply_filter(col, zs[:1], clamped)
@@ -514,4 +514,7 @@ def test_one_read_pass1_z_tail_responses_reproduce_the_tile_local_scans():
         _host_plan((64, 64, 256), scans, path=capi.RF_PATH_TILED_FUSED, flags=capi.RF_PLAN_STAGED_PASS1).table("H_z")
     with pytest.raises(Exception):
         _host_plan((64, 64, 256), [(0, True, [1, 1]), (1, True, [1, 1]), (2, True, [1, 1])], dtype=np.int32,
-                   path=capi.RF_PATH_TILED_FUSED).table("H_z")
+                   path=capi.RF_PATH_TILED_FUSED, flags=capi.RF_PLAN_WALK_PASS1).table("H_z")
+    with pytest.raises(Exception):                      # 32 patch columns: not the default choice
+        _host_plan((64, 64, 256), scans, path=capi.RF_PATH_TILED_FUSED).table("H_z")
+    assert _host_plan((512, 512, 512), scans).table("H_z").size == 4 * 4 * 64

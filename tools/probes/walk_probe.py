@@ -32,7 +32,7 @@ def check():
         x = torch.from_numpy(img).cuda()
         outs = []
         for fl in (flags, flags | capi.RF_PLAN_STAGED_PASS1):
-            plan = rfa.Plan(shape, scans, clamped=clamped, flags=fl, path=capi.RF_PATH_TILED_FUSED)
+            plan = rfa.Plan(shape, scans, clamped=clamped, flags=fl | (0 if fl & capi.RF_PLAN_STAGED_PASS1 else capi.RF_PLAN_WALK_PASS1), path=capi.RF_PATH_TILED_FUSED)
             out = torch.empty_like(x)
             plan.execute([x], [out]); torch.cuda.synchronize()
             outs.append((out.cpu().numpy(), None))
@@ -52,7 +52,7 @@ def check():
 def timeit(n, shape=None):
     shape = shape or (n, n, n)
     x = torch.rand(shape, device="cuda"); out = torch.empty_like(x)
-    for label, fl in (("staged", capi.RF_PLAN_STAGED_PASS1), ("walk", 0), ("staged", capi.RF_PLAN_STAGED_PASS1), ("walk", 0)):
+    for label, fl in (("staged", capi.RF_PLAN_STAGED_PASS1), ("walk", capi.RF_PLAN_WALK_PASS1), ("staged", capi.RF_PLAN_STAGED_PASS1), ("walk", capi.RF_PLAN_WALK_PASS1)):
         plan = rfa.Plan(shape, XYZ, clamped=False, flags=fl)
         for _ in range(2): plan.execute([x], [out])
         torch.cuda.synchronize()
