@@ -209,6 +209,7 @@ struct WalkArgs {
     const float *HzT;        // impulse responses of the z tails, [variant][z][4]
     int32_t TY, TZ, MZ;      // rows of a y tile (32 * parts), planes of a z tile, z tiles
     int32_t parts_log2;      // log2(TY / 32)
+    int32_t z_first_border, z_last_border;      // the slab holds the volume's first / last z tile
     int32_t nzk, KZ;         // z tails per sample (= scans along z * KZ), order of the z scans
 };
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows);

@@ -70,7 +70,7 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     const int TZ = wa.TZ;
     const int vx = (tx == 0 ? 1 : 0) | (tx == a.MX - 1 ? 2 : 0);
     const int vy = (ty == 0 ? 1 : 0) | (ty == a.MY - 1 ? 2 : 0);
-    const int vz = (tz == 0 ? 1 : 0) | (tz == wa.MZ - 1 ? 2 : 0);
+    const int vz = ((tz == 0 && wa.z_first_border) ? 1 : 0) | ((tz == wa.MZ - 1 && wa.z_last_border) ? 2 : 0);
     const int64_t Lx = a.NYP * a.NZ;
 
     const int cc = t & 63, rg = t >> 6;                              // load: 16-byte chunk, row (and row + 16)
@@ -277,7 +277,7 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
 
 }  // namespace
 
-// When pass 1 of a 3-D plan walks: f32 volumes of whole tiles (width % 256, height % TY, depth % TZ), unsharded, no pointwise
+// When pass 1 of a 3-D plan walks: f32 volumes of whole tiles (width % 256, height % TY, depth % TZ; z slabs too), no pointwise
 // stage, x, y and z scans all present, orders <= 2, at most two scans per dimension.
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows) {
     if (K < 1 || K > 2 || KZ < 1 || KZ > 2) return false;

@@ -303,7 +303,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     if constexpr (std::is_same<P, float>::value) {
         static const char *walk_knob = RF_KNOB("RF_WALK");                        // A/B: 0 = never
         const bool wanted = !(plan->flags & RF_PLAN_STAGED_PASS1) && !(walk_knob && atoi(walk_knob) == 0);
-        if (wanted && plan->ndim == 3 && !plan->sharded() && plan->n_planes == 1 && !batch && !chained && !plan->mod_form &&
+        const bool z_slabs = plan->sharded();           // z slabs: with the early exchange (plan_strided.h), whose first step this pass then is
+        if (wanted && plan->ndim == 3 && (!z_slabs || early_exchange_possible<P>(plan, 2, desc)) && plan->n_planes == 1 && !batch && !chained && !plan->mod_form &&
             !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&
             plan->dims[2].lines == NX * NY) {
             const DimInfo &dz = plan->dims[2];
@@ -312,7 +313,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy) &&
                 (patch_columns >= 256 || (plan->flags & RF_PLAN_WALK_PASS1))) {
                 const int MZ = (int)(dz.N / TZ);
-                walk_child = build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * MZ);
+                walk_child = build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * (MZ + (z_slabs ? 1 : 0)));
                 if (walk_child) {
                     // impulse responses of the z tails, transposed: [variant][z][4]
                     std::vector<S> H = build_tail_responses<S>(table_scans(dz.scan_ids), KZ, TZ, plan->clamped);
@@ -328,6 +329,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                     walk_args.HzT = (const float *)plan->upload(hHz.data(), hHz.size() * sizeof(float), &status);
                     walk_args.TY = TY; walk_args.TZ = TZ; walk_args.MZ = MZ; walk_args.nzk = nz * KZ; walk_args.KZ = KZ;
                     walk_args.parts_log2 = parts == 4 ? 2 : parts == 2 ? 1 : 0;
+                    walk_args.z_first_border = (!z_slabs || plan->shard_rank == 0) ? 1 : 0;
+                    walk_args.z_last_border = (!z_slabs || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
                     walk_args.part_stride = (int64_t)yt_pp;
                     walk_args.ytp = parts > 1 ? (float *)plan->alloc(yt_pp * parts * sizeof(float), false, &status) : nullptr;
                     walk_hook = std::make_shared<WalkHook>();

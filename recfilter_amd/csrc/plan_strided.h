@@ -54,6 +54,17 @@ inline rf_plan *build_carry_planes_plan(const rf_plan *plan, const rf_filter_des
     return child;
 }
 
+// Whether dimension d of a sharded plan takes the early exchange (below), before the helper plan has been tried.
+template <typename P>
+inline bool early_exchange_possible(const rf_plan *plan, int d, const rf_filter_desc *desc) {
+    using Acc = typename PixelTraits<P>::Acc;
+    const DimInfo &di = plan->dims[d];
+    return d == plan->ndim - 1 && plan->sharded() && desc != nullptr && d == 2 &&
+           merged_exchange_applies((int)di.scan_ids.size(), di.k, plan->shard_world) && !plan->pw.pre && !plan->pw.post &&
+           !plan->pw.in_u8 && !(plan->flags & RF_PLAN_LATE_EXCHANGE) && di.lines == plan->dims[0].N * plan->dims[1].N &&
+           sizeof(P) == sizeof(Acc);      // (the carry planes are filtered as pixels: f32 / i32)
+}
+
 // Early exchange (a z-sharded volume whose x/y stage precedes this dimension).  The operators of this dimension -- tail
 // extraction, carry recurrence, the correction by the entering carries -- act along z alone and identically on every
 // (x, y) line; the x/y filter F acts on every z plane alone and identically: they commute, borders included (everything
@@ -142,15 +153,14 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
         d_Apow = (const Acc *)plan->upload(hApow.data(), hApow.size() * sizeof(Acc), &status);
     }
     const size_t tails_pp = (size_t)n * M * K * di.lines, inc_pp = (size_t)n * K * di.lines;
-    bool early = sharded && !from_input && desc != nullptr && xy_begin != (size_t)-1 && d == 2 &&
-                 merged_exchange_applies(n, K, plan->shard_world) && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 &&
-                 !(plan->flags & RF_PLAN_LATE_EXCHANGE) && di.lines == plan->dims[0].N * plan->dims[1].N &&
-                 sizeof(P) == sizeof(Acc);      // (the carry planes are filtered as pixels: f32 / i32)
+    bool early = sharded && !from_input && xy_begin != (size_t)-1 && early_exchange_possible<P>(plan, d, desc);
     // The early exchange needs a helper plan: F over the carry planes = the x/y scans of this filter on a volume of
     // (tiles + 1) * scans * k planes, in place.  It is built BEFORE anything of the early layout is committed: a helper that
     // cannot be built (unsupported shape, out of memory) leaves the plan on the late exchange instead of failing it.
+    // (a sharded plan whose pass 1 walks has had both checked by its builder: its helper is `walk_child`)
     rf_plan *child = walk ? walk_child : nullptr;
-    if (early) {
+    if (walk && sharded && !early) { set_error("one-read pass 1 of a sharded volume needs the early exchange"); return RF_ERR_UNSUPPORTED; }
+    if (early && !walk) {
         child = build_carry_planes_plan(plan, desc, d, (int64_t)n * K * (M + 1));
         if (!child) early = false;
     }
@@ -201,9 +211,11 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
         return launch_strided_pass<P>(false, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
     };
     if (early) {
-        // the x/y stage leaves the begin phase: it is what runs beside the all-gather
-        plan->interior_steps.assign(plan->begin_steps.begin() + (std::ptrdiff_t)xy_begin, plan->begin_steps.end());
-        plan->begin_steps.resize(xy_begin);
+        // the x/y stage leaves the begin phase: it is what runs beside the all-gather (all of it but a pass 1 that also forms
+        // this dimension's tails, which the exchange waits for)
+        const size_t keep = xy_begin + (walk ? 1 : 0);
+        plan->interior_steps.assign(plan->begin_steps.begin() + (std::ptrdiff_t)keep, plan->begin_steps.end());
+        plan->begin_steps.resize(keep);
     }
     if (!walk) plan->begin_steps.push_back(p1);
 

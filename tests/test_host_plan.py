@@ -518,3 +518,8 @@ def test_one_read_pass1_z_tail_responses_reproduce_the_tile_local_scans():
     with pytest.raises(Exception):                      # 32 patch columns: not the default choice
         _host_plan((64, 64, 256), scans, path=capi.RF_PATH_TILED_FUSED).table("H_z")
     assert _host_plan((512, 512, 512), scans).table("H_z").size == 4 * 4 * 64
+    # z slabs take the one-read pass 1 with the early exchange (it is then the step the exchange waits for), not with the late one
+    slab = dict(shard_rank=3, shard_world=8)
+    assert _host_plan((256, 1024, 1024), scans, **slab).table("H_z").size == 4 * 4 * 128
+    with pytest.raises(Exception):
+        _host_plan((256, 1024, 1024), scans, flags=capi.RF_PLAN_LATE_EXCHANGE, **slab).table("H_z")
