@@ -20,7 +20,7 @@ def width(q):
 
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes", "streams", "sections", "whole") else n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes", "streams", "sections", "whole", "walk") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), width(int(rng.integers(1, 2400))))
@@ -347,3 +347,59 @@ if len(sys.argv) > 3 and sys.argv[3] == "whole":
             print(f"{case:3d} {pf.path_name:13s} {str(shape):16s} x{planes} tiles={list(pf.tiles)} order={k} scans={len(scans)} clamped={int(clamped)} err={err:.3e}",
                   "" if err < 2e-4 else "  <-- CHECK", flush=True)
     print("worst (whole)", worst)
+
+# ---- volumes of whole tiles through the one-read pass 1 (kernels_tails_walk.hip): random tile heights / z tiles, orders 1..2 per
+# stage, one or two scans per dimension, both borders; whole volumes and z slabs (emulated ranks) against the untiled path ----
+if len(sys.argv) > 3 and sys.argv[3] == "walk":
+    worst = 0.0
+    for case in range(n_cases):
+        ty, tz = int(rng.choice([32, 64, 128])), int(rng.choice([32, 64, 128]))
+        world = int(rng.choice([1, 1, 2, 3]))
+        shape = (tz * int(rng.integers(1, 4)) * world, ty * int(rng.integers(1, 5)), 256 * int(rng.integers(1, 5)))
+        kxy, kz = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        scans = []
+        nxy = int(rng.integers(1, 3))
+        for d in range(3):
+            for _ in range(nxy if d < 2 else int(rng.integers(1, 3))):
+                k = kxy if d < 2 else kz
+                a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
+        clamped = bool(rng.integers(0, 2))
+        img = torch.rand(shape, device="cuda")
+        flags = rfa.capi.RF_PLAN_TILED_ONLY | rfa.capi.RF_PLAN_TILE_ROWS(ty) | rfa.capi.RF_PLAN_TILE_PLANES(tz) | rfa.capi.RF_PLAN_WALK_PASS1
+        with rfa.Plan(shape, scans, clamped=clamped, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
+            ou = pu.execute([img])[0]
+        of = torch.empty_like(img)
+        if world == 1:
+            with rfa.Plan(shape, scans, clamped=clamped, flags=flags) as pf:
+                _, timed = pf.execute_timed([img], [of])
+                names, tiles = [k_ for k_, _ in timed], list(pf.tiles)
+        else:
+            nz = shape[0] // world
+            plans = [rfa.Plan((nz,) + shape[1:], scans, clamped=clamped, flags=flags, shard_rank=r, shard_world=world) for r in range(world)]
+            tiles, names = list(plans[0].tiles), ["walk_tails" if plans[0].has_interior else "?"]
+            try:
+                plans[0].table("H_z")
+            except Exception:
+                names = ["(two first passes)"]
+            for r in range(world):
+                plans[r].begin([img[r * nz:(r + 1) * nz]], [of[r * nz:(r + 1) * nz]])
+            for e in range(plans[0].num_exchanges):
+                nb = plans[0].exchange_bytes(e)
+                gathered = torch.empty(world * nb, dtype=torch.uint8, device="cuda")
+                for r in range(world):
+                    plans[r].exchange_local(e, gathered.data_ptr() + r * nb)
+                for r in range(world):
+                    if e == plans[0].num_exchanges - 1 and plans[r].has_interior: plans[r].interior()
+                    plans[r].exchange_apply(e, gathered.data_ptr())
+            for r in range(world):
+                plans[r].finish()
+            for p_ in plans: p_.close()
+        torch.cuda.synchronize()
+        peak = float(ou.abs().max().item())
+        err = float(((of - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
+        worst = max(worst, err)
+        took = "walk" if "walk_tails" in names else "NOT TAKEN " + str(names[:2])
+        print(f"{case:3d} {str(shape):18s} world={world} tiles={tiles} orders={kxy}/{kz} scans={len(scans)} clamped={int(clamped)} {took} err={err:.3e}",
+              "" if err < 2e-4 else "  <-- CHECK", flush=True)
+    print("worst (walk)", worst)
