@@ -5,13 +5,21 @@
 // two writes of the volume, 24 B per sample.  The z operators commute with the x/y filter (plan_strided.h, "early form"), so
 // the z tails may be taken from the RAW volume, which pass 1 of the x/y stage reads anyway.  A z tail is a sum over the TZ
 // planes of a z tile, sum_z Hz[tail][z] * v(x, y, z): whoever forms it keeps n_z * k partial sums per (x, y) sample while it
-// walks the planes.  Here a workgroup of 1024 threads owns a patch of 256 x 32 samples and walks the TZ planes of one z tile:
-// eight samples and 8 * n_z * k accumulators per thread, the whole register file of a CU for one patch.  Per plane the patch
-// goes through kernels_tails_mfma.hip's step: staged in LDS (XOR-swizzled rows), x tails on the matrix cores
-// (v_mfma_f32_4x4x1_16b_f32: wave = 64 columns x 16 rows x half of the column chunks), y tails by thread = (column, eight
-// rows).  A y tile of TY = 32 * parts rows is `parts` patches, i.e. workgroups: each stores its PART of the combined rows
-// (ytp[part]); xscan_rows_kernel, the next reader of the rows, adds the parts up as it loads them (FusedArgs::yt_parts).
-// One workgroup per CU (16 waves); D planes of a thread's loads in flight.  20 B per sample instead of 24.
+// walks the planes.  Here a workgroup of 1024 threads -- ONE per CU, sixteen waves -- owns a patch of 256 x 32 samples and
+// walks the TZ planes of one z tile: eight samples and 32 accumulator registers per thread, a quarter of the CU's register
+// file for the patch.  Per plane (32 KiB) the patch is staged in LDS and three contractions run on the matrix cores
+// (v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products per issue, exact f32 fma chains; 24 per wave and plane):
+//   x tails   wave = 16 columns x 32 rows; block = (four rows, column half), A = pixel, B = Hx[tail j][column]; the two column
+//             halves meet through one v_permlane32_swap, the sixteen waves' partial sums through an LDS stage
+//   y tails   thread = (column, eight rows); block = four adjacent columns, B = Hy[tail j][row]; lane 4 b + j ends up with
+//             tail j of the block's four columns; the four row quarters meet through an LDS stage
+//   z tails   A = the lane's own sample, straight from the load registers, B = Hz[tail j][plane]; accumulators alive across
+//             the whole walk
+// (with the products on the vector ALU the kernel took as long as the two passes it replaces: NOTES.md, round 4).
+// A y tile of TY = 32 * parts rows is `parts` patches, i.e. workgroups: each stores its PART of the combined rows (ytp[part]);
+// xscan_rows_kernel, the next reader of the rows, adds the parts up as it loads them (FusedArgs::yt_parts).
+// Patch and stages are double-buffered by the plane's parity: one workgroup barrier per plane.  Two planes of a thread's loads
+// in flight (four: no faster).  20 B per sample instead of 24 (+ 1 B of parts).
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
