@@ -289,7 +289,7 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
 // stage, x, y and z scans all present, orders <= 2, at most two scans per dimension.
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows) {
     if (K < 1 || K > 2 || KZ < 1 || KZ > 2) return false;
-    if (nx < 1 || nx > 2 || ny != nx || nz < 1 || nz > 2) return false;
+    if (nx < 1 || nx > 2 || ny < 1 || ny > 2 || nz < 1 || nz > 2) return false;
     if (TY != 32 && TY != 64 && TY != 128) return false;
     if (TZ != 32 && TZ != 64 && TZ != 128) return false;
     if (last_cols != kFusedTX || last_rows != TY) return false;
@@ -307,9 +307,9 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
                         (size_t)((nxk + 3) / 4) * 1024 + (size_t)((nyk + 3) / 4) * 128) * sizeof(float);
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
-#define RF_CASE(KK, XX)                                                                                                    \
-    if (K == KK && a.nx == XX) {                                                                                           \
-        auto kern = walk_tails_kernel<KK, XX, XX>;                                                                         \
+#define RF_CASE(KK, XX, YY)                                                                                                \
+    if (K == KK && a.nx == XX && a.ny == YY) {                                                                             \
+        auto kern = walk_tails_kernel<KK, XX, YY>;                                                                         \
         static std::atomic<bool> opted[64];                                                                                \
         std::atomic<bool> &done = opted[dev & 63];                                                                         \
         if (!done.load(std::memory_order_acquire)) {        /* more than 64 KiB of dynamic LDS: opt in, once per kernel and device */ \
@@ -320,7 +320,7 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }
-    RF_CASE(2, 2) RF_CASE(2, 1) RF_CASE(1, 2) RF_CASE(1, 1)
+    RF_CASE(2, 2, 2) RF_CASE(2, 1, 1) RF_CASE(2, 2, 1) RF_CASE(2, 1, 2) RF_CASE(1, 2, 2) RF_CASE(1, 1, 1) RF_CASE(1, 2, 1) RF_CASE(1, 1, 2)
 #undef RF_CASE
     set_error("walk tails: unsupported order %d / %d scans / %d z tails", K, a.nx, wa.nzk);
     return RF_ERR_UNSUPPORTED;

@@ -17,6 +17,8 @@ ONE_EACH = [(0, True, [1.0, 0.5, 0.25]), (1, False, [1.0, 0.5, 0.125]), (2, True
 Z_MIXED = XYZ[:4] + [(2, True, [1.0, 0.5, 0.25]), (2, False, [0.7, 0.3])]
 Z_ORDER1 = XYZ[:4] + [(2, True, [0.5, 0.5]), (2, False, [0.7, 0.3])]
 XY_ORDER1_Z2 = ORDER1[:4] + XYZ[4:]
+TWO_X_ONE_Y = XYZ[:3] + XYZ[4:]
+ONE_X_TWO_Y = XYZ[1:]
 
 
 def _cases():
@@ -33,12 +35,14 @@ def _cases():
         "z_orders_2_and_1": ((64, 64, 256), Z_MIXED, True, 0),
         "z_order_1_under_xy_order_2": ((64, 64, 256), Z_ORDER1, True, 0),
         "z_order_2_over_xy_order_1": ((64, 64, 256), XY_ORDER1_Z2, False, 0),
+        "two_x_scans_one_y_scan": ((64, 64, 512), TWO_X_ONE_Y, True, 0),
+        "one_x_scan_two_y_scans": ((64, 128, 256), ONE_X_TWO_Y, True, capi.RF_PLAN_TILE_ROWS(64)),
     }
 
 
 CASE_NAMES = ["xyz_zero", "xyz_clamped_two_tile_columns", "two_patches_per_y_tile", "four_patches_per_y_tile_clamped",
               "two_z_tiles_clamped", "three_z_tiles_of_32", "z_tile_128", "one_scan_per_dimension", "z_orders_2_and_1",
-              "z_order_1_under_xy_order_2", "z_order_2_over_xy_order_1"]
+              "z_order_1_under_xy_order_2", "z_order_2_over_xy_order_1", "two_x_scans_one_y_scan", "one_x_scan_two_y_scans"]
 
 
 def _run(shape, scans, clamped, flags, img, in_place=False):

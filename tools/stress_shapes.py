@@ -358,9 +358,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "walk":
         shape = (tz * int(rng.integers(1, 4)) * world, ty * int(rng.integers(1, 5)), 256 * int(rng.integers(1, 5)))
         kxy, kz = int(rng.integers(1, 3)), int(rng.integers(1, 3))
         scans = []
-        nxy = int(rng.integers(1, 3))
         for d in range(3):
-            for _ in range(nxy if d < 2 else int(rng.integers(1, 3))):
+            for _ in range(int(rng.integers(1, 3))):
                 k = kxy if d < 2 else kz
                 a = rng.uniform(-1.0, 1.0, size=k); a *= rng.uniform(0.2, 0.9) / np.sum(np.abs(a))
                 scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(v) for v in a]))
