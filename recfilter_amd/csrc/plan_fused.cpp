@@ -292,14 +292,14 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     // ---- 3-D volumes: pass 1 in ONE read (kernels_tails_walk.hip) ------------------------------------
     // The z tails are taken from the raw input by the pass that extracts the x/y tails (the z operators commute with the x/y
-    // filter: plan_strided.h); the z stage then has no first pass.  Unsharded f32 volumes of whole tiles without pointwise
-    // stages, of at least one patch column (256 x 32 samples x one z tile: a workgroup of 1024 threads) per compute unit --
+    // filter: plan_strided.h); the z stage then has no first pass.  f32 volumes of whole tiles without pointwise stages -- whole
+    // volumes, and z slabs that take the early exchange (the pass is then the slab's begin step) -- of at least one patch column (256 x 32 samples x one z tile: a workgroup of 1024 threads) per compute unit --
     // measured, one read against two: 256^3 (32 patch columns) 0.214 against 0.124 ms, 512^3 (256) 0.645 against 0.680,
     // 768^3 1.97 / 2.05, 1024^3 4.5 / 4.95, 2048^3 34.0 / 37.0 (profiles/r4/walk_tails_sizes.txt); RF_PLAN_WALK_PASS1: whatever
     // the size; RF_PLAN_STAGED_PASS1 keeps the two first passes.
     WalkArgs walk_args{};
     std::shared_ptr<WalkHook> walk_hook;
-    rf_plan *walk_child = nullptr;
+    std::unique_ptr<rf_plan> walk_child;             // F over the z carry planes (plan_strided.h), handed to the z stage below
     if constexpr (std::is_same<P, float>::value) {
         static const char *walk_knob = RF_KNOB("RF_WALK");                        // A/B: 0 = never
         const bool wanted = !(plan->flags & RF_PLAN_STAGED_PASS1) && !(walk_knob && atoi(walk_knob) == 0);
@@ -313,7 +313,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy) &&
                 (patch_columns >= 256 || (plan->flags & RF_PLAN_WALK_PASS1))) {
                 const int MZ = (int)(dz.N / TZ);
-                walk_child = build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * (MZ + (z_slabs ? 1 : 0)));
+                walk_child.reset(build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * (MZ + (z_slabs ? 1 : 0))));
                 if (walk_child) {
                     // impulse responses of the z tails, transposed: [variant][z][4]
                     std::vector<S> H = build_tail_responses<S>(table_scans(dz.scan_ids), KZ, TZ, plan->clamped);
@@ -633,7 +633,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         int rc;
         if constexpr (sizeof(Acc) == 4)
             rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false, desc, first_begin_step,
-                                                                         walk_hook.get(), walk_child)
+                                                                         walk_hook.get(), walk_hook ? walk_child.release() : nullptr)
                                            : add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);
         else rc = add_generic_dimension<P, S>(plan, desc->tile[2], 2, /*from_input=*/false);      // (f64: no strided kernels)
         if (rc != RF_OK) return rc;
