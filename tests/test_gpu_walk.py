@@ -128,22 +128,19 @@ def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
 
 
 def test_one_read_pass1_is_the_default_from_256_patch_columns_on():
-    """Default choice (no flag): 512^3 / 4 = 128 x 512 x 512 has 2 x 16 x 2 = 64 patch columns -> two first passes; 512 x 512 x
-    512 has 256 -> one read.  Both against the oracle on a z slab (the whole volume's f64 reference is not needed twice)."""
+    """Default choice (no flag): 128 x 512 x 512 has 2 x 16 x 2 = 64 patch columns -> two first passes; 512 x 512 x 512 has
+    256 -> one read, with either border.  Each against the f64 oracle, strict metric (1e-4)."""
+    import os
     import torch
     import recfilter_amd as rfa
     rng = np.random.default_rng(14)
-    for shape, expect in (((128, 512, 512), False), ((512, 512, 512), True)):
+    threads = min(16, os.cpu_count() or 1)
+    for shape, clamped, expect in (((128, 512, 512), False, False), ((512, 512, 512), False, True), ((512, 512, 512), True, True)):
         x = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
-        with rfa.Plan(shape, XYZ) as plan:
+        with rfa.Plan(shape, XYZ, clamped=clamped) as plan:
             out, timed = plan.execute_timed([x])
             torch.cuda.synchronize()
         steps = [k for k, _ in timed]
         assert ("walk_tails" in steps) == expect, (shape, steps)
-        if not expect:
-            want = oracle.apply_filter(x.cpu().numpy().astype(np.float64), XYZ, False)
-            assert rc.rel_err_strict(out[0].cpu().numpy(), want) < 1e-4
-        else:
-            import os
-            want = oracle.apply_filter(x.cpu().numpy().astype(np.float64), XYZ, False, threads=min(16, os.cpu_count() or 1))
-            assert rc.rel_err_strict(out[0].cpu().numpy(), want) < 1e-4
+        want = oracle.apply_filter(x.cpu().numpy().astype(np.float64), XYZ, clamped, threads=threads)
+        assert rc.rel_err_strict(out[0].cpu().numpy(), want) < 1e-4, (shape, clamped)
