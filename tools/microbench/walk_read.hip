@@ -54,6 +54,14 @@ __global__ void __launch_bounds__(1024) walk_kernel(const float *src, float *out
                 f4 *q = reinterpret_cast<f4 *>(out) + ((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 2048;
                 q[t] = acc; q[t + 1024] = acc;
             }
+            if (STORES >= 20 && t < 288) {           // the same 4.6 KiB, plane-major, under other cache policies (gfx950 sc0 / sc1 / nt bits)
+                f4 *q = &parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t];
+                if (STORES == 20) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(q), "v"(acc) : "memory");
+                if (STORES == 21) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(acc) : "memory");
+                if (STORES == 22) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(acc) : "memory");
+                if (STORES == 23) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(q), "v"(acc) : "memory");
+                if (STORES == 24) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(q), "v"(acc) : "memory");
+            }
             if (STORES == 3 && t < 288) __builtin_nontemporal_store(acc, &parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t]);
             if (BARRIER) __syncthreads();
         }
@@ -95,6 +103,11 @@ int main(int argc, char **argv) {
     time("2 in flight, barrier, 512 B of stores per plane", L(2, true, 8));
     time("2 in flight, barrier, 2 KiB of stores per plane", L(2, true, 9));
     time("2 in flight, barrier, 32 KiB of stores per plane (copy)", L(2, true, 10));
+    time("2 in flight, barrier, stores sc0", L(2, true, 20));
+    time("2 in flight, barrier, stores sc1", L(2, true, 21));
+    time("2 in flight, barrier, stores sc0 sc1", L(2, true, 22));
+    time("2 in flight, barrier, stores sc0 sc1 nt", L(2, true, 23));
+    time("2 in flight, barrier, stores sc1 nt", L(2, true, 24));
     time("2 in flight, barrier, stores of 8 planes at once", L(2, true, 6));
     time("2 in flight, barrier, stores of 32 planes at once", L(2, true, 7));
     return 0;
