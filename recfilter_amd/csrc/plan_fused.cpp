@@ -292,7 +292,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     // ---- 3-D volumes: pass 1 in ONE read (kernels_tails_walk.hip) ------------------------------------
     // The z tails are taken from the raw input by the pass that extracts the x/y tails (the z operators commute with the x/y
-    // filter: plan_strided.h); the z stage then has no first pass.  f32 volumes of whole tiles without pointwise stages -- whole
+    // filter: plan_strided.h); the z stage then has no first pass.  f32 volumes of whole tiles without a prologue (its bias is not
+    // linear) -- whole
     // volumes, and z slabs that take the early exchange (the pass is then the slab's begin step) -- of at least one patch column (256 x 32 samples x one z tile: a workgroup of 1024 threads) per compute unit --
     // measured, one read against two: 256^3 (32 patch columns) 0.214 against 0.124 ms, 512^3 (256) 0.645 against 0.680,
     // 768^3 1.97 / 2.05, 1024^3 4.5 / 4.95, 2048^3 34.0 / 37.0 (profiles/r4/walk_tails_sizes.txt); RF_PLAN_WALK_PASS1: whatever
@@ -305,7 +306,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         const bool wanted = !(plan->flags & RF_PLAN_STAGED_PASS1) && !(walk_knob && atoi(walk_knob) == 0);
         const bool z_slabs = plan->sharded();           // z slabs: with the early exchange (plan_strided.h), whose first step this pass then is
         if (wanted && plan->ndim == 3 && (!z_slabs || early_exchange_possible<P>(plan, 2, desc)) && plan->n_planes == 1 && !batch && !chained && !plan->mod_form &&
-            !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&
+            !plan->pw.pre && !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&      // (an epilogue runs behind the z stage either way)
             plan->dims[2].lines == NX * NY) {
             const DimInfo &dz = plan->dims[2];
             const int TZ = strided_tile(plan, 2), nz = (int)dz.scan_ids.size(), KZ = dz.k;

@@ -45,6 +45,7 @@ inline rf_plan *build_carry_planes_plan(const rf_plan *plan, const rf_filter_des
     cd.extent[2] = planes;
     cd.n_planes = 1;
     cd.tile[2] = 0;
+    std::memset(&cd.pointwise, 0, sizeof(cd.pointwise));      // (F alone: an epilogue of the filter is not part of it)
     cd.path = RF_PATH_TILED_FUSED;
     cd.device = plan->host_only ? RF_DEVICE_HOST_ONLY : plan->device;
     cd.shard_rank = 0; cd.shard_world = 1; cd.shard_extents = nullptr;

@@ -144,3 +144,24 @@ def test_one_read_pass1_is_the_default_from_256_patch_columns_on():
         assert ("walk_tails" in steps) == expect, (shape, steps)
         want = oracle.apply_filter(x.cpu().numpy().astype(np.float64), XYZ, clamped, threads=threads)
         assert rc.rel_err_strict(out[0].cpu().numpy(), want) < 1e-4, (shape, clamped)
+
+
+def test_one_read_pass1_with_an_epilogue():
+    """out = w_f * F(x) + w_i * x + b behind the z stage (rf_pointwise_desc, the unsharp-mask form): the plan still reads the
+    volume once for its tails; the helper that filters the z carry planes applies F alone."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    shape, scans, clamped, flags = _cases()["two_z_tiles_clamped"]
+    img = np.random.default_rng(15).random(shape, dtype=np.float32)
+    x = torch.from_numpy(img).cuda()
+    for epi in ((0.5, 0.0, 0.25), (-1.0, 2.0, 0.0)):
+        with rfa.Plan(shape, scans, clamped=clamped, flags=flags | capi.RF_PLAN_WALK_PASS1, path=capi.RF_PATH_TILED_FUSED,
+                      epilogue=epi) as plan:
+            out, timed = plan.execute_timed([x])
+            torch.cuda.synchronize()
+        assert "walk_tails" in [k for k, _ in timed]
+        f = oracle.apply_filter(img.astype(np.float64), scans, clamped)
+        want = epi[0] * f + epi[1] * img.astype(np.float64) + epi[2]
+        # (the second form cancels: the bar is relative to the filtered signal's magnitude, as tests/test_harness.py does)
+        assert np.abs(out[0].cpu().numpy() - want).max() / np.abs(f).max() < 4e-6
