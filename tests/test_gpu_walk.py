@@ -165,3 +165,49 @@ def test_one_read_pass1_with_an_epilogue():
         want = epi[0] * f + epi[1] * img.astype(np.float64) + epi[2]
         # (the second form cancels: the bar is relative to the filtered signal's magnitude, as tests/test_harness.py does)
         assert np.abs(out[0].cpu().numpy() - want).max() / np.abs(f).max() < 4e-6
+
+
+def test_one_read_plan_executes_concurrently_on_distinct_streams():
+    """executes of one plan on distinct streams may overlap.  The one-read plan carries a helper plan (the x/y filter
+    over the z carry planes) and a workspace of parts: three volumes through ONE plan on three busy streams, then from three
+    host threads at once; every result against the oracle."""
+    import threading
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    shape, scans, clamped, flags = _cases()["four_patches_per_y_tile_clamped"]
+    rng = np.random.default_rng(16)
+    imgs = [rng.random(shape, dtype=np.float32) for _ in range(3)]
+    wants = [oracle.apply_filter(im.astype(np.float64), scans, clamped) for im in imgs]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    with rfa.Plan(shape, scans, clamped=clamped, flags=flags | capi.RF_PLAN_WALK_PASS1, path=capi.RF_PATH_TILED_FUSED) as plan:
+        outs = [torch.empty_like(d) for d in dev]
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(30_000_000)
+        for rep in range(2):
+            for i in range(3):
+                plan.execute([dev[i]], [outs[i]], stream=streams[i])
+        torch.cuda.synchronize()
+        assert plan.num_instances == 3, plan.num_instances
+        for o, w in zip(outs, wants):
+            assert np.abs(o.cpu().numpy() - w).max() / np.abs(w).max() < 2e-6
+        outs2 = [torch.empty_like(d) for d in dev]
+        errors = []
+
+        def worker(i):
+            try:
+                for _ in range(3):
+                    plan.execute([dev[i]], [outs2[i]], stream=streams[i])
+            except Exception as exc:      # pragma: no cover
+                errors.append(exc)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for o, w in zip(outs2, wants):
+            assert np.abs(o.cpu().numpy() - w).max() / np.abs(w).max() < 2e-6
