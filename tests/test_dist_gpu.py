@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extents=None):
+def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extents=None, flags=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch
@@ -41,8 +41,10 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extent
         local = (n,) + tuple(shape[1:])
         inputs = [torch.from_numpy(np.ascontiguousarray(f[lo:lo + n])).cuda() for f in full]
         outputs = [torch.empty_like(t) for t in inputs]
-        filt = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, slab_extents=extents)
+        filt = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, slab_extents=extents, flags=flags)
         assert filt.plan.path_name == "tiled_fused"
+        if flags:      # the slab's begin step is the one-read pass 1: its table of z responses exists
+            assert filt.plan.table("H_z").size > 0 and filt.plan.has_interior
         for _ in range(2):                     # the second execute reuses the exchange buffers
             filt.execute(inputs, outputs)
         torch.cuda.synchronize()
@@ -51,7 +53,7 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extent
             err = rc.rel_err(outputs[p].cpu().numpy(), wants[p])
             assert err < 1e-4, f"rank {rank} plane {p}: rel err {err}"
         # steps in flight: two slots (own stream, plan, exchange buffers, output planes), five submits, one drain
-        piped = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, inflight=2, slab_extents=extents)
+        piped = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, inflight=2, slab_extents=extents, flags=flags)
         sets = [[torch.zeros_like(t) for t in inputs] for _ in range(2)]
         for i in range(5):
             piped.submit(inputs, sets[i % 2])
@@ -66,20 +68,27 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extent
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d", "rows_2d_unequal"])
+@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d", "rows_2d_unequal", "z_slabs_3d_one_read_pass1", "z_slabs_3d_one_read_unequal"])
 def test_two_processes_one_gpu(case, tmp_path):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     import ref_cases as rc
-    extents = None
-    if case == "rows_2d":
+    extents, flags = None, 0
+    if case == "z_slabs_3d_one_read_pass1":
+        # whole tiles (256 x 32 x 64 planes per slab): the slabs' begin step forms the x, y and z tails in one read
+        from recfilter_amd import capi
+        shape, scans, clamped, planes, flags = (128, 64, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], True, 1, capi.RF_PLAN_WALK_PASS1
+    elif case == "z_slabs_3d_one_read_unequal":
+        from recfilter_amd import capi
+        shape, scans, clamped, planes, flags, extents = (96, 64, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1, capi.RF_PLAN_WALK_PASS1, [64, 32]
+    elif case == "rows_2d":
         shape, scans, clamped, planes = (256, 768), rc.xy_pm(rc.GAUSS2), True, 2
     elif case == "rows_2d_unequal":
         shape, scans, clamped, planes, extents = (320, 768), rc.xy_pm(rc.GAUSS2), True, 2, [192, 128]
     else:
         shape, scans, clamped, planes = (32, 96, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path), extents), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path), extents, flags), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
