@@ -35,7 +35,8 @@ extern "C" {
 #endif
 
 #define RF_MAX_DIMS    3    /* the reference's auto-schedules stop at 3 (lib/recfilter.cpp:6,734) */
-#define RF_MAX_ORDER   8    /* feedback taps per scan */
+#define RF_MAX_ORDER   32   /* feedback taps per scan: RecFilter::add_filter takes any order (lib/recfilter.cpp:260-343);
+                             * the reference's own sweep stops at 29 (apps/audio/audio_filter_high_order.cpp:14,38) */
 #define RF_MAX_SCANS   32
 #define RF_MAX_PLANES  16
 /* desc.device value that builds the plan's host tables without touching a device; such a plan

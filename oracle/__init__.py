@@ -28,7 +28,7 @@ _NP2ORC = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
 
 class _Scan(ctypes.Structure):
     _fields_ = [("dim", ctypes.c_int), ("causal", ctypes.c_int),
-                ("order", ctypes.c_int), ("coeff", ctypes.c_float * 16)]
+                ("order", ctypes.c_int), ("coeff", ctypes.c_float * 33)]
 
 
 def build(force: bool = False) -> str:
@@ -102,8 +102,8 @@ def _scan_array(scans: Iterable[Scan]):
     arr = (_Scan * max(len(scans), 1))()
     for i, (dim, causal, coeff) in enumerate(scans):
         coeff = [float(c) for c in coeff]
-        if len(coeff) < 2 or len(coeff) > 16:
-            raise ValueError("a scan needs a feedforward and 1..15 feedback coefficients")
+        if len(coeff) < 2 or len(coeff) > 33:
+            raise ValueError("a scan needs a feedforward and 1..32 feedback coefficients")
         arr[i].dim, arr[i].causal, arr[i].order = int(dim), int(bool(causal)), len(coeff) - 1
         for j, c in enumerate(coeff):
             arr[i].coeff[j] = c

@@ -106,7 +106,7 @@ int orc_apply_scan(void *data, int dtype, int ndim, const int64_t *extent,
     if (!data || !extent || !scan) return -1;
     if (ndim < 1 || ndim > ORC_MAX_DIMS) return -2;
     if (scan->dim < 0 || scan->dim >= ndim) return -3;
-    if (scan->order < 1 || scan->order > 15) return -4; /* needs feedfwd + >=1 feedback, :274 */
+    if (scan->order < 1 || scan->order > ORC_MAX_ORDER) return -4; /* needs feedfwd + >=1 feedback, :274 */
     size_t esz = dtype_size(dtype);
     if (!esz) return -5;
 
@@ -117,9 +117,9 @@ int orc_apply_scan(void *data, int dtype, int ndim, const int64_t *extent,
     if (n <= 0 || inner <= 0 || outer <= 0) return 0;
 
     /* coefficients cast to the pixel type, lib/recfilter.cpp:324,335,338 */
-    float  cf[16];
-    double cd[16];
-    uint32_t cu[16];
+    float  cf[ORC_MAX_ORDER + 1];
+    double cd[ORC_MAX_ORDER + 1];
+    uint32_t cu[ORC_MAX_ORDER + 1];
     for (int j = 0; j <= scan->order; j++) {
         cf[j] = scan->coeff[j];
         cd[j] = (double)scan->coeff[j];

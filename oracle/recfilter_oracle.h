@@ -42,6 +42,8 @@ extern "C" {
 enum { ORC_F32 = 0, ORC_F64 = 1, ORC_I32 = 2, ORC_I16 = 3 };
 enum { ORC_BORDER_ZERO = 0, ORC_BORDER_CLAMP = 1 };
 enum { ORC_MAX_DIMS = 4 };
+enum { ORC_MAX_ORDER = 32 };   /* the reference takes any order (lib/recfilter.cpp:260-343); its own sweep stops at 29
+                               * (apps/audio/audio_filter_high_order.cpp:14,38) */
 
 /* One scan = one RecFilter::add_filter call.
  * coeff[0] = feedforward, coeff[1..order] = feedback (added, not subtracted). */
@@ -49,7 +51,7 @@ typedef struct {
     int    dim;        /* 0 = x (fastest varying), 1 = y, 2 = z, 3 = w            */
     int    causal;     /* 1: +dim, 0: -dim                                          */
     int    order;      /* number of feedback coefficients                           */
-    float  coeff[16];  /* feedforward + feedback, as floats like the reference      */
+    float  coeff[ORC_MAX_ORDER + 1];  /* feedforward + feedback, as floats like the reference */
 } orc_scan;
 
 /* Apply ONE scan in place to a dense x-fastest array (lib/recfilter.cpp:302-343).

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RECFILTER_AMD_LIB") or os.path.join(_PKG, "librecfilt
 CSRC = os.path.join(_PKG, "csrc")
 
 RF_MAX_DIMS = 3
-RF_MAX_ORDER = 8
+RF_MAX_ORDER = 32
 RF_MAX_SCANS = 32
 RF_MAX_PLANES = 16
 RF_DEVICE_HOST_ONLY = -2

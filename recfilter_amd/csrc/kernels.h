@@ -89,6 +89,10 @@ int launch_generic_pass1(const P *src, GenericDimArgs<typename PixelTraits<P>::A
 // (the carry recurrence itself is the blocked scan of kernels_carry.hip, declared in kernels_fused.h)
 template <typename Acc>
 int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream);
+// orders above 8: the carry recurrence of the scans [s_begin, s_end) as one thread per line (kernels_generic.hip)
+constexpr int kCarryBlockMaxOrder = 8;   // what launch_carry_block (kernels_carry.hip) is instantiated for
+template <typename Acc>
+int launch_generic_carry_serial(GenericDimArgs<Acc> a, uint32_t causal_mask, int s_begin, int s_end, Acc *send, hipStream_t stream);
 // incoming[s] = sum over the slabs before this one (in scan direction) of (A^M)^(distance-1) * their exit tails
 template <typename Acc>
 int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, int64_t rank_stride,

@@ -33,12 +33,16 @@ __device__ __forceinline__ int64_t line_base(const LineGeom &g, int64_t line) {
 // One in-tile scan step shared by every kernel in this file.  hist[j] is the output at
 // direction position p-1-j (from this tile or from the carry), y0 the first output of a
 // clamped border tile.
-template <typename Acc>
+// KMAX: the order bucket the kernel is instantiated for -- kLowOrder (8) for the orders every tiled path takes, RF_MAX_ORDER
+// (32) for the direct form of the reference's high-order sweeps (apps/audio/audio_filter_high_order.cpp:38-42); the
+// register window of the recurrence is KMAX deep.
+constexpr int kLowOrder = 8;
+template <typename Acc, int KMAX>
 __device__ __forceinline__ Acc scan_step(Acc x, int p, const DevScan<Acc> &sc, int k, bool clamp_first,
-                                         Acc (&hist)[RF_MAX_ORDER], Acc &y0) {
+                                         Acc (&hist)[KMAX], Acc &y0) {
     Acc acc = sc.b * x;
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) {
+    for (int j = 0; j < KMAX; j++) {
         if (j < k) {
             Acc g = hist[j];
             if (clamp_first && p <= j) g = (p == 0) ? x : y0;
@@ -46,14 +50,14 @@ __device__ __forceinline__ Acc scan_step(Acc x, int p, const DevScan<Acc> &sc, i
         }
     }
 #pragma unroll
-    for (int j = RF_MAX_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+    for (int j = KMAX - 1; j > 0; j--) hist[j] = hist[j - 1];
     hist[0] = acc;
     if (p == 0) y0 = acc;
     return acc;
 }
 
 // ---------------------------------------------------------------------------------------
-template <typename P>
+template <typename P, int KMAX>
 __global__ void __launch_bounds__(kBlock)
 untiled_scan_kernel(const P *__restrict__ in, P *__restrict__ out, LineGeom g,
                     DevScan<typename PixelTraits<P>::Acc> sc, int clamped) {
@@ -62,15 +66,15 @@ untiled_scan_kernel(const P *__restrict__ in, P *__restrict__ out, LineGeom g,
     int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (line >= g.lines) return;
     int64_t base = line_base(g, line);
-    Acc hist[RF_MAX_ORDER];
+    Acc hist[KMAX];
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) hist[j] = Acc(0);
+    for (int j = 0; j < KMAX; j++) hist[j] = Acc(0);
     Acc y0 = Acc(0);
     for (int64_t r = 0; r < g.n; r++) {
         int64_t i = sc.causal ? r : g.n - 1 - r;
-        int p = r < RF_MAX_ORDER ? (int)r : RF_MAX_ORDER;  // only p <= j matters
+        int p = r < KMAX ? (int)r : KMAX;  // only p <= j matters
         Acc x = Tr::load(in[base + i * g.inner]);
-        Acc y = scan_step<Acc>(x, p, sc, sc.order, clamped != 0, hist, y0);
+        Acc y = scan_step<Acc, KMAX>(x, p, sc, sc.order, clamped != 0, hist, y0);
         out[base + i * g.inner] = Tr::store(y);
     }
 }
@@ -287,11 +291,11 @@ __device__ __forceinline__ int tile_variant(const GenericDimArgs<Acc> &a, int t)
 }
 
 // carry entering tile t for scan s: complete tail of the previous tile, or the slab's incoming carry
-template <typename Acc>
+template <typename Acc, int KMAX>
 __device__ __forceinline__ void load_carry(const GenericDimArgs<Acc> &a, int s, bool causal, int t, int64_t line,
-                                           Acc (&c)[RF_MAX_ORDER]) {
+                                           Acc (&c)[KMAX]) {
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) c[j] = Acc(0);
+    for (int j = 0; j < KMAX; j++) c[j] = Acc(0);
     if (tile_is_first(a, causal, t)) {
         for (int j = 0; j < a.k; j++) c[j] = a.incoming[((int64_t)s * a.k + j) * a.g.lines + line];
     } else {
@@ -300,7 +304,7 @@ __device__ __forceinline__ void load_carry(const GenericDimArgs<Acc> &a, int s, 
     }
 }
 
-template <typename P, bool kFinal>
+template <typename P, bool kFinal, int KMAX>
 __global__ void __launch_bounds__(kBlock)
 generic_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, GenericDimArgs<typename PixelTraits<P>::Acc> a) {
     using Tr = PixelTraits<P>;
@@ -318,14 +322,14 @@ generic_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, GenericDimAr
         DevScan<Acc> sc = a.scans[s];
         bool causal = sc.causal != 0;
         bool clamp_first = a.clamped && tile_is_border(a, causal, t);
-        Acc hist[RF_MAX_ORDER];
+        Acc hist[KMAX];
 #pragma unroll
-        for (int j = 0; j < RF_MAX_ORDER; j++) hist[j] = Acc(0);
-        if (kFinal) load_carry(a, s, causal, t, line, hist);
+        for (int j = 0; j < KMAX; j++) hist[j] = Acc(0);
+        if (kFinal) load_carry<Acc, KMAX>(a, s, causal, t, line, hist);
         Acc y0 = Acc(0);
         for (int p = 0; p < a.T; p++) {
             int m = causal ? p : a.T - 1 - p;
-            v[m] = scan_step<Acc>(v[m], p < RF_MAX_ORDER ? p : RF_MAX_ORDER, sc, a.k, clamp_first, hist, y0);
+            v[m] = scan_step<Acc, KMAX>(v[m], p < KMAX ? p : KMAX, sc, a.k, clamp_first, hist, y0);
         }
         if (!kFinal) {
             // tail r = value at direction position T-1-r, extracted right after the scan
@@ -342,7 +346,7 @@ generic_pass_kernel(const P *__restrict__ src, P *__restrict__ dst, GenericDimAr
 }
 
 // add the effect of the slab's incoming carry to every tile's complete tail
-template <typename Acc>
+template <typename Acc, int KMAX>
 __global__ void __launch_bounds__(kBlock)
 generic_carry_apply_kernel(GenericDimArgs<Acc> a, int s) {
     int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -350,15 +354,15 @@ generic_carry_apply_kernel(GenericDimArgs<Acc> a, int s) {
     const int k = a.k;
     const bool causal = a.scans[s].causal != 0;
     const Acc *A = a.A + (int64_t)s * k * k;
-    Acc x[RF_MAX_ORDER];
+    Acc x[KMAX];
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
+    for (int j = 0; j < KMAX; j++) x[j] = Acc(0);
     for (int j = 0; j < k; j++) x[j] = a.incoming[((int64_t)s * k + j) * a.g.lines + line];
     for (int i = 0; i < a.M; i++) {
         int t = causal ? i : a.M - 1 - i;
-        Acc nx[RF_MAX_ORDER];
+        Acc nx[KMAX];
 #pragma unroll
-        for (int j = 0; j < RF_MAX_ORDER; j++) nx[j] = Acc(0);
+        for (int j = 0; j < KMAX; j++) nx[j] = Acc(0);
         for (int r = 0; r < k; r++)
             for (int j = 0; j < k; j++) nx[r] = nx[r] + A[r * k + j] * x[j];
         for (int r = 0; r < k; r++) {
@@ -368,22 +372,70 @@ generic_carry_apply_kernel(GenericDimArgs<Acc> a, int s) {
     }
 }
 
+// The cross-tile recurrence of orders above kLowOrder on this path (integer and f64 pixels, shapes the matrix path of
+// kernels_matrix.hip does not take): one thread per line walks the tiles in scan direction -- the reference's own schedule
+// (gpu_auto_inter_schedule, lib/recfilter.cpp:763-785) -- for the scans [s_begin, s_end) of the dimension:
+//     tail_s[t] += sum_{q<s} W[v][q][s] * (carry entering tile t of scan q) + A_s * tail_s[t -/+ 1]
+// with zero state entering the slab (what the slab's incoming carry adds is carry_apply's), exit carries to `send`.
+// The blocked parallel scan of kernels_carry.hip keeps its k-vectors in registers and stops at kLowOrder.
+template <typename Acc>
+__global__ void __launch_bounds__(kBlock)
+generic_carry_serial_kernel(GenericDimArgs<Acc> a, uint32_t causal_mask, int s_begin, int s_end, Acc *__restrict__ send) {
+    const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (line >= a.g.lines) return;
+    const int k = a.k, M = a.M, n = a.n_scans;
+    const int64_t L = a.g.lines;
+    for (int s = s_begin; s < s_end; s++) {
+        const bool causal = ((causal_mask >> s) & 1u) != 0;
+        const Acc *Am = a.A + (int64_t)s * k * k;
+        Acc x[RF_MAX_ORDER];
+        for (int j = 0; j < k; j++) x[j] = Acc(0);
+        for (int i = 0; i < M; i++) {
+            const int tt = causal ? i : M - 1 - i;
+            const int v = tile_variant(a, tt);
+            Acc cur[RF_MAX_ORDER];
+            for (int r = 0; r < k; r++) cur[r] = a.tails[tail_idx(a, s, tt, r, line)];
+            for (int q = 0; q < s; q++) {
+                const bool qc = ((causal_mask >> q) & 1u) != 0;
+                const bool q_first = qc ? (tt == 0) : (tt == M - 1);
+                const int tp = qc ? tt - 1 : tt + 1;
+                const Acc *Wm = a.W + ((((int64_t)v * n + q) * n + s) * k) * k;
+                for (int o = 0; o < k; o++) {
+                    const Acc c = q_first ? a.incoming[((int64_t)q * k + o) * L + line] : a.tails[tail_idx(a, q, tp, o, line)];
+                    for (int r = 0; r < k; r++) cur[r] = cur[r] + Wm[r * k + o] * c;
+                }
+            }
+            for (int r = 0; r < k; r++) {
+                Acc acc = cur[r];
+                for (int j = 0; j < k; j++) acc = acc + Am[r * k + j] * x[j];
+                cur[r] = acc;
+            }
+            for (int r = 0; r < k; r++) {
+                x[r] = cur[r];
+                a.tails[tail_idx(a, s, tt, r, line)] = cur[r];
+            }
+        }
+        if (send != nullptr)
+            for (int r = 0; r < k; r++) send[((int64_t)(s - s_begin) * k + r) * L + line] = x[r];
+    }
+}
+
 // The same update with every tile independent: tail(t) += A^(i+1) * incoming, the powers tabulated on the host
 // (GenericDimArgs::Apow).  Thread = line, blockIdx.y = a chunk of kApplyTiles tiles; the matrix of a tile is
 // wave-uniform (scalar loads), the tails are read and written once, coalesced across lines.  The serial kernel above
 // walks the tiles of a line in one thread -- a chain of dependent read-modify-writes that took 0.33 ms per scan on a
 // cfg3 slab; this one is bound by the tails' traffic.
 constexpr int kApplyTiles = 8;
-template <typename Acc>
+template <typename Acc, int KMAX>
 __global__ void __launch_bounds__(kBlock)
 carry_apply_parallel_kernel(GenericDimArgs<Acc> a, int s) {
     const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (line >= a.g.lines) return;
     const int k = a.k;
     const bool causal = a.scans[s].causal != 0;
-    Acc x[RF_MAX_ORDER];
+    Acc x[KMAX];
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
+    for (int j = 0; j < KMAX; j++) x[j] = Acc(0);
     for (int j = 0; j < k; j++) x[j] = a.incoming[((int64_t)s * k + j) * a.g.lines + line];
     const int i0 = (int)blockIdx.y * kApplyTiles;
     // all loads of the chunk first, then the stores: interleaved, every store could alias the next load and the
@@ -409,7 +461,7 @@ carry_apply_parallel_kernel(GenericDimArgs<Acc> a, int s) {
     }
 }
 
-template <typename Acc>
+template <typename Acc, int KMAX>
 __global__ void __launch_bounds__(kBlock)
 gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gathered, int64_t rank_stride,
                        int64_t plane_offset, int rank, int world, const Acc *__restrict__ AM) {
@@ -417,16 +469,16 @@ gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gat
     if (line >= a.g.lines) return;
     const int k = a.k;
     const bool causal = a.scans[s].causal != 0;
-    Acc x[RF_MAX_ORDER];
+    Acc x[KMAX];
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) x[j] = Acc(0);
+    for (int j = 0; j < KMAX; j++) x[j] = Acc(0);
     // walk the slabs that precede this one in scan direction, nearest last
     int count = causal ? rank : world - 1 - rank;
     for (int i = 0; i < count; i++) {
         int h = causal ? i : world - 1 - i;
-        Acc nx[RF_MAX_ORDER];
+        Acc nx[KMAX];
 #pragma unroll
-        for (int j = 0; j < RF_MAX_ORDER; j++) nx[j] = Acc(0);
+        for (int j = 0; j < KMAX; j++) nx[j] = Acc(0);
         for (int r = 0; r < k; r++) {
             Acc acc = gathered[h * rank_stride + plane_offset + (int64_t)r * a.g.lines + line];
             for (int j = 0; j < k; j++) acc = acc + AM[(h * k + r) * k + j] * x[j];      // AM[h] = A^(tiles of slab h)
@@ -445,7 +497,7 @@ gather_incoming_kernel(GenericDimArgs<Acc> a, int s, const Acc *__restrict__ gat
 // direction is E_s[h].  One thread per line walks the slabs for every scan in order; the carries entering EVERY
 // slab are kept (the cross terms of later scans need them), n * world * k values in a private array.
 constexpr int kMergeMaxState = 128;
-template <typename Acc>
+template <typename Acc, int KMAX>
 __global__ void __launch_bounds__(kBlock)
 merged_gather_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered, int64_t rank_stride, int64_t plane_offset,
                      int rank, int world, const Acc *__restrict__ X) {
@@ -456,13 +508,13 @@ merged_gather_kernel(GenericDimArgs<Acc> a, const Acc *__restrict__ gathered, in
     Acc in[kMergeMaxState];
     for (int s = 0; s < n; s++) {
         const bool causal = a.scans[s].causal != 0;
-        Acc prev[RF_MAX_ORDER];
+        Acc prev[KMAX];
         for (int j = 0; j < k; j++) prev[j] = Acc(0);
         for (int i = 0; i < world; i++) {
             const int h = causal ? i : world - 1 - i;
             for (int j = 0; j < k; j++) in[(s * world + h) * k + j] = prev[j];
             if (i == world - 1) break;        // nobody follows the last slab
-            Acc e[RF_MAX_ORDER];
+            Acc e[KMAX];
             for (int r = 0; r < k; r++) {
                 Acc acc = gathered[h * rank_stride + plane_offset + ((int64_t)s * k + r) * L + line];
                 for (int q = 0; q <= s; q++) {
@@ -597,24 +649,36 @@ template <typename P>
 int launch_untiled_scan(const P *in, P *out, LineGeom g, const DevScan<typename PixelTraits<P>::Acc> &sc,
                         bool clamped, hipStream_t stream) {
     if (g.lines <= 0 || g.n <= 0) return RF_OK;
-    hipLaunchKernelGGL(untiled_scan_kernel<P>, dim3(grid_for(g.lines)), dim3(kBlock), 0, stream, in, out, g, sc,
-                       clamped ? 1 : 0);
+    if (sc.order <= kLowOrder)
+        hipLaunchKernelGGL((untiled_scan_kernel<P, kLowOrder>), dim3(grid_for(g.lines)), dim3(kBlock), 0, stream, in, out, g, sc,
+                           clamped ? 1 : 0);
+    else
+        hipLaunchKernelGGL((untiled_scan_kernel<P, RF_MAX_ORDER>), dim3(grid_for(g.lines)), dim3(kBlock), 0, stream, in, out, g, sc,
+                           clamped ? 1 : 0);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
 
 template <typename P>
 int launch_generic_pass1(const P *src, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream) {
-    hipLaunchKernelGGL((generic_pass_kernel<P, false>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
-                       (P *)nullptr, a);
+    if (a.k <= kLowOrder)
+        hipLaunchKernelGGL((generic_pass_kernel<P, false, kLowOrder>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
+                           (P *)nullptr, a);
+    else
+        hipLaunchKernelGGL((generic_pass_kernel<P, false, RF_MAX_ORDER>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
+                           (P *)nullptr, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
 
 template <typename P>
 int launch_generic_pass2(const P *src, P *dst, GenericDimArgs<typename PixelTraits<P>::Acc> a, hipStream_t stream) {
-    hipLaunchKernelGGL((generic_pass_kernel<P, true>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
-                       dst, a);
+    if (a.k <= kLowOrder)
+        hipLaunchKernelGGL((generic_pass_kernel<P, true, kLowOrder>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
+                           dst, a);
+    else
+        hipLaunchKernelGGL((generic_pass_kernel<P, true, RF_MAX_ORDER>), dim3(grid_for(a.g.lines * a.M)), dim3(kBlock), 0, stream, src,
+                           dst, a);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -623,10 +687,21 @@ template <typename Acc>
 int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream) {
     if (a.Apow != nullptr && a.M > 0) {
         dim3 grid(grid_for(a.g.lines), (unsigned)((a.M + kApplyTiles - 1) / kApplyTiles));
-        hipLaunchKernelGGL(carry_apply_parallel_kernel<Acc>, grid, dim3(kBlock), 0, stream, a, s);
+        if (a.k <= kLowOrder) hipLaunchKernelGGL((carry_apply_parallel_kernel<Acc, kLowOrder>), grid, dim3(kBlock), 0, stream, a, s);
+        else hipLaunchKernelGGL((carry_apply_parallel_kernel<Acc, RF_MAX_ORDER>), grid, dim3(kBlock), 0, stream, a, s);
     } else {
-        hipLaunchKernelGGL(generic_carry_apply_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
+        if (a.k <= kLowOrder) hipLaunchKernelGGL((generic_carry_apply_kernel<Acc, kLowOrder>), dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
+        else hipLaunchKernelGGL((generic_carry_apply_kernel<Acc, RF_MAX_ORDER>), dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s);
     }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+template <typename Acc>
+int launch_generic_carry_serial(GenericDimArgs<Acc> a, uint32_t causal_mask, int s_begin, int s_end, Acc *send, hipStream_t stream) {
+    if (a.g.lines <= 0 || a.M <= 0 || s_end <= s_begin) return RF_OK;
+    hipLaunchKernelGGL(generic_carry_serial_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, causal_mask, s_begin,
+                       s_end, send);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -634,8 +709,12 @@ int launch_generic_carry_apply(GenericDimArgs<Acc> a, int s, hipStream_t stream)
 template <typename Acc>
 int launch_gather_incoming(GenericDimArgs<Acc> a, int s, const Acc *gathered, int64_t rank_stride,
                            int64_t plane_offset, int rank, int world, const Acc *AM, hipStream_t stream) {
-    hipLaunchKernelGGL(gather_incoming_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s, gathered,
-                       rank_stride, plane_offset, rank, world, AM);
+    if (a.k <= kLowOrder)
+        hipLaunchKernelGGL((gather_incoming_kernel<Acc, kLowOrder>), dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s, gathered,
+                           rank_stride, plane_offset, rank, world, AM);
+    else
+        hipLaunchKernelGGL((gather_incoming_kernel<Acc, RF_MAX_ORDER>), dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, s, gathered,
+                           rank_stride, plane_offset, rank, world, AM);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -657,8 +736,8 @@ int launch_merged_gather(GenericDimArgs<Acc> a, const Acc *gathered, int64_t ran
 #undef RF_CASE
     }
     if (a.n_scans * world * a.k > kMergeMaxState) { set_error("merged exchange: too many carries per line"); return RF_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(merged_gather_kernel<Acc>, dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, gathered,
-                       rank_stride, plane_offset, rank, world, X);
+    hipLaunchKernelGGL((merged_gather_kernel<Acc, kLowOrder>), dim3(grid_for(a.g.lines)), dim3(kBlock), 0, stream, a, gathered,
+                       rank_stride, plane_offset, rank, world, X);      // (the merged exchange takes orders <= 3, plan_generic.h)
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -859,6 +938,7 @@ RF_INSTANTIATE_PIXEL(int16_t)
 
 #define RF_INSTANTIATE_ACC(Acc)                                                                                    \
     template int launch_generic_carry_apply<Acc>(GenericDimArgs<Acc>, int, hipStream_t);                           \
+    template int launch_generic_carry_serial<Acc>(GenericDimArgs<Acc>, uint32_t, int, int, Acc *, hipStream_t);    \
     template int launch_gather_incoming<Acc>(GenericDimArgs<Acc>, int, const Acc *, int64_t, int64_t, int, int,    \
                                              const Acc *, hipStream_t);                                            \
     template int launch_merged_gather<Acc>(GenericDimArgs<Acc>, const Acc *, int64_t, int64_t, int, int, const Acc *, \

@@ -9,6 +9,7 @@
 
 namespace rf {
 
+constexpr int kOvMaxOrder = 8;       // feedback taps per scan on the overlapped path (its k-vectors live in registers)
 constexpr int kOvMaxTile = 4096;      // samples per N-D tile (LDS: 16 KiB f32 / 32 KiB f64)
 
 template <typename Acc>

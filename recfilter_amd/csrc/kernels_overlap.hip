@@ -33,10 +33,10 @@ constexpr int kOvThreads = 256;
 
 template <typename Acc>
 __device__ __forceinline__ Acc ov_scan_step(Acc x, int p, const DevScan<Acc> &sc, int k, bool clamp_first,
-                                            Acc (&hist)[RF_MAX_ORDER], Acc &y0) {
+                                            Acc (&hist)[kOvMaxOrder], Acc &y0) {
     Acc acc = sc.b * x;
 #pragma unroll
-    for (int j = 0; j < RF_MAX_ORDER; j++) {
+    for (int j = 0; j < kOvMaxOrder; j++) {
         if (j < k) {
             Acc g = hist[j];
             if (clamp_first && p <= j) g = (p == 0) ? x : y0;
@@ -44,7 +44,7 @@ __device__ __forceinline__ Acc ov_scan_step(Acc x, int p, const DevScan<Acc> &sc
         }
     }
 #pragma unroll
-    for (int j = RF_MAX_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+    for (int j = kOvMaxOrder - 1; j > 0; j--) hist[j] = hist[j - 1];
     hist[0] = acc;
     if (p == 0) y0 = acc;
     return acc;
@@ -115,9 +115,9 @@ __device__ __forceinline__ void ov_scan_dim(const OvArgs<Acc> &a, const OvTile<A
         int base;
         int64_t line;
         ov_line(a, tl, e, i, base, line);
-        Acc hist[RF_MAX_ORDER];
+        Acc hist[kOvMaxOrder];
 #pragma unroll
-        for (int j = 0; j < RF_MAX_ORDER; j++) hist[j] = Acc(0);
+        for (int j = 0; j < kOvMaxOrder; j++) hist[j] = Acc(0);
         if (MODE == 2 && !first) {
             const int tp = causal ? tl.t[e] - 1 : tl.t[e] + 1;
             for (int j = 0; j < k; j++) hist[j] = d.tails[(((int64_t)s * d.M + tp) * k + j) * d.lines + line];
@@ -126,7 +126,7 @@ __device__ __forceinline__ void ov_scan_dim(const OvArgs<Acc> &a, const OvTile<A
         for (int p = 0; p < T; p++) {
             const int m = causal ? p : T - 1 - p;
             const Acc x = tile[base + m * stride];
-            tile[base + m * stride] = ov_scan_step<Acc>(x, p < RF_MAX_ORDER ? p : RF_MAX_ORDER, sc, k, clamp_first, hist, y0);
+            tile[base + m * stride] = ov_scan_step<Acc>(x, p < kOvMaxOrder ? p : kOvMaxOrder, sc, k, clamp_first, hist, y0);
         }
         if (MODE == 0 || MODE == 1) {
             for (int r = 0; r < k; r++) {             // hist[r] = output at direction position T-1-r = tail r
@@ -197,7 +197,7 @@ ov_residual_kernel(OvArgs<Acc> a, int dim) {
                 const bool first = causal ? (tl.t[e] == 0) : (tl.t[e] == d.M - 1);
                 if (first) continue;
                 const int tp = causal ? tl.t[e] - 1 : tl.t[e] + 1;
-                Acc c[RF_MAX_ORDER];
+                Acc c[kOvMaxOrder];
                 for (int o = 0; o < d.k; o++) c[o] = d.tails[(((int64_t)q * d.M + tp) * d.k + o) * d.lines + line];
                 const Acc *G = d.G + ((size_t)(v * d.n + q) * d.T) * d.k;
                 for (int m = 0; m < d.T; m++) {

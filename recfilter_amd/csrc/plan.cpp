@@ -217,7 +217,7 @@ std::vector<int> cascade_stage_of_scans(const rf_filter_desc *desc) {
         for (int i = 0; i < desc->n_scans; i++) {
             const rf_scan_desc &r = desc->scans[i];
             if (r.dim != d) continue;
-            if (r.order > kFusedMaxK && !sections_ok) return {};
+            if (r.order > kFusedMaxK && (!sections_ok || r.order > kFusedMaxMod)) return {};
             const int w = r.order <= kFusedMaxK ? 1 : (r.order + 1) / 2;
             if (w > kFusedMaxScans) return {};
             if (used + w > kFusedMaxScans || (padded_1d && !r.causal && seen_causal)) { cur++; used = 0; seen_causal = false; }
@@ -518,8 +518,11 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     // The rewrite is kept only if it makes the fused path applicable; every other path runs the scans as given.
     if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) &&
         (plan->dtype == RF_F32 || plan->dtype == RF_F64) && !(desc->flags & RF_PLAN_NO_SECTIONS)) {
-        bool high = false;
-        for (const Scan &sc : plan->scans) high = high || sc.order > kFusedMaxK;
+        // (orders above kFusedMaxMod = 8 are never sectioned: the direct form on the matrix path is well conditioned
+        // where a long cascade of f32 resonators is not, and a border modification touches at most eight samples)
+        bool high = false, too_high = false;
+        for (const Scan &sc : plan->scans) { high = high || sc.order > kFusedMaxK; too_high = too_high || sc.order > kFusedMaxMod; }
+        if (too_high) high = false;
         const bool mod = plan->clamped;
         if (mod && (plan->dtype != RF_F32 || desc->ndim < 2 || plan->sharded())) high = false;
         if (high) {
@@ -529,7 +532,8 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
             for (const Scan &sc : plan->scans) {
                 std::vector<Scan> sec;
                 if (sc.order <= kFusedMaxK) sec.push_back(sc);
-                else ok = ok && split_into_sections(sc, kFusedMaxK, [dtype](double v) { return cast_coeff(v, dtype); }, sec);
+                else ok = ok && split_into_sections(sc, kFusedMaxK, [dtype](double v) { return cast_coeff(v, dtype); }, sec) &&
+                          (dtype != RF_F32 || sections_well_conditioned(sc, sec));
                 if (!ok) break;
                 if (mod) {
                     // the modification of the scan as given, carried by its first section

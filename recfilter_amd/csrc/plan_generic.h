@@ -416,6 +416,9 @@ int add_generic_dimension(rf_plan *plan, int tile_hint, int d, bool from_input_f
             // signal (one line) does not degenerate into one thread walking every tile
             cs.run = [plan, args_for, s, ex_index, plane_stride, k, causal_mask, dACp, C](int pl) {
                 Acc *send = ex_index >= 0 ? (Acc *)plan->exchanges[ex_index].send : nullptr;
+                if (k > kCarryBlockMaxOrder)        // (orders 9..32: one thread per line, kernels_generic.hip)
+                    return launch_generic_carry_serial<Acc>(args_for(pl), causal_mask, s, s + 1, send ? send + pl * plane_stride : nullptr,
+                                                            plan->stream);
                 return launch_carry_block<Acc>(k, args_for(pl), causal_mask, s, s + 1, send ? send + pl * plane_stride : nullptr,
                                                dACp, C, plan->stream);
             };

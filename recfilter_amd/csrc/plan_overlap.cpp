@@ -25,6 +25,7 @@ bool overlap_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, st
         if (T <= 0) return no("every filtered dimension needs an explicit tile width (RecFilter::split)");
         if (di.N % T != 0) return no("tile width does not divide the extent");
         if (T < di.k) return no("tile narrower than the filter order");
+        if (di.k > kOvMaxOrder) return no("orders above 8 run on the matrix / generic paths");
         vol *= T;
     }
     if (filtered < 1) return no("no scans");

@@ -120,4 +120,41 @@ bool split_into_sections(const Scan &s, int max_order, Cast cast, std::vector<Sc
     return err <= 2e-6 * scale;                                   // sections rounded to the pixel type still give this filter
 }
 
+// Conditioning of a cascade of sections in the pixel's arithmetic.  The recomposed denominator may match to rounding while the
+// cascade is still a poor way to EVALUATE the filter: poles spread over a circle make every section a sharp resonator whose
+// gain the next one cancels (the dummy polynomial of apps/audio/audio_filter_high_order.cpp:41-42 -- all feedback 0.01 --
+// loses 5e-5 at order 15 in f32).  So the plan tries it: a probe signal (an impulse plus a fixed pseudo-random sequence)
+// through the sections in float arithmetic against the direct form in double; the sections are kept only if they stay
+// within `bar` of it (relative to the peak).  f64 pixels pass by construction (the probe would measure 1e-13).
+inline bool sections_well_conditioned(const Scan &direct, const std::vector<Scan> &sections, double bar = 2e-5) {
+    const int L = 512;
+    std::vector<double> x(L), ref(L);
+    uint32_t lcg = 12345u;
+    for (int i = 0; i < L; i++) { lcg = lcg * 1664525u + 1013904223u; x[i] = (double)(lcg >> 8) / 16777216.0 - 0.5; }
+    x[0] += 1.0;
+    for (int i = 0; i < L; i++) {
+        double acc = direct.b * x[i];
+        for (int j = 0; j < direct.order && j < i; j++) acc += direct.a[j] * ref[i - 1 - j];
+        ref[i] = acc;
+    }
+    std::vector<float> cur(L);
+    for (int i = 0; i < L; i++) cur[i] = (float)x[i];
+    for (const Scan &sec : sections) {
+        std::vector<float> nxt(L);
+        for (int i = 0; i < L; i++) {
+            float acc = (float)sec.b * cur[i];
+            for (int j = 0; j < sec.order && j < i; j++) acc = std::fmaf((float)sec.a[j], nxt[i - 1 - j], acc);
+            nxt[i] = acc;
+        }
+        cur.swap(nxt);
+    }
+    double peak = 0.0, err = 0.0;
+    for (int i = 0; i < L; i++) {
+        if (!std::isfinite(ref[i]) || !std::isfinite((double)cur[i])) return false;
+        peak = std::max(peak, std::fabs(ref[i]));
+        err = std::max(err, std::fabs((double)cur[i] - ref[i]));
+    }
+    return err <= bar * std::max(peak, 1e-30);
+}
+
 }  // namespace rf

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from recfilter_amd import capi
+
 from tiled_emulator import scan_tile
 
 TX, SEG = 256, 16
@@ -26,9 +28,10 @@ def _f32(c):
 def plan_scans(plan):
     """The scans as the plan runs them (rf_plan_table("scans"): after the rewrite of high orders into sections), as
     (dim, causal, [b, a...]) plus, per scan, its border modification (mod_n, [g...]) -- mod_n < 0: native clamped prologue."""
-    t = plan.table("scans").reshape(-1, 21)
+    K = capi.RF_MAX_ORDER
+    t = plan.table("scans").reshape(-1, 5 + 2 * K)
     scans = [(int(r[0]), bool(r[1]), [float(r[3])] + [float(v) for v in r[4:4 + int(r[2])]]) for r in t]
-    mods = [(int(r[12]), [float(v) for v in r[13:21]]) for r in t]
+    mods = [(int(r[4 + K]), [float(v) for v in r[5 + K:5 + 2 * K]]) for r in t]
     return scans, mods
 
 

@@ -1,0 +1,97 @@
+"""Scans of order 9..32 in their direct form through the C ABI (RecFilter::add_filter takes any order,
+/root/reference/lib/recfilter.cpp:260-343; the reference's own sweep runs orders 1, 3, .. 29,
+apps/audio/audio_filter_high_order.cpp:14,38-42) against the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle
+import ref_cases as rc
+
+pytestmark = pytest.mark.gpu
+
+from recfilter_amd import capi
+
+TOL = 1e-4     # north_star: 1e-4 relative for floating point; integers bit-exact
+
+
+def stable_coeff(order, seed, b=0.4, mass=0.85):
+    """[b, a1..a_order] with sum |a| = mass < 1 (bounded-input bounded-output whatever the signs)."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(order) * np.exp(-0.15 * np.arange(order))
+    a *= mass / np.abs(a).sum()
+    return [b] + [float(np.float32(v)) for v in a]
+
+
+def audio_coeff(order):
+    return [1.0] + [0.01] * order        # apps/audio/audio_filter_high_order.cpp:41-42
+
+
+def int_coeff(order, seed):
+    rng = np.random.default_rng(seed)
+    return [1.0] + [float(v) for v in rng.integers(-2, 3, order)]
+
+
+def _run(shape, scans, dtype=np.float32, clamped=False, planes=1, tile=None, path=0, seed=77, inplace=False, flags=None):
+    import torch
+    import recfilter_amd as rfa
+    imgs = [rc.random_image(shape, dtype, seed + i) for i in range(planes)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    with rfa.Plan(shape, scans, dtype=dtype, clamped=clamped, planes=planes, tile=tile, path=path, flags=flags) as plan:
+        outs = plan.execute(dev, dev if inplace else None)
+        torch.cuda.synchronize()
+        info = (plan.path, plan.tiles)
+    return imgs, [o.cpu().numpy() for o in outs], info
+
+
+def _check(imgs, outs, scans, clamped, tol=TOL):
+    for im, out in zip(imgs, outs):
+        if np.issubdtype(im.dtype, np.integer):
+            np.testing.assert_array_equal(out, oracle.apply_filter(im, scans, clamped))
+        else:
+            want = oracle.apply_filter(im.astype(np.float64), scans, clamped)
+            err = rc.rel_err(out, want)
+            assert err < tol, f"rel err {err}"
+
+
+@pytest.mark.parametrize("path", [1, 2], ids=["untiled", "tiled_generic"])
+@pytest.mark.parametrize("order", [9, 12, 16, 23, 29, 32])
+@pytest.mark.parametrize("clamped", [False, True])
+def test_direct_form_always_correct_paths_f32(order, clamped, path):
+    """The always-correct paths (one recurrence per line; per-dimension tiles with a run-time width) with a 32-deep window."""
+    scans = [(0, True, stable_coeff(order, order)), (1, False, stable_coeff(order, 100 + order)), (0, False, audio_coeff(order))]
+    imgs, outs, (got, tiles) = _run((96, 160), scans, clamped=clamped, path=path, tile=[32, 32] if path == 2 else None)
+    assert got == path
+    _check(imgs, outs, scans, clamped)
+
+
+@pytest.mark.parametrize("path", [1, 2], ids=["untiled", "tiled_generic"])
+@pytest.mark.parametrize("dtype", [np.float64, np.int32, np.int16])
+def test_direct_form_other_pixel_types(dtype, path):
+    if np.issubdtype(dtype, np.integer):
+        scans = [(0, True, int_coeff(17, 1)), (1, False, int_coeff(32, 2)), (1, True, int_coeff(9, 3))]
+    else:
+        scans = [(0, True, stable_coeff(17, 1)), (1, False, stable_coeff(32, 2)), (1, True, stable_coeff(9, 3))]
+    for clamped in (False, True):
+        imgs, outs, (got, _) = _run((64, 96), scans, dtype, clamped=clamped, planes=2, path=path, tile=[32, 32] if path == 2 else None)
+        assert got == path
+        _check(imgs, outs, scans, clamped, tol=1e-10 if dtype == np.float64 else TOL)
+
+
+def test_direct_form_3d_and_1d_generic():
+    scans = [(0, True, stable_coeff(11, 5)), (1, False, stable_coeff(13, 6)), (2, True, stable_coeff(20, 7)), (2, False, audio_coeff(29))]
+    imgs, outs, (got, _) = _run((40, 64, 96), scans, path=2, tile=[32, 32, 20], inplace=True)
+    assert got == 2
+    _check(imgs, outs, scans, False)
+    s1 = [(0, True, audio_coeff(29)), (0, False, stable_coeff(10, 8))]
+    for clamped in (False, True):
+        sig, out, (got, _) = _run((4096,), s1, path=2, tile=[64], clamped=clamped)
+        assert got == 2
+        _check(sig, out, s1, clamped)
+
+
+def test_orders_above_32_are_refused_and_32_is_accepted():
+    import recfilter_amd as rfa
+    with pytest.raises(Exception):
+        rfa.Plan((256,), [(0, True, [1.0] + [0.001] * 33)])
+    with rfa.Plan((256,), [(0, True, [1.0] + [0.001] * 32)]) as plan:
+        assert plan.path in (1, 2, 5)

@@ -278,12 +278,7 @@ def _audio(kind):
         expect = None
         if kind == "high_order":
             coeff = [1.0] + [0.01] * param         # "dummy coeff, for performance comparison only"
-            # orders above 3 run as first/second-order sections with the same transfer function (exact for the zero
-            # border the app uses), which keeps them on the fused kernels; checked against the direct form
-            for sec in rfa.second_order_sections(coeff):
-                F.add_filter(+x, sec)
-            from scipy.signal import lfilter
-            expect = lambda _w, im: lfilter([coeff[0]], [1.0] + [-c for c in coeff[1:]], im)
+            F.add_filter(+x, coeff)                # the direct form, as the app has it: orders up to 32 go through the C ABI
         else:
             for _ in range(param + 1):
                 F.add_filter(+x, [1.0, 0.1, 0.1])
@@ -313,9 +308,8 @@ APPS = {
     "diff_gauss": app_dog,
 }
 SWEEP_APPS = {      # the 1-D apps sweep a filter parameter at one width instead (apps/audio/*.cpp)
-    # the app sweeps orders 1..29 step 2; orders above 3 run here as f32 first/second-order sections, and that cascade
-    # is ill-conditioned for the app's dummy polynomial above order 15 (see recfilter_amd.second_order_sections)
-    "audio_high_order": (_audio("high_order"), lambda rfa: range(1, 16, 2)),
+    # "for (int order=1; order<MAX_ORDER; order+=2)", MAX_ORDER 30 (apps/audio/audio_filter_high_order.cpp:14,38)
+    "audio_high_order": (_audio("high_order"), lambda rfa: range(1, 30, 2)),
     "audio_biquads": (_audio("biquads"), lambda rfa: range(1, 16)),
 }
 
