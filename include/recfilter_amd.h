@@ -67,11 +67,17 @@ typedef enum {
     RF_PATH_TILED_FUSED = 3,   /* tiled, LDS-staged fused x/y tiles with fixed MI355X tile shapes; a filter with more
                                 * than four scans in a dimension runs as successive stages of such plans inside the
                                 * one plan (stage 0 reads the input, later stages filter the output planes in place) */
-    RF_PATH_TILED_OVERLAPPED = 4 /* tiled, ALL dimensions in one pass 1 / one pass 2 with the cross-dimension
+    RF_PATH_TILED_OVERLAPPED = 4, /* tiled, ALL dimensions in one pass 1 / one pass 2 with the cross-dimension
                                   * residuals of lib/split.cpp:1215-1633 between every pair of dimensions (x->y, x->z,
                                   * y->z): the reference's fully overlapped N-D tiling.  Needs an explicit tile width
                                   * for every filtered dimension, tile volume <= 4096 samples; RF_PATH_AUTO picks it
                                   * for such filters when the fused path does not apply */
+    RF_PATH_TILED_MATRIX = 5     /* tiled, one scan at a time, every stage a dense f32 GEMM on the matrix cores
+                                  * (kernels_matrix.hip): tail extraction H[k x T] . tile, the carry recurrence as a chain
+                                  * of k x k products, the final pass as 32 x 32 impulse-response blocks.  Scans of ANY
+                                  * order up to RF_MAX_ORDER in their direct form (the reference's apps sweep orders up to
+                                  * 29); f32 pixels, filtered extents that are multiples of 32.  RF_PATH_AUTO picks it for
+                                  * filters with a scan of order above 3 that the fused path (sections) does not take */
 } rf_path;
 
 /* one RecFilter::add_filter(+-dim, {feedfwd, fb1..fbk}) call, lib/recfilter.cpp:264-343 */

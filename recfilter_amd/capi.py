@@ -26,7 +26,7 @@ RF_F32, RF_F64, RF_I32, RF_I16 = range(4)
 RF_BORDER_ZERO, RF_BORDER_CLAMP = 0, 1
 RF_POINTWISE_PRE, RF_POINTWISE_POST = 1, 2
 RF_IN_PIXEL, RF_IN_U8 = 0, 1
-RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED, RF_PATH_TILED_OVERLAPPED = range(5)
+RF_PATH_AUTO, RF_PATH_UNTILED, RF_PATH_TILED_GENERIC, RF_PATH_TILED_FUSED, RF_PATH_TILED_OVERLAPPED, RF_PATH_TILED_MATRIX = range(6)
 # rf_filter_desc.flags (plan options; the library reads no environment variable)
 RF_PLAN_FORCE_EXCHANGE, RF_PLAN_TILED_ONLY, RF_PLAN_NO_CASCADE, RF_PLAN_NO_SECTIONS = 0x01, 0x02, 0x04, 0x08
 RF_PLAN_NO_PLANE_BATCH, RF_PLAN_STREAM_PASS1, RF_PLAN_STAGED_PASS1, RF_PLAN_LATE_EXCHANGE = 0x10, 0x20, 0x40, 0x80
@@ -45,7 +45,7 @@ def RF_PLAN_TILE_PLANES(n: int) -> int:
 
 PATH_NAMES = {RF_PATH_AUTO: "auto", RF_PATH_UNTILED: "untiled",
               RF_PATH_TILED_GENERIC: "tiled_generic", RF_PATH_TILED_FUSED: "tiled_fused",
-              RF_PATH_TILED_OVERLAPPED: "tiled_overlapped"}
+              RF_PATH_TILED_OVERLAPPED: "tiled_overlapped", RF_PATH_TILED_MATRIX: "tiled_matrix"}
 
 # every symbol include/recfilter_amd.h declares
 EXPORTED_SYMBOLS = [

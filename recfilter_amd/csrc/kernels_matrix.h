@@ -1,0 +1,62 @@
+// kernels_matrix.h -- argument blocks and launchers of the matrix path (kernels_matrix.hip): scans of any order up to
+// RF_MAX_ORDER = 32 in their direct form, every stage of the tiled algorithm a small dense f32 GEMM on the matrix cores.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rf_internal.h"
+
+namespace rf {
+
+constexpr int kMxSB = 32;                  // sub-block: samples one 32x32x2 MFMA chain covers
+constexpr int kMxWaves = 4;                // waves per workgroup of the pass kernels
+constexpr int kMxUnits = 32 * kMxWaves;    // units (line, tile) per workgroup: one per lane column
+constexpr int kMxMaxNB = 4;                // sub-blocks per tile: T <= 128 (128 units x 128 samples of LDS)
+constexpr int kMxChunk = 16;               // tiles per chunk of the carry chain (levels of the blocked scan)
+constexpr int kMxTopMax = 24;              // a sequence this short is chained in one go
+
+// How the units of a scanned dimension lie in memory:
+//   MX_X1  scan along x, few lines (1-D signals): unit U = line * M + tile, a workgroup takes 128 consecutive units =
+//          128 * T consecutive samples; lane = tile
+//   MX_XL  scan along x, >= 32 lines: a workgroup takes 128 consecutive lines of one tile; lane = line
+//   MX_Y   scan along y or z: a workgroup takes 128 consecutive columns of one tile; lane = column
+enum MxMode { MX_X1 = 0, MX_XL = 1, MX_Y = 2 };
+
+struct MxPassArgs {
+    int32_t mode;
+    int32_t T, NB, M;          // tile width, sub-blocks per tile, tiles per line
+    int32_t k;                 // feedback order (rows of a tail)
+    int32_t causal;
+    int32_t clamped;           // the tile where the scan enters the image takes the border correction
+    int64_t N, inner, lines;   // extent and stride of the scanned dimension, number of lines
+    int64_t units;             // lines * M
+    const float *G, *R;        // A-operand fragments [16][64] of the sub-block operators (see kernels_matrix.hip)
+    const float *dG;           // [32]: what a clamped border adds to the first sub-block per unit first sample
+    const float *H;            // A-operand fragments [NB][16][64] of the tail extraction
+    const float *dH;           // [32]: ... to the tile-local tail
+    float *tails;              // [r][unit]; unit = line * M + tile (MX_X1) or tile * lines + line
+};
+
+// One level of the carry chain / of its propagation.  Column c of the launch (a lane) is split as c_hi = c / cdiv,
+// c_lo = c % cdiv; its element of step j, row r is seq[base + c_hi * s_hi + c_lo * s_lo + j * s_j + r * s_r].
+struct MxChainArgs {
+    float *seq;
+    float *exits;              // next level: exits[c_hi * e_hi + c_lo * e_lo + r * e_r]; null on the top level
+    const float *A;            // A-operand fragments [16][64] of the level's transfer matrix
+    const float *P;            // propagation: fragments [C][16][64] of its powers 1..C
+    int32_t k, C;
+    int32_t chunk_is_lo;       // the chunk index is c_lo (MX_X1) or c_hi
+    int64_t ncols, cdiv;
+    int64_t base, s_hi, s_lo, s_j, s_r;
+    int64_t e_hi, e_lo, e_r;
+    int64_t Mtot;              // elements per line on this level (the last chunk may be short)
+};
+
+int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream);
+int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream);
+int launch_mx_chain(const MxChainArgs &a, hipStream_t stream);
+int launch_mx_apply(const MxChainArgs &a, hipStream_t stream);
+
+}  // namespace rf

@@ -1,0 +1,423 @@
+// kernels_matrix.hip -- the matrix path: scans of ANY order up to RF_MAX_ORDER = 32 in their direct form, every stage of
+// the tiled algorithm a small dense f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain).
+//
+// RecFilter::add_filter takes any order (lib/recfilter.cpp:260-343) and the reference's own app sweeps one scan of order
+// 1, 3, .. 29 (apps/audio/audio_filter_high_order.cpp:14,38-42).  The fused kernels keep an order <= 3 recurrence in
+// registers; above that the recurrence itself stops being the cheap part and the tiling algebra of lib/split.cpp turns into
+// what north_star reserves the matrix cores for.  Per scan, tile of T = 32 NB samples, sub-blocks of 32 samples:
+//
+//   pass 1   tail extraction (extract_tails_from_each_scan, lib/split.cpp:256-499): the k-sample tail of the tile-local scan
+//            is LINEAR in the tile -- tails[k x units] = H[k x T] . tile[T x units]: one GEMM, no recurrence runs.
+//   chain    cross-tile carry recurrence (create_complete_tail_term, lib/split.cpp:743-867): c_t = l_t + A c_(t-1), A = k x k:
+//            a chain of GEMMs [k x k] . [k x 32 columns], blocked over chunks of 16 tiles (levels: chunk exits are a shorter
+//            sequence with the transfer matrix A^16, and so on), then propagated down with the tabulated powers of A.
+//   pass 2   final pass (add_residuals_to_final_result, lib/split.cpp:1647-1780): the tile is recomputed sub-block by
+//            sub-block, y_b = G x_b + R y_(b-1), G = 32 x 32 impulse-response (Toeplitz, triangular) matrix of the scan,
+//            R = 32 x 32 effect of the previous sub-block's outputs (k non-zero columns); the first sub-block takes the
+//            neighbouring tile's completed tail in y_(-1)'s place.
+//
+// Lanes are UNITS (a line's tile): lane l = 32 h + u holds column u of every 32 x 32 operand, and the 32-sample direction of
+// a sub-block is the K index of the MFMA.  The accumulator layout of a 32 x 32 result puts row (t>>2)*8 + 4h + (t&3) in
+// register t of lane half h -- so the K index is ASSIGNED in that order (step t of the k loop <-> that row pair): then a
+// result is the next product's B operand with no lane movement (y_(b-1) in pass 2, c_(t-1) in the chain), and the A
+// operands (the constant matrices) are stored pre-permuted as fragments frag[t][lane] = Mat[lane & 31][row(t, lane >> 5)].
+//
+// The image goes through LDS both ways (coalesced 16-byte accesses; a 128-unit x T-sample block per workgroup), so one
+// kernel body serves scans along x (lane = line, or lane = tile for 1-D signals) and along y / z (lane = column).
+// A clamped border is the zero-border operator plus a rank-one term in the scan's first sample (what the clamped prologue of
+// lib/recfilter.cpp:330-336 adds is linear in x_0): dG / dH, applied by the lanes whose tile is where the scan enters the image.
+#include "kernels_matrix.h"
+
+namespace rf {
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMxThreads = 64 * kMxWaves;
+constexpr int kMxPitchY = kMxUnits + 8;      // LDS pitch of a [sample][unit] block: the two lane halves (rows 4 apart) hit disjoint banks
+
+__device__ __forceinline__ int mx_row(int t, int h) { return ((t >> 2) << 3) + (h << 2) + (t & 3); }
+
+__device__ __forceinline__ floatx16 mx_zero() {
+    floatx16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+
+// geometry of the workgroup's block: rows x cols of the LDS image, where it lies in the plane
+struct MxBlock {
+    int64_t gbase, gpitch;     // element offset of (row 0, col 0), elements between rows
+    int rows, cols;            // extent of the LDS image
+    int rows_valid, cols_valid;
+    int pitch;                 // LDS pitch in floats
+    int tile;                  // MX_XL / MX_Y: the tile of the block
+    int64_t first;             // first unit (MX_X1), line (MX_XL) or line of column 0 (MX_Y)
+};
+
+template <bool XM>
+__device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
+    MxBlock b;
+    if constexpr (XM) {
+        b.rows = kMxUnits; b.cols = a.T; b.pitch = a.T + 4; b.cols_valid = a.T;
+        if (a.mode == MX_X1) {
+            const int64_t U0 = (int64_t)blockIdx.x * kMxUnits;
+            b.gbase = U0 * a.T; b.gpitch = a.T; b.tile = 0; b.first = U0;
+            const int64_t left = a.units - U0;
+            b.rows_valid = left < kMxUnits ? (int)left : kMxUnits;
+        } else {
+            const int64_t L0 = (int64_t)blockIdx.x * kMxUnits;
+            b.tile = (int)blockIdx.y;
+            b.gbase = L0 * a.N + (int64_t)b.tile * a.T; b.gpitch = a.N; b.first = L0;
+            const int64_t left = a.lines - L0;
+            b.rows_valid = left < kMxUnits ? (int)left : kMxUnits;
+        }
+    } else {
+        const int64_t c0 = (int64_t)blockIdx.x * kMxUnits, outer = blockIdx.z;
+        b.tile = (int)blockIdx.y;
+        b.rows = a.T; b.cols = kMxUnits; b.pitch = kMxPitchY; b.rows_valid = a.T;
+        b.gbase = (outer * a.N + (int64_t)b.tile * a.T) * a.inner + c0; b.gpitch = a.inner;
+        b.first = outer * a.inner + c0;
+        const int64_t left = a.inner - c0;
+        b.cols_valid = left < kMxUnits ? (int)left : kMxUnits;
+    }
+    return b;
+}
+
+__device__ __forceinline__ void mx_load_block(const float *__restrict__ src, float *lds, const MxBlock &b) {
+    const int w4 = b.cols >> 2, total = b.rows * w4;
+    for (int f = (int)threadIdx.x; f < total; f += kMxThreads) {
+        const int row = f / w4, c = (f - row * w4) << 2;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row < b.rows_valid && c < b.cols_valid) v = *reinterpret_cast<const float4 *>(src + b.gbase + (int64_t)row * b.gpitch + c);
+        *reinterpret_cast<float4 *>(lds + row * b.pitch + c) = v;
+    }
+}
+
+__device__ __forceinline__ void mx_store_block(float *__restrict__ dst, const float *lds, const MxBlock &b) {
+    const int w4 = b.cols >> 2, total = b.rows * w4;
+    for (int f = (int)threadIdx.x; f < total; f += kMxThreads) {
+        const int row = f / w4, c = (f - row * w4) << 2;
+        if (row < b.rows_valid && c < b.cols_valid)
+            *reinterpret_cast<float4 *>(dst + b.gbase + (int64_t)row * b.gpitch + c) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
+    }
+}
+
+// the 32 samples of sub-block sb of this lane's unit, in K order: x[t] = sample row(t, h)
+template <bool XM>
+__device__ __forceinline__ void mx_read_sub(const float *lds, int pitch, int mine, int h, int sb, float (&x)[16]) {
+    if constexpr (XM) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4 *>(lds + mine * pitch + 32 * sb + 8 * q + 4 * h);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++) x[t] = lds[(32 * sb + mx_row(t, h)) * pitch + mine];
+    }
+}
+
+template <bool XM>
+__device__ __forceinline__ void mx_write_sub(float *lds, int pitch, int mine, int h, int sb, const floatx16 &y) {
+    if constexpr (XM) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4 *>(lds + mine * pitch + 32 * sb + 8 * q + 4 * h) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++) lds[(32 * sb + mx_row(t, h)) * pitch + mine] = y[t];
+    }
+}
+
+// this lane's unit
+struct MxLane {
+    bool valid, enters;        // enters: the scan enters the image in this tile
+    int tile;
+    int64_t tidx, prev_tidx;   // index of the unit's tail / of the tail it takes its carry from (scan direction)
+};
+
+template <bool XM>
+__device__ __forceinline__ MxLane mx_lane(const MxPassArgs &a, const MxBlock &b, int mine) {
+    MxLane l;
+    int64_t line;
+    if (XM && a.mode == MX_X1) {
+        const int64_t U = b.first + mine;
+        l.valid = mine < b.rows_valid;
+        const int64_t Uc = l.valid ? U : 0;
+        line = Uc / a.M;
+        l.tile = (int)(Uc - line * a.M);
+        l.tidx = Uc;
+        l.prev_tidx = a.causal ? Uc - 1 : Uc + 1;
+    } else {
+        l.valid = XM ? mine < b.rows_valid : mine < b.cols_valid;
+        line = l.valid ? b.first + mine : 0;
+        l.tile = b.tile;
+        l.tidx = (int64_t)l.tile * a.lines + line;
+        l.prev_tidx = l.tidx + (a.causal ? -a.lines : a.lines);
+    }
+    l.enters = a.causal ? l.tile == 0 : l.tile == a.M - 1;
+    return l;
+}
+
+// ---- pass 1: tails[k x units] = H[k x T] . tile[T x units] ------------------------------------------------------------
+template <bool XM>
+__global__ void __launch_bounds__(kMxThreads)
+mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mx_lds[];
+    const MxBlock blk = mx_block<XM>(a);
+    mx_load_block(src, mx_lds, blk);
+    __syncthreads();
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
+    const int mine = 32 * w + u;
+    const MxLane ln = mx_lane<XM>(a, blk, mine);
+    floatx16 acc = mx_zero();
+    for (int sb = 0; sb < a.NB; sb++) {
+        float x[16];
+        mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
+        const float *Hf = a.H + (size_t)sb * 16 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
+    }
+    if (a.clamped && ln.valid && ln.enters) {
+        const int m0 = a.causal ? 0 : a.T - 1;
+        const float x0 = XM ? mx_lds[mine * blk.pitch + m0] : mx_lds[m0 * blk.pitch + mine];
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc[t] = fmaf(a.dH[mx_row(t, h)], x0, acc[t]);
+    }
+    if (ln.valid) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int r = mx_row(t, h);
+            if (r < a.k) a.tails[(int64_t)r * a.units + ln.tidx] = acc[t];
+        }
+    }
+}
+
+// ---- pass 2: y_b = G x_b + R y_(b-1) ----------------------------------------------------------------------------------
+template <bool XM>
+__global__ void __launch_bounds__(kMxThreads)
+mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mx_lds[];
+    const MxBlock blk = mx_block<XM>(a);
+    mx_load_block(src, mx_lds, blk);
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
+    const int mine = 32 * w + u;
+    const MxLane ln = mx_lane<XM>(a, blk, mine);
+    float Gf[16], Rf[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) { Gf[t] = a.G[t * 64 + lane]; Rf[t] = a.R[t * 64 + lane]; }
+    // K steps of R that are not all zero: the k most recent rows of the previous sub-block (wave-uniform)
+    const int nl = 4 * ((a.k + 7) >> 3), t_lo = a.causal ? 16 - nl : 0, t_hi = t_lo + nl;
+    // the completed tail of the neighbouring tile, laid out as the rows of a sub-block that precedes the tile
+    floatx16 prev = mx_zero();
+    if (ln.valid && !ln.enters) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int i = mx_row(t, h), r = a.causal ? 31 - i : i;
+            if (r < a.k) prev[t] = a.tails[(int64_t)r * a.units + ln.prev_tidx];
+        }
+    }
+    __syncthreads();
+    for (int bi = 0; bi < a.NB; bi++) {
+        const int sb = a.causal ? bi : a.NB - 1 - bi;
+        float x[16];
+        mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
+        floatx16 c = mx_zero();
+        if (bi == 0 && a.clamped && ln.valid && ln.enters) {
+            const int m0 = a.causal ? 0 : a.T - 1;
+            const float x0 = XM ? mx_lds[mine * blk.pitch + m0] : mx_lds[m0 * blk.pitch + mine];
+#pragma unroll
+            for (int t = 0; t < 16; t++) c[t] = a.dG[mx_row(t, h)] * x0;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Gf[t], x[t], c, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (t >= t_lo && t < t_hi) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Rf[t], prev[t], c, 0, 0, 0);
+        prev = c;
+        mx_write_sub<XM>(mx_lds, blk.pitch, mine, h, sb, c);
+    }
+    __syncthreads();
+    mx_store_block(dst, mx_lds, blk);
+}
+
+// ---- the carry chain: x_j = s_j + A x_(j-1) over the steps of a chunk, 32 columns per wave ----------------------------
+struct MxCol {
+    bool valid;
+    int64_t off, eoff, eprev;      // element offsets: the column's first element, its exit, the exit of the chunk before it
+    int len, chunk;
+};
+
+__device__ __forceinline__ MxCol mx_col(const MxChainArgs &a, int64_t c) {
+    MxCol col;
+    col.valid = c < a.ncols;
+    const int64_t cc = col.valid ? c : 0;
+    const int64_t c_hi = cc / a.cdiv, c_lo = cc - c_hi * a.cdiv;
+    const int64_t chunk = a.chunk_is_lo ? c_lo : c_hi;
+    col.chunk = (int)chunk;
+    const int64_t left = a.Mtot - chunk * a.C;
+    col.len = left < a.C ? (int)left : a.C;
+    col.off = a.base + c_hi * a.s_hi + c_lo * a.s_lo;
+    col.eoff = c_hi * a.e_hi + c_lo * a.e_lo;
+    col.eprev = col.eoff - (a.chunk_is_lo ? a.e_lo : a.e_hi);
+    return col;
+}
+
+__global__ void __launch_bounds__(kMxThreads)
+mx_chain_kernel(MxChainArgs a) {
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
+    const MxCol col = mx_col(a, ((int64_t)blockIdx.x * kMxWaves + w) * 32 + u);
+    const int nl = 4 * ((a.k + 7) >> 3);
+    float Af[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) Af[t] = a.A[t * 64 + lane];
+    floatx16 x = mx_zero();
+    auto load = [&](int j) {
+        floatx16 s = mx_zero();
+        if (col.valid && j < col.len) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int r = mx_row(t, h);
+                if (t < nl && r < a.k) s[t] = a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r];
+            }
+        }
+        return s;
+    };
+    floatx16 cur = load(0);
+    for (int j = 0; j < a.C; j++) {
+        const floatx16 nxt = load(j + 1 < a.C ? j + 1 : j);      // requested before this step's arithmetic and stores
+        floatx16 c = cur;
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (t < nl) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[t], x[t], c, 0, 0, 0);
+        if (col.valid && j < col.len) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int r = mx_row(t, h);
+                if (t < nl && r < a.k) a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r] = c[t];
+            }
+            x = c;
+        }
+        cur = nxt;
+    }
+    if (a.exits != nullptr && col.valid) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int r = mx_row(t, h);
+            if (t < nl && r < a.k) a.exits[col.eoff + (int64_t)r * a.e_r] = x[t];
+        }
+    }
+}
+
+// ---- propagation: element j of a chunk += (A^(j+1)) . (completed exit of the chunk before it) --------------------------
+__global__ void __launch_bounds__(kMxThreads)
+mx_apply_kernel(MxChainArgs a) {
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
+    const MxCol col = mx_col(a, ((int64_t)blockIdx.x * kMxWaves + w) * 32 + u);
+    const int j = (int)blockIdx.y;
+    const int nl = 4 * ((a.k + 7) >> 3);
+    const bool on = col.valid && col.chunk >= 1 && j < col.len;
+    floatx16 c = mx_zero(), e = mx_zero();
+    if (on) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int r = mx_row(t, h);
+            if (t < nl && r < a.k) {
+                e[t] = a.exits[col.eprev + (int64_t)r * a.e_r];
+                c[t] = a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r];
+            }
+        }
+    }
+    const float *Pf = a.P + (size_t)j * 16 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 16; t++)
+        if (t < nl) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Pf[t * 64], e[t], c, 0, 0, 0);
+    if (on) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int r = mx_row(t, h);
+            if (t < nl && r < a.k) a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r] = c[t];
+        }
+    }
+}
+
+size_t mx_lds_bytes(const MxPassArgs &a) {
+    return a.mode == MX_Y ? (size_t)a.T * kMxPitchY * sizeof(float) : (size_t)kMxUnits * (a.T + 4) * sizeof(float);
+}
+
+dim3 mx_grid(const MxPassArgs &a) {
+    if (a.mode == MX_X1) return dim3((unsigned)((a.units + kMxUnits - 1) / kMxUnits));
+    if (a.mode == MX_XL) return dim3((unsigned)((a.lines + kMxUnits - 1) / kMxUnits), (unsigned)a.M);
+    return dim3((unsigned)((a.inner + kMxUnits - 1) / kMxUnits), (unsigned)a.M, (unsigned)(a.lines / a.inner));
+}
+
+int mx_check(const MxPassArgs &a) {
+    if (a.T != 32 * a.NB || a.NB < 1 || a.NB > kMxMaxNB || a.k < 1 || a.k > 32 || a.M < 1 || a.N != (int64_t)a.M * a.T) {
+        set_error("matrix path: bad tile geometry (T %d, NB %d, M %d, k %d)", a.T, a.NB, a.M, a.k);
+        return RF_ERR_INVALID_ARG;
+    }
+    const dim3 g = mx_grid(a);
+    if (g.y > 65535u || g.z > 65535u || (a.mode == MX_Y && (a.inner % 4 != 0 || a.lines % a.inner != 0))) {
+        set_error("matrix path: extents out of range");
+        return RF_ERR_UNSUPPORTED;
+    }
+    return RF_OK;
+}
+
+template <typename K>
+int mx_allow_lds(K kern, size_t lds) {
+    if (lds > 64 * 1024) RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return RF_OK;
+}
+
+}  // namespace
+
+int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
+    if (int rc = mx_check(a)) return rc;
+    const size_t lds = mx_lds_bytes(a);
+    if (a.mode == MX_Y) {
+        if (int rc = mx_allow_lds(mx_pass1_kernel<false>, lds)) return rc;
+        hipLaunchKernelGGL(mx_pass1_kernel<false>, mx_grid(a), dim3(kMxThreads), lds, stream, src, a);
+    } else {
+        if (int rc = mx_allow_lds(mx_pass1_kernel<true>, lds)) return rc;
+        hipLaunchKernelGGL(mx_pass1_kernel<true>, mx_grid(a), dim3(kMxThreads), lds, stream, src, a);
+    }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream) {
+    if (int rc = mx_check(a)) return rc;
+    const size_t lds = mx_lds_bytes(a);
+    if (a.mode == MX_Y) {
+        if (int rc = mx_allow_lds(mx_pass2_kernel<false>, lds)) return rc;
+        hipLaunchKernelGGL(mx_pass2_kernel<false>, mx_grid(a), dim3(kMxThreads), lds, stream, src, dst, a);
+    } else {
+        if (int rc = mx_allow_lds(mx_pass2_kernel<true>, lds)) return rc;
+        hipLaunchKernelGGL(mx_pass2_kernel<true>, mx_grid(a), dim3(kMxThreads), lds, stream, src, dst, a);
+    }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+int launch_mx_chain(const MxChainArgs &a, hipStream_t stream) {
+    if (a.ncols <= 0 || a.C <= 0) return RF_OK;
+    const int64_t blocks = (a.ncols + kMxUnits - 1) / kMxUnits;
+    if (blocks >= (1ll << 31)) { set_error("matrix path: too many chain columns"); return RF_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(mx_chain_kernel, dim3((unsigned)blocks), dim3(kMxThreads), 0, stream, a);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+int launch_mx_apply(const MxChainArgs &a, hipStream_t stream) {
+    if (a.ncols <= 0 || a.C <= 0) return RF_OK;
+    const int64_t blocks = (a.ncols + kMxUnits - 1) / kMxUnits;
+    if (blocks >= (1ll << 31)) { set_error("matrix path: too many chain columns"); return RF_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(mx_apply_kernel, dim3((unsigned)blocks, (unsigned)a.C), dim3(kMxThreads), 0, stream, a);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+}  // namespace rf

@@ -21,6 +21,8 @@ int build_fused_plan(rf_plan *plan, const rf_filter_desc *desc);  // plan_fused.
 bool fused_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why);
 int build_overlap_plan(rf_plan *plan, const rf_filter_desc *desc);  // plan_overlap.cpp
 bool overlap_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why);
+int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc);   // plan_matrix.cpp
+bool matrix_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why);
 
 namespace {
 
@@ -631,6 +633,9 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         // a filter split() along two or more dimensions with small tiles: the fully overlapped tiling (two passes over
         // the image instead of two per dimension)
         else if (filtered_dims >= 2 && overlap_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_OVERLAPPED;
+        // orders above 3 that did not become sections (orders above 8; cascades of f32 resonators the conditioning probe of
+        // sections.h rejected; borders and shapes the section rewrite does not take): the direct form on the matrix cores
+        else if (max_order > kFusedMaxK && matrix_plan_applicable(plan.get(), desc, &why)) path = RF_PATH_TILED_MATRIX;
         // what the fused kernels do not take (f64 pixels): the line-parallel untiled kernels beat the per-dimension tiled
         // passes of the generic path at every size measured (profiles/r2/paths_4096.txt), unless the user tiled the filter
         else if (!user_tiles && !plan->sharded() && small_limit > 0 && line_scans_applicable(plan.get()))
@@ -641,7 +646,11 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         set_error("overlapped tiled path not applicable: %s", why.c_str());
         return RF_ERR_UNSUPPORTED;
     }
-    if (path < RF_PATH_UNTILED || path > RF_PATH_TILED_OVERLAPPED) { set_error("unknown path %d", path); return RF_ERR_INVALID_ARG; }
+    if (path == RF_PATH_TILED_MATRIX && !matrix_plan_applicable(plan.get(), desc, &why)) {
+        set_error("matrix path not applicable: %s", why.c_str());
+        return RF_ERR_UNSUPPORTED;
+    }
+    if (path < RF_PATH_UNTILED || path > RF_PATH_TILED_MATRIX) { set_error("unknown path %d", path); return RF_ERR_INVALID_ARG; }
     if (path == RF_PATH_TILED_FUSED && !fused_plan_applicable(plan.get(), desc, &why)) {
         set_error("fused tiled path not applicable: %s", why.c_str());
         return RF_ERR_UNSUPPORTED;
@@ -651,6 +660,7 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         plan->path = p;
         if (p == RF_PATH_TILED_FUSED) return build_fused_plan(plan.get(), desc);
         if (p == RF_PATH_TILED_OVERLAPPED) return build_overlap_plan(plan.get(), desc);
+        if (p == RF_PATH_TILED_MATRIX) return build_matrix_plan(plan.get(), desc);
         switch (desc->dtype) {
             case RF_F32: return build_for_pixel<float>(plan.get(), desc, p);
             case RF_F64: return build_for_pixel<double>(plan.get(), desc, p);

@@ -1,0 +1,303 @@
+// plan_matrix.cpp -- RF_PATH_TILED_MATRIX: the host side of kernels_matrix.hip.
+//
+// One stage per scan, in the plan's scan order (grouped by dimension; scans of different dimensions commute and the scans
+// of one dimension are successive in-place passes, lib/recfilter.cpp:302-343): pass 1 (tail extraction), the carry chain
+// with its levels, pass 2.  Every matrix the kernels multiply with is built here by running the scan recurrence (scan_tile,
+// tables.h) on unit vectors in double and rounding once to f32:
+//   G  (32 x 32)   column j = the zero-border scan of a 32-sample sub-block whose only non-zero sample is j
+//   R  (32 x 32)   column i = what a unit OUTPUT at row i of the previous sub-block (in scan direction) adds to this one
+//   dG (32)        clamped border: what the prologue of lib/recfilter.cpp:330-336 adds to the first sub-block per unit x_0
+//   H  (k x T)     the tile-local tail per unit input sample (extract_tails_from_each_scan, lib/split.cpp:256-499); dH as dG
+//   A  (k x k)     carry -> next carry across one tile (matrix_R's tail rows, lib/coefficients.cpp:51-83, lib/split.cpp:770)
+// and the chain levels' A^(16^l) and their powers 1..16 (tabulated in double: no chain of f32 products).
+#include <algorithm>
+#include <cstring>
+
+#include "kernels_matrix.h"
+#include "plan.h"
+#include "plan_generic.h"
+
+namespace rf {
+
+bool matrix_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std::string *why) {
+    auto no = [&](const char *msg) { if (why) *why = msg; return false; };
+    (void)desc;
+    if (plan->dtype != RF_F32) return no("the matrix cores take f32 pixels (integer and f64 filters run on the generic path)");
+    if (plan->sharded()) return no("the matrix path runs on one device");
+    if (plan->scans.empty()) return no("no scans");
+    for (int d = 0; d < plan->ndim; d++) {
+        const DimInfo &di = plan->dims[d];
+        if (di.scan_ids.empty()) continue;
+        if (di.N % kMxSB != 0) return no("a filtered extent is not a multiple of 32");
+        if (d > 0 && di.stride % 4 != 0) return no("rows are not 16-byte aligned");
+        if (d > 0 && di.lines / di.stride > 65535) return no("too many planes");
+        if (di.N / kMxSB > 65535 * (int64_t)kMxMaxNB) return no("extent too large");
+    }
+    return true;
+}
+
+namespace {
+
+inline int mx_row(int t, int h) { return ((t >> 2) << 3) + (h << 2) + (t & 3); }
+
+// A-operand fragments of a 32 x 32 matrix (row-major, out row x K index): frag[t][lane] = Mat[lane & 31][row(t, lane >> 5)]
+void pack_fragments(const double *mat, std::vector<float> &out) {
+    for (int t = 0; t < 16; t++)
+        for (int lane = 0; lane < 64; lane++) out.push_back((float)mat[(lane & 31) * 32 + mx_row(t, lane >> 5)]);
+}
+
+std::vector<double> pad32(const std::vector<double> &m, int k) {
+    std::vector<double> p(32 * 32, 0.0);
+    for (int r = 0; r < k; r++)
+        for (int j = 0; j < k; j++) p[r * 32 + j] = m[r * k + j];
+    return p;
+}
+
+struct StageTables {
+    std::vector<double> G, R, dG, H, dH, A;      // dense, as documented above (H: 32 x T, rows >= k zero; A: k x k)
+};
+
+StageTables build_stage_tables(const Scan &scan, int T, bool clamped) {
+    const int k = scan.order;
+    ScanS<double> ts = make_table_scan<double>(scan);
+    ts.mod_n = -1;
+    StageTables t;
+    t.G.assign(32 * 32, 0.0); t.R.assign(32 * 32, 0.0); t.dG.assign(32, 0.0);
+    t.H.assign((size_t)32 * T, 0.0); t.dH.assign(32, 0.0); t.A.assign((size_t)k * k, 0.0);
+    std::vector<double> v(std::max(T, 32));
+    for (int j = 0; j < 32; j++) {
+        std::fill(v.begin(), v.end(), 0.0);
+        v[j] = 1.0;
+        scan_tile<double>(v.data(), 32, k, ts, false, nullptr);
+        for (int i = 0; i < 32; i++) t.G[i * 32 + j] = v[i];
+    }
+    for (int i = 0; i < 32; i++) {
+        const int j = ts.causal ? 31 - i : i;          // row i of the previous sub-block is y[-1-j] of this one
+        if (j >= k) continue;
+        double carry[RF_MAX_ORDER] = {0};
+        carry[j] = 1.0;
+        std::fill(v.begin(), v.end(), 0.0);
+        scan_tile<double>(v.data(), 32, k, ts, false, carry);
+        for (int m = 0; m < 32; m++) t.R[m * 32 + i] = v[m];
+    }
+    auto tail_pos = [&](int r) { return ts.causal ? T - 1 - r : r; };
+    for (int m = 0; m < T; m++) {
+        std::fill(v.begin(), v.end(), 0.0);
+        v[m] = 1.0;
+        scan_tile<double>(v.data(), T, k, ts, false, nullptr);
+        for (int r = 0; r < k; r++) t.H[(size_t)r * T + m] = v[tail_pos(r)];
+    }
+    for (int j = 0; j < k; j++) {
+        double carry[RF_MAX_ORDER] = {0};
+        carry[j] = 1.0;
+        std::fill(v.begin(), v.end(), 0.0);
+        scan_tile<double>(v.data(), T, k, ts, false, carry);
+        for (int r = 0; r < k; r++) t.A[(size_t)r * k + j] = v[tail_pos(r)];
+    }
+    if (clamped) {
+        // the clamped prologue reads x_0 and y_0 = (b + sum a) x_0 where the zero border reads zeros: the difference of the
+        // two scans is linear in the first sample alone
+        std::vector<double> vc(std::max(T, 32), 0.0);
+        const int m32 = ts.causal ? 0 : 31, mT = ts.causal ? 0 : T - 1;
+        vc[m32] = 1.0;
+        scan_tile<double>(vc.data(), 32, k, ts, true, nullptr);
+        for (int i = 0; i < 32; i++) t.dG[i] = vc[i] - t.G[i * 32 + m32];
+        std::fill(vc.begin(), vc.end(), 0.0);
+        vc[mT] = 1.0;
+        scan_tile<double>(vc.data(), T, k, ts, true, nullptr);
+        for (int r = 0; r < k; r++) t.dH[r] = vc[tail_pos(r)] - t.H[(size_t)r * T + mT];
+    }
+    return t;
+}
+
+}  // namespace
+
+int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
+    (void)desc;
+    int status = RF_OK;
+    plan->vector_access = true;
+    const int np = plan->n_planes;
+
+    struct Level {
+        int64_t M = 0;           // elements per line
+        bool top = false;
+        const float *A = nullptr, *P = nullptr;
+    };
+    struct Stage {
+        MxPassArgs pass{};
+        std::vector<Level> levels;
+        int scan = 0;
+    };
+    std::vector<Stage> stages;
+    size_t tails_floats = 0;                 // per plane, max over the stages (they run one after the other)
+    std::vector<size_t> level_floats;        // [l-1] per plane, max over the stages
+
+    for (int d = 0; d < plan->ndim; d++) {
+        DimInfo &di = plan->dims[d];
+        if (di.scan_ids.empty()) continue;
+        const int64_t blocks = di.N / kMxSB;
+        int NB = 1;
+        for (int nb = kMxMaxNB; nb >= 1; nb--)
+            if (blocks % nb == 0) { NB = nb; break; }
+        const int T = kMxSB * NB;
+        di.T = T;
+        di.M = di.N / T;
+        const int mode = d > 0 ? MX_Y : (di.lines >= 32 ? MX_XL : MX_X1);
+        for (int id : di.scan_ids) {
+            const Scan &scan = plan->scans[(size_t)id];
+            const int k = scan.order;
+            StageTables tb = build_stage_tables(scan, T, plan->clamped);
+            const std::string tag = std::to_string(id);
+            plan->tables["mx_G_" + tag] = tb.G;
+            plan->tables["mx_R_" + tag] = tb.R;
+            plan->tables["mx_dG_" + tag] = tb.dG;
+            plan->tables["mx_H_" + tag] = tb.H;
+            plan->tables["mx_dH_" + tag] = tb.dH;
+            plan->tables["mx_A_" + tag] = tb.A;
+
+            Stage st;
+            st.scan = id;
+            MxPassArgs &pa = st.pass;
+            pa.mode = mode; pa.T = T; pa.NB = NB; pa.M = (int32_t)di.M; pa.k = k;
+            pa.causal = scan.causal ? 1 : 0;
+            pa.clamped = plan->clamped ? 1 : 0;
+            pa.N = di.N; pa.inner = di.stride; pa.lines = di.lines; pa.units = di.lines * di.M;
+            std::vector<float> fG, fR, fH, fdG(32), fdH(32);
+            pack_fragments(tb.G.data(), fG);
+            pack_fragments(tb.R.data(), fR);
+            for (int b = 0; b < NB; b++) {
+                std::vector<double> Hb(32 * 32, 0.0);
+                for (int r = 0; r < 32; r++)
+                    for (int i = 0; i < 32; i++) Hb[r * 32 + i] = tb.H[(size_t)r * T + 32 * b + i];
+                pack_fragments(Hb.data(), fH);
+            }
+            for (int i = 0; i < 32; i++) { fdG[i] = (float)tb.dG[i]; fdH[i] = (float)tb.dH[i]; }
+            pa.G = (const float *)plan->upload(fG.data(), fG.size() * sizeof(float), &status);
+            pa.R = (const float *)plan->upload(fR.data(), fR.size() * sizeof(float), &status);
+            pa.H = (const float *)plan->upload(fH.data(), fH.size() * sizeof(float), &status);
+            pa.dG = (const float *)plan->upload(fdG.data(), fdG.size() * sizeof(float), &status);
+            pa.dH = (const float *)plan->upload(fdH.data(), fdH.size() * sizeof(float), &status);
+            tails_floats = std::max(tails_floats, (size_t)k * (size_t)pa.units);
+
+            // chain levels: the sequence of a level is the chunk exits of the level below, its transfer matrix that level's
+            // to the power of the chunk length
+            std::vector<double> B = tb.A;
+            std::vector<double> levels_info;
+            for (int64_t Ml = di.M;; Ml = (Ml + kMxChunk - 1) / kMxChunk) {
+                Level lv;
+                lv.M = Ml;
+                lv.top = Ml <= kMxTopMax;
+                std::vector<float> fA;
+                pack_fragments(pad32(B, k).data(), fA);
+                lv.A = (const float *)plan->upload(fA.data(), fA.size() * sizeof(float), &status);
+                levels_info.push_back((double)Ml);
+                if (!lv.top) {
+                    std::vector<float> fP;
+                    std::vector<double> pw = B;
+                    for (int j = 0; j < kMxChunk; j++) {
+                        pack_fragments(pad32(pw, k).data(), fP);
+                        if (j + 1 < kMxChunk) pw = mat_mul<double>(pw, B, k);
+                    }
+                    lv.P = (const float *)plan->upload(fP.data(), fP.size() * sizeof(float), &status);
+                    B = pw;                                  // B^16: the transfer matrix of the level above
+                }
+                const size_t l = st.levels.size();
+                if (l >= 1) {
+                    if (level_floats.size() < l) level_floats.resize(l, 0);
+                    level_floats[l - 1] = std::max(level_floats[l - 1], (size_t)k * (size_t)di.lines * (size_t)Ml);
+                }
+                st.levels.push_back(lv);
+                if (lv.top) break;
+            }
+            plan->tables["mx_levels_" + tag] = levels_info;
+            stages.push_back(st);
+        }
+    }
+    if (status != RF_OK) return status;
+
+    float *tails = (float *)plan->alloc(tails_floats * np * sizeof(float), false, &status);
+    std::vector<float *> level_buf;
+    for (size_t l = 0; l < level_floats.size(); l++) level_buf.push_back((float *)plan->alloc(level_floats[l] * np * sizeof(float), false, &status));
+    if (status != RF_OK) return status;
+
+    bool first_stage = true;
+    for (const Stage &st : stages) {
+        const Scan &scan = plan->scans[(size_t)st.scan];
+        const std::string nm = std::string(1, "xyz"[scan.dim]) + (scan.causal ? "+" : "-") + std::to_string(st.scan);
+        const bool from_input = first_stage;
+        first_stage = false;
+        MxPassArgs base = st.pass;
+        const size_t tails_pp = tails_floats;
+        auto pass_args = [base, tails, tails_pp](int pl) {
+            MxPassArgs a = base;
+            a.tails = tails + (size_t)pl * tails_pp;
+            return a;
+        };
+        Step p1;
+        p1.name = "mx_pass1_" + nm;
+        p1.run = [plan, pass_args, from_input](int pl) {
+            const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
+            return launch_mx_pass1(src, pass_args(pl), plan->stream);
+        };
+        plan->begin_steps.push_back(p1);
+
+        // the chain: up the levels, then the propagation down
+        const int k = base.k, nlev = (int)st.levels.size();
+        const bool x1 = base.mode == MX_X1, causal = base.causal != 0;
+        const int64_t lines = base.lines;
+        std::vector<MxChainArgs> chain((size_t)nlev);
+        for (int l = 0; l < nlev; l++) {
+            const Level &lv = st.levels[(size_t)l];
+            MxChainArgs c{};
+            c.A = lv.A; c.P = lv.P; c.k = k;
+            c.Mtot = lv.M;
+            c.C = lv.top ? (int32_t)lv.M : kMxChunk;
+            const int64_t nch = lv.top ? 1 : (lv.M + kMxChunk - 1) / kMxChunk;
+            c.ncols = lines * nch;
+            c.s_r = lines * lv.M;
+            const bool reversed = l == 0 && !causal;      // level 0 lives in memory order, the levels above in scan order
+            if (x1) {
+                c.chunk_is_lo = 1; c.cdiv = nch;
+                c.s_hi = lv.M; c.s_lo = reversed ? -(int64_t)c.C : c.C; c.s_j = reversed ? -1 : 1;
+                c.base = reversed ? lv.M - 1 : 0;
+                c.e_hi = nch; c.e_lo = 1; c.e_r = lines * nch;
+            } else {
+                c.chunk_is_lo = 0; c.cdiv = lines;
+                c.s_hi = (reversed ? -(int64_t)c.C : (int64_t)c.C) * lines; c.s_lo = 1; c.s_j = reversed ? -lines : lines;
+                c.base = reversed ? (lv.M - 1) * lines : 0;
+                c.e_hi = lines; c.e_lo = 1; c.e_r = lines * nch;
+            }
+            chain[(size_t)l] = c;
+        }
+        std::vector<size_t> lf = level_floats;
+        auto chain_args = [chain, tails, tails_pp, level_buf, lf](int l, int pl) {
+            MxChainArgs c = chain[(size_t)l];
+            c.seq = l == 0 ? tails + (size_t)pl * tails_pp : level_buf[(size_t)l - 1] + (size_t)pl * lf[(size_t)l - 1];
+            c.exits = (size_t)l + 1 < chain.size() ? level_buf[(size_t)l] + (size_t)pl * lf[(size_t)l] : nullptr;
+            return c;
+        };
+        for (int l = 0; l < nlev; l++) {
+            Step cs;
+            cs.name = "mx_chain" + std::to_string(l) + "_" + nm;
+            cs.run = [plan, chain_args, l](int pl) { return launch_mx_chain(chain_args(l, pl), plan->stream); };
+            plan->begin_steps.push_back(cs);
+        }
+        for (int l = nlev - 2; l >= 0; l--) {
+            Step as;
+            as.name = "mx_apply" + std::to_string(l) + "_" + nm;
+            as.run = [plan, chain_args, l](int pl) { return launch_mx_apply(chain_args(l, pl), plan->stream); };
+            plan->begin_steps.push_back(as);
+        }
+
+        Step p2;
+        p2.name = "mx_pass2_" + nm;
+        p2.run = [plan, pass_args, from_input](int pl) {
+            const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
+            return launch_mx_pass2(src, (float *)plan->out[pl], pass_args(pl), plan->stream);
+        };
+        plan->begin_steps.push_back(p2);
+    }
+    return status;
+}
+
+}  // namespace rf

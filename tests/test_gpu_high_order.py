@@ -95,3 +95,68 @@ def test_orders_above_32_are_refused_and_32_is_accepted():
         rfa.Plan((256,), [(0, True, [1.0] + [0.001] * 33)])
     with rfa.Plan((256,), [(0, True, [1.0] + [0.001] * 32)]) as plan:
         assert plan.path in (1, 2, 5)
+
+
+# ---- the matrix path (RF_PATH_TILED_MATRIX, kernels_matrix.hip): every stage a GEMM on the matrix cores ----------------
+MX = capi.RF_PATH_TILED_MATRIX
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+@pytest.mark.parametrize("order", [1, 2, 5, 8, 9, 12, 16, 17, 24, 29, 32])
+def test_matrix_path_1d_every_order(order, clamped):
+    """One causal scan, as apps/audio/audio_filter_high_order.cpp:57-66 has it, and an anticausal one behind it."""
+    scans = [(0, True, audio_coeff(order)), (0, False, stable_coeff(order, order))]
+    sig, out, (path, tiles) = _run((1 << 16,), scans, clamped=clamped, path=MX)
+    assert path == MX and tiles[0] == 128
+    _check(sig, out, scans, clamped)
+
+
+@pytest.mark.parametrize("n", [32, 64, 96, 160, 32 * 25, 32 * 1031, 128 * 4099, 1 << 22])
+def test_matrix_path_1d_lengths_and_chain_levels(n):
+    """Tile widths 32 / 64 / 96 / 128, sequences short enough for one chain launch and long enough for three levels,
+    partial last chunks (a prime number of tiles)."""
+    scans = [(0, False, stable_coeff(32, 9)), (0, True, stable_coeff(20, 10))]
+    for clamped in (False, True):
+        sig, out, (path, _) = _run((n,), scans, clamped=clamped, path=MX)
+        assert path == MX
+        _check(sig, out, scans, clamped)
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+@pytest.mark.parametrize("shape", [(96, 160), (200, 256), (33, 128), (1024, 2048), (7, 96), (128, 32)])
+def test_matrix_path_2d_order_12_x_and_y(shape, clamped):
+    """The 2-D order-12 causal + anticausal x/y filter: lane = line along x (or lane = tile when the image has fewer than
+    32 rows), lane = column along y; line counts that are not multiples of the 128 a workgroup takes."""
+    c = stable_coeff(12, 3)
+    scans = [(0, True, c), (0, False, c)]
+    if shape[0] % 32 == 0:
+        scans += [(1, True, c), (1, False, c)]
+    imgs, outs, (path, _) = _run(shape, scans, clamped=clamped, path=MX, planes=2)
+    assert path == MX
+    _check(imgs, outs, scans, clamped)
+
+
+def test_matrix_path_3d_inplace_and_auto():
+    scans = [(2, False, stable_coeff(9, 1)), (0, True, stable_coeff(17, 2)), (1, False, stable_coeff(32, 4)), (0, False, stable_coeff(4, 5))]
+    for clamped in (False, True):
+        imgs, outs, (path, tiles) = _run((64, 96, 160), scans, clamped=clamped, inplace=True)
+        assert path == MX and list(tiles) == [32, 96, 64]         # automatic for orders above 8
+        _check(imgs, outs, scans, clamped)
+    # widths whose rows are 16-byte aligned but not a multiple of 128 columns (partial column blocks along y / z)
+    imgs, outs, (path, _) = _run((32, 64, 36), [(1, True, stable_coeff(10, 6)), (2, False, stable_coeff(11, 7))], clamped=True)
+    assert path == MX
+    _check(imgs, outs, [(1, True, stable_coeff(10, 6)), (2, False, stable_coeff(11, 7))], True)
+
+
+def test_matrix_path_integrators_and_growing_filters():
+    """Poles on the unit circle: a summed-area table written as one order-2 scan per direction, integer-valued weights --
+    the impulse-response blocks grow linearly and every product is exact in f32 while the sums stay below 2^24."""
+    scans = [(0, True, [1.0, 2.0, -1.0]), (1, True, [1.0, 1.0])]
+    import torch
+    import recfilter_amd as rfa
+    img = np.random.default_rng(3).integers(0, 3, (64, 96)).astype(np.float32)
+    with rfa.Plan(img.shape, scans, path=MX) as plan:
+        out = plan.execute([torch.from_numpy(img).cuda()])[0].cpu().numpy()
+    want = oracle.apply_filter(img.astype(np.float64), scans, False)
+    assert want.max() < 2 ** 24
+    np.testing.assert_array_equal(out, want.astype(np.float32))

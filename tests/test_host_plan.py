@@ -523,3 +523,52 @@ def test_one_read_pass1_z_tail_responses_reproduce_the_tile_local_scans():
     assert _host_plan((256, 1024, 1024), scans, **slab).table("H_z").size == 4 * 4 * 128
     with pytest.raises(Exception):
         _host_plan((256, 1024, 1024), scans, flags=capi.RF_PLAN_LATE_EXCHANGE, **slab).table("H_z")
+
+
+# ---- the matrix path (orders up to 32 in their direct form): its tables replayed in numpy against the untiled oracle ----
+def _stable(order, seed, b=0.4, mass=0.85):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(order) * np.exp(-0.15 * np.arange(order))
+    a *= mass / np.abs(a).sum()
+    return [b] + [float(np.float32(v)) for v in a]
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+@pytest.mark.parametrize("case", ["audio_1d", "xy_pm_12", "xyz_mixed", "order32_1d_levels"])
+def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
+    import matrix_emulator as mxe
+    if case == "audio_1d":            # apps/audio/audio_filter_high_order.cpp:41-42 at its highest order
+        shape, scans = (4096,), [(0, True, [1.0] + [0.01] * 29)]
+    elif case == "xy_pm_12":
+        c = _stable(12, 3)
+        shape, scans = (96, 160), [(0, True, c), (0, False, c), (1, True, c), (1, False, c)]
+    elif case == "xyz_mixed":
+        shape, scans = (64, 32, 96), [(2, False, _stable(9, 1)), (0, True, _stable(17, 2)), (1, False, _stable(32, 4)), (0, False, _stable(4, 5))]
+    else:                             # 1024 tiles of 32: three levels of the chain (1024 -> 64 -> 4)
+        shape, scans = (32 * 1024 + 0,), [(0, False, _stable(32, 9)), (0, True, _stable(20, 10))]
+        shape = (32 * 1031,)          # a prime number of tiles: partial last chunks on every level
+    with rfa.Plan(shape, scans, clamped=clamped, path=capi.RF_PATH_TILED_MATRIX, device=capi.RF_DEVICE_HOST_ONLY) as plan:
+        assert plan.path == capi.RF_PATH_TILED_MATRIX
+        img = rc.random_image(shape, np.float32, 5)
+        got = mxe.run(plan, img, clamped)
+    want = oracle.apply_filter(img.astype(np.float64), scans, clamped)
+    assert rc.rel_err(got, want) < 2e-5
+
+
+def test_matrix_path_choice_and_refusals():
+    H = dict(device=capi.RF_DEVICE_HOST_ONLY)
+    hi = [(0, True, [1.0] + [0.01] * 15)]
+    with rfa.Plan((1 << 16,), hi, **H) as plan:                       # automatic: orders above 8 in their direct form
+        assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.tiles[0] == 128
+    with rfa.Plan((96, 160), [(1, False, _stable(9, 1))], clamped=True, **H) as plan:
+        assert plan.path == capi.RF_PATH_TILED_MATRIX and tuple(plan.tiles)[:2] == (0, 96)
+    with rfa.Plan((100, 160), [(1, False, _stable(9, 1))], **H) as plan:          # 100 rows: not a multiple of 32
+        assert plan.path != capi.RF_PATH_TILED_MATRIX
+    with rfa.Plan((96, 160), [(1, False, [1.0] + [1.0] * 9)], dtype=np.int32, **H) as plan:
+        assert plan.path != capi.RF_PATH_TILED_MATRIX
+    with pytest.raises(rfa.RecFilterError):
+        rfa.Plan((100, 160), [(1, False, _stable(9, 1))], path=capi.RF_PATH_TILED_MATRIX, **H)
+    # an ill-conditioned cascade is not sectioned (sections.h, sections_well_conditioned): order 7 of the audio app's
+    # polynomial stays a direct form
+    with rfa.Plan((1 << 16,), [(0, True, [1.0] + [0.01] * 3)], **H) as plan:
+        assert plan.path in (capi.RF_PATH_TILED_FUSED, capi.RF_PATH_UNTILED)
