@@ -376,6 +376,26 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
             raise SystemExit(f"bench.py: sharded result differs from the unsharded plan on the gathered image: "
                              f"max rel err {parity:.3e} > {SHARDED_PARITY_BAR:g} ({name}, {joined} rank(s))")
 
+    # --- phases of one sharded step (outside the timed region): HIP events on the step's stream at the boundaries of the
+    # stepping protocol, so that the first run on real xGMI says where a step's time goes -- begin (pass 1 + slab-local
+    # carries), interior (the work enqueued beside the all-gather), exchange_wait (the stream blocked on the collective beyond
+    # that), apply, finish.  Mean of 5 steps after 2 unrecorded ones; MAX over ranks per phase.
+    phases = None
+    if stepping:
+        acc = {}
+        for i in range(7):
+            ph = filt.profile_step(inputs, outputs)
+            if i >= 2:
+                for k_, v_ in ph.items():
+                    acc[k_] = acc.get(k_, 0.0) + v_ / 5.0
+        keys = ["begin_ms", "interior_ms", "exchange_wait_ms", "apply_ms", "finish_ms"]
+        t = torch.tensor([acc[k_] for k_ in keys], device="cuda", dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases = {k_: round(float(v_), 4) for k_, v_ in zip(keys, t.tolist())}
+        phases["allgather_bytes"] = int(round(acc["allgather_bytes"]))
+        phases["exchanges_per_step"] = int(round(acc["exchanges"]))
+
     whole = 8.0 * total_px / (ms_per_step * 1e-3) / 1e9      # 8 B per f32 sample per filter
     line = {
         "metric": metric_name(name, cfg["shape"], planes),
@@ -405,6 +425,10 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
         # max over ranks and samples of |sharded - unsharded| / max(|unsharded|, 1e-6), the unsharded plan run on the gathered
         # image; null when nothing was sharded (one rank, plain execute)
         "sharded_parity": parity, "sharded_parity_bar": SHARDED_PARITY_BAR,
+        # one sharded step taken apart (HIP events on its stream, max over ranks; null when nothing was sharded): where the
+        # time of a step goes -- a run on real xGMI whose exchange_wait_ms is not ~0 has a collective the interior work does
+        # not cover
+        "step_phases": phases,
         "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / joined, 4),
         "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
         "roofline": roofline,

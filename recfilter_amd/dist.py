@@ -79,17 +79,28 @@ class ShardedFilter:
             self._gathered[key] = torch.empty(nbytes * self.world, dtype=torch.uint8, device=like.device)
         return self._send[key], self._gathered[key]
 
-    def _run(self, slot, inputs, outputs, stream=None):
+    def _run(self, slot, inputs, outputs, stream=None, marks=None):
+        """marks: a list that receives (phase, event) pairs recorded on the step's stream at the phase boundaries
+        (profile_step below); None in normal operation."""
         plan = self.plans[slot]
         kw = {} if stream is None else {"stream": stream}       # (the numpy stand-in of the CPU tests has no streams)
         if self.world == 1 and not self.force_exchange:
             return plan.execute(inputs, outputs, **kw)
+
+        def mark(phase):
+            if marks is not None:
+                import torch
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(inputs[0].device))
+                marks.append((phase, ev))
+        mark("start")
         plan.begin(inputs, outputs, **kw)
         try:
             n_ex = plan.num_exchanges
             for i in range(n_ex):
                 send, gathered = self._buffers((slot, i), plan, inputs[0])
                 plan.exchange_local(i, send.data_ptr())
+                mark("begin")                # pass 1, the slab-local carry stages, the exit carries
                 # issued after what the current stream holds (the exit carries); asynchronous to what follows on it
                 if self.collective is not None:
                     work = self.collective(gathered, send)
@@ -98,10 +109,14 @@ class ShardedFilter:
                     work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
                 if i == n_ex - 1 and getattr(plan, "has_interior", False):
                     plan.interior()          # exchange-independent work (a z-sharded volume's x/y stage) beside the collective
+                mark("interior")
                 if work is not None:
                     work.wait()              # the current stream waits for the gathered carries
+                mark("exchange_wait")        # what the stream spent blocked on the collective BEYOND its own interior work
                 plan.exchange_apply(i, gathered.data_ptr())
+                mark("apply")
             plan.finish()
+            mark("finish")
         except BaseException:
             # a collective that raised, a stepping call that failed: hand the execution instance back (rf_plan_abort), so
             # that the next execute of this thread starts afresh instead of finding the plan "begun"
@@ -110,6 +125,26 @@ class ShardedFilter:
                 abort()
             raise
         return outputs
+
+    def profile_step(self, inputs, outputs):
+        """One sharded execute on the current stream with HIP events at the phase boundaries: milliseconds the STREAM spent in
+        begin (pass 1 + slab-local carries + exit carries), interior (the exchange-independent work enqueued beside the
+        collective), exchange_wait (blocked on the all-gather beyond that), apply (entering carries), finish (final pass);
+        allgather_bytes = bytes every rank receives per step.  Synchronises the device.  With several exchanges per step the
+        phases of all of them add up.  A plain (unsharded, unforced) filter has no phases: {}."""
+        import torch
+        if self.world == 1 and not self.force_exchange:
+            return {}
+        marks = []
+        self._run(0, inputs, outputs, marks=marks)
+        torch.cuda.synchronize()
+        out = {"begin_ms": 0.0, "interior_ms": 0.0, "exchange_wait_ms": 0.0, "apply_ms": 0.0, "finish_ms": 0.0}
+        for (_, e0), (phase, e1) in zip(marks, marks[1:]):
+            out[phase + "_ms"] += e0.elapsed_time(e1)
+        plan = self.plans[0]
+        out["allgather_bytes"] = int(sum(plan.exchange_bytes(i) for i in range(plan.num_exchanges)) * self.world)
+        out["exchanges"] = int(plan.num_exchanges)
+        return out
 
     def execute(self, inputs, outputs):
         """One filter execution on this rank's slab.  Asynchronous on the current stream for a

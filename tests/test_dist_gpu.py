@@ -118,6 +118,11 @@ def test_bench_two_ranks_over_gloo(launcher):
     assert "all-gather" in d["config"]["sharding"] and d["roofline"]["kernel"] in ("fused_pass2", "fused_tails")     # (the dominant one; a toss-up at this size)
     # the sharded result was checked against the unsharded plan on the gathered 2048 x 1024 image
     assert d["config"]["global_shape"] == [2048, 1024] and 0 <= d["sharded_parity"] < 1e-4 and "configs" not in d
+    # the step taken apart with HIP events on its stream: every phase present, the exit carries of both y scans counted
+    ph = d["step_phases"]
+    assert all(ph[k] >= 0 for k in ("begin_ms", "interior_ms", "exchange_wait_ms", "apply_ms", "finish_ms"))
+    assert ph["begin_ms"] > 0 and ph["finish_ms"] > 0 and ph["exchanges_per_step"] == 1
+    assert ph["allgather_bytes"] == 2 * (2 * 2 * 1024 * 4)        # two ranks x (two scans x order 2 x 1024 columns x 4 bytes)
 
 
 def test_bench_fails_on_a_corrupted_exchange():
@@ -171,6 +176,7 @@ def test_bench_strong_scaling_volume_two_ranks_over_gloo():
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and c["path"] == "tiled_fused"
     assert c["exchange"] == "stepping" and c["collectives_per_step"] == 1 and c["interior_beside_collective"] is True
+    assert d["step_phases"]["interior_ms"] > 0 and d["step_phases"]["allgather_bytes"] == 2 * (2 * 2 * 256 * 256 * 4)
     assert "128x256x256" in c["workload"] and c["global_shape"] == [256, 256, 256] and 0 <= d["sharded_parity"] < 1e-4
 
 
