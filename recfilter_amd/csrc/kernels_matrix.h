@@ -11,7 +11,10 @@
 namespace rf {
 
 constexpr int kMxSB = 32;                  // sub-block: samples one 32x32x2 MFMA chain covers
-constexpr int kMxWaves = 4;                // waves per workgroup of the pass kernels
+#ifndef RF_MX_WAVES
+#define RF_MX_WAVES 4
+#endif
+constexpr int kMxWaves = RF_MX_WAVES;                // waves per workgroup of the pass kernels
 constexpr int kMxUnits = 32 * kMxWaves;    // units (line, tile) per workgroup: one per lane column
 constexpr int kMxMaxNB = 4;                // sub-blocks per tile: T <= 128 (128 units x 128 samples of LDS)
 constexpr int kMxChunk = 16;               // tiles per chunk of the carry chain (levels of the blocked scan)
@@ -36,21 +39,22 @@ struct MxPassArgs {
     const float *dG;           // [32]: what a clamped border adds to the first sub-block per unit first sample
     const float *H;            // A-operand fragments [NB][16][64] of the tail extraction
     const float *dH;           // [32]: ... to the tile-local tail
-    float *tails;              // [r][unit]; unit = line * M + tile (MX_X1) or tile * lines + line
+    float *tails;              // [unit][KP], KP = 8 ceil(k / 8); unit = line * M + tile (MX_X1) or tile * lines + line
 };
 
-// One level of the carry chain / of its propagation.  Column c of the launch (a lane) is split as c_hi = c / cdiv,
-// c_lo = c % cdiv; its element of step j, row r is seq[base + c_hi * s_hi + c_lo * s_lo + j * s_j + r * s_r].
+// One level of the carry chain / of its propagation.  An ELEMENT is a k-vector stored as KP = 8 ceil(k / 8) floats (rows
+// fastest, zero padded).  Column c of the launch (a lane) is split as c_hi = c / cdiv, c_lo = c % cdiv; its element of
+// step j is element number base + c_hi * s_hi + c_lo * s_lo + j * s_j of seq.
 struct MxChainArgs {
     float *seq;
-    float *exits;              // next level: exits[c_hi * e_hi + c_lo * e_lo + r * e_r]; null on the top level
+    float *exits;              // next level: element c_hi * e_hi + c_lo * e_lo; null on the top level
     const float *A;            // A-operand fragments [16][64] of the level's transfer matrix
     const float *P;            // propagation: fragments [C][16][64] of its powers 1..C
     int32_t k, C;
     int32_t chunk_is_lo;       // the chunk index is c_lo (MX_X1) or c_hi
     int64_t ncols, cdiv;
-    int64_t base, s_hi, s_lo, s_j, s_r;
-    int64_t e_hi, e_lo, e_r;
+    int64_t base, s_hi, s_lo, s_j;
+    int64_t e_hi, e_lo;
     int64_t Mtot;              // elements per line on this level (the last chunk may be short)
 };
 

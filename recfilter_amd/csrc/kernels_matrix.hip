@@ -85,20 +85,34 @@ __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
     return b;
 }
 
+// Every thread moves 4 NB chunks of 16 bytes; all of them are requested before the first one is stored to LDS (a loop
+// that loads and stores chunk by chunk is a chain of 4 NB dependent round trips to HBM per workgroup).
+template <bool XM, int NB>
 __device__ __forceinline__ void mx_load_block(const float *__restrict__ src, float *lds, const MxBlock &b) {
-    const int w4 = b.cols >> 2, total = b.rows * w4;
-    for (int f = (int)threadIdx.x; f < total; f += kMxThreads) {
-        const int row = f / w4, c = (f - row * w4) << 2;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (row < b.rows_valid && c < b.cols_valid) v = *reinterpret_cast<const float4 *>(src + b.gbase + (int64_t)row * b.gpitch + c);
-        *reinterpret_cast<float4 *>(lds + row * b.pitch + c) = v;
+    constexpr int W4 = XM ? 8 * NB : kMxUnits / 4;        // 16-byte chunks per row of the LDS image
+    float4 v[4 * NB];
+#pragma unroll
+    for (int it = 0; it < 4 * NB; it++) {
+        const int f = (int)threadIdx.x + kMxThreads * it;
+        const int row = f / W4, c = (f - row * W4) << 2;
+        v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row < b.rows_valid && c < b.cols_valid) v[it] = *reinterpret_cast<const float4 *>(src + b.gbase + (int64_t)row * b.gpitch + c);
+    }
+#pragma unroll
+    for (int it = 0; it < 4 * NB; it++) {
+        const int f = (int)threadIdx.x + kMxThreads * it;
+        const int row = f / W4, c = (f - row * W4) << 2;
+        *reinterpret_cast<float4 *>(lds + row * b.pitch + c) = v[it];
     }
 }
 
+template <bool XM, int NB>
 __device__ __forceinline__ void mx_store_block(float *__restrict__ dst, const float *lds, const MxBlock &b) {
-    const int w4 = b.cols >> 2, total = b.rows * w4;
-    for (int f = (int)threadIdx.x; f < total; f += kMxThreads) {
-        const int row = f / w4, c = (f - row * w4) << 2;
+    constexpr int W4 = XM ? 8 * NB : kMxUnits / 4;
+#pragma unroll
+    for (int it = 0; it < 4 * NB; it++) {
+        const int f = (int)threadIdx.x + kMxThreads * it;
+        const int row = f / W4, c = (f - row * W4) << 2;
         if (row < b.rows_valid && c < b.cols_valid)
             *reinterpret_cast<float4 *>(dst + b.gbase + (int64_t)row * b.gpitch + c) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
     }
@@ -162,23 +176,30 @@ __device__ __forceinline__ MxLane mx_lane(const MxPassArgs &a, const MxBlock &b,
 }
 
 // ---- pass 1: tails[k x units] = H[k x T] . tile[T x units] ------------------------------------------------------------
-template <bool XM>
+// Tails are stored [unit][KP], KP = k rounded up to 8 (the rows k .. KP-1 are zeros): registers 4q .. 4q+3 of a lane are
+// four consecutive rows, so every tail access of the path is a 16-byte access.
+template <bool XM, int NB>
 __global__ void __launch_bounds__(kMxThreads)
 mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     const MxBlock blk = mx_block<XM>(a);
-    mx_load_block(src, mx_lds, blk);
-    __syncthreads();
+    mx_load_block<XM, NB>(src, mx_lds, blk);
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const int mine = 32 * w + u;
     const MxLane ln = mx_lane<XM>(a, blk, mine);
+    float Hf[NB][16];                                      // requested while the block is on its way
+#pragma unroll
+    for (int sb = 0; sb < NB; sb++)
+#pragma unroll
+        for (int t = 0; t < 16; t++) Hf[sb][t] = a.H[(sb * 16 + t) * 64 + lane];
+    __syncthreads();
     floatx16 acc = mx_zero();
-    for (int sb = 0; sb < a.NB; sb++) {
+#pragma unroll
+    for (int sb = 0; sb < NB; sb++) {
         float x[16];
         mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
-        const float *Hf = a.H + (size_t)sb * 16 * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
+        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[sb][t], x[t], acc, 0, 0, 0);
     }
     if (a.clamped && ln.valid && ln.enters) {
         const int m0 = a.causal ? 0 : a.T - 1;
@@ -187,21 +208,22 @@ mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
         for (int t = 0; t < 16; t++) acc[t] = fmaf(a.dH[mx_row(t, h)], x0, acc[t]);
     }
     if (ln.valid) {
+        const int KP = 8 * ((a.k + 7) >> 3);
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int r = mx_row(t, h);
-            if (r < a.k) a.tails[(int64_t)r * a.units + ln.tidx] = acc[t];
+        for (int q = 0; q < 4; q++) {
+            const int r0 = 8 * q + 4 * h;
+            if (r0 < KP) *reinterpret_cast<float4 *>(a.tails + ln.tidx * KP + r0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
     }
 }
 
 // ---- pass 2: y_b = G x_b + R y_(b-1) ----------------------------------------------------------------------------------
-template <bool XM>
+template <bool XM, int NB>
 __global__ void __launch_bounds__(kMxThreads)
 mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     const MxBlock blk = mx_block<XM>(a);
-    mx_load_block(src, mx_lds, blk);
+    mx_load_block<XM, NB>(src, mx_lds, blk);
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const int mine = 32 * w + u;
     const MxLane ln = mx_lane<XM>(a, blk, mine);
@@ -209,19 +231,26 @@ mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassAr
 #pragma unroll
     for (int t = 0; t < 16; t++) { Gf[t] = a.G[t * 64 + lane]; Rf[t] = a.R[t * 64 + lane]; }
     // K steps of R that are not all zero: the k most recent rows of the previous sub-block (wave-uniform)
-    const int nl = 4 * ((a.k + 7) >> 3), t_lo = a.causal ? 16 - nl : 0, t_hi = t_lo + nl;
-    // the completed tail of the neighbouring tile, laid out as the rows of a sub-block that precedes the tile
+    const int nl = 4 * ((a.k + 7) >> 3), KP = 2 * nl, t_lo = a.causal ? 16 - nl : 0, t_hi = t_lo + nl;
+    // the completed tail of the neighbouring tile, laid out as the rows of a sub-block that precedes the tile:
+    // row i of it is tail 31 - i (causal: the most recent output is the last row) or tail i (anticausal)
     floatx16 prev = mx_zero();
     if (ln.valid && !ln.enters) {
+        const float *tp = a.tails + ln.prev_tidx * KP;
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int i = mx_row(t, h), r = a.causal ? 31 - i : i;
-            if (r < a.k) prev[t] = a.tails[(int64_t)r * a.units + ln.prev_tidx];
+        for (int q = 0; q < 4; q++) {
+            const int r_lo = a.causal ? 28 - 8 * q - 4 * h : 8 * q + 4 * h;
+            if (r_lo < KP) {
+                const float4 v = *reinterpret_cast<const float4 *>(tp + r_lo);
+                if (a.causal) { prev[4 * q] = v.w; prev[4 * q + 1] = v.z; prev[4 * q + 2] = v.y; prev[4 * q + 3] = v.x; }
+                else          { prev[4 * q] = v.x; prev[4 * q + 1] = v.y; prev[4 * q + 2] = v.z; prev[4 * q + 3] = v.w; }
+            }
         }
     }
     __syncthreads();
-    for (int bi = 0; bi < a.NB; bi++) {
-        const int sb = a.causal ? bi : a.NB - 1 - bi;
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        const int sb = a.causal ? bi : NB - 1 - bi;
         float x[16];
         mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
         floatx16 c = mx_zero();
@@ -240,13 +269,14 @@ mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassAr
         mx_write_sub<XM>(mx_lds, blk.pitch, mine, h, sb, c);
     }
     __syncthreads();
-    mx_store_block(dst, mx_lds, blk);
+    mx_store_block<XM, NB>(dst, mx_lds, blk);
 }
 
 // ---- the carry chain: x_j = s_j + A x_(j-1) over the steps of a chunk, 32 columns per wave ----------------------------
+// Elements are [KP] rows, rows fastest: NLQ = KP / 8 sixteen-byte pieces per lane and element.
 struct MxCol {
     bool valid;
-    int64_t off, eoff, eprev;      // element offsets: the column's first element, its exit, the exit of the chunk before it
+    int64_t off, eoff, eprev;      // element indices: the column's first element, its exit, the exit of the chunk before it
     int len, chunk;
 };
 
@@ -265,81 +295,79 @@ __device__ __forceinline__ MxCol mx_col(const MxChainArgs &a, int64_t c) {
     return col;
 }
 
+constexpr int kMxAhead = 4;        // elements of the chain requested ahead of the step that consumes them
+
+template <int NLQ>
 __global__ void __launch_bounds__(kMxThreads)
 mx_chain_kernel(MxChainArgs a) {
+    constexpr int NL = 4 * NLQ, KP = 8 * NLQ;
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const MxCol col = mx_col(a, ((int64_t)blockIdx.x * kMxWaves + w) * 32 + u);
-    const int nl = 4 * ((a.k + 7) >> 3);
-    float Af[16];
+    float Af[NL];
 #pragma unroll
-    for (int t = 0; t < 16; t++) Af[t] = a.A[t * 64 + lane];
-    floatx16 x = mx_zero();
-    auto load = [&](int j) {
-        floatx16 s = mx_zero();
-        if (col.valid && j < col.len) {
+    for (int t = 0; t < NL; t++) Af[t] = a.A[t * 64 + lane];
+    auto elem = [&](int j) { return a.seq + (col.off + (int64_t)j * a.s_j) * KP + 4 * h; };
+    float4 ring[kMxAhead][NLQ];
+    auto request = [&](int slot, int j) {
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const int r = mx_row(t, h);
-                if (t < nl && r < a.k) s[t] = a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r];
-            }
+        for (int q = 0; q < NLQ; q++) {
+            ring[slot][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (col.valid && j < col.len) ring[slot][q] = *reinterpret_cast<const float4 *>(elem(j) + 8 * q);
         }
-        return s;
     };
-    floatx16 cur = load(0);
-    for (int j = 0; j < a.C; j++) {
-        const floatx16 nxt = load(j + 1 < a.C ? j + 1 : j);      // requested before this step's arithmetic and stores
-        floatx16 c = cur;
 #pragma unroll
-        for (int t = 0; t < 16; t++)
-            if (t < nl) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[t], x[t], c, 0, 0, 0);
-        if (col.valid && j < col.len) {
+    for (int d = 0; d < kMxAhead; d++) request(d, d);
+    floatx16 x = mx_zero();
+    for (int j0 = 0; j0 < a.C; j0 += kMxAhead) {
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const int r = mx_row(t, h);
-                if (t < nl && r < a.k) a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r] = c[t];
+        for (int d = 0; d < kMxAhead; d++) {
+            const int j = j0 + d;
+            floatx16 c = mx_zero();
+#pragma unroll
+            for (int q = 0; q < NLQ; q++) { c[4 * q] = ring[d][q].x; c[4 * q + 1] = ring[d][q].y; c[4 * q + 2] = ring[d][q].z; c[4 * q + 3] = ring[d][q].w; }
+            request(d, j + kMxAhead);                       // before this step's arithmetic and stores
+#pragma unroll
+            for (int t = 0; t < NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[t], x[t], c, 0, 0, 0);
+            if (col.valid && j < col.len) {
+#pragma unroll
+                for (int q = 0; q < NLQ; q++) *reinterpret_cast<float4 *>(elem(j) + 8 * q) = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+                x = c;
             }
-            x = c;
         }
-        cur = nxt;
     }
     if (a.exits != nullptr && col.valid) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int r = mx_row(t, h);
-            if (t < nl && r < a.k) a.exits[col.eoff + (int64_t)r * a.e_r] = x[t];
-        }
+        for (int q = 0; q < NLQ; q++)
+            *reinterpret_cast<float4 *>(a.exits + col.eoff * KP + 8 * q + 4 * h) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     }
 }
 
 // ---- propagation: element j of a chunk += (A^(j+1)) . (completed exit of the chunk before it) --------------------------
+template <int NLQ>
 __global__ void __launch_bounds__(kMxThreads)
 mx_apply_kernel(MxChainArgs a) {
+    constexpr int NL = 4 * NLQ, KP = 8 * NLQ;
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const MxCol col = mx_col(a, ((int64_t)blockIdx.x * kMxWaves + w) * 32 + u);
     const int j = (int)blockIdx.y;
-    const int nl = 4 * ((a.k + 7) >> 3);
     const bool on = col.valid && col.chunk >= 1 && j < col.len;
     floatx16 c = mx_zero(), e = mx_zero();
+    float *mine = a.seq + (col.off + (int64_t)j * a.s_j) * KP + 4 * h;
     if (on) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int r = mx_row(t, h);
-            if (t < nl && r < a.k) {
-                e[t] = a.exits[col.eprev + (int64_t)r * a.e_r];
-                c[t] = a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r];
-            }
+        for (int q = 0; q < NLQ; q++) {
+            const float4 ev = *reinterpret_cast<const float4 *>(a.exits + col.eprev * KP + 8 * q + 4 * h);
+            const float4 cv = *reinterpret_cast<const float4 *>(mine + 8 * q);
+            e[4 * q] = ev.x; e[4 * q + 1] = ev.y; e[4 * q + 2] = ev.z; e[4 * q + 3] = ev.w;
+            c[4 * q] = cv.x; c[4 * q + 1] = cv.y; c[4 * q + 2] = cv.z; c[4 * q + 3] = cv.w;
         }
     }
     const float *Pf = a.P + (size_t)j * 16 * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 16; t++)
-        if (t < nl) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Pf[t * 64], e[t], c, 0, 0, 0);
+    for (int t = 0; t < NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Pf[t * 64], e[t], c, 0, 0, 0);
     if (on) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int r = mx_row(t, h);
-            if (t < nl && r < a.k) a.seq[col.off + (int64_t)j * a.s_j + (int64_t)r * a.s_r] = c[t];
-        }
+        for (int q = 0; q < NLQ; q++) *reinterpret_cast<float4 *>(mine + 8 * q) = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
     }
 }
 
@@ -374,16 +402,19 @@ int mx_allow_lds(K kern, size_t lds) {
 
 }  // namespace
 
+#define RF_MX_PASS(KERNEL, XMODE, ...)                                                                                        \
+    switch (a.NB) {                                                                                                          \
+        case 1: if (int rc = mx_allow_lds(KERNEL<XMODE, 1>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 1>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
+        case 2: if (int rc = mx_allow_lds(KERNEL<XMODE, 2>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 2>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
+        case 3: if (int rc = mx_allow_lds(KERNEL<XMODE, 3>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 3>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
+        default: if (int rc = mx_allow_lds(KERNEL<XMODE, 4>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 4>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
+    }
+
 int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
     if (int rc = mx_check(a)) return rc;
     const size_t lds = mx_lds_bytes(a);
-    if (a.mode == MX_Y) {
-        if (int rc = mx_allow_lds(mx_pass1_kernel<false>, lds)) return rc;
-        hipLaunchKernelGGL(mx_pass1_kernel<false>, mx_grid(a), dim3(kMxThreads), lds, stream, src, a);
-    } else {
-        if (int rc = mx_allow_lds(mx_pass1_kernel<true>, lds)) return rc;
-        hipLaunchKernelGGL(mx_pass1_kernel<true>, mx_grid(a), dim3(kMxThreads), lds, stream, src, a);
-    }
+    if (a.mode == MX_Y) { RF_MX_PASS(mx_pass1_kernel, false, src, a) }
+    else { RF_MX_PASS(mx_pass1_kernel, true, src, a) }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -391,22 +422,24 @@ int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
 int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream) {
     if (int rc = mx_check(a)) return rc;
     const size_t lds = mx_lds_bytes(a);
-    if (a.mode == MX_Y) {
-        if (int rc = mx_allow_lds(mx_pass2_kernel<false>, lds)) return rc;
-        hipLaunchKernelGGL(mx_pass2_kernel<false>, mx_grid(a), dim3(kMxThreads), lds, stream, src, dst, a);
-    } else {
-        if (int rc = mx_allow_lds(mx_pass2_kernel<true>, lds)) return rc;
-        hipLaunchKernelGGL(mx_pass2_kernel<true>, mx_grid(a), dim3(kMxThreads), lds, stream, src, dst, a);
-    }
+    if (a.mode == MX_Y) { RF_MX_PASS(mx_pass2_kernel, false, src, dst, a) }
+    else { RF_MX_PASS(mx_pass2_kernel, true, src, dst, a) }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
+#undef RF_MX_PASS
 
 int launch_mx_chain(const MxChainArgs &a, hipStream_t stream) {
     if (a.ncols <= 0 || a.C <= 0) return RF_OK;
     const int64_t blocks = (a.ncols + kMxUnits - 1) / kMxUnits;
     if (blocks >= (1ll << 31)) { set_error("matrix path: too many chain columns"); return RF_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(mx_chain_kernel, dim3((unsigned)blocks), dim3(kMxThreads), 0, stream, a);
+    const dim3 grid((unsigned)blocks), block(kMxThreads);
+    switch ((a.k + 7) >> 3) {
+        case 1: hipLaunchKernelGGL(mx_chain_kernel<1>, grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(mx_chain_kernel<2>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(mx_chain_kernel<3>, grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(mx_chain_kernel<4>, grid, block, 0, stream, a); break;
+    }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -415,7 +448,13 @@ int launch_mx_apply(const MxChainArgs &a, hipStream_t stream) {
     if (a.ncols <= 0 || a.C <= 0) return RF_OK;
     const int64_t blocks = (a.ncols + kMxUnits - 1) / kMxUnits;
     if (blocks >= (1ll << 31)) { set_error("matrix path: too many chain columns"); return RF_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(mx_apply_kernel, dim3((unsigned)blocks, (unsigned)a.C), dim3(kMxThreads), 0, stream, a);
+    const dim3 grid((unsigned)blocks, (unsigned)a.C), block(kMxThreads);
+    switch ((a.k + 7) >> 3) {
+        case 1: hipLaunchKernelGGL(mx_apply_kernel<1>, grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(mx_apply_kernel<2>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(mx_apply_kernel<3>, grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(mx_apply_kernel<4>, grid, block, 0, stream, a); break;
+    }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }

@@ -31,7 +31,9 @@ bool matrix_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std
         if (di.N % kMxSB != 0) return no("a filtered extent is not a multiple of 32");
         if (d > 0 && di.stride % 4 != 0) return no("rows are not 16-byte aligned");
         if (d > 0 && di.lines / di.stride > 65535) return no("too many planes");
-        if (di.N / kMxSB > 65535 * (int64_t)kMxMaxNB) return no("extent too large");
+        // (lane = line / column: the tile index is a grid dimension; 1-D signals -- lane = tile -- have no such bound)
+        const bool tile_in_grid = d > 0 || di.lines >= 32;
+        if (tile_in_grid && di.N / kMxSB > 65535) return no("extent too large");
     }
     return true;
 }
@@ -177,7 +179,8 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             pa.H = (const float *)plan->upload(fH.data(), fH.size() * sizeof(float), &status);
             pa.dG = (const float *)plan->upload(fdG.data(), fdG.size() * sizeof(float), &status);
             pa.dH = (const float *)plan->upload(fdH.data(), fdH.size() * sizeof(float), &status);
-            tails_floats = std::max(tails_floats, (size_t)k * (size_t)pa.units);
+            const size_t KP = 8 * (size_t)((k + 7) / 8);       // rows of a stored k-vector
+            tails_floats = std::max(tails_floats, KP * (size_t)pa.units);
 
             // chain levels: the sequence of a level is the chunk exits of the level below, its transfer matrix that level's
             // to the power of the chunk length
@@ -204,7 +207,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
                 const size_t l = st.levels.size();
                 if (l >= 1) {
                     if (level_floats.size() < l) level_floats.resize(l, 0);
-                    level_floats[l - 1] = std::max(level_floats[l - 1], (size_t)k * (size_t)di.lines * (size_t)Ml);
+                    level_floats[l - 1] = std::max(level_floats[l - 1], KP * (size_t)di.lines * (size_t)Ml);
                 }
                 st.levels.push_back(lv);
                 if (lv.top) break;
@@ -254,18 +257,17 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             c.C = lv.top ? (int32_t)lv.M : kMxChunk;
             const int64_t nch = lv.top ? 1 : (lv.M + kMxChunk - 1) / kMxChunk;
             c.ncols = lines * nch;
-            c.s_r = lines * lv.M;
             const bool reversed = l == 0 && !causal;      // level 0 lives in memory order, the levels above in scan order
             if (x1) {
                 c.chunk_is_lo = 1; c.cdiv = nch;
                 c.s_hi = lv.M; c.s_lo = reversed ? -(int64_t)c.C : c.C; c.s_j = reversed ? -1 : 1;
                 c.base = reversed ? lv.M - 1 : 0;
-                c.e_hi = nch; c.e_lo = 1; c.e_r = lines * nch;
+                c.e_hi = nch; c.e_lo = 1;
             } else {
                 c.chunk_is_lo = 0; c.cdiv = lines;
                 c.s_hi = (reversed ? -(int64_t)c.C : (int64_t)c.C) * lines; c.s_lo = 1; c.s_j = reversed ? -lines : lines;
                 c.base = reversed ? (lv.M - 1) * lines : 0;
-                c.e_hi = lines; c.e_lo = 1; c.e_r = lines * nch;
+                c.e_hi = lines; c.e_lo = 1;
             }
             chain[(size_t)l] = c;
         }
