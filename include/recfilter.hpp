@@ -173,6 +173,7 @@ class RecFilter {
         std::vector<Scan> scans;
         std::map<std::string, int> tile;
         bool clamped = false, tiled = false, compiled = false, has_consumer = false;
+        bool merged = false;                     // the plan holds the scans of the whole cascade this stage ends (compile_jit)
         RecFilterPointwise consumer;
         rf_plan *plan = nullptr;
         void *stream = nullptr;                  // HIP stream of enqueue() / realize() (set_stream); null = default stream
@@ -398,13 +399,43 @@ public:
         vec_width() = v;
     }
 
+    /** The stages of the cascade this filter ends, head first, when the whole chain IS one filter: the scans of a cascade
+     *  are the scans of the filter it was made from (lib/reorder.cpp:100-176 distributes them over Funcs that read one
+     *  another), scans of different dimensions commute and the scans of a dimension stay in order -- so the last stage's
+     *  result is the result of ONE plan on the head's input with all the scans in stage order, which moves every sample once
+     *  per pass instead of once per pass and stage (gaussian_1xy_2xy, apps/gaussian/gaussian_filter_1xy_2xy.cpp:44-54: four
+     *  scans per dimension of order <= 2 = one fused stage).  Empty when a stage boundary carries something the merged plan
+     *  cannot express (a consumer fused into an upstream stage, stages of different borders or extents) or merge_cascades()
+     *  is off. */
+    static bool &merge_cascades() { static bool on = true; return on; }
+    std::vector<const Contents *> cascade_chain() const {
+        std::vector<const Contents *> chain;
+        if (!merge_cascades() || !c->source || c->shard_world > 1) return chain;
+        for (const Contents *p = c.get(); p; p = p->source.get()) chain.insert(chain.begin(), p);
+        for (const Contents *p : chain) {
+            bool same = p->dims.size() == c->dims.size() && p->clamped == c->clamped && (p == c.get() || !p->has_consumer);
+            for (size_t i = 0; same && i < p->dims.size(); i++)
+                same = p->dims[i].var() == c->dims[i].var() && p->dims[i].num_pixels() == c->dims[i].num_pixels();
+            if (!same) return {};
+        }
+        return chain;
+    }
+
     /** lib/recfilter.cpp:918-930: builds the plan (tiling tables + kernels), replaces Func::compile_jit */
     void compile_jit(std::string = "") {
         if (c->dims.empty()) fail("filter has no definition");
         if (c->plan) { rf_plan_destroy(c->plan); c->plan = nullptr; }
-        std::vector<rf_scan_desc> sd(c->scans.size());
+        const std::vector<const Contents *> chain = cascade_chain();
+        c->merged = !chain.empty();
+        std::vector<Scan> all;                              // the stage's scans, or those of the whole cascade in stage order
+        if (c->merged) { for (const Contents *p : chain) all.insert(all.end(), p->scans.begin(), p->scans.end()); }
+        else all = c->scans;
+        const Contents *head = c->merged ? chain.front() : c.get();
+        bool tiled = c->tiled;
+        for (const Contents *p : chain) tiled = tiled || p->tiled;
+        std::vector<rf_scan_desc> sd(all.size());
         for (size_t i = 0; i < sd.size(); i++) {
-            const Scan &s = c->scans[i];
+            const Scan &s = all[i];
             if ((int)s.coeff.size() - 1 > RF_MAX_ORDER) fail("filter order above RF_MAX_ORDER");
             sd[i].dim = s.dim; sd[i].causal = s.causal; sd[i].order = (int)s.coeff.size() - 1; sd[i].feedfwd = s.coeff[0];
             for (size_t j = 1; j < s.coeff.size(); j++) sd[i].feedback[j - 1] = s.coeff[j];
@@ -419,14 +450,15 @@ public:
         d.dtype = dtype(); d.n_planes = (int)n_planes();
         d.border = c->clamped ? RF_BORDER_CLAMP : RF_BORDER_ZERO;
         d.n_scans = (int)sd.size(); d.scans = sd.data();
-        d.path = c->tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
+        d.path = tiled ? RF_PATH_AUTO : RF_PATH_UNTILED;
         d.device = -1; d.shard_rank = c->shard_rank; d.shard_world = c->shard_world;
         d.shard_extents = c->shard_extents.empty() ? nullptr : c->shard_extents.data();
         d.flags = c->plan_flags;
-        if (!c->source && !c->inputs.empty() && c->inputs[0].bytes) d.pointwise.in_dtype = RF_IN_U8;
-        if (!c->source && !c->inputs.empty() && (c->inputs[0].scale != 1.0f || c->inputs[0].bias != 0.0f)) {
+        // (the defining expression belongs to the stage that reads the image: this one, or the head of the merged cascade)
+        if (!head->source && !head->inputs.empty() && head->inputs[0].bytes) d.pointwise.in_dtype = RF_IN_U8;
+        if (!head->source && !head->inputs.empty() && (head->inputs[0].scale != 1.0f || head->inputs[0].bias != 0.0f)) {
             d.pointwise.flags |= RF_POINTWISE_PRE;
-            d.pointwise.pre_scale = c->inputs[0].scale; d.pointwise.pre_bias = c->inputs[0].bias;
+            d.pointwise.pre_scale = head->inputs[0].scale; d.pointwise.pre_bias = head->inputs[0].bias;
         }
         if (c->has_consumer) {
             d.pointwise.flags |= RF_POINTWISE_POST;
@@ -442,7 +474,11 @@ public:
     void execute_chain() {
         if (!c->compiled) compile_jit();
         std::vector<const void *> in;
-        if (c->source) { RecFilter up(c->source); up.execute_chain(); for (void *p : up.c->out) in.push_back(p); }
+        if (c->merged) {                          // the whole cascade is this one plan: it reads the head's image
+            const Contents *head = c.get();
+            while (head->source) head = head->source.get();
+            for (auto &i : head->inputs) in.push_back(i.ptr);
+        } else if (c->source) { RecFilter up(c->source); up.execute_chain(); for (void *p : up.c->out) in.push_back(p); }
         else for (auto &i : c->inputs) in.push_back(i.ptr);
         const size_t bytes = plane_elems() * dtype_size(dtype());
         if (c->out.size() != in.size()) {

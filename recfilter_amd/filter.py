@@ -331,6 +331,36 @@ class RecFilter:
             c = c["source"]._contents
         return c["inputs"]
 
+    # Set False to run the stages of a cascade as separate plans, each reading the previous stage's device buffer (the
+    # reference's structure; 12 bytes per sample and stage boundary more).
+    merge_cascades = True
+
+    def _cascade_chain(self):
+        """The stages of the cascade this filter ends, head first, when the whole chain IS one filter: the scans of a
+        cascade are the scans of the filter it was made from (lib/reorder.cpp:100-176 distributes them over Funcs that read
+        one another), scans of different dimensions commute and the scans of a dimension stay in order -- so the last
+        stage's result is the result of ONE plan on the head's input with all the scans in stage order.  That plan moves
+        every sample once per pass instead of once per pass AND stage: gaussian_1xy_2xy (apps/gaussian/
+        gaussian_filter_1xy_2xy.cpp:44-54) is four scans per dimension of order <= 2, i.e. one fused stage.  None when a
+        stage boundary carries something the merged plan cannot express (a consumer fused into an upstream stage, a
+        defining expression on a downstream one, stages of different borders or extents)."""
+        c = self._contents
+        if not RecFilter.merge_cascades or c["source"] is None or not isinstance(c["source"], RecFilter):
+            return None
+        chain = [self]
+        while isinstance(chain[0]._contents["source"], RecFilter):
+            chain.insert(0, chain[0]._contents["source"])
+        if chain[0]._contents["source"] is not None:
+            return None
+        sig = [(d.var(), d.num_pixels()) for d in c["dims"]]
+        for st in chain:
+            sc = st._contents
+            if [(d.var(), d.num_pixels()) for d in sc["dims"]] != sig or sc["clamped"] != c["clamped"]:
+                return None
+        if any(st._contents["epilogue"] is not None for st in chain[:-1]) or any(st._contents["prologue"] is not None for st in chain[1:]):
+            return None
+        return chain
+
     def compile_jit(self, filename: str = "", path: Optional[int] = None) -> None:
         c = self._contents
         if not c["dims"]:
@@ -338,11 +368,18 @@ class RecFilter:
         inputs = self._root_inputs()
         shape = tuple(d.num_pixels() for d in reversed(c["dims"]))
         tile = [c["tile"].get(d.var(), 0) for d in c["dims"]]
+        chain = self._cascade_chain()
+        scans, prologue, tiled = c["scans"], c["prologue"], c["tiled"]
+        if chain is not None:
+            scans = [s for st in chain for s in st._contents["scans"]]
+            prologue = chain[0]._contents["prologue"]
+            tiled = any(st._contents["tiled"] for st in chain)
         if path is None:
-            path = capi.RF_PATH_AUTO if c["tiled"] else capi.RF_PATH_UNTILED
-        c["plan"] = Plan(shape, c["scans"], dtype=inputs[0].dtype, clamped=c["clamped"], planes=len(inputs),
+            path = capi.RF_PATH_AUTO if tiled else capi.RF_PATH_UNTILED
+        c["plan"] = Plan(shape, scans, dtype=inputs[0].dtype, clamped=c["clamped"], planes=len(inputs),
                          tile=tile, path=path, device=inputs[0].device.index or 0,
-                         prologue=c["prologue"], epilogue=c["epilogue"])
+                         prologue=prologue, epilogue=c["epilogue"])
+        c["merged_stages"] = len(chain) if chain is not None else 0
         c["compiled"] = True
 
     def _execute_chain(self, fresh_outputs: bool):
@@ -351,7 +388,10 @@ class RecFilter:
         c = self._contents
         if not c["compiled"]:
             self.compile_jit()
-        inputs = c["source"]._execute_chain(False) if c["source"] is not None else c["inputs"]
+        if c.get("merged_stages"):
+            inputs = self._root_inputs()          # the whole cascade is this one plan (compile_jit, _cascade_chain)
+        else:
+            inputs = c["source"]._execute_chain(False) if c["source"] is not None else c["inputs"]
         reuse = None if fresh_outputs else c.get("outputs")
         c["outputs"] = c["plan"].execute(inputs, reuse)
         return c["outputs"]

@@ -163,6 +163,23 @@ def test_cascade_and_overlap_front_end():
     by_dim = F.cascade_by_dimension()
     out2 = by_dim[-1].realize()[0].cpu().numpy()
     assert rc.rel_err(out2, want) < TOL
+    # A cascade IS the filter it was made from (scans of different dimensions commute, the scans of a dimension stay in
+    # order): the last stage runs ONE plan with the scans of every stage -- four per dimension of order <= 2 here, one
+    # fused stage instead of two -- and an upstream stage asked for its own result still gives that.
+    assert fc[-1]._contents["merged_stages"] == 2 and by_dim[-1]._contents["merged_stages"] == 2
+    assert fc[-1].plan().num_kernels <= 5
+    first = fc[0].realize()[0].cpu().numpy()
+    assert rc.rel_err(first, oracle.apply_filter(img.astype(np.float64), F._contents["scans"][:4], True)) < TOL
+    rfa.RecFilter.merge_cascades = False
+    try:
+        chained = F.cascade([0, 1, 2, 3], [4, 5, 6, 7])
+        for f in chained:
+            f.split_all_dimensions(16)
+        out3 = chained[-1].realize()[0].cpu().numpy()
+        assert chained[-1]._contents["merged_stages"] == 0 and rc.rel_err(out3, want) < TOL
+    finally:
+        rfa.RecFilter.merge_cascades = True
+    assert rc.rel_err(out, out3.astype(np.float64)) < 1e-5
 
 
 def test_cascade_and_overlap_keep_the_prologue():
