@@ -119,6 +119,7 @@ def test_bench_two_ranks_over_gloo(launcher):
     # the sharded result was checked against the unsharded plan on the gathered 2048 x 1024 image
     assert d["config"]["global_shape"] == [2048, 1024] and 0 <= d["sharded_parity"] < 1e-4 and "configs" not in d
     # the step taken apart with HIP events on its stream: every phase present, the exit carries of both y scans counted
+    assert 0 <= d["sharded_parity_sat"] < 1e-4          # ... and for a summed-area table over the same slabs (non-decaying carries)
     ph = d["step_phases"]
     assert all(ph[k] >= 0 for k in ("begin_ms", "interior_ms", "exchange_wait_ms", "apply_ms", "finish_ms"))
     assert ph["begin_ms"] > 0 and ph["finish_ms"] > 0 and ph["exchanges_per_step"] == 1

@@ -15,6 +15,13 @@ cd $root
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 python3 tools/pmc_summary.py $(ls $out/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $out/pmc_write/*/*counter_collection.csv | head -1) $out/pmc_traffic.json
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+# config 5 at 2048^3 (the `configs[0]` line of a default run): its own two PMC passes -> pmc_traffic_cfg5_2048.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc5_$c -- python3 $root/bench.py --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1)
+done
+python3 tools/pmc_summary.py $(ls $out/pmc5_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $out/pmc5_WRITE_SIZE/*/*counter_collection.csv | head -1) $out/pmc_traffic_cfg5_2048.json
+rm -rf $out/pmc5_FETCH_SIZE $out/pmc5_WRITE_SIZE
+cp $out/pmc_traffic_cfg5_2048.json $root/profiles/$tag/pmc_traffic_cfg5_2048.json
 # the bench line LAST, with the fresh PMC summary in place: bench.py reports `traffic` only from a summary collected on the
 # kernel sources that are running (git_head is stamped afterwards, where .git exists: tools/stamp_head.py)
 mkdir -p $root/profiles/$tag && cp $out/pmc_traffic.json $root/profiles/$tag/pmc_traffic.json

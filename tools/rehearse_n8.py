@@ -80,9 +80,16 @@ def main():
     import ref_cases as rc
     cfg3 = dict(rc.BASELINE_CONFIGS["cfg3_gaussian2_xy"])
     emulate("cfg3 weak", (args.slab, 16384), args.world, cfg3)
+    # The same slabs with carries that do not decay (bench.py's `sharded_parity_sat`): with cfg3's poles (0.79) every carry
+    # from beyond the neighbouring slab is below one ulp after 16384 rows, so the line above cannot see a wrong multi-hop
+    # table (A^M, X[q][s] over two or more slabs); a summed-area table hands every slab the sum over ALL slabs before it.
+    sat2 = {"scans": [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], "clamped": False}
+    emulate("summed-area table weak", (args.slab, 16384), args.world, sat2)
     if args.cfg5:
         cfg5 = dict(rc.BASELINE_CONFIGS["cfg5_generic_xyz"])
         emulate("cfg5 strong", (args.cfg5 // args.world, args.cfg5, args.cfg5), args.world, cfg5)
+        sat3 = {"scans": [(d, True, [1.0, 1.0]) for d in range(3)], "clamped": False}
+        emulate("summed-volume table strong", (args.cfg5 // args.world, args.cfg5, args.cfg5), args.world, sat3)
 
 
 if __name__ == "__main__":
