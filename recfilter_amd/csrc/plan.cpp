@@ -525,6 +525,10 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
         bool high = false, too_high = false;
         for (const Scan &sc : plan->scans) { high = high || sc.order > kFusedMaxK; too_high = too_high || sc.order > kFusedMaxMod; }
         if (too_high) high = false;
+        // ONE scan of a 1-D signal (apps/audio/audio_filter_high_order.cpp): its direct form on the matrix path is four
+        // launches whatever the order (10,000,000 samples: 0.065 ms at orders 4..16), its two or three sections on the fused
+        // kernels take 0.086-0.115 ms (profiles/r5/matrix_audio_sweep.txt)
+        if (high && desc->path == RF_PATH_AUTO && desc->ndim == 1 && desc->n_scans == 1 && matrix_plan_applicable(plan.get(), desc, nullptr)) high = false;
         const bool mod = plan->clamped;
         if (mod && (plan->dtype != RF_F32 || desc->ndim < 2 || plan->sharded())) high = false;
         if (high) {
@@ -575,7 +579,9 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
 
     // A clamped 1-D signal: the zero-border fused plan plus the border corrections (plan_clamp1d.h).
     if ((desc->path == RF_PATH_AUTO || desc->path == RF_PATH_TILED_FUSED) && desc->ndim == 1 && plan->clamped && plan->dtype == RF_F32 &&
-        !plan->sharded() && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && desc->n_scans >= 1) {
+        !plan->sharded() && !plan->pw.pre && !plan->pw.post && !plan->pw.in_u8 && desc->n_scans >= 1 &&
+        // (one scan of order above 3: the matrix path, as for the zero border above)
+        !(desc->path == RF_PATH_AUTO && desc->n_scans == 1 && plan->scans[0].order > kFusedMaxK && matrix_plan_applicable(plan.get(), desc, nullptr))) {
         const int rc = build_clamped_1d(desc, plan.get());
         if (rc == RF_OK) { save_desc(plan.get(), desc); if (int fb = plan->finish_build()) return fb; *out = plan.release(); return RF_OK; }
         if (rc != RF_ERR_UNSUPPORTED) return rc;

@@ -123,6 +123,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
     struct Level {
         int64_t M = 0;           // elements per line
         bool top = false;
+        bool zero = false;       // the level's transfer matrix is all zeros once rounded to f32: its chain is the identity
         const float *A = nullptr, *P = nullptr;
     };
     struct Stage {
@@ -192,8 +193,10 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
                 lv.top = Ml <= kMxTopMax;
                 std::vector<float> fA;
                 pack_fragments(pad32(B, k).data(), fA);
+                lv.zero = std::all_of(fA.begin(), fA.end(), [](float v) { return v == 0.0f; });
                 lv.A = (const float *)plan->upload(fA.data(), fA.size() * sizeof(float), &status);
                 levels_info.push_back((double)Ml);
+                levels_info.push_back(lv.zero ? 1.0 : 0.0);
                 if (!lv.top) {
                     std::vector<float> fP;
                     std::vector<double> pw = B;
@@ -278,13 +281,18 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             c.exits = (size_t)l + 1 < chain.size() ? level_buf[(size_t)l] + (size_t)pl * lf[(size_t)l] : nullptr;
             return c;
         };
-        for (int l = 0; l < nlev; l++) {
+        // A transfer matrix that is all zeros in f32 -- a filter that has decayed below the smallest float across a tile (the
+        // audio app's 0.01 taps after 128 samples), or across 16, 256 ... tiles on the levels above -- makes that level's chain
+        // the identity and everything above it a sum of zeros: those launches are left out (bit-identical: they would add +0).
+        int live = 0;                         // levels whose chain runs
+        while (live < nlev && !st.levels[(size_t)live].zero) live++;
+        for (int l = 0; l < live; l++) {
             Step cs;
             cs.name = "mx_chain" + std::to_string(l) + "_" + nm;
             cs.run = [plan, chain_args, l](int pl) { return launch_mx_chain(chain_args(l, pl), plan->stream); };
             plan->begin_steps.push_back(cs);
         }
-        for (int l = nlev - 2; l >= 0; l--) {
+        for (int l = std::min(live - 1, nlev - 2); l >= 0; l--) {
             Step as;
             as.name = "mx_apply" + std::to_string(l) + "_" + nm;
             as.run = [plan, chain_args, l](int pl) { return launch_mx_apply(chain_args(l, pl), plan->stream); };

@@ -568,6 +568,16 @@ def test_matrix_path_choice_and_refusals():
         assert plan.path != capi.RF_PATH_TILED_MATRIX
     with pytest.raises(rfa.RecFilterError):
         rfa.Plan((100, 160), [(1, False, _stable(9, 1))], path=capi.RF_PATH_TILED_MATRIX, **H)
+    # chain levels whose transfer matrix rounds to zero in f32 are left out: the audio app's taps decay to 4e-5 across one tile
+    # of 128 samples and to nothing across sixteen (pass 1, chain 0, apply 0, pass 2); a slowly decaying filter keeps the levels
+    with rfa.Plan((1 << 20,), [(0, True, [1.0] + [0.01] * 29)], **H) as plan:
+        assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.num_kernels == 4
+        assert list(plan.table("mx_levels_0").reshape(-1, 2)[:, 1]) == [0.0, 1.0, 1.0, 1.0]
+    with rfa.Plan((1 << 20,), [(0, True, [0.01] + [0.099] * 10)], **H) as plan:          # sum of the taps 0.99
+        assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.num_kernels == 8
+        assert list(plan.table("mx_levels_0").reshape(-1, 2)[:, 1]) == [0.0, 0.0, 0.0, 1.0]
+    with rfa.Plan((1 << 20,), [(0, True, [1.0, 2.0, -1.0] + [0.0] * 6)], **H) as plan:          # an integrator: nothing decays
+        assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.num_kernels == 9
     # an ill-conditioned cascade is not sectioned (sections.h, sections_well_conditioned): order 7 of the audio app's
     # polynomial stays a direct form
     with rfa.Plan((1 << 16,), [(0, True, [1.0] + [0.01] * 3)], **H) as plan:

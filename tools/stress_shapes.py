@@ -20,7 +20,7 @@ def width(q):
 
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 worst = 0.0
-for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes", "streams", "sections", "whole", "walk") else n_cases):
+for case in range(0 if len(sys.argv) > 3 and sys.argv[3] in ("overlap", "big", "f64", "1d", "shard", "planes", "streams", "sections", "whole", "walk", "matrix") else n_cases):
     ndim = 2 if case % 4 else 3
     if ndim == 2:
         shape = (int(rng.integers(1, 9000)), width(int(rng.integers(1, 2400))))
@@ -402,3 +402,48 @@ if len(sys.argv) > 3 and sys.argv[3] == "walk":
         print(f"{case:3d} {str(shape):18s} world={world} tiles={tiles} orders={kxy}/{kz} scans={len(scans)} clamped={int(clamped)} {took} err={err:.3e}",
               "" if err < 2e-4 else "  <-- CHECK", flush=True)
     print("worst (walk)", worst)
+
+
+# ---- the matrix path (path 5: orders up to 32 in their direct form, every stage a GEMM on the matrix cores) on random shapes,
+# orders, directions, borders and plane counts against the serial untiled kernel (one recurrence per line, the literal operator)
+if len(sys.argv) > 3 and sys.argv[3] == "matrix":
+    worst = 0.0
+    for case in range(n_cases):
+        kind = case % 4
+        if kind == 0:        # 1-D signals: lane = tile; every tile width, several chain levels
+            shape = (32 * int(rng.integers(1, 40000)),)
+        elif kind == 3:      # volumes
+            shape = (32 * int(rng.integers(1, 5)), 32 * int(rng.integers(1, 8)), 4 * int(rng.integers(1, 90)))
+        else:                # images: lane = line along x (lane = tile below 32 rows), lane = column along y
+            shape = (int(rng.integers(1, 1500)), 32 * int(rng.integers(1, 70)))
+        ndim = len(shape)
+        scans = []
+        for d in range(ndim):
+            n_d = shape[ndim - 1 - d]
+            if n_d % 32 != 0 or (d > 0 and shape[-1] % 4 != 0):
+                continue
+            for _ in range(int(rng.integers(0, 3)) + (1 if d == 0 else 0)):
+                k = int(rng.integers(1, 33))
+                a = rng.standard_normal(k) * np.exp(-rng.uniform(0.05, 0.4) * np.arange(k))
+                a *= rng.uniform(0.3, 0.95) / np.sum(np.abs(a))
+                scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(np.float32(v)) for v in a]))
+        if shape[-1] % 32 != 0:
+            scans = [s for s in scans if s[0] != 0] or [(ndim - 1, True, [1.0, 0.5])]
+            if shape[0] % 32 != 0:
+                continue
+        clamped = bool(rng.integers(0, 2))
+        planes = int(rng.integers(1, 4)) if kind else 1
+        imgs = [torch.rand(shape, device="cuda") for _ in range(planes)]
+        with rfa.Plan(shape, scans, clamped=clamped, planes=planes, path=5) as pm, \
+                rfa.Plan(shape, scans, clamped=clamped, planes=planes, path=1, flags=rfa.capi.RF_PLAN_SERIAL_UNTILED) as pu:
+            om, ou = pm.execute(imgs), pu.execute(imgs)
+            torch.cuda.synchronize()
+            err = 0.0
+            for a_, b_ in zip(om, ou):
+                peak = float(b_.abs().max().item())
+                err = max(err, float(((a_ - b_).abs() / torch.clamp(b_.abs(), min=1e-2 * peak)).max().item()))
+            worst = max(worst, err)
+            orders = [len(s[2]) - 1 for s in scans]
+            print(f"{case:3d} matrix {str(shape):22s} tiles={pm.tiles} orders={orders} clamped={int(clamped)} planes={planes} err={err:.3e}",
+                  "" if err < 2e-4 else "  <-- CHECK", flush=True)
+    print("worst", worst)
