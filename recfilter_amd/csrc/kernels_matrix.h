@@ -40,6 +40,15 @@ struct MxPassArgs {
     const float *H;            // A-operand fragments [NB][16][64] of the tail extraction
     const float *dH;           // [32]: ... to the tile-local tail
     float *tails;              // [unit][KP], KP = 8 ceil(k / 8); unit = line * M + tile (MX_X1) or tile * lines + line
+    // The stage that follows (pass 2 only): the final pass holds the finished block in LDS, which is exactly what the NEXT
+    // scan's pass 1 would read from HBM -- so it contracts it with the next scan's H and stores that scan's tile-local tails
+    // (lib/reorder.cpp:100-176 chains stages through memory; VERDICT r4 "next" 3).  next: 0 none; 1 the next scan runs along
+    // the same dimension (same units); 2 this scan runs along x with lane = line and the next one along y of a 2-D image whose
+    // 128 x 128 blocks coincide (lane = column of the same block).
+    int32_t next;
+    int32_t next_k, next_causal;
+    const float *next_H, *next_dH;
+    float *next_tails;
 };
 
 // One level of the carry chain / of its propagation.  An ELEMENT is a k-vector stored as KP = 8 ceil(k / 8) floats (rows

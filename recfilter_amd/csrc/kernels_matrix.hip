@@ -217,6 +217,37 @@ mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
     }
 }
 
+// The tile-local tails of the NEXT scan from the finished block in LDS (MxPassArgs::next): that scan's pass 1, without its read
+// of the image.  XV: how the next scan sees the block -- its samples along a row of the LDS image (true) or down a column.
+template <bool XV, int NB>
+__device__ __forceinline__ void mx_next_tails(const MxPassArgs &a, const float *lds, int pitch, int mine, int h, int lane, bool valid,
+                                              int tile, int tiles, int64_t tidx) {
+    floatx16 acc = mx_zero();
+#pragma unroll
+    for (int sb = 0; sb < NB; sb++) {
+        float x[16];
+        mx_read_sub<XV>(lds, pitch, mine, h, sb, x);
+        const float *Hf = a.next_H + (size_t)sb * 16 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
+    }
+    const bool enters = a.next_causal ? tile == 0 : tile == tiles - 1;
+    if (a.clamped && valid && enters) {
+        const int m0 = a.next_causal ? 0 : 32 * NB - 1;
+        const float x0 = XV ? lds[mine * pitch + m0] : lds[m0 * pitch + mine];
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc[t] = fmaf(a.next_dH[mx_row(t, h)], x0, acc[t]);
+    }
+    if (valid) {
+        const int KP = 8 * ((a.next_k + 7) >> 3);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r0 = 8 * q + 4 * h;
+            if (r0 < KP) *reinterpret_cast<float4 *>(a.next_tails + tidx * KP + r0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+}
+
 // ---- pass 2: y_b = G x_b + R y_(b-1) ----------------------------------------------------------------------------------
 template <bool XM, int NB>
 __global__ void __launch_bounds__(kMxThreads)
@@ -270,6 +301,15 @@ mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassAr
     }
     __syncthreads();
     mx_store_block<XM, NB>(dst, mx_lds, blk);
+    if (a.next == 1) mx_next_tails<XM, NB>(a, mx_lds, blk.pitch, mine, h, lane, ln.valid, ln.tile, a.M, ln.tidx);
+    if constexpr (XM) {
+        if (a.next == 2) {
+            // the block seen by the y scans: lane = column mine of x tile blk.tile, samples = the block's 128 rows = y tile blockIdx.x
+            const int ytile = (int)blockIdx.x, MY = (int)(a.lines / a.T);
+            const int64_t column = (int64_t)blk.tile * a.T + mine;
+            mx_next_tails<false, NB>(a, mx_lds, blk.pitch, mine, h, lane, true, ytile, MY, (int64_t)ytile * a.N + column);
+        }
+    }
 }
 
 // ---- the carry chain: x_j = s_j + A x_(j-1) over the steps of a chunk, 32 columns per wave ----------------------------

@@ -221,31 +221,53 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
     }
     if (status != RF_OK) return status;
 
-    float *tails = (float *)plan->alloc(tails_floats * np * sizeof(float), false, &status);
+    // Which stages hand the next one its tile-local tails (MxPassArgs::next): consecutive scans of one dimension always; the
+    // last x scan to the first y scan of a 2-D image whose 128 x 128 blocks coincide.  The receiving stage has no pass 1.
+    for (size_t i = 0; i + 1 < stages.size(); i++) {
+        MxPassArgs &a = stages[i].pass;
+        const MxPassArgs &b = stages[i + 1].pass;
+        const int da = plan->scans[(size_t)stages[i].scan].dim, db = plan->scans[(size_t)stages[i + 1].scan].dim;
+        int next = 0;
+        if (da == db) next = 1;
+        else if (plan->ndim == 2 && da == 0 && db == 1 && a.mode == MX_XL && a.T == 128 && b.T == 128 && a.N % 128 == 0 && a.lines % 128 == 0) next = 2;
+        if (RF_KNOB("RF_MX_NO_NEXT") != nullptr) next = 0;      // A/B: every stage with its own pass 1
+        a.next = next;
+        if (next) { a.next_k = b.k; a.next_causal = b.causal; a.next_H = b.H; a.next_dH = b.dH; }
+    }
+    // (two tail buffers: a final pass reads its own stage's completed tails while it writes the next stage's local ones)
+    float *tails_ab[2];
+    tails_ab[0] = (float *)plan->alloc(tails_floats * np * sizeof(float), false, &status);
+    tails_ab[1] = stages.size() > 1 ? (float *)plan->alloc(tails_floats * np * sizeof(float), false, &status) : tails_ab[0];
     std::vector<float *> level_buf;
     for (size_t l = 0; l < level_floats.size(); l++) level_buf.push_back((float *)plan->alloc(level_floats[l] * np * sizeof(float), false, &status));
     if (status != RF_OK) return status;
 
     bool first_stage = true;
-    for (const Stage &st : stages) {
+    for (size_t si = 0; si < stages.size(); si++) {
+        const Stage &st = stages[si];
+        float *tails = tails_ab[si & 1], *tails_next = tails_ab[(si + 1) & 1];
+        const bool has_pass1 = si == 0 || stages[si - 1].pass.next == 0;
         const Scan &scan = plan->scans[(size_t)st.scan];
         const std::string nm = std::string(1, "xyz"[scan.dim]) + (scan.causal ? "+" : "-") + std::to_string(st.scan);
         const bool from_input = first_stage;
         first_stage = false;
         MxPassArgs base = st.pass;
         const size_t tails_pp = tails_floats;
-        auto pass_args = [base, tails, tails_pp](int pl) {
+        auto pass_args = [base, tails, tails_next, tails_pp](int pl) {
             MxPassArgs a = base;
             a.tails = tails + (size_t)pl * tails_pp;
+            a.next_tails = tails_next + (size_t)pl * tails_pp;
             return a;
         };
-        Step p1;
-        p1.name = "mx_pass1_" + nm;
-        p1.run = [plan, pass_args, from_input](int pl) {
-            const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
-            return launch_mx_pass1(src, pass_args(pl), plan->stream);
-        };
-        plan->begin_steps.push_back(p1);
+        if (has_pass1) {
+            Step p1;
+            p1.name = "mx_pass1_" + nm;
+            p1.run = [plan, pass_args, from_input](int pl) {
+                const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
+                return launch_mx_pass1(src, pass_args(pl), plan->stream);
+            };
+            plan->begin_steps.push_back(p1);
+        }
 
         // the chain: up the levels, then the propagation down
         const int k = base.k, nlev = (int)st.levels.size();

@@ -1529,7 +1529,12 @@ def test_high_order_sections_other_cases():
     imgs, outs, (path, _) = _run((256, 512), scans, clamped=False)
     assert path == 3
     _check(imgs, outs, scans, False)
-    sig, out1, (path, _) = _run((8192 * 4,), [(0, True, o8)], clamped=False)       # (RF_MAX_ORDER is 8)
+    # ONE scan of a 1-D signal takes its direct form on the matrix path since round 5 (four launches whatever the order);
+    # asked for by name, the fused kernels still run its sections on the chained-rows path
+    sig, out1, (path, _) = _run((8192 * 4,), [(0, True, o8)], clamped=False)
+    assert path == capi.RF_PATH_TILED_MATRIX
+    _check(sig, out1, [(0, True, o8)], False)
+    sig, out1, (path, _) = _run((8192 * 4,), [(0, True, o8)], clamped=False, path=3)
     assert path == 3
     _check(sig, out1, [(0, True, o8)], False)
     o6c = _from_poles([0.6 + 0.2j, 0.6 - 0.2j, 0.4 + 0.4j, 0.4 - 0.4j, -0.5 + 0.2j, -0.5 - 0.2j])
@@ -1604,7 +1609,12 @@ def test_1d_fused_any_length(n):
     _check(imgs, outs, scans, False)
     o5 = _from_poles([0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j])
     imgs, outs, (path, _) = _run((n,), [(0, False, o5)], clamped=False, inplace=True)
+    # (ONE scan of order above 3: the matrix path where its tiles divide the length, round 5; else sections on the fused kernels)
+    assert path == (capi.RF_PATH_TILED_MATRIX if n % 32 == 0 else 3)
+    _check(imgs, outs, [(0, False, o5)], False)
+    imgs, outs, (path, _) = _run((n,), [(0, False, o5)], clamped=False, inplace=True, path=3)
     assert path == 3
+    _check(imgs, outs, [(0, False, o5)], False)
     scans = [(0, True, rc.GAUSS2), (0, False, rc.GAUSS2)]
     imgs, outs, (path, _) = _run((n,), scans, clamped=False)
     assert path == 3                    # two stages of an in-plan cascade: each copies only the signal out of its padding
@@ -1804,5 +1814,10 @@ def test_clamped_1d_high_order_scans():
     o8 = _from_poles([0.7, -0.6, 0.5 + 0.4j, 0.5 - 0.4j, -0.3 + 0.5j, -0.3 - 0.5j, 0.2 + 0.7j, 0.2 - 0.7j])
     for scans in ([(0, True, o5), (0, False, o5)], [(0, False, o8)], [(0, True, o8), (0, True, rc.GAUSS3), (0, False, o5)]):
         imgs, outs, (path, _) = _run((300_000,), scans, clamped=True)
-        assert path == 3
+        # (ONE scan of order above 3 takes the matrix path since round 5; asked for by name the fused kernels still take it)
+        assert path == (capi.RF_PATH_TILED_MATRIX if len(scans) == 1 else 3)
         _check(imgs, outs, scans, True)
+        if len(scans) == 1:
+            imgs, outs, (path, _) = _run((300_000,), scans, clamped=True, path=3)
+            assert path == 3
+            _check(imgs, outs, scans, True)
