@@ -143,10 +143,15 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     const int64_t zg0 = (int64_t)tz * TZ;
     float *const ybase = wa.ytp + (int64_t)h * wa.part_stride + a.yt_index(0, ty, 0, K, (int64_t)tx * kFusedTX + a.NXP * zg0);
     float *const xbase = a.xt + ((int64_t)tx * K) * Lx + (int64_t)ty * wa.TY + kRows * h + a.NYP * zg0;
+    // (the x tails of a plane are nxk * 8 chunks of four rows: one flushing wave per 32 of them -- wave 8, and wave 9 for the
+    //  six tails of an order-3 pair)
+    constexpr int kXChunks = nxk * (kRows / 4), kXWaves = (kXChunks + 31) / 32;
+    static_assert(nyk <= 8 && kXWaves <= 2, "flushing waves: y parts on waves 0 .. nyk - 1, x tails on waves 8 and 9");
+    const int xu = 32 * (w - 8) + (t & 31);                                                 // this lane's chunk of the x tails (waves 8, 9)
     uint32_t foff = 0;
     if (w < nyk) foff = (uint32_t)(t * 4);                                                  // [jr][256]: jr = t >> 6, chunk t & 63
-    else if (w == 8) {
-        const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, sr = u >> 3, q = u & 7;
+    else if (w >= 8 && w < 8 + kXWaves) {
+        const int u = xu < kXChunks ? xu : 0, sr = u >> 3, q = u & 7;
         foff = (uint32_t)((((int64_t)(sr / K) * a.MX * K + sr % K) * Lx + 4 * q));
     }
     auto flush = [&](int zl, int par) {                             // zl: the plane, counted inside the z tile; par: its parity
@@ -157,16 +162,16 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
 #pragma unroll
             for (int q = 1; q < 4; q++) v = v + ys[(q * nyk + jr) * 64 + c4];
             *reinterpret_cast<F4 *>(ybase + (int64_t)zl * ystride + foff) = v;
-        } else if (w == 8) {
+        } else if (w >= 8 && w < 8 + kXWaves) {
             // lanes u and u + 32 each add up eight of the sixteen waves' partial sums, the halves meet across the wave
             const F4 *xs = stage4 + par * kXs4;
-            const int u = (t & 31) < nxk * (kRows / 4) ? (t & 31) : 0, half8 = (t >> 5) & 1;
-            F4 v = xs[(8 * half8) * nxk * (kRows / 4) + u];
+            const int u = xu < kXChunks ? xu : 0, half8 = (t >> 5) & 1;
+            F4 v = xs[(8 * half8) * kXChunks + u];
 #pragma unroll
-            for (int p = 1; p < 8; p++) v = v + xs[(8 * half8 + p) * nxk * (kRows / 4) + u];
+            for (int p = 1; p < 8; p++) v = v + xs[(8 * half8 + p) * kXChunks + u];
 #pragma unroll
             for (int i = 0; i < 4; i++) v[i] = sum_lanes_xor_32(v[i]);
-            if ((t & 63) < nxk * (kRows / 4)) *reinterpret_cast<F4 *>(xbase + (int64_t)zl * xstride + foff) = v;
+            if ((t & 63) < 32 && xu < kXChunks) *reinterpret_cast<F4 *>(xbase + (int64_t)zl * xstride + foff) = v;
         }
     };
 
@@ -288,7 +293,7 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
 // When pass 1 of a 3-D plan walks: f32 volumes of whole tiles (width % 256, height % TY, depth % TZ; z slabs too), no pointwise
 // stage, x, y and z scans all present, orders <= 2, at most two scans per dimension.
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows) {
-    if (K < 1 || K > 2 || KZ < 1 || KZ > 2) return false;
+    if (K < 1 || K > 3 || KZ < 1 || KZ > 2) return false;          // (order 3 along x / y; the four z accumulators per sample stay)
     if (nx < 1 || nx > 2 || ny < 1 || ny > 2 || nz < 1 || nz > 2) return false;
     if (TY != 32 && TY != 64 && TY != 128) return false;
     if (TZ != 32 && TZ != 64 && TZ != 128) return false;
@@ -321,6 +326,7 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
         return RF_OK;                                                                                                      \
     }
     RF_CASE(2, 2, 2) RF_CASE(2, 1, 1) RF_CASE(2, 2, 1) RF_CASE(2, 1, 2) RF_CASE(1, 2, 2) RF_CASE(1, 1, 1) RF_CASE(1, 2, 1) RF_CASE(1, 1, 2)
+    RF_CASE(3, 2, 2) RF_CASE(3, 1, 1) RF_CASE(3, 2, 1) RF_CASE(3, 1, 2)
 #undef RF_CASE
     set_error("walk tails: unsupported order %d / %d scans / %d z tails", K, a.nx, wa.nzk);
     return RF_ERR_UNSUPPORTED;

@@ -366,7 +366,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     // (its carry scan reads six rows per tile and line), order 1 is unchanged either way.
     static const bool yt_row_major = RF_KNOB("RF_YT_ROW_MAJOR") != nullptr;      // A/B runs
     static const bool yt_force_tile = RF_KNOB("RF_YT_TILE_MAJOR") != nullptr;    // A/B runs: order 3 too
-    const bool yt_tile_major = !yt_row_major && !y_sharded && ny > 0 && (K <= 2 || yt_force_tile) && Ly % kFusedTX == 0 &&
+    // (the one-read pass 1 of a volume stores a tile's combined rows as one run: tile-major for order 3 as well)
+    const bool yt_tile_major = !yt_row_major && !y_sharded && ny > 0 && (K <= 2 || yt_force_tile || walk) && Ly % kFusedTX == 0 &&
                                Ly == NXP * (int64_t)NZ;
     fbase.yt_tile_major = yt_tile_major ? 1 : 0;
     fbase.lin_limit = in_place_tail ? dx.N : 0;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Pass 1 of a 3-D plan in one read (kernels_tails_walk.hip) against the two first passes (RF_PLAN_STAGED_PASS1): results
 on small volumes (against the oracle too), step times and kernel times at 1024^3 / 2048^3.
-  walk_probe.py [check] [time 1024] [time 2048]"""
+  walk_probe.py [check] [time 1024] [time 2048] [time3 1024: order 3 along x / y]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -49,11 +49,15 @@ def check():
     print("worst", worst)
     assert worst < 2e-5
 
-def timeit(n, shape=None):
+G3 = rc.GAUSS3
+XY3 = [(0, True, G3), (0, False, G3), (1, True, G3), (1, False, G3)] + XYZ[4:]      # order 3 along x / y, order 2 along z (round 5)
+
+def timeit(n, shape=None, scans=None):
     shape = shape or (n, n, n)
+    scans = scans or XYZ
     x = torch.rand(shape, device="cuda"); out = torch.empty_like(x)
     for label, fl in (("staged", capi.RF_PLAN_STAGED_PASS1), ("walk", capi.RF_PLAN_WALK_PASS1), ("staged", capi.RF_PLAN_STAGED_PASS1), ("walk", capi.RF_PLAN_WALK_PASS1)):
-        plan = rfa.Plan(shape, XYZ, clamped=False, flags=fl)
+        plan = rfa.Plan(shape, scans, clamped=False, flags=fl)
         for _ in range(2): plan.execute([x], [out])
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -77,5 +81,6 @@ if __name__ == "__main__":
     while i < len(args):
         if args[i] == "check": check(); i += 1
         elif args[i] == "time": timeit(int(args[i + 1])); i += 2
+        elif args[i] == "time3": timeit(int(args[i + 1]), scans=XY3); i += 2
         elif args[i] == "shape": timeit(0, tuple(int(v) for v in args[i + 1].split("x"))); i += 2
         else: raise SystemExit(__doc__)
