@@ -357,6 +357,8 @@ def main(argv=None):
         print("\n".join(sorted(list(APPS) + list(SWEEP_APPS))))
         return 0
     import recfilter_amd as rfa
+    if os.environ.get("PROFILE_APP_CHAINED_CASCADES"):      # A/B: the stages of a cascade as separate plans (the reference's structure)
+        rfa.RecFilter.merge_cascades = False
     os.makedirs(args.outdir, exist_ok=True)
     if args.app in SWEEP_APPS:
         build, params = SWEEP_APPS[args.app]
