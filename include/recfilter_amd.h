@@ -293,6 +293,9 @@ int rf_box_difference(const void *in, void *out, int ndim, const int64_t *extent
                       const int32_t *order, void *stream);
 
 /* ---- clamped tap combinations (the other pointwise-with-offsets Funcs of the reference's apps) -------- */
+/* HARNESS UTILITY, OUTSIDE THE HOT PATH: SURVEY.md 2c marks apps/DoG out of scope; this entry point exists so that
+ * tools/profile_app.py can run the reference's diff_gauss app end to end on device buffers.  Nothing of the tiled
+ * recursive-filter path (plans, kernels, sharding) uses it; a drop-in integration does not need to bind it. */
 /* out(p) = sum_t weight_t * in_planes[plane_t]( clamp(p + offset_t) ),  clamp per dimension to [0, extent-1].
  * Covers every difference operator the apps put behind a summed-area table that rf_box_difference does not:
  * apps/DoG/diff_gauss.cpp:176-197 (diff_op_x / diff_op_y: taps +B, -1 (twice), -2B-2, one division; diff_op_xy with two
