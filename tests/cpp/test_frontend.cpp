@@ -209,6 +209,36 @@ int main() {
         failures += !(ms > 0.0f);
         (void)hipFree(d);
     }
+    {   // apps/audio/audio_filter_high_order.cpp:38-73: one causal scan of order 1, 3, .. 29 ("dummy coeff": 0.01) over a 1-D
+        // signal, tiled and non-tiled; orders above 8 run in their direct form on the matrix cores (RF_PATH_TILED_MATRIX)
+        const int width = 1 << 18, tile_width = 32;
+        std::vector<float> image = random_image((size_t)width, 7);
+        float *d = upload(image);
+        double worst = 0.0;
+        int high_path = -1;
+        for (int order = 1; order < 30; order += 2) {
+            std::vector<float> coeffs(order + 1, 0.01f);
+            coeffs[0] = 1.0f;
+            RecFilterDim x("x", width);
+            RecFilter F("R_tiled");
+            F(x) = RecFilterImage(d);
+            F.add_filter(+x, coeffs);
+            F.split(x, tile_width);
+            std::vector<float> out = F.realize().to_host<float>();
+            std::vector<float> ref = image;
+            loop_scan(ref, width, 1, 1, 0, true, coeffs);
+            worst = std::max(worst, rel_err(ref, out));
+            if (order == 29) {
+                const std::string syn = F.print_synopsis();
+                const size_t at = syn.find("plan: path ");
+                if (at != std::string::npos) high_path = std::atoi(syn.c_str() + at + 11);
+            }
+        }
+        report("audio_high_order (orders 1..29)", worst);
+        std::printf("%-34s order 29 runs on path %d %s\n", "", high_path, high_path == RF_PATH_TILED_MATRIX ? "ok" : "FAILED");
+        failures += high_path != RF_PATH_TILED_MATRIX;
+        (void)hipFree(d);
+    }
     {   // apps/usm/unsharp_mask_optimized.cpp: USM = (1+w)*I - w*Blur(I), Blur computed at USM's tiles; the input is
         // defined as image/255 like demo/demo_gaussian_filter.cpp:51-53.  Reference result: untiled blur + host loop.
         const int width = 512, height = 256;

@@ -342,3 +342,42 @@ def test_final_pass_split_into_whole_tiles_and_edge_strips(case):
         else:
             want = oracle.apply_filter(im.astype(np.float64), scans, clamped, threads=_threads())
             assert _floor_err(out, want) < TOL
+
+
+# ---- the reference's high-order audio sweep at bench size: 10,000,000 samples, orders 1, 3, .. 29 in their direct form --------
+def test_audio_high_order_sweep_10m_samples():
+    """apps/audio/audio_filter_high_order.cpp:38-73 at the size the audio apps are quoted on: every order of the sweep, one causal
+    scan with the app's taps, against the f64 oracle on ALL samples (78125 tiles of 128: every level of the carry chain)."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    n = 10_000_000
+    sig = rc.random_image((n,), np.float32, 21)
+    dev = torch.from_numpy(sig).cuda()
+    for order in range(1, 30, 2):
+        scans = [(0, True, [1.0] + [0.01] * order)]
+        with rfa.Plan((n,), scans) as plan:
+            assert plan.path == (capi.RF_PATH_TILED_MATRIX if order > 3 else 3), (order, plan.path_name)
+            got = plan.execute([dev])[0].cpu().numpy()
+        want = oracle.apply_filter(sig.astype(np.float64), scans, False)
+        assert rc.rel_err(got, want) < TOL, order
+
+
+def test_order_12_and_32_images_4096_against_oracle():
+    """2-D causal + anticausal x / y filters of order 12 (clamped) and 32 (zero border) at 4096^2 on the matrix path."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    rng = np.random.default_rng(5)
+    for order, clamped in ((12, True), (32, False)):
+        a = rng.standard_normal(order) * np.exp(-0.15 * np.arange(order))
+        a *= 0.85 / np.abs(a).sum()
+        c = [0.4] + [float(np.float32(v)) for v in a]
+        scans = [(0, True, c), (0, False, c), (1, True, c), (1, False, c)]
+        img = rc.random_image((4096, 4096), np.float32, 3)
+        dev = torch.from_numpy(img).cuda()
+        with rfa.Plan(img.shape, scans, clamped=clamped) as plan:
+            assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.num_kernels == 13      # one pass 1; per scan chain 0, apply 0, pass 2
+            got = plan.execute([dev])[0].cpu().numpy()
+        want = oracle.apply_filter(img.astype(np.float64), scans, clamped, threads=_threads())
+        assert _floor_err(got, want) < TOL, (order, clamped)
