@@ -76,7 +76,7 @@ typedef enum {
                                   * (kernels_matrix.hip): tail extraction H[k x T] . tile, the carry recurrence as a chain
                                   * of k x k products, the final pass as 32 x 32 impulse-response blocks.  Scans of ANY
                                   * order up to RF_MAX_ORDER in their direct form (the reference's apps sweep orders up to
-                                  * 29); f32 pixels, filtered extents that are multiples of 32.  RF_PATH_AUTO picks it for
+                                  * 29); f32 pixels, any extents whose width is a multiple of 4 samples.  RF_PATH_AUTO picks it for
                                   * filters with a scan of order above 3 that the fused path (sections) does not take */
 } rf_path;
 

@@ -34,6 +34,9 @@ struct MxPassArgs {
     int32_t causal;
     int32_t clamped;           // the tile where the scan enters the image takes the border correction
     int64_t N, inner, lines;   // extent and stride of the scanned dimension, number of lines
+    int32_t ragged;            // the tiles do not divide the extent (off != 0 or M T != N): elements are checked one by one
+    int64_t off;               // tile t covers the samples [t T - off, (t + 1) T - off): the tiles need not divide N, the padding
+                               // (zeros, never stored) lies where the scan LEAVES the image -- 0 for a causal scan, M T - N otherwise
     int64_t units;             // lines * M
     const float *G, *R;        // A-operand fragments [16][64] of the sub-block operators (see kernels_matrix.hip)
     const float *dG;           // [32]: what a clamped border adds to the first sub-block per unit first sample

@@ -54,22 +54,57 @@ struct MxBlock {
     int pitch;                 // LDS pitch in floats
     int tile;                  // MX_XL / MX_Y: the tile of the block
     int64_t first;             // first unit (MX_X1), line (MX_XL) or line of column 0 (MX_Y)
+    int64_t s0;                // MX_XL / MX_Y: the sample the block's tile starts at (tile * T - off: may be negative)
+    int lo, hi;                // MX_XL / MX_Y: the samples [lo, hi) of the block's tile exist
+    int last_hi;               // how many samples of the LAST tile exist
 };
+
+// Where element (row, chunk column c) of the block lies in the plane and whether it exists.  Tiles need not divide the extent:
+// tile t covers the samples [t T - off, (t + 1) T - off), and whatever falls outside [0, N) loads as zeros and is never stored.
+// The padding is always on the side where the scan LEAVES the image (off = 0 for a causal scan, M T - N for an anticausal one):
+// zeros behind the last sample change nothing for the samples in front of them, and the tile where the scan enters is whole.
+template <bool XM>
+__device__ __forceinline__ bool mx_element(const MxPassArgs &a, const MxBlock &b, int row, int c, int64_t &offset) {
+    // samples [lo, hi) of a tile exist: everything but the first tile starts at 0, everything but the last one ends at T
+    if constexpr (XM) {
+        if (a.mode == MX_X1) {
+            const int64_t U = b.first + row;
+            int64_t tile = U;
+            offset = b.gbase + (int64_t)(row * a.T + c);                       // a 1-D signal: its tiles follow one another in memory
+            if (a.lines != 1) {
+                const int64_t line = U / a.M;
+                tile = U - line * a.M;
+                offset = line * a.N + tile * a.T - a.off + c;
+            }
+            const int lo = tile == 0 ? (int)a.off : 0, hi = tile == a.M - 1 ? b.last_hi : a.T;
+            return row < b.rows_valid && c >= lo && c < hi;
+        }
+        offset = b.gbase + (int64_t)row * b.gpitch + c;
+        return row < b.rows_valid && c >= b.lo && c < b.hi;
+    } else {
+        offset = b.gbase + (int64_t)row * b.gpitch + c;
+        return c < b.cols_valid && row >= b.lo && row < b.hi;
+    }
+}
 
 template <bool XM>
 __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
     MxBlock b;
+    b.last_hi = (int)(a.N + a.off - (int64_t)(a.M - 1) * a.T);
+    b.lo = 0; b.hi = a.T;
     if constexpr (XM) {
         b.rows = kMxUnits; b.cols = a.T; b.pitch = a.T + 4; b.cols_valid = a.T;
         if (a.mode == MX_X1) {
             const int64_t U0 = (int64_t)blockIdx.x * kMxUnits;
-            b.gbase = U0 * a.T; b.gpitch = a.T; b.tile = 0; b.first = U0;
+            b.gbase = U0 * a.T - a.off; b.gpitch = a.T; b.tile = 0; b.first = U0; b.s0 = 0;          // (per row: mx_element)
             const int64_t left = a.units - U0;
             b.rows_valid = left < kMxUnits ? (int)left : kMxUnits;
         } else {
             const int64_t L0 = (int64_t)blockIdx.x * kMxUnits;
             b.tile = (int)blockIdx.y;
-            b.gbase = L0 * a.N + (int64_t)b.tile * a.T; b.gpitch = a.N; b.first = L0;
+            b.s0 = (int64_t)b.tile * a.T - a.off;
+            b.lo = b.tile == 0 ? (int)a.off : 0; b.hi = b.tile == a.M - 1 ? b.last_hi : a.T;
+            b.gbase = L0 * a.N + b.s0; b.gpitch = a.N; b.first = L0;
             const int64_t left = a.lines - L0;
             b.rows_valid = left < kMxUnits ? (int)left : kMxUnits;
         }
@@ -77,7 +112,9 @@ __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
         const int64_t c0 = (int64_t)blockIdx.x * kMxUnits, outer = blockIdx.z;
         b.tile = (int)blockIdx.y;
         b.rows = a.T; b.cols = kMxUnits; b.pitch = kMxPitchY; b.rows_valid = a.T;
-        b.gbase = (outer * a.N + (int64_t)b.tile * a.T) * a.inner + c0; b.gpitch = a.inner;
+        b.s0 = (int64_t)b.tile * a.T - a.off;
+        b.lo = b.tile == 0 ? (int)a.off : 0; b.hi = b.tile == a.M - 1 ? b.last_hi : a.T;
+        b.gbase = (outer * a.N + b.s0) * a.inner + c0; b.gpitch = a.inner;
         b.first = outer * a.inner + c0;
         const int64_t left = a.inner - c0;
         b.cols_valid = left < kMxUnits ? (int)left : kMxUnits;
@@ -88,15 +125,28 @@ __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
 // Every thread moves 4 NB chunks of 16 bytes; all of them are requested before the first one is stored to LDS (a loop
 // that loads and stores chunk by chunk is a chain of 4 NB dependent round trips to HBM per workgroup).
 template <bool XM, int NB>
-__device__ __forceinline__ void mx_load_block(const float *__restrict__ src, float *lds, const MxBlock &b) {
+__device__ __forceinline__ void mx_load_block(const float *__restrict__ src, float *lds, const MxPassArgs &a, const MxBlock &b) {
     constexpr int W4 = XM ? 8 * NB : kMxUnits / 4;        // 16-byte chunks per row of the LDS image
     float4 v[4 * NB];
+    if (!a.ragged) {          // tiles that divide the extent (wave-uniform): rows and columns of the block exist or not as a whole
 #pragma unroll
-    for (int it = 0; it < 4 * NB; it++) {
-        const int f = (int)threadIdx.x + kMxThreads * it;
-        const int row = f / W4, c = (f - row * W4) << 2;
-        v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (row < b.rows_valid && c < b.cols_valid) v[it] = *reinterpret_cast<const float4 *>(src + b.gbase + (int64_t)row * b.gpitch + c);
+        for (int it = 0; it < 4 * NB; it++) {
+            const int f = (int)threadIdx.x + kMxThreads * it;
+            const int row = f / W4, c = (f - row * W4) << 2;
+            v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (row < b.rows_valid && c < b.cols_valid) v[it] = *reinterpret_cast<const float4 *>(src + b.gbase + (int64_t)row * b.gpitch + c);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 4 * NB; it++) {
+            const int f = (int)threadIdx.x + kMxThreads * it;
+            const int row = f / W4, c = (f - row * W4) << 2;
+            // (branch-free: an element that does not exist reads the plane's first chunk and is replaced by zeros)
+            int64_t o;
+            const bool ok = mx_element<XM>(a, b, row, c, o);
+            const float4 got = *reinterpret_cast<const float4 *>(src + (ok ? o : 0));
+            v[it] = ok ? got : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
 #pragma unroll
     for (int it = 0; it < 4 * NB; it++) {
@@ -107,14 +157,24 @@ __device__ __forceinline__ void mx_load_block(const float *__restrict__ src, flo
 }
 
 template <bool XM, int NB>
-__device__ __forceinline__ void mx_store_block(float *__restrict__ dst, const float *lds, const MxBlock &b) {
+__device__ __forceinline__ void mx_store_block(float *__restrict__ dst, const float *lds, const MxPassArgs &a, const MxBlock &b) {
     constexpr int W4 = XM ? 8 * NB : kMxUnits / 4;
+    if (!a.ragged) {
 #pragma unroll
-    for (int it = 0; it < 4 * NB; it++) {
-        const int f = (int)threadIdx.x + kMxThreads * it;
-        const int row = f / W4, c = (f - row * W4) << 2;
-        if (row < b.rows_valid && c < b.cols_valid)
-            *reinterpret_cast<float4 *>(dst + b.gbase + (int64_t)row * b.gpitch + c) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
+        for (int it = 0; it < 4 * NB; it++) {
+            const int f = (int)threadIdx.x + kMxThreads * it;
+            const int row = f / W4, c = (f - row * W4) << 2;
+            if (row < b.rows_valid && c < b.cols_valid)
+                *reinterpret_cast<float4 *>(dst + b.gbase + (int64_t)row * b.gpitch + c) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 4 * NB; it++) {
+            const int f = (int)threadIdx.x + kMxThreads * it;
+            const int row = f / W4, c = (f - row * W4) << 2;
+            int64_t o;
+            if (mx_element<XM>(a, b, row, c, o)) *reinterpret_cast<float4 *>(dst + o) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
+        }
     }
 }
 
@@ -183,7 +243,7 @@ __global__ void __launch_bounds__(kMxThreads)
 mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     const MxBlock blk = mx_block<XM>(a);
-    mx_load_block<XM, NB>(src, mx_lds, blk);
+    mx_load_block<XM, NB>(src, mx_lds, a, blk);
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const int mine = 32 * w + u;
     const MxLane ln = mx_lane<XM>(a, blk, mine);
@@ -254,7 +314,7 @@ __global__ void __launch_bounds__(kMxThreads)
 mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     const MxBlock blk = mx_block<XM>(a);
-    mx_load_block<XM, NB>(src, mx_lds, blk);
+    mx_load_block<XM, NB>(src, mx_lds, a, blk);
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const int mine = 32 * w + u;
     const MxLane ln = mx_lane<XM>(a, blk, mine);
@@ -300,7 +360,7 @@ mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassAr
         mx_write_sub<XM>(mx_lds, blk.pitch, mine, h, sb, c);
     }
     __syncthreads();
-    mx_store_block<XM, NB>(dst, mx_lds, blk);
+    mx_store_block<XM, NB>(dst, mx_lds, a, blk);
     if (a.next == 1) mx_next_tails<XM, NB>(a, mx_lds, blk.pitch, mine, h, lane, ln.valid, ln.tile, a.M, ln.tidx);
     if constexpr (XM) {
         if (a.next == 2) {
@@ -422,7 +482,8 @@ dim3 mx_grid(const MxPassArgs &a) {
 }
 
 int mx_check(const MxPassArgs &a) {
-    if (a.T != 32 * a.NB || a.NB < 1 || a.NB > kMxMaxNB || a.k < 1 || a.k > 32 || a.M < 1 || a.N != (int64_t)a.M * a.T) {
+    if (a.T != 32 * a.NB || a.NB < 1 || a.NB > kMxMaxNB || a.k < 1 || a.k > 32 || a.M < 1 || a.off < 0 || a.off >= a.T ||
+        (int64_t)a.M * a.T < a.N + a.off || (int64_t)(a.M - 1) * a.T >= a.N + a.off || (a.mode != MX_Y && (a.N % 4 != 0 || a.off % 4 != 0))) {
         set_error("matrix path: bad tile geometry (T %d, NB %d, M %d, k %d)", a.T, a.NB, a.M, a.k);
         return RF_ERR_INVALID_ARG;
     }

@@ -28,7 +28,8 @@ bool matrix_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std
     for (int d = 0; d < plan->ndim; d++) {
         const DimInfo &di = plan->dims[d];
         if (di.scan_ids.empty()) continue;
-        if (di.N % kMxSB != 0) return no("a filtered extent is not a multiple of 32");
+        // (the tiles need not divide the extent -- kernels_matrix.hip, mx_element -- but the passes move 16 bytes per lane)
+        if (d == 0 && di.N % 4 != 0) return no("the width is not a multiple of 4 samples");
         if (d > 0 && di.stride % 4 != 0) return no("rows are not 16-byte aligned");
         if (d > 0 && di.lines / di.stride > 65535) return no("too many planes");
         // (lane = line / column: the tile index is a grid dimension; 1-D signals -- lane = tile -- have no such bound)
@@ -138,13 +139,19 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
     for (int d = 0; d < plan->ndim; d++) {
         DimInfo &di = plan->dims[d];
         if (di.scan_ids.empty()) continue;
-        const int64_t blocks = di.N / kMxSB;
-        int NB = 1;
-        for (int nb = kMxMaxNB; nb >= 1; nb--)
-            if (blocks % nb == 0) { NB = nb; break; }
+        // tile width: the widest of 128 / 96 / 64 / 32 that divides the extent; an extent that is no multiple of 32 takes tiles of
+        // 128 (one tile of 32 .. 128 when it is shorter) and pads the last one where the scan leaves the image (MxPassArgs::off)
+        int NB = kMxMaxNB;
+        if (di.N % kMxSB == 0) {
+            const int64_t blocks = di.N / kMxSB;
+            for (int nb = kMxMaxNB; nb >= 1; nb--)
+                if (blocks % nb == 0) { NB = nb; break; }
+        } else if (di.N < kMxSB * kMxMaxNB) {
+            NB = (int)((di.N + kMxSB - 1) / kMxSB);
+        }
         const int T = kMxSB * NB;
         di.T = T;
-        di.M = di.N / T;
+        di.M = (di.N + T - 1) / T;
         const int mode = d > 0 ? MX_Y : (di.lines >= 32 ? MX_XL : MX_X1);
         for (int id : di.scan_ids) {
             const Scan &scan = plan->scans[(size_t)id];
@@ -165,6 +172,8 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             pa.causal = scan.causal ? 1 : 0;
             pa.clamped = plan->clamped ? 1 : 0;
             pa.N = di.N; pa.inner = di.stride; pa.lines = di.lines; pa.units = di.lines * di.M;
+            pa.off = scan.causal ? 0 : di.M * T - di.N;
+            pa.ragged = di.M * T != di.N ? 1 : 0;
             std::vector<float> fG, fR, fH, fdG(32), fdH(32);
             pack_fragments(tb.G.data(), fG);
             pack_fragments(tb.R.data(), fR);
@@ -216,6 +225,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
                 if (lv.top) break;
             }
             plan->tables["mx_levels_" + tag] = levels_info;
+            plan->tables["mx_geom_" + tag] = {(double)T, (double)di.M, (double)pa.off};
             stages.push_back(st);
         }
     }
@@ -228,7 +238,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         const MxPassArgs &b = stages[i + 1].pass;
         const int da = plan->scans[(size_t)stages[i].scan].dim, db = plan->scans[(size_t)stages[i + 1].scan].dim;
         int next = 0;
-        if (da == db) next = 1;
+        if (da == db && a.off == b.off) next = 1;            // (the same tiles: a causal / anticausal pair only when they divide the extent)
         else if (plan->ndim == 2 && da == 0 && db == 1 && a.mode == MX_XL && a.T == 128 && b.T == 128 && a.N % 128 == 0 && a.lines % 128 == 0) next = 2;
         if (RF_KNOB("RF_MX_NO_NEXT") != nullptr) next = 0;      // A/B: every stage with its own pass 1
         a.next = next;

@@ -71,8 +71,13 @@ def run(plan, img, clamped):
         v = np.moveaxis(out, axis, -1)
         shp = v.shape
         N = shp[-1]
-        M = N // T
-        x = np.ascontiguousarray(v).reshape(-1, M, T)
+        Tg, M, off = (int(g) for g in plan.table(f"mx_geom_{i}"))
+        assert Tg == T and (M - 1) * T < N + off <= M * T and (off == 0 or not causal)
+        # tiles that do not divide the extent: zeros where the scan leaves the image (behind the end for a causal scan, in front
+        # of the start for an anticausal one), never stored
+        padded = np.zeros(v.shape[:-1] + (M * T,), dtype=np.float32)
+        padded[..., off:off + N] = v
+        x = padded.reshape(-1, M, T)
         first_tile, m0 = (0, 0) if causal else (M - 1, T - 1)
         # pass 1
         local = np.einsum("lmt,rt->lmr", x, H[:k]).astype(np.float32)
@@ -98,5 +103,5 @@ def run(plan, img, clamped):
                 c = c.astype(np.float32)
                 y[:, t, 32 * sb:32 * sb + 32] = c
                 prev = c
-        out = np.moveaxis(y.reshape(shp), -1, axis)
+        out = np.moveaxis(y.reshape(shp[:-1] + (M * T,))[..., off:off + N], -1, axis)
     return np.ascontiguousarray(out)

@@ -160,3 +160,20 @@ def test_matrix_path_integrators_and_growing_filters():
     want = oracle.apply_filter(img.astype(np.float64), scans, False)
     assert want.max() < 2 ** 24
     np.testing.assert_array_equal(out, want.astype(np.float32))
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+@pytest.mark.parametrize("shape", [(77, 300), (20,), (50, 33, 68), (1000, 1004), (130, 4100), (10_000_004,), (3, 36), (129, 128)])
+def test_matrix_path_extents_no_tile_divides(shape, clamped):
+    """Tiles need not divide the extent: the padding (zeros, never stored) lies where each scan leaves the image, so the tile where
+    it enters is whole -- causal and anticausal scans of one dimension then tile differently.  Widths multiples of 4, any height /
+    depth; shorter than a tile, shorter than the order."""
+    nd = len(shape)
+    scans = [(0, True, stable_coeff(12, 3)), (0, False, stable_coeff(29, 4))]
+    if nd >= 2:
+        scans += [(1, True, stable_coeff(9, 5)), (1, False, stable_coeff(30, 8))]
+    if nd == 3:
+        scans += [(2, False, stable_coeff(17, 2)), (2, True, audio_coeff(11))]
+    imgs, outs, (path, tiles) = _run(shape, scans, clamped=clamped, path=MX, planes=2 if nd == 2 else 1)
+    assert path == MX
+    _check(imgs, outs, scans, clamped)

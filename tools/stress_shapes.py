@@ -410,24 +410,26 @@ if len(sys.argv) > 3 and sys.argv[3] == "matrix":
     worst = 0.0
     for case in range(n_cases):
         kind = case % 4
+        ragged = case % 8 >= 4      # extents no tile divides (widths multiples of 4): padding where each scan leaves the image
         if kind == 0:        # 1-D signals: lane = tile; every tile width, several chain levels
-            shape = (32 * int(rng.integers(1, 40000)),)
+            shape = (4 * int(rng.integers(1, 320000)),) if ragged else (32 * int(rng.integers(1, 40000)),)
         elif kind == 3:      # volumes
-            shape = (32 * int(rng.integers(1, 5)), 32 * int(rng.integers(1, 8)), 4 * int(rng.integers(1, 90)))
+            shape = (int(rng.integers(1, 160)), int(rng.integers(1, 260)), 4 * int(rng.integers(1, 90))) if ragged else \
+                    (32 * int(rng.integers(1, 5)), 32 * int(rng.integers(1, 8)), 4 * int(rng.integers(1, 90)))
         else:                # images: lane = line along x (lane = tile below 32 rows), lane = column along y
-            shape = (int(rng.integers(1, 1500)), 32 * int(rng.integers(1, 70)))
+            shape = (int(rng.integers(1, 1500)), 4 * int(rng.integers(1, 560))) if ragged else (int(rng.integers(1, 1500)), 32 * int(rng.integers(1, 70)))
         ndim = len(shape)
         scans = []
         for d in range(ndim):
             n_d = shape[ndim - 1 - d]
-            if n_d % 32 != 0 or (d > 0 and shape[-1] % 4 != 0):
+            if (not ragged and n_d % 32 != 0) or (d > 0 and shape[-1] % 4 != 0):
                 continue
             for _ in range(int(rng.integers(0, 3)) + (1 if d == 0 else 0)):
                 k = int(rng.integers(1, 33))
                 a = rng.standard_normal(k) * np.exp(-rng.uniform(0.05, 0.4) * np.arange(k))
                 a *= rng.uniform(0.3, 0.95) / np.sum(np.abs(a))
                 scans.append((d, bool(rng.integers(0, 2)), [float(rng.uniform(0.3, 1.5))] + [float(np.float32(v)) for v in a]))
-        if shape[-1] % 32 != 0:
+        if shape[-1] % 32 != 0 and not ragged:
             scans = [s for s in scans if s[0] != 0] or [(ndim - 1, True, [1.0, 0.5])]
             if shape[0] % 32 != 0:
                 continue
