@@ -376,12 +376,12 @@ public:
         c->consumer = consumer;
         c->has_consumer = true;
     }
-    /** lib/recfilter.cpp:473-573, compute_at(RecFilter external): a SCHEDULE directive there -- this filter's stages are
-     *  computed inside the tiles of the filter that consumes it; the result is the same with or without it.  Accepted as
-     *  a hint and recorded: a filter defined on another filter's output (cascade stages, R2(x,y) = R1's realization)
-     *  already reads the producer's device-resident planes, and each filter is two passes over them whatever the
-     *  directive says. */
-    void compute_at(RecFilter external) { c->schedule_log->push_back("compute_at(" + external.c->name + "): accepted as a hint"); }
+    /** lib/recfilter.cpp:473-573, compute_at(RecFilter external): a SCHEDULE directive there -- this filter's result is
+     *  computed inside the tiles of the RecFilter that consumes it instead of going through memory; the result is the same
+     *  with or without it.  Here a filter defined on another filter's output (cascade stages, R2(x,y) = R1) is realized as
+     *  ONE plan over the head's input (cascade_chain below): the producer's result never exists in memory, which is what the
+     *  directive asks for, so it is recorded and needs nothing else (no app or test of the reference uses it). */
+    void compute_at(RecFilter external) { c->schedule_log->push_back("compute_at(" + external.c->name + "): the consumer's plan holds this filter's scans"); }
     void gpu_auto_schedule(int = 32) {}
     void gpu_auto_full_schedule(int = 32) {}
     void gpu_auto_inter_schedule() {}
