@@ -305,7 +305,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         static const char *walk_knob = RF_KNOB("RF_WALK");                        // A/B: 0 = never
         const bool wanted = !(plan->flags & RF_PLAN_STAGED_PASS1) && !(walk_knob && atoi(walk_knob) == 0);
         const bool z_slabs = plan->sharded();           // z slabs: with the early exchange (plan_strided.h), whose first step this pass then is
-        if (wanted && plan->ndim == 3 && (!z_slabs || early_exchange_possible<P>(plan, 2, desc)) && plan->n_planes == 1 && !batch && !chained && !plan->mod_form &&
+        if (wanted && plan->ndim == 3 && (!z_slabs || early_exchange_possible<P>(plan, 2, desc)) && !batch && !chained && !plan->mod_form &&
             !plan->pw.pre && !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&      // (an epilogue runs behind the z stage either way)
             plan->dims[2].lines == NX * NY) {
             const DimInfo &dz = plan->dims[2];
@@ -333,7 +333,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                     walk_args.z_first_border = (!z_slabs || plan->shard_rank == 0) ? 1 : 0;
                     walk_args.z_last_border = (!z_slabs || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
                     walk_args.part_stride = (int64_t)yt_pp;
-                    walk_args.ytp = parts > 1 ? (float *)plan->alloc(yt_pp * parts * sizeof(float), false, &status) : nullptr;
+                    walk_args.ytp = parts > 1 ? (float *)plan->alloc(yt_pp * parts * np * sizeof(float), false, &status) : nullptr;      // (per Tuple plane)
                     walk_hook = std::make_shared<WalkHook>();
                     if (status != RF_OK) return status;
                 }
@@ -389,6 +389,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         FusedArgs<Acc> a = fbase;
         a.xt = xt + (size_t)pl * xt_pp;
         a.yt = yt + (size_t)pl * yt_pp;
+        if (a.ytp != nullptr) a.ytp = a.ytp + (size_t)pl * yt_pp * (size_t)a.yt_parts;       // (the parts of the one-read pass 1)
         a.y_incoming = yin + (size_t)pl * yin_pp;
         a.x_incoming = xin + (size_t)pl * xin_pp;
         a.plane_batch = batch ? 1 : 0;
@@ -438,8 +439,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         if constexpr (std::is_same<P, float>::value) {
             if (walk_hook) {
                 WalkArgs wa = walk_args;
-                wa.zt = walk_hook->zt;
-                if (!wa.ytp) wa.ytp = a.yt;                 // one patch per y tile: the combined rows go where they belong
+                wa.zt = walk_hook->zt + (size_t)pl * walk_hook->zt_stride;
+                if (wa.ytp) wa.ytp = const_cast<float *>(a.ytp);       // this plane's parts (fargs)
+                else wa.ytp = a.yt;                         // one patch per y tile: the combined rows go where they belong
                 return launch_walk_tails(K, (const float *)plan->in[pl], a, wa, d_Hx, d_Hy, plan->stream);
             }
         }

@@ -31,7 +31,8 @@ inline int strided_tile(const rf_plan *plan, int d) {
 // What pass 1 of the x/y stage needs to know when it also forms this dimension's tails (kernels_tails_walk.hip): the strided
 // dimension then has no first pass of its own.  Filled by add_strided_dimension.
 struct WalkHook {
-    float *zt = nullptr;          // the dimension's tails, [s][t][r][line]
+    float *zt = nullptr;          // the dimension's tails, [s][t][r][line] (plane 0)
+    size_t zt_stride = 0;         // elements between the tails of consecutive Tuple planes
 };
 
 // The x/y filter F over `planes` carry planes of dimension d, in place: a fused x/y plan of its own (null: cannot be built).
@@ -206,7 +207,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
 
     Step p1;
     p1.name = "strided_pass1_" + dn;
-    if (walk) walk->zt = reinterpret_cast<float *>(tails);
+    if (walk) { walk->zt = reinterpret_cast<float *>(tails); walk->zt_stride = tails_stride; }
     p1.run = [plan, sargs, K, TZ, from_input, early](int pl) {
         const P *src = (from_input || early) ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
         return launch_strided_pass<P>(false, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);

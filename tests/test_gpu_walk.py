@@ -102,9 +102,32 @@ def test_one_read_pass1_in_place():
     assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
 
 
-@pytest.mark.parametrize("what", ["int32", "partial_tile_rows", "prologue", "planes"])   # (asked for, refused by the shape rules)
+@pytest.mark.parametrize("clamped", [False, True])
+def test_one_read_pass1_tuple_planes(clamped):
+    """A Tuple volume (three planes, order 3 along x / y -- the shape of BASELINE config 4 with a third dimension): every plane
+    through the one-read pass 1, its own z tails, parts and carry planes (round 5)."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    shape, planes = (64, 128, 512), 3
+    rng = np.random.default_rng(17)
+    imgs = [rng.random(shape, dtype=np.float32) for _ in range(planes)]
+    xs = [torch.from_numpy(im).cuda() for im in imgs]
+    outs = [torch.empty_like(x) for x in xs]
+    with rfa.Plan(shape, XY_ORDER3, clamped=clamped, planes=planes, flags=capi.RF_PLAN_WALK_PASS1 | capi.RF_PLAN_TILE_ROWS(64),
+                  path=capi.RF_PATH_TILED_FUSED) as plan:
+        _, timed = plan.execute_timed(xs, outs)
+        torch.cuda.synchronize()
+    steps = [k for k, _ in timed]
+    assert "walk_tails" in steps and "carry_planes_xy" in steps and "strided_pass1_z" not in steps, steps
+    for im, out in zip(imgs, outs):
+        want = oracle.apply_filter(im.astype(np.float64), XY_ORDER3, clamped)
+        assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-5
+
+
+@pytest.mark.parametrize("what", ["int32", "partial_tile_rows", "prologue"])   # (asked for, refused by the shape rules)
 def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
-    """Integer pixels, a height that is not whole tiles, a pointwise stage, Tuple planes: the z stage runs its own first pass."""
+    """Integer pixels, a height that is not whole tiles, a pointwise stage: the z stage runs its own first pass."""
     import torch
     import recfilter_amd as rfa
     from recfilter_amd import capi
