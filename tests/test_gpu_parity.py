@@ -1609,8 +1609,8 @@ def test_1d_fused_any_length(n):
     _check(imgs, outs, scans, False)
     o5 = _from_poles([0.8, 0.5 + 0.3j, 0.5 - 0.3j, -0.2 + 0.6j, -0.2 - 0.6j])
     imgs, outs, (path, _) = _run((n,), [(0, False, o5)], clamped=False, inplace=True)
-    # (ONE scan of order above 3: the matrix path where its tiles divide the length, round 5; else sections on the fused kernels)
-    assert path == (capi.RF_PATH_TILED_MATRIX if n % 32 == 0 else 3)
+    # (ONE scan of order above 3: the matrix path for lengths that are multiples of 4 samples, round 5; else sections on the fused kernels)
+    assert path == (capi.RF_PATH_TILED_MATRIX if n % 4 == 0 else 3)
     _check(imgs, outs, [(0, False, o5)], False)
     imgs, outs, (path, _) = _run((n,), [(0, False, o5)], clamped=False, inplace=True, path=3)
     assert path == 3
