@@ -239,3 +239,31 @@ def test_tiled_cpu_counterpart_clamped_and_mixed_tiles(coeff, clamped, tile):
     work = img.copy()
     oracle.apply_filter_tiled(work, rc.xy_pm(coeff), clamped, tile=tile, inplace=True)
     assert rc.rel_err(work, want) < 5e-5
+
+
+@pytest.mark.parametrize("order", [9, 12, 17, 24, 29, 32])
+def test_high_order_scans_against_scipy_lfilter(order):
+    """The orders round 5 added (RF_MAX_ORDER 32; the reference's sweep: apps/audio/audio_filter_high_order.cpp:38-42) against
+    scipy.signal.lfilter / lfiltic: zero border, causal and anticausal, along x and y; and the clamped border through lfilter
+    with the initial state "every previous output equals y[0]" (as test_clamped_scan_against_lfilter_with_initial_state)."""
+    from scipy.signal import lfilter, lfiltic
+    rng = np.random.default_rng(500 + order)
+    a = rng.standard_normal(order) * np.exp(-0.15 * np.arange(order))
+    a *= 0.85 / np.abs(a).sum()
+    for coeff in ([1.0] + [0.01] * order, [0.4] + [float(np.float32(v)) for v in a]):
+        coeff = [float(np.float32(v)) for v in coeff]
+        img = rng.standard_normal((7, 300))
+        for dim in (0, 1):
+            for causal in (True, False):
+                want = _lfilter_scan(img, causal, coeff) if dim == 0 else _lfilter_scan(img.T, causal, coeff).T
+                got = oracle.apply_filter(img, [(dim, causal, coeff)], clamped=False)
+                assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, float(np.max(np.abs(want))))
+        x = rng.standard_normal(400)
+        b, den = [coeff[0]], [1.0] + [-c for c in coeff[1:]]
+        y0 = (coeff[0] + sum(coeff[1:])) * x[0]
+        rest, _ = lfilter(b, den, x[1:], zi=lfiltic(b, den, y=[y0] * order))
+        want = np.concatenate([[y0], rest])
+        got = oracle.apply_filter(x, [(0, True, coeff)], clamped=True)
+        assert np.max(np.abs(got - want)) < 1e-10
+        got_rev = oracle.apply_filter(x[::-1].copy(), [(0, False, coeff)], clamped=True)
+        assert np.max(np.abs(got_rev[::-1] - want)) < 1e-10
