@@ -124,6 +124,10 @@ typedef struct {
  *   RF_PLAN_NO_CASCADE      a filter the fused kernels cannot take in one piece (more than four scans per dimension)
  *                           is not split into successive fused stages inside the plan; it runs as given on another path.
  *   RF_PLAN_NO_SECTIONS     scans of order 4..8 are not rewritten into sections of order <= 3.
+ *   RF_PLAN_NO_OVERLAP      the consecutive same-direction scans of a 1-D signal (zero border, f32) are not merged into one
+ *                           scan of their product transfer function (overlap_feedback_coeff, lib/iir_coeff.cpp:236-263) for
+ *                           the matrix path -- what RF_PATH_AUTO does where a host-side probe finds the merged direct form
+ *                           within 2e-5 of the cascade and fewer stages result (five biquads: two fused stages -> one scan).
  *   RF_PLAN_NO_PLANE_BATCH  the planes of a 2-D Tuple run as separate launches instead of one batched launch per step.
  *   RF_PLAN_STREAM_PASS1 /  pass 1 of the fused path as the LDS-DMA streaming kernel wherever its shape rules allow,
  *   RF_PLAN_STAGED_PASS1    whatever the image size / never (default: single planes of at least 2048 tiles).
@@ -159,7 +163,8 @@ typedef struct {
 #define RF_PLAN_SERIAL_UNTILED  0x01000000u
 #define RF_PLAN_MFMA_PASS1      0x02000000u
 #define RF_PLAN_WALK_PASS1      0x04000000u
-#define RF_PLAN_ALL_FLAGS       0x070000ffu
+#define RF_PLAN_NO_OVERLAP      0x08000000u
+#define RF_PLAN_ALL_FLAGS       0x0f0000ffu
 #define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
 #define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
 

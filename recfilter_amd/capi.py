@@ -33,6 +33,7 @@ RF_PLAN_NO_PLANE_BATCH, RF_PLAN_STREAM_PASS1, RF_PLAN_STAGED_PASS1, RF_PLAN_LATE
 RF_PLAN_SERIAL_UNTILED = 0x01000000
 RF_PLAN_MFMA_PASS1 = 0x02000000
 RF_PLAN_WALK_PASS1 = 0x04000000
+RF_PLAN_NO_OVERLAP = 0x08000000
 
 
 def RF_PLAN_TILE_ROWS(n: int) -> int:

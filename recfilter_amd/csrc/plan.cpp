@@ -435,6 +435,59 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     int world = desc->shard_world < 1 ? 1 : desc->shard_world;
     if (desc->shard_rank < 0 || desc->shard_rank >= world) { set_error("shard_rank out of range"); return RF_ERR_INVALID_ARG; }
 
+    // ---- merged runs (1-D signals) -------------------------------------------------------------------------------------
+    // Consecutive scans of one direction with a zero border are ONE scan whose transfer function is the product of theirs --
+    // the reference's overlap_to_higher_order_filter (lib/reorder.cpp:231-381), which a caller applies by hand.  On a 1-D
+    // signal the fused kernels take four scans per stage (~50 us + 18 us per scan at 10,000,000 samples) while the matrix
+    // path takes a scan of ANY order up to 32 in four launches (~68 us): fifteen biquads (apps/audio/audio_filter_biquads.cpp)
+    // are four fused stages or one scan of order 30.  Done where it leaves fewer stages AND a probe finds the merged direct form,
+    // evaluated in f32, within 2e-5 of the cascade (sections.h); the plan then IS the plan of the merged scan list.
+    if (desc->path == RF_PATH_AUTO && desc->ndim == 1 && desc->border == RF_BORDER_ZERO && desc->dtype == RF_F32 && world == 1 &&
+        !(desc->flags & (RF_PLAN_FORCE_EXCHANGE | RF_PLAN_NO_OVERLAP)) && desc->n_scans >= 2 && desc->extent[0] >= 8192 && desc->extent[0] % 4 == 0) {
+        std::vector<rf_scan_desc> merged;
+        bool ok = true, any = false;
+        for (int i = 0; i < desc->n_scans && ok; ) {
+            int j = i, order = 0;
+            std::vector<Scan> run;
+            while (j < desc->n_scans && (desc->scans[j].causal != 0) == (desc->scans[i].causal != 0) && order + desc->scans[j].order <= RF_MAX_ORDER) {
+                Scan s;
+                s.causal = desc->scans[j].causal != 0; s.order = desc->scans[j].order; s.b = (double)desc->scans[j].feedfwd;
+                for (int e = 0; e < s.order; e++) s.a[e] = (double)desc->scans[j].feedback[e];
+                order += s.order;
+                run.push_back(s);
+                j++;
+            }
+            if (run.size() == 1) { merged.push_back(desc->scans[i]); i = j; continue; }
+            std::vector<double> fb(run[0].a, run[0].a + run[0].order);
+            double b = run[0].b;
+            for (size_t q = 1; q < run.size(); q++) {
+                fb = multiply_feedback(fb, std::vector<double>(run[q].a, run[q].a + run[q].order));
+                b *= run[q].b;
+            }
+            rf_scan_desc m{};
+            m.dim = 0; m.causal = desc->scans[i].causal; m.order = (int32_t)fb.size(); m.feedfwd = (float)b;
+            for (size_t e = 0; e < fb.size(); e++) m.feedback[e] = (float)fb[e];
+            Scan ms;
+            ms.causal = m.causal != 0; ms.order = m.order; ms.b = (double)m.feedfwd;
+            for (int e = 0; e < m.order; e++) ms.a[e] = (double)m.feedback[e];
+            ok = merged_well_conditioned(run, ms);
+            merged.push_back(m);
+            any = true;
+            i = j;
+        }
+        // what each form costs, in the units above: a fused stage holds four scans (and a causal scan behind an anticausal one of a
+        // padded signal starts a new stage, cascade_stage_of_scans); the matrix path runs every scan of order above 3 by itself
+        const int fused_stages = (desc->n_scans + kFusedMaxScans - 1) / kFusedMaxScans;
+        const double fused_cost = 50.0 * fused_stages + 18.0 * desc->n_scans, matrix_cost = 68.0 * (double)merged.size();
+        if (ok && any && matrix_cost < fused_cost) {
+            rf_filter_desc md = *desc;
+            md.scans = merged.data();
+            md.n_scans = (int32_t)merged.size();
+            md.flags |= RF_PLAN_NO_OVERLAP;
+            return build_plan(&md, out);
+        }
+    }
+
     const bool host_only = desc->device == RF_DEVICE_HOST_ONLY;
     int device = desc->device;
     if (!host_only) {

@@ -157,4 +157,40 @@ inline bool sections_well_conditioned(const Scan &direct, const std::vector<Scan
     return err <= bar * std::max(peak, 1e-30);
 }
 
+// The other direction (plan.cpp, "merged runs"): consecutive scans of one direction with a ZERO border are one scan whose
+// transfer function is the product of theirs (overlap_feedback_coeff, lib/iir_coeff.cpp:236-263; the reference's
+// overlap_to_higher_order_filter, lib/reorder.cpp:231-381, does this on request).  Whether the direct form of the product,
+// evaluated in f32, is a good way to compute the cascade is again tried, not assumed: the cascade in double against the merged
+// scan in float on the probe signal.
+inline bool merged_well_conditioned(const std::vector<Scan> &cascade, const Scan &merged, double bar = 2e-5) {
+    const int L = 768;
+    std::vector<double> cur(L);
+    uint32_t lcg = 4242u;
+    for (int i = 0; i < L; i++) { lcg = lcg * 1664525u + 1013904223u; cur[i] = (double)(lcg >> 8) / 16777216.0 - 0.5; }
+    cur[0] += 1.0;
+    std::vector<float> x32(L), y32(L);
+    for (int i = 0; i < L; i++) x32[i] = (float)cur[i];
+    for (const Scan &sc : cascade) {
+        std::vector<double> nxt(L);
+        for (int i = 0; i < L; i++) {
+            double acc = sc.b * cur[i];
+            for (int j = 0; j < sc.order && j < i; j++) acc += sc.a[j] * nxt[i - 1 - j];
+            nxt[i] = acc;
+        }
+        cur.swap(nxt);
+    }
+    for (int i = 0; i < L; i++) {
+        float acc = (float)merged.b * x32[i];
+        for (int j = 0; j < merged.order && j < i; j++) acc = std::fmaf((float)merged.a[j], y32[i - 1 - j], acc);
+        y32[i] = acc;
+    }
+    double peak = 0.0, err = 0.0;
+    for (int i = 0; i < L; i++) {
+        if (!std::isfinite(cur[i]) || !std::isfinite((double)y32[i])) return false;
+        peak = std::max(peak, std::fabs(cur[i]));
+        err = std::max(err, std::fabs((double)y32[i] - cur[i]));
+    }
+    return err <= bar * std::max(peak, 1e-30);
+}
+
 }  // namespace rf

@@ -692,9 +692,50 @@ def test_unsharp_mask_front_end():
     (10 << 20, [(0, True, [1.0, 0.1, 0.1])] * 4),        # apps/audio/audio_filter_biquads.cpp: cascaded biquads
 ], ids=["8k_o1", "24k_gauss2_pm", "1M_gauss3_pm", "1M_mixed4", "10M_biquads4"])
 def test_long_1d_signal_chained_rows(n, scans):
-    imgs, outs, (path, tiles) = _run((n,), scans, planes=2 if n <= (1 << 20) else 1)
+    # (RF_PLAN_NO_OVERLAP: the scans as given on the fused kernels -- since round 5 the automatic plan merges the four biquads
+    # into one scan of order 8 for the matrix path, below)
+    imgs, outs, (path, tiles) = _run((n,), scans, planes=2 if n <= (1 << 20) else 1, flags=TILED | capi.RF_PLAN_NO_OVERLAP)
     assert path == 3 and tiles == (256,)
     _check(imgs, outs, scans, False)
+
+
+def test_runs_of_same_direction_scans_of_a_signal_are_merged():
+    """apps/audio/audio_filter_biquads.cpp: n biquads behind one another are ONE scan whose transfer function is the product of
+    theirs (overlap_feedback_coeff, lib/iir_coeff.cpp:236-263); the automatic plan of a 1-D signal merges such runs where that
+    leaves fewer stages and the merged direct form passes the conditioning probe -- fifteen biquads: one scan of order 30 on the
+    matrix path, four launches.  Mixed directions merge run by run; a clamped border, an integer signal and RF_PLAN_NO_OVERLAP keep
+    the scans as given."""
+    import torch
+    import recfilter_amd as rfa
+    n = 1 << 20
+    biquad = (0, True, [1.0, 0.1, 0.1])
+    for count in (2, 5, 15):
+        scans = [biquad] * count
+        imgs, outs, (path, _) = _run((n,), scans)
+        assert path == capi.RF_PATH_TILED_MATRIX
+        _check(imgs, outs, scans, False)
+        with rfa.Plan((n,), scans, flags=TILED) as plan:
+            assert plan.num_kernels in (2, 4)          # (these poles decay to nothing across a tile: no carry chain at all)
+            merged = plan.table("scans").reshape(-1, 5 + 2 * capi.RF_MAX_ORDER)
+            assert merged.shape[0] == 1 and int(merged[0][2]) == 2 * count
+    mixed = [(0, True, rc.GAUSS3), (0, True, rc.GAUSS2), (0, True, [0.7, 0.3]), (0, False, rc.GAUSS2), (0, False, rc.GAUSS2), (0, False, [0.6, 0.4])]
+    imgs, outs, (path, _) = _run((n,), mixed)
+    _check(imgs, outs, mixed, False)
+    # (these recursive Gaussians have their poles at 0.8 .. 0.9: the merged direct forms of order 6 and 5 fail the conditioning probe
+    # in f32 and the scans stay as given -- an in-plan cascade of two fused stages)
+    with rfa.Plan((n,), mixed, flags=TILED) as plan:
+        assert plan.path == 3
+    mild = [(0, True, [0.5, 0.3, 0.1]), (0, True, [0.8, 0.2]), (0, True, [0.7, 0.2, -0.1]), (0, False, [0.6, 0.3]), (0, False, [0.9, 0.1, 0.05]), (0, False, [0.6, 0.4])]
+    imgs, outs, (path, _) = _run((n,), mild)
+    _check(imgs, outs, mild, False)
+    with rfa.Plan((n,), mild, flags=TILED) as plan:
+        orders = [int(r[2]) for r in plan.table("scans").reshape(-1, 5 + 2 * capi.RF_MAX_ORDER)]
+        assert sum(orders) == 9 and len(orders) <= 4        # merged run by run (orders 5 and 4), then sections of order <= 3: four scans instead of six
+    for kw in (dict(clamped=True), dict(dtype=np.int32), dict(flags=TILED | capi.RF_PLAN_NO_OVERLAP)):
+        sc = [(0, True, [1.0, 1.0])] * 3 if kw.get("dtype") is not None else [biquad] * 3
+        imgs, outs, (path, _) = _run((n,), sc, **kw)
+        assert path == 3
+        _check(imgs, outs, sc, kw.get("clamped", False))
 
 
 def test_long_1d_signal_int32_prefix_sum_bit_exact_and_fallbacks():
