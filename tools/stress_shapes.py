@@ -315,8 +315,21 @@ if len(sys.argv) > 3 and sys.argv[3] == "sections":
             peak = float(ou.abs().max().item())
             err = float(((of - ou).abs() / torch.clamp(ou.abs(), min=1e-2 * peak)).max().item())
             worst = max(worst, err)
+            extra = ""
+            if err >= 1e-4 and img.numel() <= (1 << 24):
+                # which of the two f32 evaluations is off: both against the f64 oracle, and the direct form on the matrix path
+                import oracle
+                want = oracle.apply_filter(img.cpu().numpy().astype(np.float64), scans, clamped)
+                e_f, e_u = rc.rel_err(of.cpu().numpy(), want), rc.rel_err(ou.cpu().numpy(), want)
+                extra = f"  [vs f64 oracle: this plan {e_f:.2e}, untiled f32 {e_u:.2e}"
+                try:
+                    with rfa.Plan(shape, scans, clamped=clamped, path=5) as pm:
+                        extra += f", matrix path {rc.rel_err(pm.execute([img])[0].cpu().numpy(), want):.2e}"
+                except Exception:
+                    pass
+                extra += "]"
             print(f"{case:3d} {pf.path_name:13s} {str(shape):22s} orders={[len(co) - 1 for _, _, co in scans]} clamped={int(clamped)} err={err:.3e}",
-                  "" if err < 2e-4 else "  <-- CHECK", flush=True)
+                  ("" if err < 2e-4 else "  <-- CHECK") + extra, flush=True)
     print("worst (sections)", worst)
 
 # ---- images of whole tiles (what the matrix-core pass 1 takes), orders 1..3, one or two scans per dimension, planes ----
