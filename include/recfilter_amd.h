@@ -240,6 +240,7 @@ int rf_plan_execute_timed(rf_plan *plan, const void *const *in_planes, void *con
  *     rf_plan_begin(...)                         pass 1 + every slab-local carry stage
  *     for e in 0 .. rf_plan_num_exchanges()-1:   ONE for all scans of the sharded dimension (orders <= 3, at most
  *                                                4 scans, scans * world * order <= 128), else one per scan
+ *                                                (RF_PATH_TILED_MATRIX: always one per scan along the sharded dimension)
  *         rf_plan_exchange_local(e, send)        slab-local recurrence; writes this slab's exit
  *                                                carries (rf_plan_exchange_bytes(e) bytes) to `send`
  *         -- caller all-gathers `send` over the ranks into `gathered` (world * bytes, rank-major;

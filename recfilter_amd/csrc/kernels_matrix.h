@@ -43,6 +43,11 @@ struct MxPassArgs {
     const float *H;            // A-operand fragments [NB][16][64] of the tail extraction
     const float *dH;           // [32]: ... to the tile-local tail
     float *tails;              // [unit][KP], KP = 8 ceil(k / 8); unit = line * M + tile (MX_X1) or tile * lines + line
+    // A slab of a sharded image (the outermost dimension, MX_Y): whether it holds the image's first / last tile along the
+    // dimension (else the scan enters the slab from a neighbouring one) and the carry that enters it, [line][KP] (zeros before the
+    // exchange has formed it; null for an unsharded plan)
+    int32_t slab_first, slab_last;
+    const float *incoming;
     // The stage that follows (pass 2 only): the final pass holds the finished block in LDS, which is exactly what the NEXT
     // scan's pass 1 would read from HBM -- so it contracts it with the next scan's H and stores that scan's tile-local tails
     // (lib/reorder.cpp:100-176 chains stages through memory; VERDICT r4 "next" 3).  next: 0 none; 1 the next scan runs along
@@ -64,6 +69,7 @@ struct MxChainArgs {
     const float *P;            // propagation: fragments [C][16][64] of its powers 1..C
     int32_t k, C;
     int32_t chunk_is_lo;       // the chunk index is c_lo (MX_X1) or c_hi
+    int32_t enter_fixed;       // propagation of a slab's entering carry: every element takes exits[c_lo * e_lo] (no chunk before it)
     int64_t ncols, cdiv;
     int64_t base, s_hi, s_lo, s_j;
     int64_t e_hi, e_lo;

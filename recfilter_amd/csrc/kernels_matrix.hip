@@ -207,7 +207,9 @@ __device__ __forceinline__ void mx_write_sub(float *lds, int pitch, int mine, in
 
 // this lane's unit
 struct MxLane {
-    bool valid, enters;        // enters: the scan enters the image in this tile
+    bool valid, enters;        // enters: the scan enters the slab (the image, unless it is sharded) in this tile
+    bool border;               // ... and that is where it enters the IMAGE: the clamped-border term applies, no carry comes in
+    int64_t line;
     int tile;
     int64_t tidx, prev_tidx;   // index of the unit's tail / of the tail it takes its carry from (scan direction)
 };
@@ -232,6 +234,8 @@ __device__ __forceinline__ MxLane mx_lane(const MxPassArgs &a, const MxBlock &b,
         l.prev_tidx = l.tidx + (a.causal ? -a.lines : a.lines);
     }
     l.enters = a.causal ? l.tile == 0 : l.tile == a.M - 1;
+    l.border = l.enters && (a.causal ? a.slab_first != 0 : a.slab_last != 0);
+    l.line = line;
     return l;
 }
 
@@ -261,7 +265,7 @@ mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[sb][t], x[t], acc, 0, 0, 0);
     }
-    if (a.clamped && ln.valid && ln.enters) {
+    if (a.clamped && ln.valid && ln.border) {
         const int m0 = a.causal ? 0 : a.T - 1;
         const float x0 = XM ? mx_lds[mine * blk.pitch + m0] : mx_lds[m0 * blk.pitch + mine];
 #pragma unroll
@@ -291,7 +295,7 @@ __device__ __forceinline__ void mx_next_tails(const MxPassArgs &a, const float *
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
     }
-    const bool enters = a.next_causal ? tile == 0 : tile == tiles - 1;
+    const bool enters = (a.next_causal ? tile == 0 : tile == tiles - 1) && (a.next_causal ? a.slab_first != 0 : a.slab_last != 0);
     if (a.clamped && valid && enters) {
         const int m0 = a.next_causal ? 0 : 32 * NB - 1;
         const float x0 = XV ? lds[mine * pitch + m0] : lds[m0 * pitch + mine];
@@ -326,8 +330,9 @@ mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassAr
     // the completed tail of the neighbouring tile, laid out as the rows of a sub-block that precedes the tile:
     // row i of it is tail 31 - i (causal: the most recent output is the last row) or tail i (anticausal)
     floatx16 prev = mx_zero();
-    if (ln.valid && !ln.enters) {
-        const float *tp = a.tails + ln.prev_tidx * KP;
+    if (ln.valid && (!ln.enters || (a.incoming != nullptr && !ln.border))) {
+        // (the first tile of a slab that is not the image's: what the slabs before it hand over)
+        const float *tp = ln.enters ? a.incoming + ln.line * KP : a.tails + ln.prev_tidx * KP;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int r_lo = a.causal ? 28 - 8 * q - 4 * h : 8 * q + 4 * h;
@@ -345,7 +350,7 @@ mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassAr
         float x[16];
         mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
         floatx16 c = mx_zero();
-        if (bi == 0 && a.clamped && ln.valid && ln.enters) {
+        if (bi == 0 && a.clamped && ln.valid && ln.border) {
             const int m0 = a.causal ? 0 : a.T - 1;
             const float x0 = XM ? mx_lds[mine * blk.pitch + m0] : mx_lds[m0 * blk.pitch + mine];
 #pragma unroll
@@ -391,7 +396,7 @@ __device__ __forceinline__ MxCol mx_col(const MxChainArgs &a, int64_t c) {
     col.len = left < a.C ? (int)left : a.C;
     col.off = a.base + c_hi * a.s_hi + c_lo * a.s_lo;
     col.eoff = c_hi * a.e_hi + c_lo * a.e_lo;
-    col.eprev = col.eoff - (a.chunk_is_lo ? a.e_lo : a.e_hi);
+    col.eprev = a.enter_fixed ? c_lo * a.e_lo : col.eoff - (a.chunk_is_lo ? a.e_lo : a.e_hi);
     return col;
 }
 
@@ -450,7 +455,7 @@ mx_apply_kernel(MxChainArgs a) {
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const MxCol col = mx_col(a, ((int64_t)blockIdx.x * kMxWaves + w) * 32 + u);
     const int j = (int)blockIdx.y;
-    const bool on = col.valid && col.chunk >= 1 && j < col.len;
+    const bool on = col.valid && (col.chunk >= 1 || a.enter_fixed != 0) && j < col.len;
     floatx16 c = mx_zero(), e = mx_zero();
     float *mine = a.seq + (col.off + (int64_t)j * a.s_j) * KP + 4 * h;
     if (on) {

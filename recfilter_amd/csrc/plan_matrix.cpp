@@ -23,8 +23,15 @@ bool matrix_plan_applicable(const rf_plan *plan, const rf_filter_desc *desc, std
     auto no = [&](const char *msg) { if (why) *why = msg; return false; };
     (void)desc;
     if (plan->dtype != RF_F32) return no("the matrix cores take f32 pixels (integer and f64 filters run on the generic path)");
-    if (plan->sharded()) return no("the matrix path runs on one device");
     if (plan->scans.empty()) return no("no scans");
+    if (plan->sharded()) {
+        // slabs of the outermost dimension (one carry exchange per scan along it): equal slabs of whole tiles
+        if (plan->ndim < 2) return no("a 1-D signal is not sharded");
+        for (int64_t e : plan->shard_extents)
+            if (e != plan->dims[plan->ndim - 1].N) return no("the matrix path shards into slabs of equal extent");
+        if (plan->dims[plan->ndim - 1].N % kMxSB != 0) return no("a slab of the sharded dimension is not a multiple of 32 samples");
+        if (plan->pw.pre || plan->pw.post) return no("pointwise stages of a sharded plan run on the fused path");
+    }
     for (int d = 0; d < plan->ndim; d++) {
         const DimInfo &di = plan->dims[d];
         if (di.scan_ids.empty()) continue;
@@ -131,6 +138,8 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         MxPassArgs pass{};
         std::vector<Level> levels;
         int scan = 0;
+        bool sharded_dim = false;           // a scan along the sharded dimension: an exchange of its exit carries follows its chain
+        const float *AM = nullptr, *PM = nullptr;      // fragments of A^M (slab transfer) and of A^1 .. A^M
     };
     std::vector<Stage> stages;
     size_t tails_floats = 0;                 // per plane, max over the stages (they run one after the other)
@@ -174,6 +183,23 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             pa.N = di.N; pa.inner = di.stride; pa.lines = di.lines; pa.units = di.lines * di.M;
             pa.off = scan.causal ? 0 : di.M * T - di.N;
             pa.ragged = di.M * T != di.N ? 1 : 0;
+            const bool sharded_dim = plan->sharded() && d == plan->ndim - 1;
+            pa.slab_first = (!sharded_dim || plan->shard_rank == 0) ? 1 : 0;
+            pa.slab_last = (!sharded_dim || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
+            pa.incoming = nullptr;
+            st.sharded_dim = sharded_dim;
+            if (sharded_dim) {
+                // what carries a slab's entering state to its exit, and to each of its tiles: A^M, A^1 .. A^M (in double, rounded once)
+                std::vector<float> fAM, fPM;
+                std::vector<double> pw = tb.A;
+                for (int64_t i = 0; i < di.M; i++) {
+                    pack_fragments(pad32(pw, k).data(), fPM);
+                    if (i + 1 < di.M) pw = mat_mul<double>(pw, tb.A, k);
+                }
+                pack_fragments(pad32(pw, k).data(), fAM);
+                st.AM = (const float *)plan->upload(fAM.data(), fAM.size() * sizeof(float), &status);
+                st.PM = (const float *)plan->upload(fPM.data(), fPM.size() * sizeof(float), &status);
+            }
             std::vector<float> fG, fR, fH, fdG(32), fdH(32);
             pack_fragments(tb.G.data(), fG);
             pack_fragments(tb.R.data(), fR);
@@ -239,7 +265,8 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         const int da = plan->scans[(size_t)stages[i].scan].dim, db = plan->scans[(size_t)stages[i + 1].scan].dim;
         int next = 0;
         if (da == db && a.off == b.off) next = 1;            // (the same tiles: a causal / anticausal pair only when they divide the extent)
-        else if (plan->ndim == 2 && da == 0 && db == 1 && a.mode == MX_XL && a.T == 128 && b.T == 128 && a.N % 128 == 0 && a.lines % 128 == 0) next = 2;
+        else if (plan->ndim == 2 && da == 0 && db == 1 && a.mode == MX_XL && a.T == 128 && b.T == 128 && a.N % 128 == 0 && a.lines % 128 == 0 &&
+                 !plan->sharded()) next = 2;       // (a slab's y tiles have their own border rules: MxPassArgs::slab_first / slab_last)
         if (RF_KNOB("RF_MX_NO_NEXT") != nullptr) next = 0;      // A/B: every stage with its own pass 1
         a.next = next;
         if (next) { a.next_k = b.k; a.next_causal = b.causal; a.next_H = b.H; a.next_dH = b.dH; }
@@ -252,6 +279,19 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
     for (size_t l = 0; l < level_floats.size(); l++) level_buf.push_back((float *)plan->alloc(level_floats[l] * np * sizeof(float), false, &status));
     if (status != RF_OK) return status;
 
+    // Steps accumulate in `pending`; a scan along the sharded dimension cuts the list at its exchange: what came before goes to
+    // the begin phase (first exchange) or in front of the next exchange's local step, what follows the last exchange is the finish.
+    std::vector<Step> pending;
+    size_t max_lines_kp = 0;
+    for (const Stage &st : stages)
+        if (st.sharded_dim) max_lines_kp = std::max(max_lines_kp, (size_t)st.pass.lines * 8 * (size_t)((st.pass.k + 7) / 8));
+    const int world = plan->shard_world;
+    float *incoming_buf = nullptr, *rank_scratch = nullptr;
+    if (plan->sharded()) {
+        incoming_buf = (float *)plan->alloc(max_lines_kp * np * sizeof(float), true, &status);
+        rank_scratch = (float *)plan->alloc(max_lines_kp * np * (size_t)world * sizeof(float), true, &status);
+        if (status != RF_OK) return status;
+    }
     bool first_stage = true;
     for (size_t si = 0; si < stages.size(); si++) {
         const Stage &st = stages[si];
@@ -263,10 +303,13 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         first_stage = false;
         MxPassArgs base = st.pass;
         const size_t tails_pp = tails_floats;
-        auto pass_args = [base, tails, tails_next, tails_pp](int pl) {
+        const size_t lines_kp = (size_t)base.lines * 8 * (size_t)((base.k + 7) / 8);       // one k-vector per line
+        const bool sharded_dim = st.sharded_dim;
+        auto pass_args = [base, tails, tails_next, tails_pp, sharded_dim, incoming_buf, lines_kp](int pl) {
             MxPassArgs a = base;
             a.tails = tails + (size_t)pl * tails_pp;
             a.next_tails = tails_next + (size_t)pl * tails_pp;
+            if (sharded_dim) a.incoming = incoming_buf + (size_t)pl * lines_kp;
             return a;
         };
         if (has_pass1) {
@@ -276,7 +319,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
                 const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
                 return launch_mx_pass1(src, pass_args(pl), plan->stream);
             };
-            plan->begin_steps.push_back(p1);
+            pending.push_back(p1);
         }
 
         // the chain: up the levels, then the propagation down
@@ -322,13 +365,86 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             Step cs;
             cs.name = "mx_chain" + std::to_string(l) + "_" + nm;
             cs.run = [plan, chain_args, l](int pl) { return launch_mx_chain(chain_args(l, pl), plan->stream); };
-            plan->begin_steps.push_back(cs);
+            pending.push_back(cs);
         }
         for (int l = std::min(live - 1, nlev - 2); l >= 0; l--) {
             Step as;
             as.name = "mx_apply" + std::to_string(l) + "_" + nm;
             as.run = [plan, chain_args, l](int pl) { return launch_mx_apply(chain_args(l, pl), plan->stream); };
-            plan->begin_steps.push_back(as);
+            pending.push_back(as);
+        }
+
+        if (sharded_dim) {
+            // ---- the exchange of this scan: the slab's exit carry (its completed tail of the last tile in scan direction, with
+            // zero entering state) -> all-gather -> every rank chains the exits of the slabs before it with A^M (the same chain
+            // kernel, the ranks as its steps) -> the carry entering this slab, propagated through its tiles with A^1 .. A^M;
+            // the final pass takes it in the first tile's y_(-1).
+            const int64_t M = base.M;
+            const int rank = plan->shard_rank;
+            const int ex_index = (int)plan->exchanges.size();
+            rf_plan::Exchange ex;
+            ex.bytes = lines_kp * np * sizeof(float);
+            ex.scratch = plan->alloc(ex.bytes, true, &status);
+            if (status != RF_OK) return status;
+            ex.send = ex.scratch;
+            const float *AM = st.AM;
+            const int kk = base.k;
+            ex.form_incoming = [plan, rank_scratch, incoming_buf, lines_kp, np, world, rank, causal, AM, kk, lines](const void *gathered) -> int {
+                // (the gathered buffer is the caller's: the chain runs on a copy; rank-major, [rank][plane][line][KP])
+                RF_HIP_CHECK(hipMemcpyAsync(rank_scratch, gathered, lines_kp * np * (size_t)world * sizeof(float), hipMemcpyDeviceToDevice, plan->stream));
+                const int j = causal ? rank : world - 1 - rank;                  // this slab's place in scan order
+                for (int pl = 0; pl < np; pl++) {
+                    if (world > 1) {
+                        MxChainArgs c{};
+                        c.seq = rank_scratch; c.exits = nullptr; c.A = AM; c.P = nullptr; c.k = kk; c.C = world; c.Mtot = world;
+                        c.chunk_is_lo = 0; c.enter_fixed = 0; c.ncols = lines; c.cdiv = lines;
+                        c.s_lo = 1; c.s_hi = 0; c.s_j = (causal ? 1 : -1) * (int64_t)np * lines;
+                        c.base = (int64_t)pl * lines + (causal ? 0 : (int64_t)(world - 1) * np * lines);
+                        c.e_hi = 0; c.e_lo = 0;
+                        if (int rc = launch_mx_chain(c, plan->stream)) return rc;
+                    }
+                    float *inc = incoming_buf + (size_t)pl * lines_kp;
+                    if (j == 0) RF_HIP_CHECK(hipMemsetAsync(inc, 0, lines_kp * sizeof(float), plan->stream));
+                    else {
+                        const int h = causal ? rank - 1 : rank + 1;          // the slab before this one in scan direction
+                        RF_HIP_CHECK(hipMemcpyAsync(inc, rank_scratch + ((size_t)h * np + pl) * lines_kp, lines_kp * sizeof(float),
+                                                    hipMemcpyDeviceToDevice, plan->stream));
+                    }
+                }
+                return (int)RF_OK;
+            };
+            plan->exchanges.push_back(ex);
+            Step xs;
+            xs.name = "mx_exits_" + nm;
+            xs.run = [plan, tails, tails_pp, lines_kp, M, causal, ex_index, lines](int pl) -> int {
+                float *send = (float *)plan->exchanges[(size_t)ex_index].send;
+                const float *exit_tail = tails + (size_t)pl * tails_pp + (size_t)(causal ? M - 1 : 0) * lines_kp;      // [tile][line][KP]
+                (void)lines;
+                RF_HIP_CHECK(hipMemcpyAsync(send + (size_t)pl * lines_kp, exit_tail, lines_kp * sizeof(float), hipMemcpyDeviceToDevice, plan->stream));
+                return (int)RF_OK;
+            };
+            if (ex_index == 0) {
+                for (Step &p : pending) plan->begin_steps.push_back(p);
+                plan->exchange_local_steps.push_back({xs});
+            } else {
+                pending.push_back(xs);
+                plan->exchange_local_steps.push_back(pending);
+            }
+            pending.clear();
+            // propagation of the entering carry through the slab's tiles: tail(t) += A^(i+1) incoming
+            MxChainArgs ap = chain[0];
+            ap.P = st.PM; ap.C = (int32_t)M; ap.Mtot = M; ap.ncols = lines; ap.cdiv = lines; ap.chunk_is_lo = 0; ap.enter_fixed = 1;
+            ap.s_hi = 0; ap.s_lo = 1; ap.s_j = causal ? lines : -lines; ap.base = causal ? 0 : (M - 1) * lines;
+            ap.e_hi = 0; ap.e_lo = 1;
+            Step as;
+            as.name = "mx_incoming_" + nm;
+            as.run = [plan, ap, tails, tails_pp, incoming_buf, lines_kp](int pl) {
+                MxChainArgs c = ap;
+                c.seq = tails + (size_t)pl * tails_pp;
+                c.exits = incoming_buf + (size_t)pl * lines_kp;
+                return launch_mx_apply(c, plan->stream);
+            };
+            plan->exchange_apply_steps.push_back({as});
         }
 
         Step p2;
@@ -337,8 +453,11 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
             return launch_mx_pass2(src, (float *)plan->out[pl], pass_args(pl), plan->stream);
         };
-        plan->begin_steps.push_back(p2);
+        pending.push_back(p2);
     }
+    // what follows the last exchange is the finish phase (an unsharded plan: everything is its begin phase)
+    if (plan->exchanges.empty()) for (Step &p : pending) plan->begin_steps.push_back(p);
+    else for (Step &p : pending) plan->finish_steps.push_back(p);
     return status;
 }
 

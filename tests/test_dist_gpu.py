@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extents=None, flags=0):
+def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extents=None, flags=0, expect_path="tiled_fused"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch
@@ -42,7 +42,7 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extent
         inputs = [torch.from_numpy(np.ascontiguousarray(f[lo:lo + n])).cuda() for f in full]
         outputs = [torch.empty_like(t) for t in inputs]
         filt = ShardedFilter(local, scans, clamped=clamped, planes=planes, rank=rank, world=world, slab_extents=extents, flags=flags)
-        assert filt.plan.path_name == "tiled_fused"
+        assert filt.plan.path_name == expect_path
         if flags:      # the slab's begin step is the one-read pass 1: its table of z responses exists
             assert filt.plan.table("H_z").size > 0 and filt.plan.has_interior
         for _ in range(2):                     # the second execute reuses the exchange buffers
@@ -68,12 +68,13 @@ def _worker(rank, world, port, shape, scans, clamped, planes, result_dir, extent
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d", "rows_2d_unequal", "z_slabs_3d_one_read_pass1", "z_slabs_3d_one_read_unequal"])
+@pytest.mark.parametrize("case", ["rows_2d", "z_slabs_3d", "rows_2d_unequal", "z_slabs_3d_one_read_pass1", "z_slabs_3d_one_read_unequal",
+                                  "rows_2d_order_12_matrix_path"])
 def test_two_processes_one_gpu(case, tmp_path):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     import ref_cases as rc
-    extents, flags = None, 0
+    extents, flags, expect_path = None, 0, "tiled_fused"
     if case == "z_slabs_3d_one_read_pass1":
         # whole tiles (256 x 32 x 64 planes per slab): the slabs' begin step forms the x, y and z tails in one read
         from recfilter_amd import capi
@@ -81,6 +82,13 @@ def test_two_processes_one_gpu(case, tmp_path):
     elif case == "z_slabs_3d_one_read_unequal":
         from recfilter_amd import capi
         shape, scans, clamped, planes, flags, extents = (96, 64, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1, capi.RF_PLAN_WALK_PASS1, [64, 32]
+    elif case == "rows_2d_order_12_matrix_path":
+        # orders above 8 shard on the matrix path: one exchange per y scan, the ranks' exits chained with A^M on the matrix cores
+        rng = np.random.default_rng(12)
+        a = rng.standard_normal(12) * np.exp(-0.15 * np.arange(12))
+        a *= 0.9 / np.abs(a).sum()
+        c12 = [0.4] + [float(np.float32(v)) for v in a]
+        shape, scans, clamped, planes, expect_path = (256, 512), [(0, True, c12), (0, False, c12), (1, True, c12), (1, False, c12)], True, 2, "tiled_matrix"
     elif case == "rows_2d":
         shape, scans, clamped, planes = (256, 768), rc.xy_pm(rc.GAUSS2), True, 2
     elif case == "rows_2d_unequal":
@@ -88,7 +96,7 @@ def test_two_processes_one_gpu(case, tmp_path):
     else:
         shape, scans, clamped, planes = (32, 96, 256), rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"], False, 1
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path), extents, flags), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, shape, scans, clamped, planes, str(tmp_path), extents, flags, expect_path), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
@@ -266,7 +274,7 @@ for name, shape, scans, clamped, planes, interior in cases:
     for inflight in (1, 2):
         filt = ShardedFilter(shape, scans, clamped=clamped, planes=planes, rank=0, world=1, force_exchange=True,
                              inflight=inflight, flags=capi.RF_PLAN_TILED_ONLY)
-        assert filt.plan.path_name == "tiled_fused" and filt.plan.num_exchanges == 1 and filt.plan.has_interior == interior, name
+        assert filt.plan.path_name == expect_path and filt.plan.num_exchanges == 1 and filt.plan.has_interior == interior, name
         before = issued[0]
         sets = [[torch.zeros_like(t) for t in dev] for _ in range(inflight)]
         for i in range(2 * inflight + 1):

@@ -177,3 +177,62 @@ def test_matrix_path_extents_no_tile_divides(shape, clamped):
     imgs, outs, (path, tiles) = _run(shape, scans, clamped=clamped, path=MX, planes=2 if nd == 2 else 1)
     assert path == MX
     _check(imgs, outs, scans, clamped)
+
+
+def _emulate_ranks(local_shape, world, scans, clamped, planes=1, path=0):
+    """`world` slabs of one image through the stepping protocol on ONE device: one plan per rank, the all-gather a rank-major
+    device buffer (tools/rehearse_n8.py does the same at bench size).  Returns the inputs, the concatenated result, the paths."""
+    import torch
+    import recfilter_amd as rfa
+    global_shape = (local_shape[0] * world,) + tuple(local_shape[1:])
+    rng = np.random.default_rng(31)
+    whole = [torch.from_numpy(rng.random(global_shape, dtype=np.float32)).cuda() for _ in range(planes)]
+    outs = [torch.empty_like(w) for w in whole]
+    ins_r = [[w.split(local_shape[0])[r] for w in whole] for r in range(world)]
+    outs_r = [[o.split(local_shape[0])[r] for o in outs] for r in range(world)]
+    plans = [rfa.Plan(local_shape, scans, clamped=clamped, planes=planes, shard_rank=r, shard_world=world, path=path) for r in range(world)]
+    for r in range(world):
+        plans[r].begin(ins_r[r], outs_r[r])
+    for e in range(plans[0].num_exchanges):
+        nbytes = plans[0].exchange_bytes(e)
+        gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            plans[r].exchange_local(e, gathered.data_ptr() + r * nbytes)
+        for r in range(world):
+            plans[r].exchange_apply(e, gathered.data_ptr())
+    for r in range(world):
+        plans[r].finish()
+    torch.cuda.synchronize()
+    paths = [p.path for p in plans]
+    n_ex = plans[0].num_exchanges
+    for p in plans:
+        p.close()
+    return [w.cpu().numpy() for w in whole], [o.cpu().numpy() for o in outs], paths, n_ex
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+@pytest.mark.parametrize("case", ["rows_3_ranks", "rows_8_ranks_slow_decay", "z_slabs_2_ranks", "planes"])
+def test_matrix_path_sharded_slabs(case, clamped):
+    """High-order filters over the GPUs of a node: slabs of the outermost dimension, one exchange of the k-row exit
+    carries per scan along it -- every rank chains the gathered exits with A^M on the matrix cores, propagates its entering carry
+    through its tiles with A^1 .. A^M, and the final pass takes it in the first tile.  Emulated ranks on one device against the
+    oracle on the whole image."""
+    planes = 1
+    if case == "rows_3_ranks":
+        local, world = (128, 256), 3
+        scans = [(0, True, stable_coeff(9, 1)), (0, False, stable_coeff(12, 2)), (1, True, stable_coeff(12, 3)), (1, False, stable_coeff(17, 4)), (1, True, audio_coeff(29))]
+    elif case == "rows_8_ranks_slow_decay":       # poles close to 1: carries that cross several slabs
+        local, world = (32, 160), 8
+        scans = [(1, True, [0.02, 0.98]), (1, False, [0.05, 1.6, -0.65]), (1, True, stable_coeff(9, 5, mass=0.97))]
+    elif case == "z_slabs_2_ranks":
+        local, world = (64, 40, 128), 2
+        scans = [(2, True, stable_coeff(10, 6)), (0, False, stable_coeff(9, 7)), (1, True, stable_coeff(11, 8)), (2, False, stable_coeff(13, 9))]
+    else:
+        local, world, planes = (96, 128), 2, 3
+        scans = [(1, False, stable_coeff(20, 10)), (0, True, stable_coeff(9, 11))]
+    imgs, outs, paths, n_ex = _emulate_ranks(local, world, scans, clamped, planes, path=MX)
+    assert all(p == MX for p in paths)
+    assert n_ex == sum(1 for s in scans if s[0] == len(local) - 1)          # one exchange per scan along the sharded dimension
+    for im, out in zip(imgs, outs):
+        want = oracle.apply_filter(im.astype(np.float64), scans, clamped)
+        assert rc.rel_err(out, want) < TOL
