@@ -591,3 +591,19 @@ def test_matrix_path_choice_and_refusals():
     # polynomial stays a direct form
     with rfa.Plan((1 << 16,), [(0, True, [1.0] + [0.01] * 3)], **H) as plan:
         assert plan.path in (capi.RF_PATH_TILED_FUSED, capi.RF_PATH_UNTILED)
+
+
+def test_matrix_path_sharded_plan_structure():
+    """A row-sharded filter of order 12 (host-only plans, no device): the matrix path, one exchange per scan along the sharded
+    dimension, `lines x 8 ceil(k / 8)` floats per plane and rank; unequal slabs and 1-D signals are refused there."""
+    H = dict(device=capi.RF_DEVICE_HOST_ONLY)
+    c12, c20 = _stable(12, 3), _stable(20, 4)
+    scans = [(0, True, c12), (1, True, c12), (1, False, c20), (0, False, c12)]
+    for rank in range(4):
+        with rfa.Plan((128, 512), scans, planes=2, shard_rank=rank, shard_world=4, **H) as plan:
+            assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.num_exchanges == 2
+            assert plan.exchange_bytes(0) == 2 * 512 * 16 * 4 and plan.exchange_bytes(1) == 2 * 512 * 24 * 4
+    with rfa.Plan((128, 512), scans, shard_rank=1, shard_world=2, shard_extents=[256, 128], **H) as plan:
+        assert plan.path != capi.RF_PATH_TILED_MATRIX            # unequal slabs: the generic path's per-slab transfer tables
+    with pytest.raises(rfa.RecFilterError):
+        rfa.Plan((128, 512), scans, shard_rank=1, shard_world=2, shard_extents=[256, 128], path=capi.RF_PATH_TILED_MATRIX, **H)
