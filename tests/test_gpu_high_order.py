@@ -236,3 +236,20 @@ def test_matrix_path_sharded_slabs(case, clamped):
     for im, out in zip(imgs, outs):
         want = oracle.apply_filter(im.astype(np.float64), scans, clamped)
         assert rc.rel_err(out, want) < TOL
+
+
+def test_matrix_path_with_pointwise_stages():
+    """A defining expression `scale * in + bias` and a pointwise consumer `w_f * F + w_i * x' + bias` (rf_pointwise_desc) around a
+    high-order filter: stand-alone elementwise launches in front of the first stage and behind the last one."""
+    import torch
+    import recfilter_amd as rfa
+    c = stable_coeff(12, 3)
+    scans = [(0, True, c), (1, False, c)]
+    img = rc.random_image((96, 256), np.float32, 9)
+    dev = torch.from_numpy(img).cuda()
+    with rfa.Plan(img.shape, scans, clamped=True, prologue=(0.5, 0.25), epilogue=(2.0, -1.0, 0.125), path=MX) as plan:
+        assert plan.path == MX
+        out = plan.execute([dev])[0].cpu().numpy()
+    xp = img.astype(np.float64) * 0.5 + 0.25
+    want = 2.0 * oracle.apply_filter(xp, scans, True) - xp + 0.125
+    assert rc.rel_err(out, want) < TOL
