@@ -151,9 +151,10 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         // tile width: the widest of 128 / 96 / 64 / 32 that divides the extent; an extent that is no multiple of 32 takes tiles of
         // 128 (one tile of 32 .. 128 when it is shorter) and pads the last one where the scan leaves the image (MxPassArgs::off)
         int NB = kMxMaxNB;
+        const int nb_cap = RF_KNOB("RF_MX_NB") ? atoi(RF_KNOB("RF_MX_NB")) : kMxMaxNB;      // A/B: narrower tiles, more workgroups per CU
         if (di.N % kMxSB == 0) {
             const int64_t blocks = di.N / kMxSB;
-            for (int nb = kMxMaxNB; nb >= 1; nb--)
+            for (int nb = nb_cap; nb >= 1; nb--)
                 if (blocks % nb == 0) { NB = nb; break; }
         } else if (di.N < kMxSB * kMxMaxNB) {
             NB = (int)((di.N + kMxSB - 1) / kMxSB);
