@@ -26,6 +26,10 @@
 // kernel body serves scans along x (lane = line, or lane = tile for 1-D signals) and along y / z (lane = column).
 // A clamped border is the zero-border operator plus a rank-one term in the scan's first sample (what the clamped prologue of
 // lib/recfilter.cpp:330-336 adds is linear in x_0): dG / dH, applied by the lanes whose tile is where the scan enters the image.
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "kernels_matrix.h"
 
 namespace rf {
@@ -500,9 +504,19 @@ int mx_check(const MxPassArgs &a) {
     return RF_OK;
 }
 
+// more than 64 KiB of dynamic LDS: opt in, once per kernel and device
 template <typename K>
 int mx_allow_lds(K kern, size_t lds) {
-    if (lds > 64 * 1024) RF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds <= 64 * 1024) return RF_OK;
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> opted;
+    int dev = 0;
+    RF_HIP_CHECK(hipGetDevice(&dev));
+    const std::pair<const void *, int> key(reinterpret_cast<const void *>(kern), dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (opted.count(key)) return RF_OK;
+    RF_HIP_CHECK(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    opted.insert(key);
     return RF_OK;
 }
 
