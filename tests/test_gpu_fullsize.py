@@ -381,3 +381,28 @@ def test_order_12_and_32_images_4096_against_oracle():
             got = plan.execute([dev])[0].cpu().numpy()
         want = oracle.apply_filter(img.astype(np.float64), scans, clamped, threads=_threads())
         assert _floor_err(got, want) < TOL, (order, clamped)
+
+
+def test_matrix_path_268m_samples_index_ranges():
+    """A 1-D signal of 2^28 + 4 samples (1 GiB; 2^21 tiles: three chain levels, element offsets beyond 2^31 bytes, a last tile no
+    tile width divides) through a causal scan of order 29 and an anticausal one of order 12, against the f64 oracle on all samples."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    n = (1 << 28) + 4
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal(12) * np.exp(-0.15 * np.arange(12))
+    a *= 0.85 / np.abs(a).sum()
+    scans = [(0, True, [1.0] + [0.01] * 29), (0, False, [0.4] + [float(np.float32(v)) for v in a])]
+    sig = rng.random(n, dtype=np.float32)
+    dev = torch.from_numpy(sig).cuda()
+    with rfa.Plan((n,), scans, flags=capi.RF_PLAN_NO_OVERLAP) as plan:
+        assert plan.path == capi.RF_PATH_TILED_MATRIX
+        got = plan.execute([dev])[0].cpu().numpy()
+    del dev
+    torch.cuda.empty_cache()
+    want = oracle.apply_filter(sig.astype(np.float64), scans, False)
+    worst = 0.0
+    for lo in range(0, n, 1 << 24):
+        worst = max(worst, rc.rel_err(got[lo:lo + (1 << 24)], want[lo:lo + (1 << 24)]))
+    assert worst < TOL
