@@ -22,10 +22,13 @@
 // result is the next product's B operand with no lane movement (y_(b-1) in pass 2, c_(t-1) in the chain), and the A
 // operands (the constant matrices) are stored pre-permuted as fragments frag[t][lane] = Mat[lane & 31][row(t, lane >> 5)].
 //
-// The image goes through LDS both ways (coalesced 16-byte accesses; a 128-unit x T-sample block per workgroup), so one
-// kernel body serves scans along x (lane = line, or lane = tile for 1-D signals) and along y / z (lane = column).
+// The image goes through LDS both ways (coalesced 16-byte accesses on the HBM side, operand layout on the other), so one kernel
+// body serves scans along x (lane = line, or lane = tile for 1-D signals) and along y / z (lane = column).  The passes STREAM: a
+// wave owns 32 units and walks their tile sub-block by sub-block through a private 32 x 32 staging buffer (see "the streaming
+// passes" below).
 // A clamped border is the zero-border operator plus a rank-one term in the scan's first sample (what the clamped prologue of
 // lib/recfilter.cpp:330-336 adds is linear in x_0): dG / dH, applied by the lanes whose tile is where the scan enters the image.
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -37,9 +40,9 @@ namespace rf {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMxThreads = 64 * kMxWaves;
-constexpr int kMxPitchY = kMxUnits + 8;      // LDS pitch of a [sample][unit] block: the two lane halves (rows 4 apart) hit disjoint banks
 
 __device__ __forceinline__ int mx_row(int t, int h) { return ((t >> 2) << 3) + (h << 2) + (t & 3); }
 
@@ -50,12 +53,14 @@ __device__ __forceinline__ floatx16 mx_zero() {
     return z;
 }
 
-// geometry of the workgroup's block: rows x cols of the LDS image, where it lies in the plane
+// Geometry of the workgroup's block -- 128 units x one tile; rows = units and columns = samples for scans along x, rows = samples
+// and columns = units for y / z -- and where it lies in the plane.  Tiles need not divide the extent: tile t covers the samples
+// [t T - off, (t + 1) T - off), and whatever falls outside [0, N) loads as zeros and is never stored.  The padding is always on
+// the side where the scan LEAVES the image (off = 0 for a causal scan, M T - N for an anticausal one): zeros behind the last
+// sample change nothing for the samples in front of them, and the tile where the scan enters is whole.
 struct MxBlock {
     int64_t gbase, gpitch;     // element offset of (row 0, col 0), elements between rows
-    int rows, cols;            // extent of the LDS image
     int rows_valid, cols_valid;
-    int pitch;                 // LDS pitch in floats
     int tile;                  // MX_XL / MX_Y: the tile of the block
     int64_t first;             // first unit (MX_X1), line (MX_XL) or line of column 0 (MX_Y)
     int64_t s0;                // MX_XL / MX_Y: the sample the block's tile starts at (tile * T - off: may be negative)
@@ -63,49 +68,24 @@ struct MxBlock {
     int last_hi;               // how many samples of the LAST tile exist
 };
 
-// Where element (row, chunk column c) of the block lies in the plane and whether it exists.  Tiles need not divide the extent:
-// tile t covers the samples [t T - off, (t + 1) T - off), and whatever falls outside [0, N) loads as zeros and is never stored.
-// The padding is always on the side where the scan LEAVES the image (off = 0 for a causal scan, M T - N for an anticausal one):
-// zeros behind the last sample change nothing for the samples in front of them, and the tile where the scan enters is whole.
-template <bool XM>
-__device__ __forceinline__ bool mx_element(const MxPassArgs &a, const MxBlock &b, int row, int c, int64_t &offset) {
-    // samples [lo, hi) of a tile exist: everything but the first tile starts at 0, everything but the last one ends at T
-    if constexpr (XM) {
-        if (a.mode == MX_X1) {
-            const int64_t U = b.first + row;
-            int64_t tile = U;
-            offset = b.gbase + (int64_t)(row * a.T + c);                       // a 1-D signal: its tiles follow one another in memory
-            if (a.lines != 1) {
-                const int64_t line = U / a.M;
-                tile = U - line * a.M;
-                offset = line * a.N + tile * a.T - a.off + c;
-            }
-            const int lo = tile == 0 ? (int)a.off : 0, hi = tile == a.M - 1 ? b.last_hi : a.T;
-            return row < b.rows_valid && c >= lo && c < hi;
-        }
-        offset = b.gbase + (int64_t)row * b.gpitch + c;
-        return row < b.rows_valid && c >= b.lo && c < b.hi;
-    } else {
-        offset = b.gbase + (int64_t)row * b.gpitch + c;
-        return c < b.cols_valid && row >= b.lo && row < b.hi;
-    }
-}
-
 template <bool XM>
 __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
     MxBlock b;
     b.last_hi = (int)(a.N + a.off - (int64_t)(a.M - 1) * a.T);
     b.lo = 0; b.hi = a.T;
     if constexpr (XM) {
-        b.rows = kMxUnits; b.cols = a.T; b.pitch = a.T + 4; b.cols_valid = a.T;
+        b.cols_valid = a.T;
         if (a.mode == MX_X1) {
             const int64_t U0 = (int64_t)blockIdx.x * kMxUnits;
             b.gbase = U0 * a.T - a.off; b.gpitch = a.T; b.tile = 0; b.first = U0; b.s0 = 0;          // (per row: mx_element)
             const int64_t left = a.units - U0;
             b.rows_valid = left < kMxUnits ? (int)left : kMxUnits;
         } else {
-            const int64_t L0 = (int64_t)blockIdx.x * kMxUnits;
-            b.tile = (int)blockIdx.y;
+            // (consecutive workgroups walk ALONG the lines: with the line block as the fast index, a launch of 16384 lines keeps a
+            // 4 KiB window open in every one of them at once -- more DRAM pages than the memory holds open)
+            const int64_t lb = (int64_t)blockIdx.x / a.M;
+            const int64_t L0 = lb * kMxUnits;
+            b.tile = (int)((int64_t)blockIdx.x - lb * a.M);
             b.s0 = (int64_t)b.tile * a.T - a.off;
             b.lo = b.tile == 0 ? (int)a.off : 0; b.hi = b.tile == a.M - 1 ? b.last_hi : a.T;
             b.gbase = L0 * a.N + b.s0; b.gpitch = a.N; b.first = L0;
@@ -115,7 +95,7 @@ __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
     } else {
         const int64_t c0 = (int64_t)blockIdx.x * kMxUnits, outer = blockIdx.z;
         b.tile = (int)blockIdx.y;
-        b.rows = a.T; b.cols = kMxUnits; b.pitch = kMxPitchY; b.rows_valid = a.T;
+        b.rows_valid = a.T;
         b.s0 = (int64_t)b.tile * a.T - a.off;
         b.lo = b.tile == 0 ? (int)a.off : 0; b.hi = b.tile == a.M - 1 ? b.last_hi : a.T;
         b.gbase = (outer * a.N + b.s0) * a.inner + c0; b.gpitch = a.inner;
@@ -124,89 +104,6 @@ __device__ __forceinline__ MxBlock mx_block(const MxPassArgs &a) {
         b.cols_valid = left < kMxUnits ? (int)left : kMxUnits;
     }
     return b;
-}
-
-// Every thread moves 4 NB chunks of 16 bytes; all of them are requested before the first one is stored to LDS (a loop
-// that loads and stores chunk by chunk is a chain of 4 NB dependent round trips to HBM per workgroup).
-template <bool XM, int NB>
-__device__ __forceinline__ void mx_load_block(const float *__restrict__ src, float *lds, const MxPassArgs &a, const MxBlock &b) {
-    constexpr int W4 = XM ? 8 * NB : kMxUnits / 4;        // 16-byte chunks per row of the LDS image
-    float4 v[4 * NB];
-    if (!a.ragged) {          // tiles that divide the extent (wave-uniform): rows and columns of the block exist or not as a whole
-#pragma unroll
-        for (int it = 0; it < 4 * NB; it++) {
-            const int f = (int)threadIdx.x + kMxThreads * it;
-            const int row = f / W4, c = (f - row * W4) << 2;
-            v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (row < b.rows_valid && c < b.cols_valid) v[it] = *reinterpret_cast<const float4 *>(src + b.gbase + (int64_t)row * b.gpitch + c);
-        }
-    } else {
-#pragma unroll
-        for (int it = 0; it < 4 * NB; it++) {
-            const int f = (int)threadIdx.x + kMxThreads * it;
-            const int row = f / W4, c = (f - row * W4) << 2;
-            // (branch-free: an element that does not exist reads the plane's first chunk and is replaced by zeros)
-            int64_t o;
-            const bool ok = mx_element<XM>(a, b, row, c, o);
-            const float4 got = *reinterpret_cast<const float4 *>(src + (ok ? o : 0));
-            v[it] = ok ? got : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 4 * NB; it++) {
-        const int f = (int)threadIdx.x + kMxThreads * it;
-        const int row = f / W4, c = (f - row * W4) << 2;
-        *reinterpret_cast<float4 *>(lds + row * b.pitch + c) = v[it];
-    }
-}
-
-template <bool XM, int NB>
-__device__ __forceinline__ void mx_store_block(float *__restrict__ dst, const float *lds, const MxPassArgs &a, const MxBlock &b) {
-    constexpr int W4 = XM ? 8 * NB : kMxUnits / 4;
-    if (!a.ragged) {
-#pragma unroll
-        for (int it = 0; it < 4 * NB; it++) {
-            const int f = (int)threadIdx.x + kMxThreads * it;
-            const int row = f / W4, c = (f - row * W4) << 2;
-            if (row < b.rows_valid && c < b.cols_valid)
-                *reinterpret_cast<float4 *>(dst + b.gbase + (int64_t)row * b.gpitch + c) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
-        }
-    } else {
-#pragma unroll
-        for (int it = 0; it < 4 * NB; it++) {
-            const int f = (int)threadIdx.x + kMxThreads * it;
-            const int row = f / W4, c = (f - row * W4) << 2;
-            int64_t o;
-            if (mx_element<XM>(a, b, row, c, o)) *reinterpret_cast<float4 *>(dst + o) = *reinterpret_cast<const float4 *>(lds + row * b.pitch + c);
-        }
-    }
-}
-
-// the 32 samples of sub-block sb of this lane's unit, in K order: x[t] = sample row(t, h)
-template <bool XM>
-__device__ __forceinline__ void mx_read_sub(const float *lds, int pitch, int mine, int h, int sb, float (&x)[16]) {
-    if constexpr (XM) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 v = *reinterpret_cast<const float4 *>(lds + mine * pitch + 32 * sb + 8 * q + 4 * h);
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 16; t++) x[t] = lds[(32 * sb + mx_row(t, h)) * pitch + mine];
-    }
-}
-
-template <bool XM>
-__device__ __forceinline__ void mx_write_sub(float *lds, int pitch, int mine, int h, int sb, const floatx16 &y) {
-    if constexpr (XM) {
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            *reinterpret_cast<float4 *>(lds + mine * pitch + 32 * sb + 8 * q + 4 * h) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int t = 0; t < 16; t++) lds[(32 * sb + mx_row(t, h)) * pitch + mine] = y[t];
-    }
 }
 
 // this lane's unit
@@ -243,141 +140,349 @@ __device__ __forceinline__ MxLane mx_lane(const MxPassArgs &a, const MxBlock &b,
     return l;
 }
 
-// ---- pass 1: tails[k x units] = H[k x T] . tile[T x units] ------------------------------------------------------------
-// Tails are stored [unit][KP], KP = k rounded up to 8 (the rows k .. KP-1 are zeros): registers 4q .. 4q+3 of a lane are
-// four consecutive rows, so every tail access of the path is a 16-byte access.
-template <bool XM, int NB>
+// ---- the STREAMING passes ---------------------------------------------------------------------------------------------
+// Until round 5 the passes staged a whole 128-unit x T-sample block per workgroup: 66 KiB of LDS, two workgroups (two waves per
+// SIMD) per CU, and a wave's time was its memory time PLUS its matrix time -- at f32 the 40 MFMAs of a sub-block are no small part
+// of it (16384^2, order 12: 0.27 ms of matrix-core time against 0.37 ms of HBM time per final pass, 0.58-0.66 ms measured).  The
+// streaming passes walk the tile sub-block by sub-block instead: every WAVE owns 32 units and a private 32 x 32 staging buffer
+// (4.5-5 KiB), has the next two sub-blocks requested (one 128-byte run per unit: 16 bytes per lane, four loads each) while it
+// works on this one, and stores y_b as soon as it exists.  No workgroup barrier inside the walk, three workgroups = 12 waves per
+// CU (tools/microbench/mx_stream.hip is the gate that was measured first: 0.41-0.47 ms with 40 MFMAs per sub-block, 0.38-0.40
+// with 24; the passes: 0.38 ms without a hand-over, 0.46-0.50 with one, 0.24 for pass 1).
+constexpr int kMxStagePitchX = 36;     // [unit][32 samples + 4]
+constexpr int kMxStagePitchY = 40;     // [sample][32 units + 8]: the two lane halves (rows 4 apart) hit disjoint banks
+template <bool XM> constexpr int kMxStageFloats = 32 * (XM ? kMxStagePitchX : kMxStagePitchY);
+
+__device__ __forceinline__ void mx_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Where a lane's four 16-byte chunks of a sub-block lie.  X modes: chunk i = samples 4 lc .. 4 lc + 3 of unit lr + 8 i of the wave;
+// y / z: chunk i = units 4 lc .. of sample lr + 8 i.  Chunk i of sub-block sb sits at base[i] + sb * step and exists when its
+// position along the tile, 32 sb + p0[i], falls into [lo[i], hi[i]) (hi = 0: never).
+template <bool XM>
+struct MxStream {
+    int64_t base[4], step;
+    int lo[4], hi[4], p0[4];
+    int slot[4];               // float index of the chunk in a staging buffer
+};
+
+template <bool XM>
+__device__ __forceinline__ MxStream<XM> mx_stream(const MxPassArgs &a, const MxBlock &b, int w, int lane) {
+    MxStream<XM> st;
+    const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = lr + 8 * i;
+        if constexpr (XM) {
+            const int row = 32 * w + r;
+            const bool valid = row < b.rows_valid;
+            st.p0[i] = 4 * lc;
+            st.slot[i] = r * kMxStagePitchX + 4 * lc;
+            if (a.mode == MX_X1) {
+                const int64_t U = b.first + row;
+                int64_t tile = U;
+                st.base[i] = b.gbase + (int64_t)row * a.T + 4 * lc;
+                if (a.lines != 1) {
+                    const int64_t line = U / a.M;
+                    tile = U - line * a.M;
+                    st.base[i] = line * a.N + tile * a.T - a.off + 4 * lc;
+                }
+                st.lo[i] = tile == 0 ? (int)a.off : 0;
+                st.hi[i] = !valid ? 0 : tile == a.M - 1 ? b.last_hi : a.T;
+            } else {
+                st.base[i] = b.gbase + (int64_t)row * b.gpitch + 4 * lc;
+                st.lo[i] = b.lo;
+                st.hi[i] = valid ? b.hi : 0;
+            }
+        } else {
+            const int col = 32 * w + 4 * lc;
+            st.p0[i] = r;
+            st.slot[i] = r * kMxStagePitchY + 4 * lc;
+            st.base[i] = b.gbase + (int64_t)r * b.gpitch + col;
+            st.lo[i] = b.lo;
+            st.hi[i] = col < b.cols_valid ? b.hi : 0;
+        }
+    }
+    st.step = XM ? 32 : 32 * b.gpitch;
+    return st;
+}
+
+// The requests of a sub-block.  Nothing here may LOOK at what was loaded: a select on the loaded value right behind the load makes
+// the compiler wait for it on the spot, and a walk whose every request is waited for before the next one is issued has no
+// requests in flight (a chunk that does not exist reads the plane's first chunk; mx_stage_put replaces it by zeros).
+// NT: non-temporal accesses (the image is read once and written once: 2-5 % at 16384^2) -- but only when every 128-byte run is a
+// whole cache line.  Rows that are not multiples of 128 bytes make neighbouring sub-blocks share a line, and a line fetched with
+// the hint is gone before the next sub-block asks for its other half (16380^2, order 12: 5.07 ms with the hint, 3.4 without).
+template <bool XM, bool NT>
+__device__ __forceinline__ void mx_request(const float *__restrict__ src, const MxStream<XM> &st, int sb, floatx4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int pos = 32 * sb + st.p0[i];
+        const bool ok = pos >= st.lo[i] && pos < st.hi[i];
+        const floatx4 *from = reinterpret_cast<const floatx4 *>(src + (ok ? st.base[i] + sb * st.step : 0));
+        if constexpr (NT) v[i] = __builtin_nontemporal_load(from);
+        else v[i] = *from;
+    }
+}
+
+template <bool XM>
+__device__ __forceinline__ void mx_stage_put(float *stage, const MxStream<XM> &st, int sb, const floatx4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int pos = 32 * sb + st.p0[i];
+        const bool ok = pos >= st.lo[i] && pos < st.hi[i];
+        *reinterpret_cast<floatx4 *>(stage + st.slot[i]) = ok ? v[i] : floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+}
+
+template <bool XM>
+__device__ __forceinline__ void mx_stage_read(const float *stage, int u, int h, float (&x)[16]) {
+    if constexpr (XM) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4 *>(stage + u * kMxStagePitchX + 8 * q + 4 * h);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++) x[t] = stage[mx_row(t, h) * kMxStagePitchY + u];
+    }
+}
+
+template <bool XM>
+__device__ __forceinline__ void mx_stage_write(float *stage, int u, int h, const floatx16 &y) {
+    if constexpr (XM) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4 *>(stage + u * kMxStagePitchX + 8 * q + 4 * h) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++) stage[mx_row(t, h) * kMxStagePitchY + u] = y[t];
+    }
+}
+
+// sample m (0 .. 31) of this lane's unit in a staged sub-block
+template <bool XM>
+__device__ __forceinline__ float mx_stage_at(const float *stage, int u, int m) {
+    return XM ? stage[u * kMxStagePitchX + m] : stage[m * kMxStagePitchY + u];
+}
+
+__device__ __forceinline__ void mx_store_tail(float *tails, int64_t tidx, int k, int h, const floatx16 &acc) {
+    const int KP = 8 * ((k + 7) >> 3);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r0 = 8 * q + 4 * h;
+        if (r0 < KP) *reinterpret_cast<float4 *>(tails + tidx * KP + r0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+}
+
+// The constant operands a wave needs per sub-block (H of pass 1, the next stage's H in pass 2) and the border vectors sit in LDS,
+// copied once per workgroup: a global load inside the walk would be waited for IN ORDER, behind the requests for the next
+// sub-block that were issued before it -- the HBM latency the walk exists to hide.
+// Every load of constants is ISSUED before the first request for image data and only then waited for, so that the wait does not
+// include the image's latency.
+struct MxConsts {
+    float4 frag[kMxMaxNB];
+    float vec;
+};
+
+__device__ __forceinline__ MxConsts mx_consts_request(const float *frag, int nb, const float *vec) {
+    MxConsts c;
+#pragma unroll
+    for (int i = 0; i < kMxMaxNB; i++) {
+        c.frag[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < nb) c.frag[i] = reinterpret_cast<const float4 *>(frag)[(int)threadIdx.x + kMxThreads * i];
+    }
+    c.vec = threadIdx.x < 32 ? vec[threadIdx.x] : 0.0f;
+    return c;
+}
+
+__device__ __forceinline__ void mx_consts_store(float *lds, const MxConsts &c, int nb) {
+#pragma unroll
+    for (int i = 0; i < kMxMaxNB; i++)
+        if (i < nb) reinterpret_cast<float4 *>(lds)[(int)threadIdx.x + kMxThreads * i] = c.frag[i];
+    if (threadIdx.x < 32) lds[nb * 1024 + threadIdx.x] = c.vec;
+}
+
+template <bool XM, bool NT>
 __global__ void __launch_bounds__(kMxThreads)
-mx_pass1_kernel(const float *__restrict__ src, MxPassArgs a) {
+mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
+    float *consts = mx_lds + kMxWaves * kMxStageFloats<XM>;       // H [NB][16][64], dH [32]
     const MxBlock blk = mx_block<XM>(a);
-    mx_load_block<XM, NB>(src, mx_lds, a, blk);
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
-    const int mine = 32 * w + u;
-    const MxLane ln = mx_lane<XM>(a, blk, mine);
-    float Hf[NB][16];                                      // requested while the block is on its way
+    float *stage = mx_lds + w * kMxStageFloats<XM>;
+    const MxStream<XM> st = mx_stream<XM>(a, blk, w, lane);
+    const MxLane ln = mx_lane<XM>(a, blk, 32 * w + u);
+    const MxConsts cs = mx_consts_request(a.H, a.NB, a.dH);
+    // (pass 1 has registers to spare: the whole tile of the wave -- up to 16 KiB -- is requested at once; what bounds a walk
+    // that requests one sub-block ahead is the bytes in flight, 4 KiB per wave)
+    floatx4 pre[kMxMaxNB][4];
 #pragma unroll
-    for (int sb = 0; sb < NB; sb++)
-#pragma unroll
-        for (int t = 0; t < 16; t++) Hf[sb][t] = a.H[(sb * 16 + t) * 64 + lane];
+    for (int sb = 0; sb < kMxMaxNB; sb++)
+        if (sb < a.NB) mx_request<XM, NT>(src, st, sb, pre[sb]);
+    mx_consts_store(consts, cs, a.NB);
     __syncthreads();
     floatx16 acc = mx_zero();
+    float x0 = 0.0f;
 #pragma unroll
-    for (int sb = 0; sb < NB; sb++) {
+    for (int sb = 0; sb < kMxMaxNB; sb++) {
+        if (sb >= a.NB) break;
+        mx_stage_put<XM>(stage, st, sb, pre[sb]);
+        mx_wave_sync();
         float x[16];
-        mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
-#pragma unroll
-        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[sb][t], x[t], acc, 0, 0, 0);
-    }
-    if (a.clamped && ln.valid && ln.border) {
-        const int m0 = a.causal ? 0 : a.T - 1;
-        const float x0 = XM ? mx_lds[mine * blk.pitch + m0] : mx_lds[m0 * blk.pitch + mine];
-#pragma unroll
-        for (int t = 0; t < 16; t++) acc[t] = fmaf(a.dH[mx_row(t, h)], x0, acc[t]);
-    }
-    if (ln.valid) {
-        const int KP = 8 * ((a.k + 7) >> 3);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r0 = 8 * q + 4 * h;
-            if (r0 < KP) *reinterpret_cast<float4 *>(a.tails + ln.tidx * KP + r0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        }
-    }
-}
-
-// The tile-local tails of the NEXT scan from the finished block in LDS (MxPassArgs::next): that scan's pass 1, without its read
-// of the image.  XV: how the next scan sees the block -- its samples along a row of the LDS image (true) or down a column.
-template <bool XV, int NB>
-__device__ __forceinline__ void mx_next_tails(const MxPassArgs &a, const float *lds, int pitch, int mine, int h, int lane, bool valid,
-                                              int tile, int tiles, int64_t tidx) {
-    floatx16 acc = mx_zero();
-#pragma unroll
-    for (int sb = 0; sb < NB; sb++) {
-        float x[16];
-        mx_read_sub<XV>(lds, pitch, mine, h, sb, x);
-        const float *Hf = a.next_H + (size_t)sb * 16 * 64 + lane;
+        mx_stage_read<XM>(stage, u, h, x);
+        if (sb == (a.causal ? 0 : a.NB - 1)) x0 = mx_stage_at<XM>(stage, u, a.causal ? 0 : 31);
+        const float *Hf = consts + sb * 1024 + lane;
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
+        mx_wave_sync();
     }
-    const bool enters = (a.next_causal ? tile == 0 : tile == tiles - 1) && (a.next_causal ? a.slab_first != 0 : a.slab_last != 0);
-    if (a.clamped && valid && enters) {
-        const int m0 = a.next_causal ? 0 : 32 * NB - 1;
-        const float x0 = XV ? lds[mine * pitch + m0] : lds[m0 * pitch + mine];
+    if (a.clamped && ln.valid && ln.border) {
+        const float *dH = consts + a.NB * 1024;
 #pragma unroll
-        for (int t = 0; t < 16; t++) acc[t] = fmaf(a.next_dH[mx_row(t, h)], x0, acc[t]);
+        for (int t = 0; t < 16; t++) acc[t] = fmaf(dH[mx_row(t, h)], x0, acc[t]);
     }
-    if (valid) {
-        const int KP = 8 * ((a.next_k + 7) >> 3);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r0 = 8 * q + 4 * h;
-            if (r0 < KP) *reinterpret_cast<float4 *>(a.next_tails + tidx * KP + r0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        }
-    }
+    if (ln.valid) mx_store_tail(a.tails, ln.tidx, a.k, h, acc);
 }
 
-// ---- pass 2: y_b = G x_b + R y_(b-1) ----------------------------------------------------------------------------------
-template <bool XM, int NB>
-__global__ void __launch_bounds__(kMxThreads)
-mx_pass2_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+// NLQ = ceil(k / 8) and the direction are compile-time: the K steps of R that are not all zero -- the k most recent rows of the
+// previous sub-block -- are then a fixed set of registers, requested from LDS ahead of the MFMAs that use them.
+template <bool XM, int NLQ, bool CAUSAL, bool NT>
+__global__ void __launch_bounds__(kMxThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
+    // (one staging buffer per wave: x_b is in registers by the time y_b is written over it)
+    // constants: dG [32], pad [32], G [16][64], R [16][64], next H [NB][16][64], next dH [32] -- G and R too: the 32 registers they
+    // would take are what a second sub-block in flight takes
+    float *consts = mx_lds + kMxWaves * kMxStageFloats<XM>;
+    const float *Gl = consts + 64, *Rl = consts + 64 + 1024, *Hl = consts + 64 + 2048;
     const MxBlock blk = mx_block<XM>(a);
-    mx_load_block<XM, NB>(src, mx_lds, a, blk);
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
-    const int mine = 32 * w + u;
-    const MxLane ln = mx_lane<XM>(a, blk, mine);
-    float Gf[16], Rf[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) { Gf[t] = a.G[t * 64 + lane]; Rf[t] = a.R[t * 64 + lane]; }
-    // K steps of R that are not all zero: the k most recent rows of the previous sub-block (wave-uniform)
-    const int nl = 4 * ((a.k + 7) >> 3), KP = 2 * nl, t_lo = a.causal ? 16 - nl : 0, t_hi = t_lo + nl;
-    // the completed tail of the neighbouring tile, laid out as the rows of a sub-block that precedes the tile:
-    // row i of it is tail 31 - i (causal: the most recent output is the last row) or tail i (anticausal)
+    float *stage = mx_lds + w * kMxStageFloats<XM>;
+    const MxStream<XM> st = mx_stream<XM>(a, blk, w, lane);
+    const MxLane ln = mx_lane<XM>(a, blk, 32 * w + u);
+    const float dg = threadIdx.x < 32 ? a.dG[threadIdx.x] : 0.0f;
+    static_assert(kMxThreads == 256, "one 16-byte piece of G and of R per thread");
+    const float4 gr0 = reinterpret_cast<const float4 *>(a.G)[threadIdx.x], gr1 = reinterpret_cast<const float4 *>(a.R)[threadIdx.x];
+    const MxConsts cs = mx_consts_request(a.next ? a.next_H : a.G, a.next ? a.NB : 0, a.next ? a.next_dH : a.dG);
+    // two sub-blocks in flight per wave
+    floatx4 pre[2][4];
+    mx_request<XM, NT>(src, st, CAUSAL ? 0 : a.NB - 1, pre[0]);
+    if (a.NB > 1) mx_request<XM, NT>(src, st, CAUSAL ? 1 : a.NB - 2, pre[1]);
+    constexpr int NL = 4 * NLQ, KP = 8 * NLQ, T_LO = CAUSAL ? 16 - NL : 0;
     floatx16 prev = mx_zero();
     if (ln.valid && (!ln.enters || (a.incoming != nullptr && !ln.border))) {
-        // (the first tile of a slab that is not the image's: what the slabs before it hand over)
         const float *tp = ln.enters ? a.incoming + ln.line * KP : a.tails + ln.prev_tidx * KP;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int r_lo = a.causal ? 28 - 8 * q - 4 * h : 8 * q + 4 * h;
+            const int r_lo = CAUSAL ? 28 - 8 * q - 4 * h : 8 * q + 4 * h;
             if (r_lo < KP) {
                 const float4 v = *reinterpret_cast<const float4 *>(tp + r_lo);
-                if (a.causal) { prev[4 * q] = v.w; prev[4 * q + 1] = v.z; prev[4 * q + 2] = v.y; prev[4 * q + 3] = v.x; }
+                if (CAUSAL) { prev[4 * q] = v.w; prev[4 * q + 1] = v.z; prev[4 * q + 2] = v.y; prev[4 * q + 3] = v.x; }
                 else          { prev[4 * q] = v.x; prev[4 * q + 1] = v.y; prev[4 * q + 2] = v.z; prev[4 * q + 3] = v.w; }
             }
         }
     }
+    if (threadIdx.x < 32) consts[threadIdx.x] = dg;
+    reinterpret_cast<float4 *>(consts + 64)[threadIdx.x] = gr0;
+    reinterpret_cast<float4 *>(consts + 64 + 1024)[threadIdx.x] = gr1;
+    if (a.next) mx_consts_store(consts + 64 + 2048, cs, a.NB);      // (next dH lands behind next H)
     __syncthreads();
-#pragma unroll
-    for (int bi = 0; bi < NB; bi++) {
-        const int sb = a.causal ? bi : NB - 1 - bi;
+    floatx16 nacc = mx_zero();
+    float nx0 = 0.0f;
+    auto step = [&](int bi, floatx4 (&buf)[4]) __attribute__((always_inline)) {
+        const int sb = CAUSAL ? bi : a.NB - 1 - bi;
+        mx_stage_put<XM>(stage, st, sb, buf);
+        if (bi + 2 < a.NB) mx_request<XM, NT>(src, st, CAUSAL ? sb + 2 : sb - 2, buf);
+        mx_wave_sync();
         float x[16];
-        mx_read_sub<XM>(mx_lds, blk.pitch, mine, h, sb, x);
+        mx_stage_read<XM>(stage, u, h, x);
         floatx16 c = mx_zero();
         if (bi == 0 && a.clamped && ln.valid && ln.border) {
-            const int m0 = a.causal ? 0 : a.T - 1;
-            const float x0 = XM ? mx_lds[mine * blk.pitch + m0] : mx_lds[m0 * blk.pitch + mine];
+            const float x0 = mx_stage_at<XM>(stage, u, CAUSAL ? 0 : 31);
 #pragma unroll
-            for (int t = 0; t < 16; t++) c[t] = a.dG[mx_row(t, h)] * x0;
+            for (int t = 0; t < 16; t++) c[t] = consts[mx_row(t, h)] * x0;
         }
+        mx_wave_sync();
 #pragma unroll
-        for (int t = 0; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Gf[t], x[t], c, 0, 0, 0);
+        for (int t = 0; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Gl[t * 64 + lane], x[t], c, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 16; t++)
-            if (t >= t_lo && t < t_hi) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Rf[t], prev[t], c, 0, 0, 0);
+        for (int t = T_LO; t < T_LO + NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Rl[t * 64 + lane], prev[t], c, 0, 0, 0);
         prev = c;
-        mx_write_sub<XM>(mx_lds, blk.pitch, mine, h, sb, c);
-    }
-    __syncthreads();
-    mx_store_block<XM, NB>(dst, mx_lds, a, blk);
-    if (a.next == 1) mx_next_tails<XM, NB>(a, mx_lds, blk.pitch, mine, h, lane, ln.valid, ln.tile, a.M, ln.tidx);
-    if constexpr (XM) {
-        if (a.next == 2) {
-            // the block seen by the y scans: lane = column mine of x tile blk.tile, samples = the block's 128 rows = y tile blockIdx.x
-            const int ytile = (int)blockIdx.x, MY = (int)(a.lines / a.T);
-            const int64_t column = (int64_t)blk.tile * a.T + mine;
-            mx_next_tails<false, NB>(a, mx_lds, blk.pitch, mine, h, lane, true, ytile, MY, (int64_t)ytile * a.N + column);
+        mx_stage_write<XM>(stage, u, h, c);
+        if (a.next == 1) {
+            // the tile-local tails of the NEXT scan of this dimension: its pass 1 without its read of the image (a finished
+            // sub-block in accumulator layout IS the B operand)
+            const float *Hn = Hl + sb * 1024 + lane;
+#pragma unroll
+            for (int t = 0; t < 16; t++) nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hn[t * 64], c[t], nacc, 0, 0, 0);
         }
+        mx_wave_sync();
+        if (a.next == 1 && sb == (a.next_causal ? 0 : a.NB - 1)) nx0 = mx_stage_at<XM>(stage, u, a.next_causal ? 0 : 31);
+        if constexpr (XM) {
+            if (a.next == 2) {
+                // The first y scan's tile-local tails (MxPassArgs::next == 2): the workgroup's 128 lines are one y tile, the 32
+                // samples of this sub-block 32 of its columns.  A wave contracts ITS 32 lines (sub-block w of the y tile) with
+                // its part of the y scan's H -- the staged y_b read down its columns is the B operand --, the four partial sums
+                // meet in LDS and wave q adds up and stores rows 8 q .. 8 q + 7 of the 32 tails.
+                floatx16 part = mx_zero();
+                const float *Hy = Hl + w * 1024 + lane;
+#pragma unroll
+                for (int t = 0; t < 16; t++) part = __builtin_amdgcn_mfma_f32_32x32x2f32(Hy[t * 64], stage[mx_row(t, h) * kMxStagePitchX + u], part, 0, 0, 0);
+                const int ytile = (int)(blk.first / kMxUnits), MY = (int)(a.lines / kMxUnits);
+                const bool yenters = (a.next_causal ? ytile == 0 : ytile == MY - 1) && (a.next_causal ? a.slab_first != 0 : a.slab_last != 0);
+                if (a.clamped && yenters && w == (a.next_causal ? 0 : kMxWaves - 1)) {
+                    const float y0 = stage[(a.next_causal ? 0 : 31) * kMxStagePitchX + u];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) part[t] = fmaf(Hl[a.NB * 1024 + mx_row(t, h)], y0, part[t]);
+                }
+                float *red = consts + 64 + 2048 + a.NB * 1024 + 32;         // [wave][q][lane] pieces of 16 bytes
+                const int nq = (a.next_k + 7) >> 3;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < nq) reinterpret_cast<float4 *>(red)[(w * nq + q) * 64 + lane] = make_float4(part[4 * q], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]);
+                __syncthreads();
+                if (w < nq) {
+                    float4 sum = reinterpret_cast<const float4 *>(red)[w * 64 + lane];
+#pragma unroll
+                    for (int ww = 1; ww < kMxWaves; ww++) {
+                        const float4 v = reinterpret_cast<const float4 *>(red)[(ww * nq + w) * 64 + lane];
+                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    }
+                    const int64_t column = (int64_t)blk.tile * a.T + 32 * sb + u;
+                    *reinterpret_cast<float4 *>(a.next_tails + ((int64_t)ytile * a.N + column) * (8 * nq) + 8 * w + 4 * h) = sum;
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pos = 32 * sb + st.p0[i];
+            if (pos >= st.lo[i] && pos < st.hi[i])
+            {
+                const floatx4 y = *reinterpret_cast<const floatx4 *>(stage + st.slot[i]);
+                floatx4 *to = reinterpret_cast<floatx4 *>(dst + st.base[i] + sb * st.step);
+                if constexpr (NT) __builtin_nontemporal_store(y, to);
+                else *to = y;
+            }
+        }
+        mx_wave_sync();
+    };
+    for (int bi = 0; bi < a.NB; bi += 2) {
+        step(bi, pre[0]);
+        if (bi + 1 < a.NB) step(bi + 1, pre[1]);
+    }
+    if (a.next == 1) {
+        const bool nenters = (a.next_causal ? ln.tile == 0 : ln.tile == a.M - 1) && (a.next_causal ? a.slab_first != 0 : a.slab_last != 0);
+        if (a.clamped && ln.valid && nenters) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) nacc[t] = fmaf(Hl[a.NB * 1024 + mx_row(t, h)], nx0, nacc[t]);
+        }
+        if (ln.valid) mx_store_tail(a.next_tails, ln.tidx, a.next_k, h, nacc);
     }
 }
 
@@ -480,13 +585,9 @@ mx_apply_kernel(MxChainArgs a) {
     }
 }
 
-size_t mx_lds_bytes(const MxPassArgs &a) {
-    return a.mode == MX_Y ? (size_t)a.T * kMxPitchY * sizeof(float) : (size_t)kMxUnits * (a.T + 4) * sizeof(float);
-}
-
 dim3 mx_grid(const MxPassArgs &a) {
     if (a.mode == MX_X1) return dim3((unsigned)((a.units + kMxUnits - 1) / kMxUnits));
-    if (a.mode == MX_XL) return dim3((unsigned)((a.lines + kMxUnits - 1) / kMxUnits), (unsigned)a.M);
+    if (a.mode == MX_XL) return dim3((unsigned)(((a.lines + kMxUnits - 1) / kMxUnits) * a.M));
     return dim3((unsigned)((a.inner + kMxUnits - 1) / kMxUnits), (unsigned)a.M, (unsigned)(a.lines / a.inner));
 }
 
@@ -496,6 +597,7 @@ int mx_check(const MxPassArgs &a) {
         set_error("matrix path: bad tile geometry (T %d, NB %d, M %d, k %d)", a.T, a.NB, a.M, a.k);
         return RF_ERR_INVALID_ARG;
     }
+    if (a.mode == MX_XL && ((a.lines + kMxUnits - 1) / kMxUnits) * a.M >= (1ll << 31)) { set_error("matrix path: extents out of range"); return RF_ERR_UNSUPPORTED; }
     const dim3 g = mx_grid(a);
     if (g.y > 65535u || g.z > 65535u || (a.mode == MX_Y && (a.inner % 4 != 0 || a.lines % a.inner != 0))) {
         set_error("matrix path: extents out of range");
@@ -504,50 +606,57 @@ int mx_check(const MxPassArgs &a) {
     return RF_OK;
 }
 
-// more than 64 KiB of dynamic LDS: opt in, once per kernel and device
-template <typename K>
-int mx_allow_lds(K kern, size_t lds) {
-    if (lds <= 64 * 1024) return RF_OK;
-    static std::mutex mu;
-    static std::set<std::pair<const void *, int>> opted;
-    int dev = 0;
-    RF_HIP_CHECK(hipGetDevice(&dev));
-    const std::pair<const void *, int> key(reinterpret_cast<const void *>(kern), dev);
-    std::lock_guard<std::mutex> lock(mu);
-    if (opted.count(key)) return RF_OK;
-    RF_HIP_CHECK(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    opted.insert(key);
-    return RF_OK;
-}
-
 }  // namespace
 
-#define RF_MX_PASS(KERNEL, XMODE, ...)                                                                                        \
-    switch (a.NB) {                                                                                                          \
-        case 1: if (int rc = mx_allow_lds(KERNEL<XMODE, 1>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 1>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
-        case 2: if (int rc = mx_allow_lds(KERNEL<XMODE, 2>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 2>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
-        case 3: if (int rc = mx_allow_lds(KERNEL<XMODE, 3>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 3>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
-        default: if (int rc = mx_allow_lds(KERNEL<XMODE, 4>, lds)) return rc; hipLaunchKernelGGL((KERNEL<XMODE, 4>), mx_grid(a), dim3(kMxThreads), lds, stream, __VA_ARGS__); break; \
-    }
+// whether every 128-byte run of a sub-block is one whole cache line (the non-temporal variants, mx_request)
+static bool mx_whole_lines(const MxPassArgs &a, const void *src, const void *dst) {
+    const int64_t pitch = a.mode == MX_Y ? a.inner : (a.mode == MX_XL || a.lines != 1) ? a.N : 32;
+    return ((uintptr_t)src | (uintptr_t)dst) % 128 == 0 && pitch % 32 == 0 && a.off % 32 == 0;
+}
 
+// LDS of a pass: the waves' staging buffers and the constants; more than 64 KiB would need an opt-in per kernel and the passes
+// stay well below it on purpose (three or four workgroups per CU)
 int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
     if (int rc = mx_check(a)) return rc;
-    const size_t lds = mx_lds_bytes(a);
-    if (a.mode == MX_Y) { RF_MX_PASS(mx_pass1_kernel, false, src, a) }
-    else { RF_MX_PASS(mx_pass1_kernel, true, src, a) }
+    const size_t consts = ((size_t)a.NB * 1024 + 32) * sizeof(float);
+    const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
+    if (mx_whole_lines(a, src, src)) {
+        if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, true>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);
+        else hipLaunchKernelGGL((mx_pass1s_kernel<true, true>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
+    } else {
+        if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, false>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);
+        else hipLaunchKernelGGL((mx_pass1s_kernel<true, false>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
+    }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
 
 int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream) {
     if (int rc = mx_check(a)) return rc;
-    const size_t lds = mx_lds_bytes(a);
-    if (a.mode == MX_Y) { RF_MX_PASS(mx_pass2_kernel, false, src, dst, a) }
-    else { RF_MX_PASS(mx_pass2_kernel, true, src, dst, a) }
+    if (a.next == 2 && (a.mode != MX_XL || a.ragged || a.lines % kMxUnits != 0 || a.NB != kMxWaves)) { set_error("matrix path: bad x -> y hand-over"); return RF_ERR_INVALID_ARG; }
+    const size_t consts = (64 + 2048 + (a.next ? (size_t)a.NB * 1024 + 32 : 0) + (a.next == 2 ? (size_t)((a.next_k + 7) >> 3) * kMxWaves * 64 * 4 : 0)) * sizeof(float);
+    const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
+#define RF_MX_P2S_NT(NLQ, NT)                                                                                                          \
+    if (a.mode == MX_Y) {                                                                                                              \
+        if (a.causal) hipLaunchKernelGGL((mx_pass2s_kernel<false, NLQ, true, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);   \
+        else hipLaunchKernelGGL((mx_pass2s_kernel<false, NLQ, false, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);           \
+    } else {                                                                                                                           \
+        if (a.causal) hipLaunchKernelGGL((mx_pass2s_kernel<true, NLQ, true, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);    \
+        else hipLaunchKernelGGL((mx_pass2s_kernel<true, NLQ, false, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);            \
+    }
+#define RF_MX_P2S(NLQ) if (whole) { RF_MX_P2S_NT(NLQ, true) } else { RF_MX_P2S_NT(NLQ, false) }
+    const bool whole = mx_whole_lines(a, src, dst);
+    switch ((a.k + 7) >> 3) {
+        case 1: RF_MX_P2S(1) break;
+        case 2: RF_MX_P2S(2) break;
+        case 3: RF_MX_P2S(3) break;
+        default: RF_MX_P2S(4) break;
+    }
+#undef RF_MX_P2S
+#undef RF_MX_P2S_NT
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
-#undef RF_MX_PASS
 
 int launch_mx_chain(const MxChainArgs &a, hipStream_t stream) {
     if (a.ncols <= 0 || a.C <= 0) return RF_OK;

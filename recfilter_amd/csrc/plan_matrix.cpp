@@ -269,6 +269,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         else if (plan->ndim == 2 && da == 0 && db == 1 && a.mode == MX_XL && a.T == 128 && b.T == 128 && a.N % 128 == 0 && a.lines % 128 == 0 &&
                  !plan->sharded()) next = 2;       // (a slab's y tiles have their own border rules: MxPassArgs::slab_first / slab_last)
         if (RF_KNOB("RF_MX_NO_NEXT") != nullptr) next = 0;      // A/B: every stage with its own pass 1
+        if (RF_KNOB("RF_MX_NO_NEXT2") != nullptr && next == 2) next = 0;
         a.next = next;
         if (next) { a.next_k = b.k; a.next_causal = b.causal; a.next_H = b.H; a.next_dH = b.dH; }
     }
