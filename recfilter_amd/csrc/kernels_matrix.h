@@ -16,7 +16,7 @@ constexpr int kMxSB = 32;                  // sub-block: samples one 32x32x2 MFM
 #endif
 constexpr int kMxWaves = RF_MX_WAVES;                // waves per workgroup of the pass kernels
 constexpr int kMxUnits = 32 * kMxWaves;    // units (line, tile) per workgroup: one per lane column
-constexpr int kMxMaxNB = 4;                // sub-blocks per tile: T <= 128 (128 units x 128 samples of LDS)
+constexpr int kMxMaxNB = 8;                // sub-blocks per tile: T <= 256 (the H fragments of a tile sit in LDS: 4 KiB per sub-block)
 constexpr int kMxChunk = 16;               // tiles per chunk of the carry chain (levels of the blocked scan)
 constexpr int kMxTopMax = 24;              // a sequence this short is chained in one go
 
@@ -54,7 +54,7 @@ struct MxPassArgs {
     // the same dimension (same units); 2 this scan runs along x with lane = line and the next one along y of a 2-D image whose
     // 128 x 128 blocks coincide (lane = column of the same block).
     int32_t next;
-    int32_t next_k, next_causal;
+    int32_t next_k, next_causal, next_NB;      // (next_NB: sub-blocks of the next scan's tile = of its H)
     const float *next_H, *next_dH;
     float *next_tails;
 };

@@ -318,20 +318,18 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
     const MxStream<XM> st = mx_stream<XM>(a, blk, w, lane);
     const MxLane ln = mx_lane<XM>(a, blk, 32 * w + u);
     const MxConsts cs = mx_consts_request(a.H, a.NB, a.dH);
-    // (pass 1 has registers to spare: the whole tile of the wave -- up to 16 KiB -- is requested at once; what bounds a walk
-    // that requests one sub-block ahead is the bytes in flight, 4 KiB per wave)
-    floatx4 pre[kMxMaxNB][4];
+    // (pass 1 has registers to spare: four sub-blocks -- 16 KiB per wave -- are in flight)
+    floatx4 pre[4][4];
 #pragma unroll
-    for (int sb = 0; sb < kMxMaxNB; sb++)
-        if (sb < a.NB) mx_request<XM, NT>(src, st, sb, pre[sb]);
+    for (int d = 0; d < 4; d++)
+        if (d < a.NB) mx_request<XM, NT>(src, st, d, pre[d]);
     mx_consts_store(consts, cs, a.NB);
     __syncthreads();
     floatx16 acc = mx_zero();
     float x0 = 0.0f;
-#pragma unroll
-    for (int sb = 0; sb < kMxMaxNB; sb++) {
-        if (sb >= a.NB) break;
-        mx_stage_put<XM>(stage, st, sb, pre[sb]);
+    auto step = [&](int sb, floatx4 (&buf)[4]) __attribute__((always_inline)) {
+        mx_stage_put<XM>(stage, st, sb, buf);
+        if (sb + 4 < a.NB) mx_request<XM, NT>(src, st, sb + 4, buf);
         mx_wave_sync();
         float x[16];
         mx_stage_read<XM>(stage, u, h, x);
@@ -340,6 +338,12 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
         mx_wave_sync();
+    };
+    for (int sb = 0; sb < a.NB; sb += 4) {
+        step(sb, pre[0]);
+        if (sb + 1 < a.NB) step(sb + 1, pre[1]);
+        if (sb + 2 < a.NB) step(sb + 2, pre[2]);
+        if (sb + 3 < a.NB) step(sb + 3, pre[3]);
     }
     if (a.clamped && ln.valid && ln.border) {
         const float *dH = consts + a.NB * 1024;
@@ -368,7 +372,7 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     const float dg = threadIdx.x < 32 ? a.dG[threadIdx.x] : 0.0f;
     static_assert(kMxThreads == 256, "one 16-byte piece of G and of R per thread");
     const float4 gr0 = reinterpret_cast<const float4 *>(a.G)[threadIdx.x], gr1 = reinterpret_cast<const float4 *>(a.R)[threadIdx.x];
-    const MxConsts cs = mx_consts_request(a.next ? a.next_H : a.G, a.next ? a.NB : 0, a.next ? a.next_dH : a.dG);
+    const MxConsts cs = mx_consts_request(a.next ? a.next_H : a.G, a.next ? a.next_NB : 0, a.next ? a.next_dH : a.dG);
     // two sub-blocks in flight per wave
     floatx4 pre[2][4];
     mx_request<XM, NT>(src, st, CAUSAL ? 0 : a.NB - 1, pre[0]);
@@ -390,7 +394,7 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     if (threadIdx.x < 32) consts[threadIdx.x] = dg;
     reinterpret_cast<float4 *>(consts + 64)[threadIdx.x] = gr0;
     reinterpret_cast<float4 *>(consts + 64 + 1024)[threadIdx.x] = gr1;
-    if (a.next) mx_consts_store(consts + 64 + 2048, cs, a.NB);      // (next dH lands behind next H)
+    if (a.next) mx_consts_store(consts + 64 + 2048, cs, a.next_NB);      // (next dH lands behind next H)
     __syncthreads();
     floatx16 nacc = mx_zero();
     float nx0 = 0.0f;
@@ -438,9 +442,9 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
                 if (a.clamped && yenters && w == (a.next_causal ? 0 : kMxWaves - 1)) {
                     const float y0 = stage[(a.next_causal ? 0 : 31) * kMxStagePitchX + u];
 #pragma unroll
-                    for (int t = 0; t < 16; t++) part[t] = fmaf(Hl[a.NB * 1024 + mx_row(t, h)], y0, part[t]);
+                    for (int t = 0; t < 16; t++) part[t] = fmaf(Hl[a.next_NB * 1024 + mx_row(t, h)], y0, part[t]);
                 }
-                float *red = consts + 64 + 2048 + a.NB * 1024 + 32;         // [wave][q][lane] pieces of 16 bytes
+                float *red = consts + 64 + 2048 + a.next_NB * 1024 + 32;         // [wave][q][lane] pieces of 16 bytes
                 const int nq = (a.next_k + 7) >> 3;
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -480,7 +484,7 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
         const bool nenters = (a.next_causal ? ln.tile == 0 : ln.tile == a.M - 1) && (a.next_causal ? a.slab_first != 0 : a.slab_last != 0);
         if (a.clamped && ln.valid && nenters) {
 #pragma unroll
-            for (int t = 0; t < 16; t++) nacc[t] = fmaf(Hl[a.NB * 1024 + mx_row(t, h)], nx0, nacc[t]);
+            for (int t = 0; t < 16; t++) nacc[t] = fmaf(Hl[a.next_NB * 1024 + mx_row(t, h)], nx0, nacc[t]);
         }
         if (ln.valid) mx_store_tail(a.next_tails, ln.tidx, a.next_k, h, nacc);
     }
@@ -633,8 +637,8 @@ int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
 
 int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream) {
     if (int rc = mx_check(a)) return rc;
-    if (a.next == 2 && (a.mode != MX_XL || a.ragged || a.lines % kMxUnits != 0 || a.NB != kMxWaves)) { set_error("matrix path: bad x -> y hand-over"); return RF_ERR_INVALID_ARG; }
-    const size_t consts = (64 + 2048 + (a.next ? (size_t)a.NB * 1024 + 32 : 0) + (a.next == 2 ? (size_t)((a.next_k + 7) >> 3) * kMxWaves * 64 * 4 : 0)) * sizeof(float);
+    if ((a.next == 2 && (a.mode != MX_XL || a.ragged || a.lines % kMxUnits != 0 || a.next_NB != kMxWaves)) || (a.next == 1 && a.next_NB != a.NB)) { set_error("matrix path: bad x -> y hand-over"); return RF_ERR_INVALID_ARG; }
+    const size_t consts = (64 + 2048 + (a.next ? (size_t)a.next_NB * 1024 + 32 : 0) + (a.next == 2 ? (size_t)((a.next_k + 7) >> 3) * kMxWaves * 64 * 4 : 0)) * sizeof(float);
     const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
 #define RF_MX_P2S_NT(NLQ, NT)                                                                                                          \
     if (a.mode == MX_Y) {                                                                                                              \

@@ -145,18 +145,32 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
     size_t tails_floats = 0;                 // per plane, max over the stages (they run one after the other)
     std::vector<size_t> level_floats;        // [l-1] per plane, max over the stages
 
+    // the last x pass of a 2-D image can hand the first y scan its tile-local tails (MxPassArgs::next == 2, below)
+    bool xy_handover = false;
+    if (plan->ndim == 2 && !plan->sharded() && !plan->dims[0].scan_ids.empty() && !plan->dims[1].scan_ids.empty() && RF_KNOB("RF_MX_NO_NEXT2") == nullptr) {
+        const DimInfo &dx = plan->dims[0], &dy = plan->dims[1];
+        const int ky = plan->scans[(size_t)dy.scan_ids.front()].order;
+        xy_handover = dx.lines >= 32 && dx.N % kMxUnits == 0 && dy.N % kMxUnits == 0 && ky <= 16;
+    }
     for (int d = 0; d < plan->ndim; d++) {
         DimInfo &di = plan->dims[d];
         if (di.scan_ids.empty()) continue;
-        // tile width: the widest of 128 / 96 / 64 / 32 that divides the extent; an extent that is no multiple of 32 takes tiles of
-        // 128 (one tile of 32 .. 128 when it is shorter) and pads the last one where the scan leaves the image (MxPassArgs::off)
-        int NB = kMxMaxNB;
-        const int nb_cap = RF_KNOB("RF_MX_NB") ? atoi(RF_KNOB("RF_MX_NB")) : kMxMaxNB;      // A/B: narrower tiles, more workgroups per CU
+        // tile width: the widest of 256 / 224 / .. / 32 that divides the extent (wide tiles halve the tails and their chain; a tile of
+        // 128 at most while the launch would otherwise not fill the CUs, and for the y scans of a 2-D image that take their
+        // tile-local tails from the last x pass -- its 128-line workgroups are their tiles -- when those tails are short enough
+        // for that to pay: 16384^2, orders 12 / 32, round 5); an extent that is no multiple of 32 takes tiles of that width
+        // (one tile of 32 .. when it is shorter) and pads the last one where the scan leaves the image (MxPassArgs::off)
+        int nb_cap = kMxMaxNB;
+        const int64_t wide_groups = (di.lines * ((di.N + kMxSB * kMxMaxNB - 1) / (kMxSB * kMxMaxNB)) + kMxUnits - 1) / kMxUnits;
+        if (wide_groups < 256) nb_cap = 4;
+        if (xy_handover && d == 1) nb_cap = 4;
+        if (RF_KNOB("RF_MX_NB")) nb_cap = atoi(RF_KNOB("RF_MX_NB"));       // A/B: narrower / wider tiles
+        int NB = nb_cap;
         if (di.N % kMxSB == 0) {
             const int64_t blocks = di.N / kMxSB;
             for (int nb = nb_cap; nb >= 1; nb--)
                 if (blocks % nb == 0) { NB = nb; break; }
-        } else if (di.N < kMxSB * kMxMaxNB) {
+        } else if (di.N < kMxSB * nb_cap) {
             NB = (int)((di.N + kMxSB - 1) / kMxSB);
         }
         const int T = kMxSB * NB;
@@ -266,12 +280,11 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         const int da = plan->scans[(size_t)stages[i].scan].dim, db = plan->scans[(size_t)stages[i + 1].scan].dim;
         int next = 0;
         if (da == db && a.off == b.off) next = 1;            // (the same tiles: a causal / anticausal pair only when they divide the extent)
-        else if (plan->ndim == 2 && da == 0 && db == 1 && a.mode == MX_XL && a.T == 128 && b.T == 128 && a.N % 128 == 0 && a.lines % 128 == 0 &&
-                 !plan->sharded()) next = 2;       // (a slab's y tiles have their own border rules: MxPassArgs::slab_first / slab_last)
+        else if (xy_handover && da == 0 && db == 1 && a.mode == MX_XL && !a.ragged && b.T == kMxUnits) next = 2;
+        // (not in a sharded plan: a slab's y tiles have their own border rules, MxPassArgs::slab_first / slab_last)
         if (RF_KNOB("RF_MX_NO_NEXT") != nullptr) next = 0;      // A/B: every stage with its own pass 1
-        if (RF_KNOB("RF_MX_NO_NEXT2") != nullptr && next == 2) next = 0;
         a.next = next;
-        if (next) { a.next_k = b.k; a.next_causal = b.causal; a.next_H = b.H; a.next_dH = b.dH; }
+        if (next) { a.next_k = b.k; a.next_causal = b.causal; a.next_NB = b.NB; a.next_H = b.H; a.next_dH = b.dH; }
     }
     // (two tail buffers: a final pass reads its own stage's completed tails while it writes the next stage's local ones)
     float *tails_ab[2];
