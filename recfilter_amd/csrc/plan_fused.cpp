@@ -436,6 +436,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         const FusedArgs<Acc> a = fargs(pl);
         (void)stream_mode;
         (void)mfma_mode;
+        (void)walk_args;
         if constexpr (std::is_same<P, float>::value) {
             if (walk_hook) {
                 WalkArgs wa = walk_args;
