@@ -137,8 +137,9 @@ typedef struct {
  *                           the order (default: orders 2 and 3).  The streaming kernel keeps what it takes.
  *   RF_PLAN_WALK_PASS1      3-D: pass 1 reads the volume ONCE and forms the x, y and z tails together (the z operators commuted
  *                           in front of the x/y filter, kernels_tails_walk.hip; 20 instead of 24 bytes per sample) wherever
- *                           its shape rules allow -- f32 volumes of whole tiles (z slabs: with the early exchange), no prologue, orders <= 3
- *                           along x / y and <= 2 along z,
+ *                           its shape rules allow -- f32 volumes whose depth is whole z tiles and whose width is a multiple of
+ *                           four (partial tiles along x and y load as zeros; z slabs: with the early exchange), a prologue
+ *                           x' = s x + b applied as the samples arrive (not 8-bit input), orders <= 3 along x / y and <= 2 along z,
  *                           one or two scans in each of the three dimensions -- whatever the size (default: volumes of at
  *                           least 256 patches of 256 x 32 samples x one z tile, one per compute unit);
  *                           RF_PLAN_STAGED_PASS1 keeps the two first passes of the x/y and z stages.

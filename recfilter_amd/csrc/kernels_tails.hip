@@ -386,7 +386,7 @@ xscan_rows_kernel(FusedArgs<Acc> a, int gj, int TY, const Acc *__restrict__ Hy, 
             tmp[i] = (tx_i < a.MX) ? yt4[row_tile_index(jr_i, tx_i) * 64 + cc] : A4{Acc(0), Acc(0), Acc(0), Acc(0)};
         }
     } else {
-        // the combined rows come in parts (FusedArgs::yt_parts; whole tiles only): add them up
+        // the combined rows come in parts (FusedArgs::yt_parts): add them up
         const A4 *p4 = reinterpret_cast<const A4 *>(a.ytp);
         const int64_t stride4 = a.yt_part_stride >> 2;
 #pragma unroll

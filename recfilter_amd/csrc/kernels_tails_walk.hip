@@ -50,13 +50,15 @@ __device__ __forceinline__ float sum_lanes_xor_32(float v) {
 // kernels_tails_mfma.hip the eight rows of the y part alone took eight address registers; this kernel has 128 in all).
 constexpr int kPitch4 = kFusedTX / 4 + 1;
 
-// K: order of the x/y stage; NX, NY: scans along x / y
-template <int K, int NX, int NY>
-__global__ void __launch_bounds__(kWalkThreads)
-walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa,
-                  const float *__restrict__ Hx,     // [vx][s][r][256]
-                  const float *__restrict__ Hy,     // [vy][j][r][TY]
-                  const float *__restrict__ HzT) {  // [vz][z][4]
+// K: order of the x/y stage; NX, NY: scans along x / y.  EDGE: the patch is not whole -- the last tile of a row may have fewer than
+// 256 columns (a multiple of four), the last tile row fewer than TY rows: what does not exist loads as zeros (the tables of the
+// last tiles are built for their extent, as for the staged pass 1) and is never stored.  Whole patches run a body of their own:
+// joined in one, the masks sit behind every load of every patch (kernels_tails.hip, WHOLE).
+template <int K, int NX, int NY, bool EDGE>
+__device__ __forceinline__ void walk_tails_body(const float *__restrict__ src, const FusedArgs<float> &a, const WalkArgs &wa,
+                                                const float *__restrict__ Hx,     // [vx][s][r][256]
+                                                const float *__restrict__ Hy,     // [vy][j][r][TY]
+                                                const float *__restrict__ HzT) {  // [vz][z][4]
     // [patch x 2][x stage: 16 waves x nxk x 32, x 2][y stage: 4 x nyk x 256, x 2][Hz: 128 x 4][B operands]: the patch and the two
     // stages are double-buffered by the plane's parity, so that a step needs ONE workgroup barrier (below)
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_raw[];
@@ -89,7 +91,16 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     const char *spb = reinterpret_cast<const char *>(src + ((int64_t)tz * TZ) * plane + ((int64_t)ty * wa.TY + kRows * h) * a.NX + (int64_t)tx * kFusedTX);
     const uint32_t off0 = (uint32_t)rg * a.row_bytes + (uint32_t)cc * 16u, off1 = off0 + 16u * a.row_bytes;
     const int64_t plane_bytes = plane * (int64_t)sizeof(float);
-    auto ld = [&](const char *pb, uint32_t off) { return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(pb + off)); };
+    // the rows rg and rg + 16 and the chunk cc of this thread: do they exist?
+    const int cols_here = tx == a.MX - 1 ? a.last_cols : kFusedTX;
+    const int rows_left = (ty == a.MY - 1 ? a.last_rows : wa.TY) - kRows * h;                 // rows of the patch that exist (may be <= 0)
+    const bool ok0 = !EDGE || (4 * cc < cols_here && rg < rows_left), ok1 = !EDGE || (4 * cc < cols_here && rg + 16 < rows_left);
+    auto ld = [&](const char *pb, uint32_t off, bool ok) {
+        // (a chunk that does not exist reads the volume's first chunk; `put` replaces it by zeros -- not here: a select behind
+        //  the load would be waited for on the spot)
+        if constexpr (EDGE) return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(ok ? pb + off : reinterpret_cast<const char *>(src)));
+        else return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(pb + off));
+    };
 
     // ---- operands that do not change from plane to plane, requested before the first pixels ----
     // x: wave w owns columns 16 w .. 16 w + 15 of all 32 rows; block b = (rows 4 (b & 7) .., column half b >> 3)
@@ -124,8 +135,8 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
         // (plane by plane, as the loop requests them: requested row by row instead -- the compiler's order without the fence --
         //  the first plane is complete only when three of the first four loads are, and the loop's wait for `its` plane became
         //  `s_waitcnt vmcnt(1)`: half of the next plane as well, every step)
-        pre[d][0] = ld(spb + d * plane_bytes, off0);
-        pre[d][1] = ld(spb + d * plane_bytes, off1);
+        pre[d][0] = ld(spb + d * plane_bytes, off0, ok0);
+        pre[d][1] = ld(spb + d * plane_bytes, off1, ok1);
         __builtin_amdgcn_sched_barrier(0);
     }
     // z accumulators: [row rg / rg + 16][element e of the lane's chunk]; lane 4 b + j, register i: tail j of column 16 b + 4 i + e
@@ -180,7 +191,15 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     // youngest operation their next wait has to count); LOAD: request plane zn + 2 into the same registers
     auto put = [&](int zn, int par, F4 &p0, F4 &p1, auto load_tag, auto between) {
         constexpr bool LOAD = decltype(load_tag)::value;
-        const F4 v0 = p0, v1 = p1;
+        F4 v0 = p0, v1 = p1;
+        if (a.pw_flags & 1) {                                      // fused prologue x' = pre_s * in + pre_b
+            v0 = v0 * a.pre_s + a.pre_b;
+            v1 = v1 * a.pre_s + a.pre_b;
+        }
+        if constexpr (EDGE) {                                      // samples beyond the image stay zero: they do not exist
+            if (!ok0) v0 = F4{0.f, 0.f, 0.f, 0.f};
+            if (!ok1) v1 = F4{0.f, 0.f, 0.f, 0.f};
+        }
         F4 *tl = tile4 + par * kTile4;
         tl[rg * kPitch4 + cc] = v0;
         tl[(rg + 16) * kPitch4 + cc] = v1;
@@ -194,8 +213,8 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
         }
         if constexpr (LOAD) {
             const char *lp = spb + (int64_t)(zn + 2) * plane_bytes;       // (wave-uniform: scalar base + lane offset)
-            p0 = ld(lp, off0);
-            p1 = ld(lp, off1);
+            p0 = ld(lp, off0, ok0);
+            p1 = ld(lp, off1, ok1);
         }
     };
 
@@ -283,21 +302,35 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
 #pragma unroll
         for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++) {
+                // (the z tails are [..][NX * NY], unpadded: nothing of a row or column that does not exist is stored)
+                if (EDGE && !(rg + 16 * k < rows_left && 16 * (lane >> 2) + 4 * i < cols_here)) continue;
                 *reinterpret_cast<F4 *>(q + k * half + 4 * i) = F4{zacc[k][0][i], zacc[k][1][i], zacc[k][2][i], zacc[k][3][i]};
+            }
     }
+}
+
+template <int K, int NX, int NY>
+__global__ void __launch_bounds__(kWalkThreads)
+walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa, const float *__restrict__ Hx, const float *__restrict__ Hy,
+                  const float *__restrict__ HzT) {
+    const int ty = blockIdx.y >> wa.parts_log2, h = blockIdx.y & ((1 << wa.parts_log2) - 1);
+    const bool whole = ((int)blockIdx.x != a.MX - 1 || a.last_cols == kFusedTX) && (ty != a.MY - 1 || a.last_rows - kRows * h >= kRows);
+    if (whole) walk_tails_body<K, NX, NY, false>(src, a, wa, Hx, Hy, HzT);
+    else walk_tails_body<K, NX, NY, true>(src, a, wa, Hx, Hy, HzT);
 }
 
 }  // namespace
 
-// When pass 1 of a 3-D plan walks: f32 volumes of whole tiles (width % 256, height % TY, depth % TZ; z slabs too), no pointwise
-// stage, x, y and z scans all present, orders <= 2, at most two scans per dimension.
+// When pass 1 of a 3-D plan walks: f32 volumes whose depth is whole z tiles (z slabs too) and whose width is a multiple of 4 (the last
+// tile of a row and the last tile row may be partial), x, y and z scans all present, orders <= 3 along x / y and <= 2 along z,
+// at most two scans per dimension.
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows) {
     if (K < 1 || K > 3 || KZ < 1 || KZ > 2) return false;          // (order 3 along x / y; the four z accumulators per sample stay)
     if (nx < 1 || nx > 2 || ny < 1 || ny > 2 || nz < 1 || nz > 2) return false;
     if (TY != 32 && TY != 64 && TY != 128) return false;
     if (TZ != 32 && TZ != 64 && TZ != 128) return false;
-    if (last_cols != kFusedTX || last_rows != TY) return false;
+    if (last_cols < 4 || last_cols > kFusedTX || last_cols % 4 != 0 || last_rows < 1 || last_rows > TY) return false;
     return true;
 }
 

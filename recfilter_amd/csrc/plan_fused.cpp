@@ -306,11 +306,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         const bool wanted = !(plan->flags & RF_PLAN_STAGED_PASS1) && !(walk_knob && atoi(walk_knob) == 0);
         const bool z_slabs = plan->sharded();           // z slabs: with the early exchange (plan_strided.h), whose first step this pass then is
         if (wanted && plan->ndim == 3 && (!z_slabs || early_exchange_possible<P>(plan, 2, desc)) && !batch && !chained && !plan->mod_form &&
-            !plan->pw.pre && !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&      // (an epilogue runs behind the z stage either way)
+            !plan->pw.in_u8 && nx > 0 && ny > 0 && !plan->dims[2].scan_ids.empty() &&      // (a prologue x' = s x + b is applied as the samples arrive; an epilogue runs behind the z stage either way)
             plan->dims[2].lines == NX * NY) {
             const DimInfo &dz = plan->dims[2];
             const int TZ = strided_tile(plan, 2), nz = (int)dz.scan_ids.size(), KZ = dz.k;
-            const int64_t patch_columns = TZ > 0 ? (int64_t)MX * (NY / 32) * (dz.N / TZ) : 0;
+            const int64_t patch_columns = TZ > 0 ? (int64_t)MX * ((NY + 31) / 32) * (dz.N / TZ) : 0;
             if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy) &&
                 (patch_columns >= 256 || (plan->flags & RF_PLAN_WALK_PASS1))) {
                 const int MZ = (int)(dz.N / TZ);

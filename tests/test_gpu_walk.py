@@ -125,9 +125,54 @@ def test_one_read_pass1_tuple_planes(clamped):
         assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-5
 
 
-@pytest.mark.parametrize("what", ["int32", "partial_tile_rows", "prologue"])   # (asked for, refused by the shape rules)
+@pytest.mark.parametrize("clamped", [False, True])
+def test_one_read_pass1_with_a_prologue(clamped):
+    """A pointwise prologue x' = 0.5 x + 0.25 (define's RHS expression, lib/recfilter.cpp:197-238) is applied to the samples as the
+    one-read pass 1 loads them: the x / y tails AND the z tails are those of the transformed volume (round 5)."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    shape = (64, 64, 512)
+    rng = np.random.default_rng(19)
+    img = rng.random(shape, dtype=np.float32)
+    x = torch.from_numpy(img).cuda()
+    out = torch.empty_like(x)
+    with rfa.Plan(shape, XYZ, clamped=clamped, flags=capi.RF_PLAN_WALK_PASS1, path=capi.RF_PATH_TILED_FUSED, prologue=(0.5, 0.25)) as plan:
+        _, timed = plan.execute_timed([x], [out])
+        torch.cuda.synchronize()
+    steps = [k for k, _ in timed]
+    assert "walk_tails" in steps and "strided_pass1_z" not in steps, steps
+    want = oracle.apply_filter(img.astype(np.float64) * 0.5 + 0.25, XYZ, clamped)
+    assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(64, 80, 256), (64, 64, 300), (32, 100, 520), (64, 33, 260), (32, 160, 1020)])
+@pytest.mark.parametrize("clamped", [False, True])
+def test_one_read_pass1_partial_tiles(shape, clamped):
+    """Heights that are not whole tile rows and widths that are not whole tiles (multiples of four): what does not exist loads as
+    zeros and is never stored (round 5; the staged pass 1 has always done so, lib/split.cpp:503-665 takes any extent the tile divides)."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    rng = np.random.default_rng(23)
+    img = rng.random(shape, dtype=np.float32)
+    x = torch.from_numpy(img).cuda()
+    out = torch.empty_like(x)
+    for scans, pro in ((XYZ, None), (XY_ORDER3, (0.5, 0.25))):
+        kw = dict(prologue=pro) if pro else {}
+        with rfa.Plan(shape, scans, clamped=clamped, flags=capi.RF_PLAN_WALK_PASS1, path=capi.RF_PATH_TILED_FUSED, **kw) as plan:
+            _, timed = plan.execute_timed([x], [out])
+            torch.cuda.synchronize()
+        steps = [k for k, _ in timed]
+        assert "walk_tails" in steps and "strided_pass1_z" not in steps, steps
+        src = img.astype(np.float64) * pro[0] + pro[1] if pro else img.astype(np.float64)
+        want = oracle.apply_filter(src, scans, clamped)
+        assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < (2e-5 if scans is XY_ORDER3 else 2e-6), (shape, clamped, pro)
+
+
+@pytest.mark.parametrize("what", ["int32", "odd_width", "u8_input"])   # (asked for, refused by the shape rules)
 def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
-    """Integer pixels, a height that is not whole tiles, a pointwise stage: the z stage runs its own first pass."""
+    """Integer pixels, a width that is no multiple of four, 8-bit input: the z stage runs its own first pass."""
     import torch
     import recfilter_amd as rfa
     from recfilter_amd import capi
@@ -138,27 +183,27 @@ def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
         scans = [(0, True, [1, 1]), (1, True, [1, 1]), (2, True, [1, 1])]
     else:
         scans = XYZ
-    if what == "partial_tile_rows":
-        shape = (64, 80, 256)
-    if what == "prologue":
-        kw["prologue"] = (0.5, 0.25)
-    if what == "planes":
-        planes = 2
+    if what == "odd_width":
+        shape = (64, 64, 258)
+    if what == "u8_input":
+        kw["input_dtype"] = np.uint8
     rng = np.random.default_rng(13)
-    imgs = [(rng.integers(0, 5, shape).astype(dtype) if dtype == np.int32 else rng.random(shape, dtype=np.float32)) for _ in range(planes)]
+    if what == "u8_input":
+        imgs = [rng.integers(0, 256, shape).astype(np.uint8)]
+    else:
+        imgs = [(rng.integers(0, 5, shape).astype(dtype) if dtype == np.int32 else rng.random(shape, dtype=np.float32)) for _ in range(planes)]
     xs = [torch.from_numpy(im).cuda() for im in imgs]
-    outs = [torch.empty_like(x) for x in xs]
+    outs = [torch.empty(shape, dtype=torch.int32 if dtype == np.int32 else torch.float32, device="cuda") for _ in xs]
     with rfa.Plan(shape, scans, dtype=dtype, planes=planes, flags=capi.RF_PLAN_WALK_PASS1, **kw) as plan:
         _, timed = plan.execute_timed(xs, outs)
         torch.cuda.synchronize()
     steps = [k for k, _ in timed]
     assert "walk_tails" not in steps and "strided_pass1_z" in steps, steps
     for im, out in zip(imgs, outs):
-        src = im.astype(np.float64) * 0.5 + 0.25 if what == "prologue" else im
         if dtype == np.int32:
-            np.testing.assert_array_equal(out.cpu().numpy(), oracle.apply_filter(src, scans, False))
+            np.testing.assert_array_equal(out.cpu().numpy(), oracle.apply_filter(im, scans, False))
         else:
-            want = oracle.apply_filter(src.astype(np.float64), scans, False)
+            want = oracle.apply_filter(im.astype(np.float64), scans, False)
             assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6
 
 
