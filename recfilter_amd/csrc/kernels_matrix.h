@@ -57,6 +57,17 @@ struct MxPassArgs {
     int32_t next_k, next_causal, next_NB;      // (next_NB: sub-blocks of the next scan's tile = of its H)
     const float *next_H, *next_dH;
     float *next_tails;
+    // A PAIR stage: a causal scan and the anticausal scan that follows it along the same dimension, in ONE final pass (the tile's
+    // causal result stays in registers: 8 instead of 16 bytes per sample and pair).  This block describes the causal scan; p_*
+    // the anticausal one.  Pass 1 forms both scans' tile-local tails from the tile: H x and H21 x, H21 = (tail extraction of the
+    // anticausal scan) . (the causal scan's tile operator); between the two carry chains the planner adds W21 . (the completed
+    // causal carry entering the tile) to the anticausal tails (create_tail_residual_term, lib/split.cpp:912-1004).
+    int32_t pair;              // 0: a stage of one scan
+    int32_t p_k;
+    const float *p_G, *p_R, *p_dG;     // pass 2: the anticausal scan's operators
+    const float *p_H, *p_dH;           // pass 1: fragments [NB][16][64] of the STACKED tail extraction -- rows 0 .. 15 the causal scan's H,
+                                       // rows 16 .. 31 H21 (a pair's tails have at most 16 rows) -- and its border vector [32] likewise
+    float *p_tails;                    // the anticausal scan's tails (pass 1: tile-local; pass 2: completed), [unit][KP]
 };
 
 // One level of the carry chain / of its propagation.  An ELEMENT is a k-vector stored as KP = 8 ceil(k / 8) floats (rows
@@ -78,6 +89,7 @@ struct MxChainArgs {
 
 int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream);
 int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream);
+int launch_mx_pass2_pair(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream);
 int launch_mx_chain(const MxChainArgs &a, hipStream_t stream);
 int launch_mx_apply(const MxChainArgs &a, hipStream_t stream);
 

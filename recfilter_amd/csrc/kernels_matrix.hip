@@ -317,7 +317,9 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
     float *stage = mx_lds + w * kMxStageFloats<XM>;
     const MxStream<XM> st = mx_stream<XM>(a, blk, w, lane);
     const MxLane ln = mx_lane<XM>(a, blk, 32 * w + u);
-    const MxConsts cs = mx_consts_request(a.H, a.NB, a.dH);
+    // (a pair stage: ONE contraction for both scans' tails -- its H has the causal scan's H in the rows 0 .. 15 and H21 in the rows
+    // 16 .. 31, its border vector likewise: a pair's tails have at most 16 rows)
+    const MxConsts cs = mx_consts_request(a.pair ? a.p_H : a.H, a.NB, a.pair ? a.p_dH : a.dH);
     // (pass 1 has registers to spare: four sub-blocks -- 16 KiB per wave -- are in flight)
     floatx4 pre[4][4];
 #pragma unroll
@@ -350,7 +352,16 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; t++) acc[t] = fmaf(dH[mx_row(t, h)], x0, acc[t]);
     }
-    if (ln.valid) mx_store_tail(a.tails, ln.tidx, a.k, h, acc);
+    if (!ln.valid) return;
+    if (a.pair) {
+        floatx16 second = mx_zero();
+#pragma unroll
+        for (int t = 0; t < 8; t++) second[t] = acc[8 + t];        // rows 16 .. 31 -> the anticausal scan's rows 0 .. 15
+        mx_store_tail(a.tails, ln.tidx, a.k, h, acc);               // (rows 0 .. KP - 1 <= 15 are stored)
+        mx_store_tail(a.p_tails, ln.tidx, a.p_k, h, second);
+    } else {
+        mx_store_tail(a.tails, ln.tidx, a.k, h, acc);
+    }
 }
 
 // NLQ = ceil(k / 8) and the direction are compile-time: the K steps of R that are not all zero -- the k most recent rows of the
@@ -490,6 +501,128 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     }
 }
 
+// ---- the final pass of a PAIR stage: y = anticausal(causal(x)) on the tile, in one read and one write ---------------------
+// Forward walk: w_b = G1 x_b + R1 w_(b-1) (w_(-1): the neighbouring tile's completed causal tail), the finished sub-blocks stay in
+// registers (accumulator layout IS the B operand of what follows: NB x 16 registers, which is why a pair's tile has at most four
+// sub-blocks); backward walk: y_b = G2 w_b + R2 y_(b+1) (y_(NB): the completed anticausal tail of the tile behind), stored as it
+// appears.  Both scans have the same number of tail pieces (NLQ).  Clamped borders: the causal scan's term dG1 x_0 in the
+// image's first tile, the anticausal scan's dG2 w_(T-1) in its last one (lib/recfilter.cpp:330-336 reads the partially
+// updated buffer: the anticausal scan's border sample is the causal RESULT).
+template <bool XM, int NLQ, bool NT>
+__global__ void __launch_bounds__(kMxThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mx_lds[];
+    // constants: dG1 [32], dG2 [32], G1, R1, G2, R2 [16][64] each
+    float *consts = mx_lds + kMxWaves * kMxStageFloats<XM>;
+    const float *G1 = consts + 64, *R1 = G1 + 1024, *G2 = R1 + 1024, *R2 = G2 + 1024;
+    const MxBlock blk = mx_block<XM>(a);
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
+    float *stage = mx_lds + w * kMxStageFloats<XM>;
+    const MxStream<XM> st = mx_stream<XM>(a, blk, w, lane);
+    const MxLane ln = mx_lane<XM>(a, blk, 32 * w + u);
+    static_assert(kMxThreads == 256, "one 16-byte piece of every operator per thread");
+    const float dg = threadIdx.x < 32 ? a.dG[threadIdx.x] : threadIdx.x < 64 ? a.p_dG[threadIdx.x - 32] : 0.0f;
+    const float4 c0 = reinterpret_cast<const float4 *>(a.G)[threadIdx.x], c1 = reinterpret_cast<const float4 *>(a.R)[threadIdx.x];
+    const float4 c2 = reinterpret_cast<const float4 *>(a.p_G)[threadIdx.x], c3 = reinterpret_cast<const float4 *>(a.p_R)[threadIdx.x];
+    floatx4 pre[2][4];
+    mx_request<XM, NT>(src, st, 0, pre[0]);
+    if (a.NB > 1) mx_request<XM, NT>(src, st, 1, pre[1]);
+    constexpr int NL = 4 * NLQ, KP = 8 * NLQ;
+    // the carries: the causal one enters from the tile in front (row i of a sub-block that precedes the tile = tail 31 - i), the
+    // anticausal one from the tile behind (row i = tail i)
+    const bool first_tile = ln.tile == 0, last_tile = ln.tile == a.M - 1;
+    floatx16 prev = mx_zero(), back = mx_zero();
+    if (ln.valid && !first_tile) {
+        const float *tp = a.tails + ln.prev_tidx * KP;          // (mx_lane: the causal scan's previous tile)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r_lo = 28 - 8 * q - 4 * h;
+            if (r_lo < KP) {
+                const float4 v = *reinterpret_cast<const float4 *>(tp + r_lo);
+                prev[4 * q] = v.w; prev[4 * q + 1] = v.z; prev[4 * q + 2] = v.y; prev[4 * q + 3] = v.x;
+            }
+        }
+    }
+    if (ln.valid && !last_tile) {
+        const float *tp = a.p_tails + (2 * ln.tidx - ln.prev_tidx) * KP;        // the tile behind: tidx + (tidx - prev_tidx)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r_lo = 8 * q + 4 * h;
+            if (r_lo < KP) {
+                const float4 v = *reinterpret_cast<const float4 *>(tp + r_lo);
+                back[4 * q] = v.x; back[4 * q + 1] = v.y; back[4 * q + 2] = v.z; back[4 * q + 3] = v.w;
+            }
+        }
+    }
+    if (threadIdx.x < 64) consts[threadIdx.x] = dg;
+    reinterpret_cast<float4 *>(consts + 64)[threadIdx.x] = c0;
+    reinterpret_cast<float4 *>(consts + 64 + 1024)[threadIdx.x] = c1;
+    reinterpret_cast<float4 *>(consts + 64 + 2048)[threadIdx.x] = c2;
+    reinterpret_cast<float4 *>(consts + 64 + 3072)[threadIdx.x] = c3;
+    __syncthreads();
+    floatx16 wv[4];
+    float w_last = 0.0f;
+    auto forward = [&](int bi, floatx4 (&buf)[4], floatx16 &out) __attribute__((always_inline)) {
+        mx_stage_put<XM>(stage, st, bi, buf);
+        if (bi + 2 < a.NB) mx_request<XM, NT>(src, st, bi + 2, buf);
+        mx_wave_sync();
+        float x[16];
+        mx_stage_read<XM>(stage, u, h, x);
+        floatx16 c = mx_zero();
+        if (bi == 0 && a.clamped && ln.valid && first_tile && a.slab_first) {
+            const float x0 = mx_stage_at<XM>(stage, u, 0);
+#pragma unroll
+            for (int t = 0; t < 16; t++) c[t] = consts[mx_row(t, h)] * x0;
+        }
+        mx_wave_sync();
+#pragma unroll
+        for (int t = 0; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(G1[t * 64 + lane], x[t], c, 0, 0, 0);
+#pragma unroll
+        for (int t = 16 - NL; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(R1[t * 64 + lane], prev[t], c, 0, 0, 0);
+        prev = c;
+        out = c;
+        if (bi == a.NB - 1) {                   // the tile's last causal output, for the anticausal scan's border term
+            mx_stage_write<XM>(stage, u, h, c);
+            mx_wave_sync();
+            w_last = mx_stage_at<XM>(stage, u, 31);
+            mx_wave_sync();
+        }
+    };
+    auto backward = [&](int bi, const floatx16 &in) __attribute__((always_inline)) {
+        floatx16 c = mx_zero();
+        if (bi == a.NB - 1 && a.clamped && ln.valid && last_tile && a.slab_last) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) c[t] = consts[32 + mx_row(t, h)] * w_last;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(G2[t * 64 + lane], in[t], c, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(R2[t * 64 + lane], back[t], c, 0, 0, 0);
+        back = c;
+        mx_stage_write<XM>(stage, u, h, c);
+        mx_wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pos = 32 * bi + st.p0[i];
+            if (pos >= st.lo[i] && pos < st.hi[i]) {
+                const floatx4 y = *reinterpret_cast<const floatx4 *>(stage + st.slot[i]);
+                floatx4 *to = reinterpret_cast<floatx4 *>(dst + st.base[i] + bi * st.step);
+                if constexpr (NT) __builtin_nontemporal_store(y, to);
+                else *to = y;
+            }
+        }
+        mx_wave_sync();
+    };
+    forward(0, pre[0], wv[0]);
+    if (a.NB > 1) forward(1, pre[1], wv[1]);
+    if (a.NB > 2) forward(2, pre[0], wv[2]);
+    if (a.NB > 3) forward(3, pre[1], wv[3]);
+    if (a.NB > 3) backward(3, wv[3]);
+    if (a.NB > 2) backward(2, wv[2]);
+    if (a.NB > 1) backward(1, wv[1]);
+    backward(0, wv[0]);
+}
+
 // ---- the carry chain: x_j = s_j + A x_(j-1) over the steps of a chunk, 32 columns per wave ----------------------------
 // Elements are [KP] rows, rows fastest: NLQ = KP / 8 sixteen-byte pieces per lane and element.
 struct MxCol {
@@ -622,15 +755,14 @@ static bool mx_whole_lines(const MxPassArgs &a, const void *src, const void *dst
 // stay well below it on purpose (three or four workgroups per CU)
 int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
     if (int rc = mx_check(a)) return rc;
+    if (a.pair && (a.causal == 0 || a.ragged || a.NB > 4 || a.k > 16 || a.p_k > 16)) { set_error("matrix path: bad pair stage"); return RF_ERR_INVALID_ARG; }
     const size_t consts = ((size_t)a.NB * 1024 + 32) * sizeof(float);
     const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
-    if (mx_whole_lines(a, src, src)) {
-        if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, true>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);
-        else hipLaunchKernelGGL((mx_pass1s_kernel<true, true>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
-    } else {
-        if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, false>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);
-        else hipLaunchKernelGGL((mx_pass1s_kernel<true, false>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
-    }
+#define RF_MX_P1S(NT)                                                                                                          \
+    if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);  \
+    else hipLaunchKernelGGL((mx_pass1s_kernel<true, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
+    if (mx_whole_lines(a, src, src)) { RF_MX_P1S(true) } else { RF_MX_P1S(false) }
+#undef RF_MX_P1S
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -658,6 +790,31 @@ int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream
     }
 #undef RF_MX_P2S
 #undef RF_MX_P2S_NT
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+int launch_mx_pass2_pair(const float *src, float *dst, const MxPassArgs &a, hipStream_t stream) {
+    if (int rc = mx_check(a)) return rc;
+    if (a.pair == 0 || a.causal == 0 || a.ragged || a.NB > 4 || ((a.k + 7) >> 3) != ((a.p_k + 7) >> 3) || a.next != 0 || a.incoming != nullptr) {
+        set_error("matrix path: bad pair stage");
+        return RF_ERR_INVALID_ARG;
+    }
+    const size_t consts = (64 + 4 * 1024) * sizeof(float);
+    const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
+    const bool whole = mx_whole_lines(a, src, dst);
+#define RF_MX_P2P_NT(NLQ, NT)                                                                                                          \
+    if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass2p_kernel<false, NLQ, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);  \
+    else hipLaunchKernelGGL((mx_pass2p_kernel<true, NLQ, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);
+#define RF_MX_P2P(NLQ) if (whole) { RF_MX_P2P_NT(NLQ, true) } else { RF_MX_P2P_NT(NLQ, false) }
+    switch ((a.k + 7) >> 3) {
+        case 1: RF_MX_P2P(1) break;
+        case 2: RF_MX_P2P(2) break;
+        case 3: RF_MX_P2P(3) break;
+        default: RF_MX_P2P(4) break;
+    }
+#undef RF_MX_P2P
+#undef RF_MX_P2P_NT
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }

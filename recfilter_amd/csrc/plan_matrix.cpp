@@ -120,6 +120,50 @@ StageTables build_stage_tables(const Scan &scan, int T, bool clamped) {
     return t;
 }
 
+// What a PAIR stage (a causal scan c, then the anticausal scan n along the same dimension; MxPassArgs::pair) needs beyond the two
+// scans' own tables, all by running the scans on unit vectors in double:
+//   H21 (32 x T, rows >= k_n zero)  tile-local tail of n applied to the tile-local result of c:  tail_n(B_c x)
+//   v21 (32)                         what the clamped border of c adds to that, per first sample of the image's first tile
+//   W21 (k_n x k_c)                  what the causal carry entering a tile adds to n's tile-local tail: tail_n(Rt_c carry)
+struct PairTables {
+    std::vector<double> H21, v21, W21;
+};
+
+PairTables build_pair_tables(const Scan &c, const Scan &n, int T, bool clamped) {
+    const int kc = c.order, kn = n.order;
+    ScanS<double> tc = make_table_scan<double>(c), tn = make_table_scan<double>(n);
+    tc.mod_n = -1; tn.mod_n = -1;
+    PairTables t;
+    t.H21.assign((size_t)32 * T, 0.0); t.v21.assign(32, 0.0); t.W21.assign((size_t)kn * kc, 0.0);
+    std::vector<double> v((size_t)T);
+    for (int m = 0; m < T; m++) {
+        std::fill(v.begin(), v.end(), 0.0);
+        v[(size_t)m] = 1.0;
+        scan_tile<double>(v.data(), T, kc, tc, false, nullptr);
+        scan_tile<double>(v.data(), T, kn, tn, false, nullptr);
+        for (int r = 0; r < kn; r++) t.H21[(size_t)r * T + m] = v[(size_t)r];       // (anticausal: tail r is sample r)
+    }
+    for (int j = 0; j < kc; j++) {
+        double carry[RF_MAX_ORDER] = {0};
+        carry[j] = 1.0;
+        std::fill(v.begin(), v.end(), 0.0);
+        scan_tile<double>(v.data(), T, kc, tc, false, carry);
+        scan_tile<double>(v.data(), T, kn, tn, false, nullptr);
+        for (int r = 0; r < kn; r++) t.W21[(size_t)r * kc + j] = v[(size_t)r];
+    }
+    if (clamped) {
+        std::vector<double> vz((size_t)T, 0.0);
+        std::fill(v.begin(), v.end(), 0.0);
+        v[0] = 1.0; vz[0] = 1.0;
+        scan_tile<double>(v.data(), T, kc, tc, true, nullptr);
+        scan_tile<double>(vz.data(), T, kc, tc, false, nullptr);
+        for (int i = 0; i < T; i++) v[(size_t)i] -= vz[(size_t)i];
+        scan_tile<double>(v.data(), T, kn, tn, false, nullptr);
+        for (int r = 0; r < kn; r++) t.v21[(size_t)r] = v[(size_t)r];
+    }
+    return t;
+}
+
 }  // namespace
 
 int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
@@ -140,6 +184,8 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         int scan = 0;
         bool sharded_dim = false;           // a scan along the sharded dimension: an exchange of its exit carries follows its chain
         const float *AM = nullptr, *PM = nullptr;      // fragments of A^M (slab transfer) and of A^1 .. A^M
+        int pair = 0;                        // 1: the causal scan of a pair stage, 2: its anticausal scan (MxPassArgs::pair)
+        const float *W21 = nullptr, *Dlast = nullptr;      // pair, first scan: fragments of W21; of dH(anticausal) (x) e_0 (clamped border)
     };
     std::vector<Stage> stages;
     size_t tails_floats = 0;                 // per plane, max over the stages (they run one after the other)
@@ -152,6 +198,28 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         const int ky = plan->scans[(size_t)dy.scan_ids.front()].order;
         xy_handover = dx.lines >= 32 && dx.N % kMxUnits == 0 && dy.N % kMxUnits == 0 && ky <= 16;
     }
+    // Pairs: a causal scan directly followed by an anticausal one along the same dimension, tails of the same number of pieces and
+    // short enough (ceil(k / 8) <= 2: above that the chain of the narrower tile costs what the saved pass gains), tiles that
+    // divide the extent, not the sharded dimension (its scans have an exchange each).
+    auto pair_at = [&](const DimInfo &di, int d, size_t i) {
+        if (RF_KNOB("RF_MX_NO_PAIR") != nullptr || i + 1 >= di.scan_ids.size()) return false;
+        if (plan->sharded() && d == plan->ndim - 1) return false;
+        const Scan &c = plan->scans[(size_t)di.scan_ids[i]], &n = plan->scans[(size_t)di.scan_ids[i + 1]];
+        return c.causal && !n.causal && (c.order + 7) / 8 == (n.order + 7) / 8 && (c.order + 7) / 8 <= 2 && di.N % kMxSB == 0;
+    };
+    std::vector<bool> dim_pairs((size_t)plan->ndim, false);
+    std::vector<int> pair_role(plan->scans.size(), 0);        // 1: the causal scan of a pair, 2: its anticausal scan
+    for (int d = 0; d < plan->ndim; d++) {
+        const DimInfo &di = plan->dims[d];
+        for (size_t i = 0; i + 1 < di.scan_ids.size(); i++)
+            if (pair_at(di, d, i)) {
+                pair_role[(size_t)di.scan_ids[i]] = 1;
+                pair_role[(size_t)di.scan_ids[i + 1]] = 2;
+                dim_pairs[(size_t)d] = true;
+                i++;
+            }
+    }
+    if (xy_handover && pair_role[(size_t)plan->dims[0].scan_ids.back()] != 0) xy_handover = false;      // (the last x pass is a pair's: no hand-over)
     for (int d = 0; d < plan->ndim; d++) {
         DimInfo &di = plan->dims[d];
         if (di.scan_ids.empty()) continue;
@@ -164,6 +232,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         const int64_t wide_groups = (di.lines * ((di.N + kMxSB * kMxMaxNB - 1) / (kMxSB * kMxMaxNB)) + kMxUnits - 1) / kMxUnits;
         if (wide_groups < 256) nb_cap = 4;
         if (xy_handover && d == 1) nb_cap = 4;
+        if (dim_pairs[(size_t)d]) nb_cap = 4;             // (a pair keeps the tile's causal result in registers)
         if (RF_KNOB("RF_MX_NB")) nb_cap = atoi(RF_KNOB("RF_MX_NB"));       // A/B: narrower / wider tiles
         int NB = nb_cap;
         if (di.N % kMxSB == 0) {
@@ -177,7 +246,10 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         di.T = T;
         di.M = (di.N + T - 1) / T;
         const int mode = d > 0 ? MX_Y : (di.lines >= 32 ? MX_XL : MX_X1);
-        for (int id : di.scan_ids) {
+        if (NB > 4)                                        // (an A/B build asked for wider tiles: no pairs)
+            for (int id : di.scan_ids) pair_role[(size_t)id] = 0;
+        for (size_t idx = 0; idx < di.scan_ids.size(); idx++) {
+            const int id = di.scan_ids[idx];
             const Scan &scan = plan->scans[(size_t)id];
             const int k = scan.order;
             StageTables tb = build_stage_tables(scan, T, plan->clamped);
@@ -203,6 +275,48 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             pa.slab_last = (!sharded_dim || plan->shard_rank == plan->shard_world - 1) ? 1 : 0;
             pa.incoming = nullptr;
             st.sharded_dim = sharded_dim;
+            st.pair = pair_role[(size_t)id];
+            pa.pair = st.pair;
+            if (st.pair == 1) {
+                const int id2 = di.scan_ids[idx + 1];
+                const Scan &scan2 = plan->scans[(size_t)id2];
+                const PairTables pt = build_pair_tables(scan, scan2, T, plan->clamped);
+                plan->tables["mx_pair_" + tag] = {(double)id2};
+                plan->tables["mx_H21_" + tag] = pt.H21;
+                plan->tables["mx_v21_" + tag] = pt.v21;
+                plan->tables["mx_W21_" + tag] = pt.W21;
+                std::vector<float> fH21, fv21(32), fW;
+                // pass 1 contracts once for both tails: the causal scan's H in the rows 0 .. 15, H21 in the rows 16 .. 31
+                for (int b = 0; b < NB; b++) {
+                    std::vector<double> Hb(32 * 32, 0.0);
+                    for (int r = 0; r < 16; r++)
+                        for (int i = 0; i < 32; i++) {
+                            Hb[r * 32 + i] = tb.H[(size_t)r * T + 32 * b + i];
+                            Hb[(16 + r) * 32 + i] = pt.H21[(size_t)r * T + 32 * b + i];
+                        }
+                    pack_fragments(Hb.data(), fH21);
+                }
+                for (int i = 0; i < 16; i++) { fv21[i] = (float)tb.dH[(size_t)i]; fv21[16 + i] = (float)pt.v21[(size_t)i]; }
+                // W21 as a 32 x 32 operand: k_n rows, k_c columns
+                std::vector<double> W32(32 * 32, 0.0);
+                for (int r = 0; r < scan2.order; r++)
+                    for (int j = 0; j < k; j++) W32[r * 32 + j] = pt.W21[(size_t)r * k + j];
+                pack_fragments(W32.data(), fW);
+                pa.p_k = scan2.order;
+                pa.p_H = (const float *)plan->upload(fH21.data(), fH21.size() * sizeof(float), &status);
+                pa.p_dH = (const float *)plan->upload(fv21.data(), fv21.size() * sizeof(float), &status);
+                st.W21 = (const float *)plan->upload(fW.data(), fW.size() * sizeof(float), &status);
+                if (plan->clamped) {
+                    // the anticausal scan's clamped border in the image's last tile: its tile-local tail gains dH_n times its first
+                    // sample, which is the causal RESULT's last sample = row 0 of the tile's completed causal tail
+                    const StageTables tb2 = build_stage_tables(scan2, T, true);
+                    std::vector<double> D32(32 * 32, 0.0);
+                    for (int r = 0; r < scan2.order; r++) D32[r * 32 + 0] = tb2.dH[(size_t)r];
+                    std::vector<float> fD;
+                    pack_fragments(D32.data(), fD);
+                    st.Dlast = (const float *)plan->upload(fD.data(), fD.size() * sizeof(float), &status);
+                }
+            }
             if (sharded_dim) {
                 // what carries a slab's entering state to its exit, and to each of its tiles: A^M, A^1 .. A^M (in double, rounded once)
                 std::vector<float> fAM, fPM;
@@ -283,6 +397,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         else if (xy_handover && da == 0 && db == 1 && a.mode == MX_XL && !a.ragged && b.T == kMxUnits) next = 2;
         // (not in a sharded plan: a slab's y tiles have their own border rules, MxPassArgs::slab_first / slab_last)
         if (RF_KNOB("RF_MX_NO_NEXT") != nullptr) next = 0;      // A/B: every stage with its own pass 1
+        if (stages[i].pair != 0 || stages[i + 1].pair == 1) next = 0;       // (a pair stage forms both scans' tails in its own pass 1)
         a.next = next;
         if (next) { a.next_k = b.k; a.next_causal = b.causal; a.next_NB = b.NB; a.next_H = b.H; a.next_dH = b.dH; }
     }
@@ -307,14 +422,15 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
         rank_scratch = (float *)plan->alloc(max_lines_kp * np * (size_t)world * sizeof(float), true, &status);
         if (status != RF_OK) return status;
     }
-    bool first_stage = true;
+    bool first_stage = true, pair_from_input = false;
     for (size_t si = 0; si < stages.size(); si++) {
         const Stage &st = stages[si];
         float *tails = tails_ab[si & 1], *tails_next = tails_ab[(si + 1) & 1];
-        const bool has_pass1 = si == 0 || stages[si - 1].pass.next == 0;
+        const bool has_pass1 = st.pair != 2 && (si == 0 || stages[si - 1].pass.next == 0);
         const Scan &scan = plan->scans[(size_t)st.scan];
         const std::string nm = std::string(1, "xyz"[scan.dim]) + (scan.causal ? "+" : "-") + std::to_string(st.scan);
-        const bool from_input = first_stage;
+        const bool from_input = st.pair == 2 ? pair_from_input : first_stage;       // (a pair's final pass reads what its pass 1 read)
+        if (st.pair == 1) pair_from_input = first_stage;
         first_stage = false;
         MxPassArgs base = st.pass;
         const size_t tails_pp = tails_floats;
@@ -324,6 +440,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             MxPassArgs a = base;
             a.tails = tails + (size_t)pl * tails_pp;
             a.next_tails = tails_next + (size_t)pl * tails_pp;
+            if (a.pair == 1) a.p_tails = tails_next + (size_t)pl * tails_pp;       // (the anticausal scan's tails: the other buffer)
             if (sharded_dim) a.incoming = incoming_buf + (size_t)pl * lines_kp;
             return a;
         };
@@ -462,7 +579,60 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             plan->exchange_apply_steps.push_back({as});
         }
 
+        if (st.pair == 1) {
+            // between the two chains: what the completed causal carry entering a tile adds to the anticausal scan's tile-local tail
+            // (one product per tile: the propagation kernel with chunks of one tile), and the anticausal scan's clamped border
+            MxChainArgs cr{};
+            cr.P = st.W21; cr.k = std::max(base.k, base.p_k); cr.C = 1; cr.Mtot = base.M; cr.enter_fixed = 0;
+            cr.ncols = lines * base.M;
+            if (x1) { cr.chunk_is_lo = 1; cr.cdiv = base.M; cr.s_hi = base.M; cr.s_lo = 1; cr.s_j = 1; cr.base = 0; cr.e_hi = base.M; cr.e_lo = 1; }
+            else { cr.chunk_is_lo = 0; cr.cdiv = lines; cr.s_hi = lines; cr.s_lo = 1; cr.s_j = lines; cr.base = 0; cr.e_hi = lines; cr.e_lo = 1; }
+            Step xs;
+            xs.name = "mx_cross_" + nm;
+            xs.run = [plan, cr, tails, tails_next, tails_pp](int pl) {
+                MxChainArgs c = cr;
+                c.seq = tails_next + (size_t)pl * tails_pp;
+                c.exits = tails + (size_t)pl * tails_pp;
+                return launch_mx_apply(c, plan->stream);
+            };
+            pending.push_back(xs);
+            if (st.Dlast != nullptr) {
+                MxChainArgs bd{};
+                bd.P = st.Dlast; bd.k = cr.k; bd.C = 1; bd.Mtot = 1; bd.enter_fixed = 1; bd.ncols = lines; bd.cdiv = lines; bd.chunk_is_lo = 0;
+                bd.s_hi = 0; bd.s_j = 0; bd.e_hi = 0;
+                const int64_t KPf = 8 * (int64_t)((cr.k + 7) / 8);
+                int64_t exit_off;
+                if (x1) { bd.base = base.M - 1; bd.s_lo = base.M; bd.e_lo = base.M; exit_off = (base.M - 1) * KPf; }
+                else { bd.base = (base.M - 1) * lines; bd.s_lo = 1; bd.e_lo = 1; exit_off = (base.M - 1) * lines * KPf; }
+                Step bs;
+                bs.name = "mx_cross_border_" + nm;
+                bs.run = [plan, bd, tails, tails_next, tails_pp, exit_off](int pl) {
+                    MxChainArgs c = bd;
+                    c.seq = tails_next + (size_t)pl * tails_pp;
+                    c.exits = tails + (size_t)pl * tails_pp + exit_off;
+                    return launch_mx_apply(c, plan->stream);
+                };
+                pending.push_back(bs);
+            }
+            continue;                                     // (the pair's final pass follows the anticausal scan's chain)
+        }
         Step p2;
+        if (st.pair == 2) {
+            // the pair's final pass: this stage's block describes the anticausal scan, the stage before it the causal one
+            const MxPassArgs first = stages[si - 1].pass;
+            p2.name = "mx_pass2_pair_" + nm;
+            p2.run = [plan, first, base, tails, tails_next, tails_pp, from_input](int pl) {
+                MxPassArgs a = first;                      // (the causal scan's geometry, G, R, dG; its completed tails: the other buffer)
+                a.tails = tails_next + (size_t)pl * tails_pp;
+                a.p_G = base.G; a.p_R = base.R; a.p_dG = base.dG; a.p_k = base.k;
+                a.p_tails = tails + (size_t)pl * tails_pp;
+                a.next = 0;
+                const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];
+                return launch_mx_pass2_pair(src, (float *)plan->out[pl], a, plan->stream);
+            };
+            pending.push_back(p2);
+            continue;
+        }
         p2.name = "mx_pass2_" + nm;
         p2.run = [plan, pass_args, from_input](int pl) {
             const float *src = from_input ? (const float *)plan->in[pl] : (const float *)plan->out[pl];

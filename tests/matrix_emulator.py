@@ -52,6 +52,71 @@ def chain_levels(local, A, causal):
     return done if causal else done[:, ::-1]
 
 
+def _pair_stage(plan, out, rows, i, p, clamped):
+    """A PAIR stage (MxPassArgs::pair): the causal scan i and the anticausal scan p of one dimension in one final pass -- pass 1 forms
+    both scans' tile-local tails (H x and H21 x), the causal carries are chained, W21 . (the carry entering a tile) and the
+    anticausal scan's clamped-border term go into the anticausal tails, those are chained, and the final pass walks the tile
+    forward (w) and backward (y)."""
+    from recfilter_amd import capi
+    dim, k1, k2 = int(rows[i][0]), int(rows[i][2]), int(rows[p][2])
+    assert bool(rows[i][1]) and not bool(rows[p][1]) and int(rows[p][0]) == dim
+    T = int(plan.tiles[dim])
+    G1, R1 = _f32(plan.table(f"mx_G_{i}").reshape(32, 32)), _f32(plan.table(f"mx_R_{i}").reshape(32, 32))
+    G2, R2 = _f32(plan.table(f"mx_G_{p}").reshape(32, 32)), _f32(plan.table(f"mx_R_{p}").reshape(32, 32))
+    dG1, dH1 = _f32(plan.table(f"mx_dG_{i}")), _f32(plan.table(f"mx_dH_{i}"))
+    dG2, dH2 = _f32(plan.table(f"mx_dG_{p}")), _f32(plan.table(f"mx_dH_{p}"))
+    H1 = _f32(plan.table(f"mx_H_{i}").reshape(32, T))
+    H21, v21 = _f32(plan.table(f"mx_H21_{i}").reshape(32, T)), _f32(plan.table(f"mx_v21_{i}"))
+    W21 = _f32(plan.table(f"mx_W21_{i}").reshape(k2, k1))
+    A1, A2 = plan.table(f"mx_A_{i}").reshape(k1, k1), plan.table(f"mx_A_{p}").reshape(k2, k2)
+    nd = out.ndim
+    axis = nd - 1 - dim
+    v = np.moveaxis(out, axis, -1)
+    shp = v.shape
+    N = shp[-1]
+    Tg, M, off = (int(g) for g in plan.table(f"mx_geom_{i}"))
+    assert Tg == T and M * T == N and off == 0
+    x = np.ascontiguousarray(v).reshape(-1, M, T).astype(np.float32)
+    NB = T // 32
+    l1 = np.einsum("lmt,rt->lmr", x, H1[:k1]).astype(np.float32)
+    l2 = np.einsum("lmt,rt->lmr", x, H21[:k2]).astype(np.float32)
+    if clamped:
+        l1[:, 0] += x[:, 0, 0][:, None] * dH1[:k1][None, :]
+        l2[:, 0] += x[:, 0, 0][:, None] * v21[:k2][None, :]
+    c1 = chain_levels(l1, A1, True)
+    for t in range(1, M):
+        l2[:, t] = l2[:, t] + c1[:, t - 1] @ W21.T
+    if clamped:
+        l2[:, M - 1] = l2[:, M - 1] + c1[:, M - 1, 0][:, None] * dH2[:k2][None, :]
+    c2 = chain_levels(l2.astype(np.float32), A2, False)
+    y = np.empty_like(x)
+    for t in range(M):
+        prev = np.zeros((x.shape[0], 32), dtype=np.float32)
+        if t > 0:
+            for r in range(k1):
+                prev[:, 31 - r] = c1[:, t - 1, r]
+        w = []
+        for b in range(NB):
+            c = x[:, t, 32 * b:32 * b + 32] @ G1.T + prev @ R1.T
+            if b == 0 and clamped and t == 0:
+                c = c + x[:, 0, 0][:, None] * dG1[None, :]
+            c = c.astype(np.float32)
+            w.append(c)
+            prev = c
+        back = np.zeros((x.shape[0], 32), dtype=np.float32)
+        if t < M - 1:
+            for r in range(k2):
+                back[:, r] = c2[:, t + 1, r]
+        for b in range(NB - 1, -1, -1):
+            c = w[b] @ G2.T + back @ R2.T
+            if b == NB - 1 and clamped and t == M - 1:
+                c = c + w[NB - 1][:, 31][:, None] * dG2[None, :]
+            c = c.astype(np.float32)
+            y[:, t, 32 * b:32 * b + 32] = c
+            back = c
+    return np.ascontiguousarray(np.moveaxis(y.reshape(shp[:-1] + (N,)), -1, axis))
+
+
 def run(plan, img, clamped):
     """The filter of a host-only RF_PATH_TILED_MATRIX plan applied to img (numpy, (z,) y, x order), stage by stage."""
     from recfilter_amd import capi
@@ -60,7 +125,18 @@ def run(plan, img, clamped):
     tiles = plan.tiles
     out = np.array(img, dtype=np.float32)
     nd = out.ndim
+    skip = set()
     for i, row in enumerate(rows):
+        if i in skip:
+            continue
+        try:
+            partner = int(plan.table(f"mx_pair_{i}")[0])
+        except Exception:
+            partner = None
+        if partner is not None:
+            out = _pair_stage(plan, out, rows, i, partner, clamped)
+            skip.add(partner)
+            continue
         dim, causal, k = int(row[0]), bool(row[1]), int(row[2])
         T = int(tiles[dim])
         G, R = _f32(plan.table(f"mx_G_{i}").reshape(32, 32)), _f32(plan.table(f"mx_R_{i}").reshape(32, 32))

@@ -377,10 +377,11 @@ def test_order_12_and_32_images_4096_against_oracle():
         img = rc.random_image((4096, 4096), np.float32, 3)
         dev = torch.from_numpy(img).cuda()
         with rfa.Plan(img.shape, scans, clamped=clamped) as plan:
-            # order 12: x tiles of 256 (16 per line: one chain launch per scan), y tiles of 128 fed by the last x pass (chain 0,
-            # apply 0); order 32: tiles of 256 in both dimensions, the y stage with its own pass 1
-            assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.tiles[:2] == ((256, 128) if order == 12 else (256, 256))
-            assert plan.num_kernels == (1 + 2 + 2 + 3 + 3 if order == 12 else 1 + 2 + 2 + 1 + 2 + 2)
+            # order 12: a pair stage per dimension (tiles of 128: pass 1, chain + apply of the causal scan, cross term and its clamped
+            # border, chain + apply of the anticausal scan, ONE final pass); order 32: tiles of 256 in both dimensions, one stage per
+            # scan, the y stage with its own pass 1
+            assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.tiles[:2] == ((128, 128) if order == 12 else (256, 256))
+            assert plan.num_kernels == (2 * (1 + 2 + 2 + 2 + 1) if order == 12 else 1 + 2 + 2 + 1 + 2 + 2)
             got = plan.execute([dev])[0].cpu().numpy()
         want = oracle.apply_filter(img.astype(np.float64), scans, clamped, threads=_threads())
         assert _floor_err(got, want) < TOL, (order, clamped)

@@ -259,3 +259,40 @@ def test_matrix_path_with_pointwise_stages():
     xp = img.astype(np.float64) * 0.5 + 0.25
     want = 2.0 * oracle.apply_filter(xp, scans, True) - xp + 0.125
     assert rc.rel_err(out, want) < TOL
+
+
+PAIR_CASES = {
+    # shape (.., y, x), scans, planes: a causal scan directly followed by an anticausal one along a dimension = one PAIR stage
+    "1d_x1_levels": ((128 * 300,), [(0, True, stable_coeff(9, 31)), (0, False, stable_coeff(16, 32))], 1),       # lane = tile; 300 tiles: two chain levels
+    "1d_few_lines": ((7, 96 * 20), [(0, True, stable_coeff(12, 33)), (0, False, stable_coeff(12, 34))], 1),      # tiles of 96, lane = tile of 7 lines
+    "2d_xy": ((384, 640), [(0, True, stable_coeff(12, 35)), (0, False, stable_coeff(11, 36)),
+                           (1, True, stable_coeff(7, 37)), (1, False, stable_coeff(5, 38))], 2),                  # tiles 128 x 128, 5 and 3 of them, two planes
+    "2d_one_tile_each": ((128, 96), [(0, True, stable_coeff(8, 39)), (0, False, stable_coeff(8, 40)),
+                                     (1, True, stable_coeff(16, 41)), (1, False, stable_coeff(9, 42))], 1),       # first tile = last tile
+    "2d_pair_and_singles": ((256, 512), [(0, True, stable_coeff(6, 43)), (0, False, stable_coeff(6, 44)), (0, True, stable_coeff(20, 45)),
+                                         (1, False, stable_coeff(4, 46)), (1, True, stable_coeff(4, 47)), (1, False, stable_coeff(3, 48))], 1),
+    "3d_z_pair": ((256, 40, 64), [(2, True, stable_coeff(10, 49)), (2, False, stable_coeff(10, 50)), (0, False, stable_coeff(5, 51))], 1),
+    "2d_partial_blocks": ((200, 416), [(0, True, stable_coeff(12, 52)), (0, False, stable_coeff(12, 53)),
+                                       (1, True, stable_coeff(12, 54)), (1, False, stable_coeff(12, 55))], 1),    # 200 lines / 416 columns: partial unit blocks; y ragged -> single stages
+}
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+@pytest.mark.parametrize("case", sorted(PAIR_CASES))
+def test_matrix_path_pair_stages(case, clamped):
+    """Causal + anticausal scans of one dimension in ONE final pass (MxPassArgs::pair): pass 1 forms both scans' tails in one
+    contraction, the causal carry entering a tile feeds the anticausal tails (lib/split.cpp:912-1004), the final pass walks the
+    tile forward and backward with the causal result in registers."""
+    import recfilter_amd as rfa
+    shape, scans, planes = PAIR_CASES[case]
+    imgs, outs, (path, _) = _run(shape, scans, clamped=clamped, planes=planes, path=capi.RF_PATH_TILED_MATRIX)
+    assert path == capi.RF_PATH_TILED_MATRIX
+    _check(imgs, outs, scans, clamped)
+    with rfa.Plan(shape, scans, clamped=clamped, planes=planes, path=capi.RF_PATH_TILED_MATRIX, device=capi.RF_DEVICE_HOST_ONLY) as host:
+        heads = 0
+        for i in range(len(scans)):                         # (the plan's order: grouped by dimension)
+            try:
+                heads += host.table(f"mx_pair_{i}").size
+            except Exception:
+                pass
+        assert heads >= 1

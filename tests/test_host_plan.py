@@ -534,7 +534,8 @@ def _stable(order, seed, b=0.4, mass=0.85):
 
 
 @pytest.mark.parametrize("clamped", [False, True])
-@pytest.mark.parametrize("case", ["audio_1d", "xy_pm_12", "xyz_mixed", "order32_1d_levels", "ragged_xy", "ragged_1d_short", "ragged_xyz"])
+@pytest.mark.parametrize("case", ["audio_1d", "xy_pm_12", "xyz_mixed", "order32_1d_levels", "ragged_xy", "ragged_1d_short", "ragged_xyz",
+                                  "pair_1d", "pair_xy_tiles", "pair_then_single"])
 def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
     import matrix_emulator as mxe
     if case == "audio_1d":            # apps/audio/audio_filter_high_order.cpp:41-42 at its highest order
@@ -544,6 +545,14 @@ def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
         shape, scans = (96, 160), [(0, True, c), (0, False, c), (1, True, c), (1, False, c)]
     elif case == "xyz_mixed":
         shape, scans = (64, 32, 96), [(2, False, _stable(9, 1)), (0, True, _stable(17, 2)), (1, False, _stable(32, 4)), (0, False, _stable(4, 5))]
+    elif case == "pair_1d":           # a causal / anticausal pair of different orders (same number of tail pieces) over 40 tiles of 128
+        shape, scans = (5120,), [(0, True, _stable(9, 11)), (0, False, _stable(16, 12))]
+    elif case == "pair_xy_tiles":     # pairs along x (4 tiles of 128) and y (3 tiles of 64): one final pass per dimension
+        c = _stable(7, 13)
+        shape, scans = (192, 512), [(0, True, c), (0, False, _stable(5, 14)), (1, True, c), (1, False, c)]
+    elif case == "pair_then_single":  # x: pair + a third scan; y: an anticausal scan in front of a causal one (no pair)
+        shape, scans = (64, 256), [(0, True, _stable(12, 15)), (0, False, _stable(12, 16)), (0, True, _stable(3, 17)),
+                                   (1, False, _stable(6, 18)), (1, True, _stable(6, 19))]
     elif case == "ragged_xy":         # extents that no tile divides: padding where each scan leaves the image
         c = _stable(12, 3)
         shape, scans = (77, 300), [(0, True, c), (0, False, c), (1, True, c), (1, False, _stable(30, 8))]
@@ -556,6 +565,8 @@ def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
         shape = (32 * 1031,)          # a prime number of tiles: partial last chunks on every level
     with rfa.Plan(shape, scans, clamped=clamped, path=capi.RF_PATH_TILED_MATRIX, device=capi.RF_DEVICE_HOST_ONLY) as plan:
         assert plan.path == capi.RF_PATH_TILED_MATRIX
+        if case.startswith("pair") or case == "xy_pm_12":        # (the first scan of a dimension, in the plan's order, heads a pair)
+            assert int(plan.table("mx_pair_0")[0]) == 1
         img = rc.random_image(shape, np.float32, 5)
         got = mxe.run(plan, img, clamped)
     want = oracle.apply_filter(img.astype(np.float64), scans, clamped)
