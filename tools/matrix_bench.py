@@ -3,6 +3,7 @@
     python tools/matrix_bench.py audio  [samples]      orders 1, 3, .. 29 of apps/audio/audio_filter_high_order.cpp, one
                                                        causal scan of a 1-D signal (default 10,000,000 samples -> 9,999,872)
     python tools/matrix_bench.py image  [size] [order] the 2-D causal + anticausal x/y filter of a given order
+    python tools/matrix_bench.py zerophase [samples] [order]  a 1-D signal through a causal and an anticausal scan of that order
     python tools/matrix_bench.py kernels ...           as above with the per-kernel HIP-event times of one execute
 
 Every row: ms per execute (HIP events around `reps` executes on the stream), Msamples/s, bytes per sample under the 8 B
@@ -68,6 +69,25 @@ def main(argv):
                 if per_kernel and order in (1, 9, 15, 29):
                     _, times = plan.execute_timed(dev)
                     print("    " + "  ".join(f"{nm}={t * 1000:.1f}us" for nm, t in times), flush=True)
+        return 0
+    if what == "zerophase":
+        n = (int(argv[1]) if len(argv) > 1 else 10_000_000) // 128 * 128
+        order = int(argv[2]) if len(argv) > 2 else 12
+        c = stable_coeff(order, 3)
+        scans = [(0, True, c), (0, False, c)]
+        sig = rc.random_image((n,), np.float32, 1)
+        dev = [torch.from_numpy(sig).cuda()]
+        with rfa.Plan((n,), scans, path=path, flags=capi.RF_PLAN_NO_OVERLAP) as plan:
+            ms, outs = time_plan(plan, dev, 20)
+            m = min(n, 1 << 20)
+            want = oracle.apply_filter(sig.astype(np.float64), scans, False)[:m]
+            err = rc.rel_err(outs[0][:m].cpu().numpy(), want)
+            gbs = 8.0 * n / ms / 1e6
+            print(f"{n} samples order {order} causal + anticausal: path {plan.path_name} tiles {plan.tiles} {ms:.4f} ms  {n / ms / 1e3:.0f} Msamples/s  "
+                  f"{gbs:.0f} GB/s = {gbs / 8000:.3f} of 8 TB/s  kernels {plan.num_kernels}  rel err {err:.2e}", flush=True)
+            if per_kernel:
+                _, times = plan.execute_timed(dev)
+                print("    " + "  ".join(f"{nm}={t * 1000:.1f}us" for nm, t in times), flush=True)
         return 0
     size = int(argv[1]) if len(argv) > 1 else 16384
     order = int(argv[2]) if len(argv) > 2 else 12

@@ -12,7 +12,7 @@ import json
 import sys
 
 NAMES = ["walk_tails_kernel", "fused_pass2_tall_kernel", "fused_pass2_kernel", "fused_tails_kernel", "mfma_tails_kernel", "stream_tails_kernel", "carry_block_kernel", "carry_pair_kernel", "xscan_rows_kernel",
-         "strided_pass_kernel", "generic_pass_kernel", "untiled_scan_kernel", "mx_pass1s_kernel", "mx_pass2s_kernel", "mx_chain_kernel", "mx_apply_kernel"]
+         "strided_pass_kernel", "generic_pass_kernel", "untiled_scan_kernel", "mx_pass1s_kernel", "mx_pass2s_kernel", "mx_pass2p_kernel", "mx_chain_kernel", "mx_apply_kernel"]
 
 
 def key(row):
