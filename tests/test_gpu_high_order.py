@@ -288,6 +288,9 @@ def test_matrix_path_pair_stages(case, clamped):
     imgs, outs, (path, _) = _run(shape, scans, clamped=clamped, planes=planes, path=capi.RF_PATH_TILED_MATRIX)
     assert path == capi.RF_PATH_TILED_MATRIX
     _check(imgs, outs, scans, clamped)
+    # in place: a wave has read its whole tile by the time its backward walk stores the first sub-block
+    imgs, outs, _ = _run(shape, scans, clamped=clamped, planes=planes, path=capi.RF_PATH_TILED_MATRIX, inplace=True)
+    _check(imgs, outs, scans, clamped)
     with rfa.Plan(shape, scans, clamped=clamped, planes=planes, path=capi.RF_PATH_TILED_MATRIX, device=capi.RF_DEVICE_HOST_ONLY) as host:
         heads = 0
         for i in range(len(scans)):                         # (the plan's order: grouped by dimension)
