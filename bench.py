@@ -41,6 +41,15 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def workload(name, size):
     import ref_cases as rc
+    if name == "order12":
+        # not a BASELINE config: the matrix path's reference point -- a 16384^2 f32 image through causal +
+        # anticausal scans of ORDER 12 along x and y, clamped border, coefficients with sum |a| = 0.85 (tools/matrix_bench.py)
+        import numpy as np
+        rng = np.random.default_rng(3)
+        a = rng.standard_normal(12) * np.exp(-0.15 * np.arange(12))
+        c = [0.4] + [float(np.float32(v)) for v in a * 0.85 / np.abs(a).sum()]
+        n = size or 16384
+        return dict(shape=(n, n), dtype=np.float32, clamped=True, planes=1, scans=[(0, True, c), (0, False, c), (1, True, c), (1, False, c)])
     cfg = dict(rc.BASELINE_CONFIGS[{"cfg2": "cfg2_summed_table", "cfg3": "cfg3_gaussian2_xy",
                                     "cfg4a": "cfg4a_bicubic_rgb", "cfg4b": "cfg4b_gaussian3_rgb",
                                     "cfg5": "cfg5_generic_xyz"}[name]])
@@ -206,7 +215,8 @@ def metric_name(workload_name, shape, planes):
     if workload_name == "cfg3" and tuple(shape) == (16384, 16384) and planes == 1:
         return "Mpixels/s + achieved HBM GB/s, 16384^2 order-2 x/y Gaussian IIR"
     what = {"cfg2": "order-1 summed-area table", "cfg3": "order-2 x/y Gaussian IIR", "cfg4a": "bicubic B-spline prefilter",
-            "cfg4b": "order-3 x/y Gaussian IIR", "cfg5": "order-2 x/y/z filter (test_generic_xyz)"}[workload_name]
+            "cfg4b": "order-3 x/y Gaussian IIR", "cfg5": "order-2 x/y/z filter (test_generic_xyz)",
+            "order12": "order-12 x/y filter, direct form (not a BASELINE config: the matrix path's reference point)"}[workload_name]
     return f"Mpixels/s + achieved HBM GB/s, {'x'.join(map(str, shape))} x{planes} {what}"
 
 
@@ -493,7 +503,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4a | cfg4b | cfg5 (default: cfg3, the configuration the "
+    ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4a | cfg4b | cfg5 | order12 (default: cfg3, the configuration the "
                     "metric is quoted on, followed by BASELINE config 5 -- 2048^3 sharded along z, strong scaling -- whose line "
                     "rides in the same JSON object under \"configs\")")
     ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
