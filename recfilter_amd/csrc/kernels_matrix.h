@@ -11,10 +11,8 @@
 namespace rf {
 
 constexpr int kMxSB = 32;                  // sub-block: samples one 32x32x2 MFMA chain covers
-#ifndef RF_MX_WAVES
-#define RF_MX_WAVES 4
-#endif
-constexpr int kMxWaves = RF_MX_WAVES;                // waves per workgroup of the pass kernels
+constexpr int kMxWaves = 4;                // waves per workgroup of the pass kernels (the final passes copy one 16-byte piece of
+                                           // every 32 x 32 operator per thread; the x -> y hand-over has one wave per sub-block of a y tile)
 constexpr int kMxUnits = 32 * kMxWaves;    // units (line, tile) per workgroup: one per lane column
 constexpr int kMxMaxNB = 8;                // sub-blocks per tile: T <= 256 (the H fragments of a tile sit in LDS: 4 KiB per sub-block)
 constexpr int kMxChunk = 16;               // tiles per chunk of the carry chain (levels of the blocked scan)

@@ -26,12 +26,11 @@
 // body serves scans along x (lane = line, or lane = tile for 1-D signals) and along y / z (lane = column).  The passes STREAM: a
 // wave owns 32 units and walks their tile sub-block by sub-block through a private 32 x 32 staging buffer (see "the streaming
 // passes" below).
+// A causal scan and the anticausal scan behind it share ONE stage where their tails are short (a PAIR: mx_pass2p_kernel and
+// MxPassArgs::pair -- pass 1 forms both scans' tails in one contraction, the final pass keeps the tile's causal result in registers).
 // A clamped border is the zero-border operator plus a rank-one term in the scan's first sample (what the clamped prologue of
 // lib/recfilter.cpp:330-336 adds is linear in x_0): dG / dH, applied by the lanes whose tile is where the scan enters the image.
 #include <cstdlib>
-#include <mutex>
-#include <set>
-#include <utility>
 
 #include "kernels_matrix.h"
 
