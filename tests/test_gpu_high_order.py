@@ -299,3 +299,47 @@ def test_matrix_path_pair_stages(case, clamped):
             except Exception:
                 pass
         assert heads >= 1
+
+
+def test_matrix_path_executes_concurrently_on_distinct_streams():
+    """executes of one plan on distinct streams may overlap -- every instance has its own tails, chain levels and
+    (pair stages) second set of tails.  Three images through ONE plan of pair stages and a single stage on three busy streams, then
+    from three host threads at once; every result against the oracle."""
+    import threading
+    import torch
+    import recfilter_amd as rfa
+    shape, scans, _ = PAIR_CASES["2d_pair_and_singles"]
+    imgs = [rc.random_image(shape, np.float32, 91 + i) for i in range(3)]
+    wants = [oracle.apply_filter(im.astype(np.float64), scans, True) for im in imgs]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    with rfa.Plan(shape, scans, clamped=True, path=capi.RF_PATH_TILED_MATRIX) as plan:
+        outs = [torch.empty_like(d) for d in dev]
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(30_000_000)
+        for rep in range(2):
+            for i in range(3):
+                plan.execute([dev[i]], [outs[i]], stream=streams[i])
+        torch.cuda.synchronize()
+        assert plan.num_instances == 3, plan.num_instances
+        for o, w in zip(outs, wants):
+            assert rc.rel_err(o.cpu().numpy(), w) < TOL
+        outs2 = [torch.empty_like(d) for d in dev]
+        errors = []
+
+        def worker(i):
+            try:
+                for _ in range(3):
+                    plan.execute([dev[i]], [outs2[i]], stream=streams[i])
+            except Exception as exc:      # pragma: no cover
+                errors.append(exc)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for o, w in zip(outs2, wants):
+            assert rc.rel_err(o.cpu().numpy(), w) < TOL
