@@ -17,6 +17,7 @@ constexpr int kMxUnits = 32 * kMxWaves;    // units (line, tile) per workgroup: 
 constexpr int kMxMaxNB = 8;                // sub-blocks per tile: T <= 256 (the H fragments of a tile sit in LDS: 4 KiB per sub-block)
 constexpr int kMxChunk = 16;               // tiles per chunk of the carry chain (levels of the blocked scan)
 constexpr int kMxTopMax = 24;              // a sequence this short is chained in one go
+constexpr int kMxTopWide = 512;            // ... when the lines alone fill the chip (plan_matrix.cpp)
 
 // How the units of a scanned dimension lie in memory:
 //   MX_X1  scan along x, few lines (1-D signals): unit U = line * M + tile, a workgroup takes 128 consecutive units =

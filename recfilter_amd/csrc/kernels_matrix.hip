@@ -645,19 +645,21 @@ __device__ __forceinline__ MxCol mx_col(const MxChainArgs &a, int64_t c) {
     return col;
 }
 
-constexpr int kMxAhead = 4;        // elements of the chain requested ahead of the step that consumes them
+// elements of the chain requested ahead of the step that consumes them: a step is 4 NLQ dependent MFMAs (0.1 us per NLQ), and
+// the requests in flight have to cover the memory latency (2-3 us) -- eight steps for short tails, four for long ones
+template <int NLQ> constexpr int kMxAhead = NLQ <= 2 ? 8 : 4;
 
 template <int NLQ>
 __global__ void __launch_bounds__(kMxThreads)
 mx_chain_kernel(MxChainArgs a) {
-    constexpr int NL = 4 * NLQ, KP = 8 * NLQ;
+    constexpr int NL = 4 * NLQ, KP = 8 * NLQ, AHEAD = kMxAhead<NLQ>;
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, h = lane >> 5, u = lane & 31;
     const MxCol col = mx_col(a, ((int64_t)blockIdx.x * kMxWaves + w) * 32 + u);
     float Af[NL];
 #pragma unroll
     for (int t = 0; t < NL; t++) Af[t] = a.A[t * 64 + lane];
     auto elem = [&](int j) { return a.seq + (col.off + (int64_t)j * a.s_j) * KP + 4 * h; };
-    float4 ring[kMxAhead][NLQ];
+    float4 ring[AHEAD][NLQ];
     auto request = [&](int slot, int j) {
 #pragma unroll
         for (int q = 0; q < NLQ; q++) {
@@ -666,16 +668,16 @@ mx_chain_kernel(MxChainArgs a) {
         }
     };
 #pragma unroll
-    for (int d = 0; d < kMxAhead; d++) request(d, d);
+    for (int d = 0; d < AHEAD; d++) request(d, d);
     floatx16 x = mx_zero();
-    for (int j0 = 0; j0 < a.C; j0 += kMxAhead) {
+    for (int j0 = 0; j0 < a.C; j0 += AHEAD) {
 #pragma unroll
-        for (int d = 0; d < kMxAhead; d++) {
+        for (int d = 0; d < AHEAD; d++) {
             const int j = j0 + d;
             floatx16 c = mx_zero();
 #pragma unroll
             for (int q = 0; q < NLQ; q++) { c[4 * q] = ring[d][q].x; c[4 * q + 1] = ring[d][q].y; c[4 * q + 2] = ring[d][q].z; c[4 * q + 3] = ring[d][q].w; }
-            request(d, j + kMxAhead);                       // before this step's arithmetic and stores
+            request(d, j + AHEAD);                       // before this step's arithmetic and stores
 #pragma unroll
             for (int t = 0; t < NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[t], x[t], c, 0, 0, 0);
             if (col.valid && j < col.len) {

@@ -354,7 +354,11 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             for (int64_t Ml = di.M;; Ml = (Ml + kMxChunk - 1) / kMxChunk) {
                 Level lv;
                 lv.M = Ml;
-                lv.top = Ml <= kMxTopMax;
+                // one chain over the whole line where the lines alone fill the chip (lane = line / column, 16384 of them = 512 waves):
+                // M dependent steps, but ONE pass over the tails instead of the two of chunks + propagation (16384^2: 69-75 us
+                // against 96-113 per scan; 8192 lines: level, profiles/r5/matrix_chain_ab.txt)
+                const int64_t top_wide = RF_KNOB("RF_MX_TOP") ? atoi(RF_KNOB("RF_MX_TOP")) : kMxTopWide;
+                lv.top = Ml <= ((mode != MX_X1 && di.lines >= 16384) ? top_wide : (int64_t)kMxTopMax);
                 std::vector<float> fA;
                 pack_fragments(pad32(B, k).data(), fA);
                 lv.zero = std::all_of(fA.begin(), fA.end(), [](float v) { return v == 0.0f; });

@@ -9,21 +9,22 @@ from __future__ import annotations
 
 import numpy as np
 
-CHUNK, TOPMAX = 16, 24       # kMxChunk, kMxTopMax (kernels_matrix.h)
+CHUNK, TOPMAX = 16, 24       # kMxChunk, kMxTopMax (kernels_matrix.h; the default when the plan's levels are not given)
 
 
 def _f32(a):
     return np.asarray(a, dtype=np.float32)
 
 
-def chain_levels(local, A, causal):
+def chain_levels(local, A, causal, nlevels=None):
     """local: [lines, M, k] tile-local tails (memory order of tiles) -> completed tails, by the blocked scheme of the
     kernels: chunk-local chains, the chunk exits as the next level's sequence with transfer matrix B^16, then the
     propagation down with B^(j+1)."""
     A64 = np.asarray(A, dtype=np.float64)
     seq = local if causal else local[:, ::-1]          # scan order
     seqs, mats = [np.array(seq, dtype=np.float32)], [A64]
-    while seqs[-1].shape[1] > TOPMAX:
+    # (the plan says how many levels it runs -- mx_levels_<scan>: a long line is chained in one go where the lines alone fill the chip)
+    while (len(seqs) < nlevels) if nlevels is not None else (seqs[-1].shape[1] > TOPMAX):
         cur, B = seqs[-1], _f32(mats[-1])
         M = cur.shape[1]
         nch = (M + CHUNK - 1) // CHUNK
@@ -83,12 +84,12 @@ def _pair_stage(plan, out, rows, i, p, clamped):
     if clamped:
         l1[:, 0] += x[:, 0, 0][:, None] * dH1[:k1][None, :]
         l2[:, 0] += x[:, 0, 0][:, None] * v21[:k2][None, :]
-    c1 = chain_levels(l1, A1, True)
+    c1 = chain_levels(l1, A1, True, len(plan.table(f"mx_levels_{i}")) // 2)
     for t in range(1, M):
         l2[:, t] = l2[:, t] + c1[:, t - 1] @ W21.T
     if clamped:
         l2[:, M - 1] = l2[:, M - 1] + c1[:, M - 1, 0][:, None] * dH2[:k2][None, :]
-    c2 = chain_levels(l2.astype(np.float32), A2, False)
+    c2 = chain_levels(l2.astype(np.float32), A2, False, len(plan.table(f"mx_levels_{p}")) // 2)
     y = np.empty_like(x)
     for t in range(M):
         prev = np.zeros((x.shape[0], 32), dtype=np.float32)
@@ -159,7 +160,7 @@ def run(plan, img, clamped):
         local = np.einsum("lmt,rt->lmr", x, H[:k]).astype(np.float32)
         if clamped:
             local[:, first_tile] += x[:, first_tile, m0][:, None] * dH[:k][None, :]
-        tails = chain_levels(local, A, causal)
+        tails = chain_levels(local, A, causal, len(plan.table(f"mx_levels_{i}")) // 2)
         # pass 2
         y = np.empty_like(x)
         NB = T // 32

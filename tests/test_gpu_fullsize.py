@@ -410,3 +410,27 @@ def test_matrix_path_268m_samples_index_ranges():
     for lo in range(0, n, 1 << 24):
         worst = max(worst, rc.rel_err(got[lo:lo + (1 << 24)], want[lo:lo + (1 << 24)]))
     assert worst < TOL
+
+
+@pytest.mark.parametrize("clamped", [False, True])
+def test_matrix_path_16384_lines_chain_in_one_go(clamped):
+    """16384 lines fill the chip by themselves: their 40 tiles are chained in ONE launch per scan (no chunks, no propagation:
+    plan_matrix.cpp, kMxTopWide) -- a pair stage along x of a 16384 x 5120 image against the f64 oracle on every pixel."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    rng = np.random.default_rng(6)
+    def coeff(order):
+        a = rng.standard_normal(order) * np.exp(-0.15 * np.arange(order))
+        return [0.4] + [float(np.float32(v)) for v in a * 0.85 / np.abs(a).sum()]
+    scans = [(0, True, coeff(12)), (0, False, coeff(9))]
+    img = rc.random_image((16384, 5120), np.float32, 4)
+    dev = torch.from_numpy(img).cuda()
+    with rfa.Plan(img.shape, scans, clamped=clamped) as plan:
+        assert plan.path == capi.RF_PATH_TILED_MATRIX and plan.tiles[0] == 128
+        # pass 1, chain (causal), cross term (+ its clamped border), chain (anticausal), the pair's final pass
+        assert plan.num_kernels == (6 if clamped else 5)
+        got = plan.execute([dev])[0].cpu().numpy()
+    del dev
+    want = oracle.apply_filter(img.astype(np.float64), scans, clamped, threads=_threads())
+    assert _floor_err(got, want) < TOL

@@ -535,7 +535,7 @@ def _stable(order, seed, b=0.4, mass=0.85):
 
 @pytest.mark.parametrize("clamped", [False, True])
 @pytest.mark.parametrize("case", ["audio_1d", "xy_pm_12", "xyz_mixed", "order32_1d_levels", "ragged_xy", "ragged_1d_short", "ragged_xyz",
-                                  "pair_1d", "pair_xy_tiles", "pair_then_single"])
+                                  "pair_1d", "pair_xy_tiles", "pair_then_single", "wide_one_chain"])
 def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
     import matrix_emulator as mxe
     if case == "audio_1d":            # apps/audio/audio_filter_high_order.cpp:41-42 at its highest order
@@ -553,6 +553,8 @@ def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
     elif case == "pair_then_single":  # x: pair + a third scan; y: an anticausal scan in front of a causal one (no pair)
         shape, scans = (64, 256), [(0, True, _stable(12, 15)), (0, False, _stable(12, 16)), (0, True, _stable(3, 17)),
                                    (1, False, _stable(6, 18)), (1, True, _stable(6, 19))]
+    elif case == "wide_one_chain":    # 16384 lines fill the chip: 29 tiles of 32 are chained in ONE go (one level), not as chunks + propagation
+        shape, scans = (16384, 32 * 29), [(0, True, _stable(9, 20)), (0, False, _stable(16, 21))]
     elif case == "ragged_xy":         # extents that no tile divides: padding where each scan leaves the image
         c = _stable(12, 3)
         shape, scans = (77, 300), [(0, True, c), (0, False, c), (1, True, c), (1, False, _stable(30, 8))]
@@ -565,7 +567,9 @@ def test_matrix_path_tables_reproduce_the_oracle(case, clamped):
         shape = (32 * 1031,)          # a prime number of tiles: partial last chunks on every level
     with rfa.Plan(shape, scans, clamped=clamped, path=capi.RF_PATH_TILED_MATRIX, device=capi.RF_DEVICE_HOST_ONLY) as plan:
         assert plan.path == capi.RF_PATH_TILED_MATRIX
-        if case.startswith("pair") or case == "xy_pm_12":        # (the first scan of a dimension, in the plan's order, heads a pair)
+        if case == "wide_one_chain":
+            assert plan.tiles[0] == 32 and list(plan.table("mx_levels_0")) == [29.0, 0.0]
+        if case.startswith("pair") or case in ("xy_pm_12", "wide_one_chain"):        # (the first scan of a dimension, in the plan's order, heads a pair)
             assert int(plan.table("mx_pair_0")[0]) == 1
         img = rc.random_image(shape, np.float32, 5)
         got = mxe.run(plan, img, clamped)
