@@ -211,7 +211,8 @@ def _emulate_ranks(local_shape, world, scans, clamped, planes=1, path=0):
 
 
 @pytest.mark.parametrize("clamped", [False, True])
-@pytest.mark.parametrize("case", ["rows_3_ranks", "rows_8_ranks_slow_decay", "z_slabs_2_ranks", "planes", "rows_ragged_width", "z_slabs_ragged_rows"])
+@pytest.mark.parametrize("case", ["rows_3_ranks", "rows_8_ranks_slow_decay", "z_slabs_2_ranks", "planes", "rows_ragged_width", "z_slabs_ragged_rows",
+                                  "rows_wide_one_chain"])
 def test_matrix_path_sharded_slabs(case, clamped):
     """High-order filters over the GPUs of a node: slabs of the outermost dimension, one exchange of the k-row exit
     carries per scan along it -- every rank chains the gathered exits with A^M on the matrix cores, propagates its entering carry
@@ -227,6 +228,9 @@ def test_matrix_path_sharded_slabs(case, clamped):
     elif case == "z_slabs_2_ranks":
         local, world = (64, 40, 128), 2
         scans = [(2, True, stable_coeff(10, 6)), (0, False, stable_coeff(9, 7)), (1, True, stable_coeff(11, 8)), (2, False, stable_coeff(13, 9))]
+    elif case == "rows_wide_one_chain":        # 16384 columns fill the chip: the 29 tiles (of 32 rows) of a slab are chained in one go (no
+        local, world = (32 * 29, 16384), 2     # propagation) before the exchange; the x scans are a pair stage
+        scans = [(0, True, stable_coeff(9, 22)), (0, False, stable_coeff(9, 23)), (1, True, stable_coeff(12, 24)), (1, False, stable_coeff(12, 25))]
     elif case == "rows_ragged_width":          # the slab-local x scans on tiles that do not divide the width
         local, world = (64, 300), 2
         scans = [(0, True, stable_coeff(9, 12)), (0, False, stable_coeff(14, 13)), (1, True, stable_coeff(10, 14)), (1, False, stable_coeff(10, 15))]
