@@ -84,6 +84,13 @@ struct MxChainArgs {
     int64_t base, s_hi, s_lo, s_j;
     int64_t e_hi, e_lo;
     int64_t Mtot;              // elements per line on this level (the last chunk may be short)
+    // The anticausal chain of a PAIR stage when it runs over the whole line in one go: the cross term is added on the way -- step j
+    // takes crossW . cross[element of step j + cross_shift] (the completed causal carry entering the tile) for j < cross_steps, and
+    // step 0 crossD . cross[its own element] (the anticausal scan's clamped border) -- instead of a launch of its own before the chain.
+    const float *cross;        // null: a plain chain
+    const float *crossW, *crossD;      // fragments [16][64]; crossD null without a clamped border
+    int64_t cross_shift;
+    int32_t cross_steps;
 };
 
 int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream);

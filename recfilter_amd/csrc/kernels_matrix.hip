@@ -649,7 +649,7 @@ __device__ __forceinline__ MxCol mx_col(const MxChainArgs &a, int64_t c) {
 // the requests in flight have to cover the memory latency (2-3 us) -- eight steps for short tails, four for long ones
 template <int NLQ> constexpr int kMxAhead = NLQ <= 2 ? 8 : 4;
 
-template <int NLQ>
+template <int NLQ, bool CROSS>
 __global__ void __launch_bounds__(kMxThreads)
 mx_chain_kernel(MxChainArgs a) {
     constexpr int NL = 4 * NLQ, KP = 8 * NLQ, AHEAD = kMxAhead<NLQ>;
@@ -667,6 +667,36 @@ mx_chain_kernel(MxChainArgs a) {
             if (col.valid && j < col.len) ring[slot][q] = *reinterpret_cast<const float4 *>(elem(j) + 8 * q);
         }
     };
+    // CROSS (MxChainArgs::cross): a second ring with the elements of the cross term -- off the dependent path, the MFMA pipe has room
+    float Wf[CROSS ? NL : 1];
+    float4 ringx[CROSS ? AHEAD : 1][NLQ];
+    auto requestx = [&](int slot, int j) {
+#pragma unroll
+        for (int q = 0; q < NLQ; q++) {
+            ringx[slot][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (col.valid && j < col.len && j < a.cross_steps)
+                ringx[slot][q] = *reinterpret_cast<const float4 *>(a.cross + (col.off + (int64_t)j * a.s_j + a.cross_shift) * KP + 4 * h + 8 * q);
+        }
+    };
+    floatx16 border = mx_zero();
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int t = 0; t < NL; t++) Wf[t] = a.crossW[t * 64 + lane];
+        if (a.crossD != nullptr) {
+            floatx16 e0 = mx_zero();
+            if (col.valid) {
+#pragma unroll
+                for (int q = 0; q < NLQ; q++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.cross + col.off * KP + 4 * h + 8 * q);
+                    e0[4 * q] = v.x; e0[4 * q + 1] = v.y; e0[4 * q + 2] = v.z; e0[4 * q + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NL; t++) border = __builtin_amdgcn_mfma_f32_32x32x2f32(a.crossD[t * 64 + lane], e0[t], border, 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < AHEAD; d++) requestx(d, d);
+    }
 #pragma unroll
     for (int d = 0; d < AHEAD; d++) request(d, d);
     floatx16 x = mx_zero();
@@ -678,6 +708,18 @@ mx_chain_kernel(MxChainArgs a) {
 #pragma unroll
             for (int q = 0; q < NLQ; q++) { c[4 * q] = ring[d][q].x; c[4 * q + 1] = ring[d][q].y; c[4 * q + 2] = ring[d][q].z; c[4 * q + 3] = ring[d][q].w; }
             request(d, j + AHEAD);                       // before this step's arithmetic and stores
+            if constexpr (CROSS) {
+                floatx16 xv = mx_zero();
+#pragma unroll
+                for (int q = 0; q < NLQ; q++) { xv[4 * q] = ringx[d][q].x; xv[4 * q + 1] = ringx[d][q].y; xv[4 * q + 2] = ringx[d][q].z; xv[4 * q + 3] = ringx[d][q].w; }
+                requestx(d, j + AHEAD);
+                if (j == 0) {
+#pragma unroll
+                    for (int t = 0; t < 16; t++) c[t] += border[t];
+                }
+#pragma unroll
+                for (int t = 0; t < NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Wf[t], xv[t], c, 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < NL; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[t], x[t], c, 0, 0, 0);
             if (col.valid && j < col.len) {
@@ -825,11 +867,18 @@ int launch_mx_chain(const MxChainArgs &a, hipStream_t stream) {
     const int64_t blocks = (a.ncols + kMxUnits - 1) / kMxUnits;
     if (blocks >= (1ll << 31)) { set_error("matrix path: too many chain columns"); return RF_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)blocks), block(kMxThreads);
+    if (a.cross != nullptr) {           // (a pair's tails have at most 16 rows)
+        if (((a.k + 7) >> 3) > 2 || a.crossW == nullptr || a.exits != nullptr) { set_error("matrix path: bad cross term"); return RF_ERR_INVALID_ARG; }
+        if (((a.k + 7) >> 3) == 1) hipLaunchKernelGGL((mx_chain_kernel<1, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((mx_chain_kernel<2, true>), grid, block, 0, stream, a);
+        RF_HIP_CHECK(hipGetLastError());
+        return RF_OK;
+    }
     switch ((a.k + 7) >> 3) {
-        case 1: hipLaunchKernelGGL(mx_chain_kernel<1>, grid, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(mx_chain_kernel<2>, grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(mx_chain_kernel<3>, grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL(mx_chain_kernel<4>, grid, block, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((mx_chain_kernel<1, false>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((mx_chain_kernel<2, false>), grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((mx_chain_kernel<3, false>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((mx_chain_kernel<4, false>), grid, block, 0, stream, a); break;
     }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;

@@ -485,11 +485,26 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             }
             chain[(size_t)l] = c;
         }
+        // A pair whose anticausal chain runs over the whole line in one go takes the cross term on the way (MxChainArgs::cross): no
+        // launch of its own in front of the chain.  `fold_at(si)`: si is the pair's first stage.
+        auto fold_at = [&stages](size_t first) {
+            const Stage &n = stages[first + 1];
+            return stages[first].pair == 1 && n.levels.size() == 1 && !n.levels[0].zero && n.pass.mode != MX_X1 && RF_KNOB("RF_MX_NO_FOLD") == nullptr;
+        };
+        if (st.pair == 2 && fold_at(si - 1)) {
+            MxChainArgs &c0 = chain[0];
+            c0.crossW = stages[si - 1].W21;
+            c0.crossD = stages[si - 1].Dlast;
+            c0.cross_shift = -lines;                   // [tile][line][KP]: the tile in front
+            c0.cross_steps = (int32_t)base.M - 1;      // (the anticausal chain starts at the last tile: step j is tile M - 1 - j, and tile 0 has none in front)
+        }
+        const bool fold_cross = st.pair == 2 && fold_at(si - 1);
         std::vector<size_t> lf = level_floats;
-        auto chain_args = [chain, tails, tails_pp, level_buf, lf](int l, int pl) {
+        auto chain_args = [chain, tails, tails_next, tails_pp, level_buf, lf, fold_cross](int l, int pl) {
             MxChainArgs c = chain[(size_t)l];
             c.seq = l == 0 ? tails + (size_t)pl * tails_pp : level_buf[(size_t)l - 1] + (size_t)pl * lf[(size_t)l - 1];
             c.exits = (size_t)l + 1 < chain.size() ? level_buf[(size_t)l] + (size_t)pl * lf[(size_t)l] : nullptr;
+            if (fold_cross && l == 0) c.cross = tails_next + (size_t)pl * tails_pp;      // (the completed causal carries: the other buffer)
             return c;
         };
         // A transfer matrix that is all zeros in f32 -- a filter that has decayed below the smallest float across a tile (the
@@ -583,6 +598,7 @@ int build_matrix_plan(rf_plan *plan, const rf_filter_desc *desc) {
             plan->exchange_apply_steps.push_back({as});
         }
 
+        if (st.pair == 1 && fold_at(si)) continue;       // (the cross term rides on the anticausal chain; the pair's final pass follows it)
         if (st.pair == 1) {
             // between the two chains: what the completed causal carry entering a tile adds to the anticausal scan's tile-local tail
             // (one product per tile: the propagation kernel with chunks of one tile), and the anticausal scan's clamped border
