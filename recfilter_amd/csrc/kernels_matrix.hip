@@ -306,9 +306,11 @@ __device__ __forceinline__ void mx_consts_store(float *lds, const MxConsts &c, i
     if (threadIdx.x < 32) lds[nb * 1024 + threadIdx.x] = c.vec;
 }
 
-template <bool XM, bool NT>
+// NBT: the tile's sub-blocks when they are the usual four (0: read from the arguments; see mx_pass2p_kernel)
+template <bool XM, bool NT, int NBT>
 __global__ void __launch_bounds__(kMxThreads)
 mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
+    const int NB = NBT ? NBT : a.NB;
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     float *consts = mx_lds + kMxWaves * kMxStageFloats<XM>;       // H [NB][16][64], dH [32]
     const MxBlock blk = mx_block<XM>(a);
@@ -318,36 +320,46 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
     const MxLane ln = mx_lane<XM>(a, blk, 32 * w + u);
     // (a pair stage: ONE contraction for both scans' tails -- its H has the causal scan's H in the rows 0 .. 15 and H21 in the rows
     // 16 .. 31, its border vector likewise: a pair's tails have at most 16 rows)
-    const MxConsts cs = mx_consts_request(a.pair ? a.p_H : a.H, a.NB, a.pair ? a.p_dH : a.dH);
+    const MxConsts cs = mx_consts_request(a.pair ? a.p_H : a.H, NB, a.pair ? a.p_dH : a.dH);
     // (pass 1 has registers to spare: four sub-blocks -- 16 KiB per wave -- are in flight)
     floatx4 pre[4][4];
 #pragma unroll
     for (int d = 0; d < 4; d++)
-        if (d < a.NB) mx_request<XM, NT>(src, st, d, pre[d]);
-    mx_consts_store(consts, cs, a.NB);
+        if (d < NB) mx_request<XM, NT>(src, st, d, pre[d]);
+    mx_consts_store(consts, cs, NB);
     __syncthreads();
     floatx16 acc = mx_zero();
     float x0 = 0.0f;
     auto step = [&](int sb, floatx4 (&buf)[4]) __attribute__((always_inline)) {
         mx_stage_put<XM>(stage, st, sb, buf);
-        if (sb + 4 < a.NB) mx_request<XM, NT>(src, st, sb + 4, buf);
+        if (sb + 4 < NB) mx_request<XM, NT>(src, st, sb + 4, buf);
         mx_wave_sync();
         float x[16];
         mx_stage_read<XM>(stage, u, h, x);
-        if (sb == (a.causal ? 0 : a.NB - 1)) x0 = mx_stage_at<XM>(stage, u, a.causal ? 0 : 31);
+        if (sb == (a.causal ? 0 : NB - 1)) x0 = mx_stage_at<XM>(stage, u, a.causal ? 0 : 31);
         const float *Hf = consts + sb * 1024 + lane;
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hf[t * 64], x[t], acc, 0, 0, 0);
         mx_wave_sync();
     };
-    for (int sb = 0; sb < a.NB; sb += 4) {
-        step(sb, pre[0]);
-        if (sb + 1 < a.NB) step(sb + 1, pre[1]);
-        if (sb + 2 < a.NB) step(sb + 2, pre[2]);
-        if (sb + 3 < a.NB) step(sb + 3, pre[3]);
+    if constexpr (NBT != 0) {
+#pragma unroll
+        for (int sb = 0; sb < NBT; sb += 4) {
+            step(sb, pre[0]);
+            if (sb + 1 < NBT) step(sb + 1, pre[1]);
+            if (sb + 2 < NBT) step(sb + 2, pre[2]);
+            if (sb + 3 < NBT) step(sb + 3, pre[3]);
+        }
+    } else {
+        for (int sb = 0; sb < NB; sb += 4) {
+            step(sb, pre[0]);
+            if (sb + 1 < NB) step(sb + 1, pre[1]);
+            if (sb + 2 < NB) step(sb + 2, pre[2]);
+            if (sb + 3 < NB) step(sb + 3, pre[3]);
+        }
     }
     if (a.clamped && ln.valid && ln.border) {
-        const float *dH = consts + a.NB * 1024;
+        const float *dH = consts + NB * 1024;
 #pragma unroll
         for (int t = 0; t < 16; t++) acc[t] = fmaf(dH[mx_row(t, h)], x0, acc[t]);
     }
@@ -365,9 +377,10 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
 
 // NLQ = ceil(k / 8) and the direction are compile-time: the K steps of R that are not all zero -- the k most recent rows of the
 // previous sub-block -- are then a fixed set of registers, requested from LDS ahead of the MFMAs that use them.
-template <bool XM, int NLQ, bool CAUSAL, bool NT>
+template <bool XM, int NLQ, bool CAUSAL, bool NT, int NBT>
 __global__ void __launch_bounds__(kMxThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+    const int NB = NBT ? NBT : a.NB;       // (NBT: the usual eight sub-blocks of a tile of 256 as a constant; see mx_pass2p_kernel)
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     // (one staging buffer per wave: x_b is in registers by the time y_b is written over it)
     // constants: dG [32], pad [32], G [16][64], R [16][64], next H [NB][16][64], next dH [32] -- G and R too: the 32 registers they
@@ -385,8 +398,8 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     const MxConsts cs = mx_consts_request(a.next ? a.next_H : a.G, a.next ? a.next_NB : 0, a.next ? a.next_dH : a.dG);
     // two sub-blocks in flight per wave
     floatx4 pre[2][4];
-    mx_request<XM, NT>(src, st, CAUSAL ? 0 : a.NB - 1, pre[0]);
-    if (a.NB > 1) mx_request<XM, NT>(src, st, CAUSAL ? 1 : a.NB - 2, pre[1]);
+    mx_request<XM, NT>(src, st, CAUSAL ? 0 : NB - 1, pre[0]);
+    if (NB > 1) mx_request<XM, NT>(src, st, CAUSAL ? 1 : NB - 2, pre[1]);
     constexpr int NL = 4 * NLQ, KP = 8 * NLQ, T_LO = CAUSAL ? 16 - NL : 0;
     floatx16 prev = mx_zero();
     if (ln.valid && (!ln.enters || (a.incoming != nullptr && !ln.border))) {
@@ -409,9 +422,9 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     floatx16 nacc = mx_zero();
     float nx0 = 0.0f;
     auto step = [&](int bi, floatx4 (&buf)[4]) __attribute__((always_inline)) {
-        const int sb = CAUSAL ? bi : a.NB - 1 - bi;
+        const int sb = CAUSAL ? bi : NB - 1 - bi;
         mx_stage_put<XM>(stage, st, sb, buf);
-        if (bi + 2 < a.NB) mx_request<XM, NT>(src, st, CAUSAL ? sb + 2 : sb - 2, buf);
+        if (bi + 2 < NB) mx_request<XM, NT>(src, st, CAUSAL ? sb + 2 : sb - 2, buf);
         mx_wave_sync();
         float x[16];
         mx_stage_read<XM>(stage, u, h, x);
@@ -436,7 +449,7 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
             for (int t = 0; t < 16; t++) nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hn[t * 64], c[t], nacc, 0, 0, 0);
         }
         mx_wave_sync();
-        if (a.next == 1 && sb == (a.next_causal ? 0 : a.NB - 1)) nx0 = mx_stage_at<XM>(stage, u, a.next_causal ? 0 : 31);
+        if (a.next == 1 && sb == (a.next_causal ? 0 : NB - 1)) nx0 = mx_stage_at<XM>(stage, u, a.next_causal ? 0 : 31);
         if constexpr (XM) {
             if (a.next == 2) {
                 // The first y scan's tile-local tails (MxPassArgs::next == 2): the workgroup's 128 lines are one y tile, the 32
@@ -486,9 +499,17 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
         }
         mx_wave_sync();
     };
-    for (int bi = 0; bi < a.NB; bi += 2) {
-        step(bi, pre[0]);
-        if (bi + 1 < a.NB) step(bi + 1, pre[1]);
+    if constexpr (NBT != 0) {
+#pragma unroll
+        for (int bi = 0; bi < NBT; bi += 2) {
+            step(bi, pre[0]);
+            if (bi + 1 < NBT) step(bi + 1, pre[1]);
+        }
+    } else {
+        for (int bi = 0; bi < NB; bi += 2) {
+            step(bi, pre[0]);
+            if (bi + 1 < NB) step(bi + 1, pre[1]);
+        }
     }
     if (a.next == 1) {
         const bool nenters = (a.next_causal ? ln.tile == 0 : ln.tile == a.M - 1) && (a.next_causal ? a.slab_first != 0 : a.slab_last != 0);
@@ -507,9 +528,12 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
 // appears.  Both scans have the same number of tail pieces (NLQ).  Clamped borders: the causal scan's term dG1 x_0 in the
 // image's first tile, the anticausal scan's dG2 w_(T-1) in its last one (lib/recfilter.cpp:330-336 reads the partially
 // updated buffer: the anticausal scan's border sample is the causal RESULT).
-template <bool XM, int NLQ, bool NT>
+// NBT: the tile's sub-blocks when they are the usual four (0: read from the arguments) -- with the count a constant no request sits
+// under a branch, and the compiler keeps count of what is in flight (behind a branch it waits for more than the step needs).
+template <bool XM, int NLQ, bool NT, int NBT>
 __global__ void __launch_bounds__(kMxThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+    const int NB = NBT ? NBT : a.NB;
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     // constants: dG1 [32], dG2 [32], G1, R1, G2, R2 [16][64] each
     float *consts = mx_lds + kMxWaves * kMxStageFloats<XM>;
@@ -525,7 +549,7 @@ mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     const float4 c2 = reinterpret_cast<const float4 *>(a.p_G)[threadIdx.x], c3 = reinterpret_cast<const float4 *>(a.p_R)[threadIdx.x];
     floatx4 pre[2][4];
     mx_request<XM, NT>(src, st, 0, pre[0]);
-    if (a.NB > 1) mx_request<XM, NT>(src, st, 1, pre[1]);
+    if (NB > 1) mx_request<XM, NT>(src, st, 1, pre[1]);
     constexpr int NL = 4 * NLQ, KP = 8 * NLQ;
     // the carries: the causal one enters from the tile in front (row i of a sub-block that precedes the tile = tail 31 - i), the
     // anticausal one from the tile behind (row i = tail i)
@@ -563,7 +587,7 @@ mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     float w_last = 0.0f;
     auto forward = [&](int bi, floatx4 (&buf)[4], floatx16 &out) __attribute__((always_inline)) {
         mx_stage_put<XM>(stage, st, bi, buf);
-        if (bi + 2 < a.NB) mx_request<XM, NT>(src, st, bi + 2, buf);
+        if (bi + 2 < NB) mx_request<XM, NT>(src, st, bi + 2, buf);
         mx_wave_sync();
         float x[16];
         mx_stage_read<XM>(stage, u, h, x);
@@ -580,7 +604,7 @@ mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
         for (int t = 16 - NL; t < 16; t++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(R1[t * 64 + lane], prev[t], c, 0, 0, 0);
         prev = c;
         out = c;
-        if (bi == a.NB - 1) {                   // the tile's last causal output, for the anticausal scan's border term
+        if (bi == NB - 1) {                   // the tile's last causal output, for the anticausal scan's border term
             mx_stage_write<XM>(stage, u, h, c);
             mx_wave_sync();
             w_last = mx_stage_at<XM>(stage, u, 31);
@@ -589,7 +613,7 @@ mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
     };
     auto backward = [&](int bi, const floatx16 &in) __attribute__((always_inline)) {
         floatx16 c = mx_zero();
-        if (bi == a.NB - 1 && a.clamped && ln.valid && last_tile && a.slab_last) {
+        if (bi == NB - 1 && a.clamped && ln.valid && last_tile && a.slab_last) {
 #pragma unroll
             for (int t = 0; t < 16; t++) c[t] = consts[32 + mx_row(t, h)] * w_last;
         }
@@ -613,12 +637,12 @@ mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
         mx_wave_sync();
     };
     forward(0, pre[0], wv[0]);
-    if (a.NB > 1) forward(1, pre[1], wv[1]);
-    if (a.NB > 2) forward(2, pre[0], wv[2]);
-    if (a.NB > 3) forward(3, pre[1], wv[3]);
-    if (a.NB > 3) backward(3, wv[3]);
-    if (a.NB > 2) backward(2, wv[2]);
-    if (a.NB > 1) backward(1, wv[1]);
+    if (NB > 1) forward(1, pre[1], wv[1]);
+    if (NB > 2) forward(2, pre[0], wv[2]);
+    if (NB > 3) forward(3, pre[1], wv[3]);
+    if (NB > 3) backward(3, wv[3]);
+    if (NB > 2) backward(2, wv[2]);
+    if (NB > 1) backward(1, wv[1]);
     backward(0, wv[0]);
 }
 
@@ -660,23 +684,21 @@ mx_chain_kernel(MxChainArgs a) {
     for (int t = 0; t < NL; t++) Af[t] = a.A[t * 64 + lane];
     auto elem = [&](int j) { return a.seq + (col.off + (int64_t)j * a.s_j) * KP + 4 * h; };
     float4 ring[AHEAD][NLQ];
+    // (requests without a branch: a load under a condition makes the compiler lose count of what is in flight, and it then waits
+    // for EVERYTHING at the top of the loop -- the memory latency once per trip; an element that does not exist reads the
+    // sequence's first one and is replaced by zeros where it is used)
     auto request = [&](int slot, int j) {
+        const float *p = (col.valid && j < col.len) ? elem(j) : a.seq + 4 * h;
 #pragma unroll
-        for (int q = 0; q < NLQ; q++) {
-            ring[slot][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (col.valid && j < col.len) ring[slot][q] = *reinterpret_cast<const float4 *>(elem(j) + 8 * q);
-        }
+        for (int q = 0; q < NLQ; q++) ring[slot][q] = *reinterpret_cast<const float4 *>(p + 8 * q);
     };
     // CROSS (MxChainArgs::cross): a second ring with the elements of the cross term -- off the dependent path, the MFMA pipe has room
     float Wf[CROSS ? NL : 1];
     float4 ringx[CROSS ? AHEAD : 1][NLQ];
     auto requestx = [&](int slot, int j) {
+        const float *p = (col.valid && j < col.len && j < a.cross_steps) ? a.cross + (col.off + (int64_t)j * a.s_j + a.cross_shift) * KP + 4 * h : a.seq + 4 * h;
 #pragma unroll
-        for (int q = 0; q < NLQ; q++) {
-            ringx[slot][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (col.valid && j < col.len && j < a.cross_steps)
-                ringx[slot][q] = *reinterpret_cast<const float4 *>(a.cross + (col.off + (int64_t)j * a.s_j + a.cross_shift) * KP + 4 * h + 8 * q);
-        }
+        for (int q = 0; q < NLQ; q++) ringx[slot][q] = *reinterpret_cast<const float4 *>(p + 8 * q);
     };
     floatx16 border = mx_zero();
     if constexpr (CROSS) {
@@ -705,13 +727,21 @@ mx_chain_kernel(MxChainArgs a) {
         for (int d = 0; d < AHEAD; d++) {
             const int j = j0 + d;
             floatx16 c = mx_zero();
+            const bool live = col.valid && j < col.len;
 #pragma unroll
-            for (int q = 0; q < NLQ; q++) { c[4 * q] = ring[d][q].x; c[4 * q + 1] = ring[d][q].y; c[4 * q + 2] = ring[d][q].z; c[4 * q + 3] = ring[d][q].w; }
+            for (int q = 0; q < NLQ; q++) {
+                c[4 * q] = live ? ring[d][q].x : 0.0f; c[4 * q + 1] = live ? ring[d][q].y : 0.0f;
+                c[4 * q + 2] = live ? ring[d][q].z : 0.0f; c[4 * q + 3] = live ? ring[d][q].w : 0.0f;
+            }
             request(d, j + AHEAD);                       // before this step's arithmetic and stores
             if constexpr (CROSS) {
                 floatx16 xv = mx_zero();
+                const bool crossed = live && j < a.cross_steps;
 #pragma unroll
-                for (int q = 0; q < NLQ; q++) { xv[4 * q] = ringx[d][q].x; xv[4 * q + 1] = ringx[d][q].y; xv[4 * q + 2] = ringx[d][q].z; xv[4 * q + 3] = ringx[d][q].w; }
+                for (int q = 0; q < NLQ; q++) {
+                    xv[4 * q] = crossed ? ringx[d][q].x : 0.0f; xv[4 * q + 1] = crossed ? ringx[d][q].y : 0.0f;
+                    xv[4 * q + 2] = crossed ? ringx[d][q].z : 0.0f; xv[4 * q + 3] = crossed ? ringx[d][q].w : 0.0f;
+                }
                 requestx(d, j + AHEAD);
                 if (j == 0) {
 #pragma unroll
@@ -801,11 +831,13 @@ int launch_mx_pass1(const float *src, const MxPassArgs &a, hipStream_t stream) {
     if (a.pair && (a.causal == 0 || a.ragged || a.NB > 4 || a.k > 16 || a.p_k > 16)) { set_error("matrix path: bad pair stage"); return RF_ERR_INVALID_ARG; }
     const size_t consts = ((size_t)a.NB * 1024 + 32) * sizeof(float);
     const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
-#define RF_MX_P1S(NT)                                                                                                          \
-    if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);  \
-    else hipLaunchKernelGGL((mx_pass1s_kernel<true, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
+#define RF_MX_P1S_NB(NT, NBT)                                                                                                       \
+    if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass1s_kernel<false, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, a);  \
+    else hipLaunchKernelGGL((mx_pass1s_kernel<true, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, a);
+#define RF_MX_P1S(NT) if (a.NB == 4) { RF_MX_P1S_NB(NT, 4) } else if (a.NB == 8) { RF_MX_P1S_NB(NT, 8) } else { RF_MX_P1S_NB(NT, 0) }
     if (mx_whole_lines(a, src, src)) { RF_MX_P1S(true) } else { RF_MX_P1S(false) }
 #undef RF_MX_P1S
+#undef RF_MX_P1S_NB
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -815,14 +847,15 @@ int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream
     if ((a.next == 2 && (a.mode != MX_XL || a.ragged || a.lines % kMxUnits != 0 || a.next_NB != kMxWaves)) || (a.next == 1 && a.next_NB != a.NB)) { set_error("matrix path: bad x -> y hand-over"); return RF_ERR_INVALID_ARG; }
     const size_t consts = (64 + 2048 + (a.next ? (size_t)a.next_NB * 1024 + 32 : 0) + (a.next == 2 ? (size_t)((a.next_k + 7) >> 3) * kMxWaves * 64 * 4 : 0)) * sizeof(float);
     const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
-#define RF_MX_P2S_NT(NLQ, NT)                                                                                                          \
+#define RF_MX_P2S_NB(NLQ, NT, NBT)                                                                                                     \
     if (a.mode == MX_Y) {                                                                                                              \
-        if (a.causal) hipLaunchKernelGGL((mx_pass2s_kernel<false, NLQ, true, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);   \
-        else hipLaunchKernelGGL((mx_pass2s_kernel<false, NLQ, false, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);           \
+        if (a.causal) hipLaunchKernelGGL((mx_pass2s_kernel<false, NLQ, true, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);   \
+        else hipLaunchKernelGGL((mx_pass2s_kernel<false, NLQ, false, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);           \
     } else {                                                                                                                           \
-        if (a.causal) hipLaunchKernelGGL((mx_pass2s_kernel<true, NLQ, true, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);    \
-        else hipLaunchKernelGGL((mx_pass2s_kernel<true, NLQ, false, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);            \
+        if (a.causal) hipLaunchKernelGGL((mx_pass2s_kernel<true, NLQ, true, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);    \
+        else hipLaunchKernelGGL((mx_pass2s_kernel<true, NLQ, false, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);            \
     }
+#define RF_MX_P2S_NT(NLQ, NT) if (a.NB == 8) { RF_MX_P2S_NB(NLQ, NT, 8) } else { RF_MX_P2S_NB(NLQ, NT, 0) }
 #define RF_MX_P2S(NLQ) if (whole) { RF_MX_P2S_NT(NLQ, true) } else { RF_MX_P2S_NT(NLQ, false) }
     const bool whole = mx_whole_lines(a, src, dst);
     switch ((a.k + 7) >> 3) {
@@ -833,6 +866,7 @@ int launch_mx_pass2(const float *src, float *dst, const MxPassArgs &a, hipStream
     }
 #undef RF_MX_P2S
 #undef RF_MX_P2S_NT
+#undef RF_MX_P2S_NB
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
@@ -846,9 +880,10 @@ int launch_mx_pass2_pair(const float *src, float *dst, const MxPassArgs &a, hipS
     const size_t consts = (64 + 4 * 1024) * sizeof(float);
     const size_t lds_x = kMxWaves * kMxStageFloats<true> * sizeof(float) + consts, lds_y = kMxWaves * kMxStageFloats<false> * sizeof(float) + consts;
     const bool whole = mx_whole_lines(a, src, dst);
-#define RF_MX_P2P_NT(NLQ, NT)                                                                                                          \
-    if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass2p_kernel<false, NLQ, NT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);  \
-    else hipLaunchKernelGGL((mx_pass2p_kernel<true, NLQ, NT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);
+#define RF_MX_P2P_NB(NLQ, NT, NBT)                                                                                                     \
+    if (a.mode == MX_Y) hipLaunchKernelGGL((mx_pass2p_kernel<false, NLQ, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_y, stream, src, dst, a);  \
+    else hipLaunchKernelGGL((mx_pass2p_kernel<true, NLQ, NT, NBT>), mx_grid(a), dim3(kMxThreads), lds_x, stream, src, dst, a);
+#define RF_MX_P2P_NT(NLQ, NT) if (a.NB == 4) { RF_MX_P2P_NB(NLQ, NT, 4) } else { RF_MX_P2P_NB(NLQ, NT, 0) }
 #define RF_MX_P2P(NLQ) if (whole) { RF_MX_P2P_NT(NLQ, true) } else { RF_MX_P2P_NT(NLQ, false) }
     switch ((a.k + 7) >> 3) {
         case 1: RF_MX_P2P(1) break;
@@ -858,6 +893,7 @@ int launch_mx_pass2_pair(const float *src, float *dst, const MxPassArgs &a, hipS
     }
 #undef RF_MX_P2P
 #undef RF_MX_P2P_NT
+#undef RF_MX_P2P_NB
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
