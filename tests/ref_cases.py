@@ -202,42 +202,150 @@ def random_image(shape, dtype=np.float32, seed=1234):
     return rng.random(size=shape, dtype=np.float32).astype(dtype)
 
 
+def cuda_image(shape, dtype=np.float32, seed=1234, lo=None, hi=None):
+    """random_image on the GPU: the values are drawn on the host from the seeded numpy generator and copied, so the input of
+    a GPU test is the same on every box (a device-side torch.rand depends on the generator state the test inherits).
+    Integers: uniform in [lo, hi) (default [0, 256))."""
+    import torch
+    dt = np.dtype(dtype)
+    if np.issubdtype(dt, np.integer):
+        img = np.random.default_rng(seed).integers(0 if lo is None else lo, 256 if hi is None else hi, size=shape).astype(dt)
+    elif dt == np.float64:
+        img = np.random.default_rng(seed).random(size=shape)
+    else:
+        img = random_image(shape, dt, seed)
+    return torch.from_numpy(np.ascontiguousarray(img)).cuda()
+
+
 def ones_image(shape, dtype=np.float32):
     """Generator (i): what the reference's generate_random_image really returns."""
     return np.ones(shape, dtype=dtype)
 
 
+def _note(metric, value, out, ref, out_dtype=None):
+    """Record mode (tests/parity_record.py, RF_RECORD_PARITY=<file>): every metric evaluation is written down with the oracle
+    call its reference came from, so that tests/metric_margin.py can replay the assertion through the f32 oracle."""
+    import parity_record
+    parity_record.note_metric(metric, value, out, ref, out_dtype)
+    return value
+
+
 def rel_err_strict(out, ref):
     """SURVEY 8d's parity metric, literally: max over pixels of |out-ref| / max(|ref|, 1e-6)
     (the comparison of lib/recfilter.h:818-821 made relative)."""
+    dt = getattr(out, "dtype", None)
     out = np.asarray(out, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
-    return float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6)))
+    return _note("strict", float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6))), out, ref, dt)
+
+
+HIGHPASS_FLOOR = 1e-1
 
 
 def rel_err_highpass_floor(out, ref):
-    """Metric for HIGH-PASS results only: |out-ref| / max(|ref|, 1 % of the image's peak magnitude).
+    """Metric for HIGH-PASS results only: |out-ref| / max(|ref|, HIGHPASS_FLOOR = 10 % of the image's peak magnitude), i.e.
+    an error of at most 1e-5 of the peak wherever the result is small.  (Rounds 2-5 used 1 %; tests/metric_margin.py showed the
+    serial f32 reference operator itself at 2-6e-5 under that floor for four to twelve scans with negative lobes -- a margin
+    of 2-4 against 1e-4, where VERDICT r5 asks for 10.)
 
     A high-pass filter such as the B-spline prefilter (apps/bspline) produces zero crossings, where a pointwise
     relative error is ill-conditioned for ANY f32 implementation (the reference's own f32 loops included) and would
     report rounding noise of 1e-7 absolute as 1e-3 "relative".  Not used where the result stays away from zero."""
+    dt = getattr(out, "dtype", None)
     out = np.asarray(out, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
-    floor = max(1e-2 * float(np.max(np.abs(ref))), 1e-30)
-    return float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), floor)))
+    floor = max(HIGHPASS_FLOOR * float(np.max(np.abs(ref))), 1e-30)
+    return _note("floor", float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), floor))), out, ref, dt)
+
+
+def rel_err_scaled(out, ref, scale):
+    """Metric for results that are SUMS OF TERMS which may cancel (a pointwise consumer `w_f F(x') + w_i x' + b`, an
+    unsharp mask, a difference of filters): |out-ref| / max(scale, 1e-6) with `scale` = the sum of the terms' magnitudes,
+    pixel by pixel.  One f32 rounding of an O(1) term is 6e-8 absolute whatever the terms cancel to; judged against the
+    result alone (4.5e-4 where -0.7 F + 1.7 x' + 0.1 nearly cancels) it reads as 2e-4 "relative" for the f32 reference
+    operator itself (tests/metric_margin.py measures the margin of every assertion)."""
+    dt = getattr(out, "dtype", None)
+    out = np.asarray(out, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), ref.shape)
+    return _note("scaled", float(np.max(np.abs(out - ref) / np.maximum(scale, 1e-6))), out, ref, dt)
 
 
 def has_zero_crossings(ref):
     """True when the reference result changes sign (or touches zero): the result of a high-pass filter, or of random
-    coefficients with negative lobes, where only the floored metric is meaningful.  A large dynamic range alone (a
-    summed-area table runs from 0.8 to 3e7) is NOT a reason to leave the strict metric."""
+    coefficients with negative lobes.  (Rounds 2-5 chose the metric with this test; it does not see a result that keeps one sign
+    and still cancels to 1e-3 of its operands at some pixel -- tests/metric_margin.py found 23 such assertions -- so rel_err no
+    longer depends on it.  pointwise_scale still uses it for the filtered term of an epilogue.)"""
     r = np.asarray(ref, dtype=np.float64)
     lo, hi = float(r.min()), float(r.max())
     return (lo < 0.0 < hi) or float(np.abs(r).min()) < 1e-6
 
 
-def rel_err(out, ref):
-    """The parity metric the tests assert against 1e-4: STRICT pointwise (rel_err_strict) wherever the reference
-    result stays away from zero -- every low-pass BASELINE config (summed-area tables, Gaussians, the 3-D filter) on
-    the positive synthetic images -- and the floored high-pass metric only for results with zero crossings."""
-    return rel_err_highpass_floor(out, ref) if has_zero_crossings(ref) else rel_err_strict(out, ref)
+LOCAL_FLOOR = 0.1        # a sample counts with at least this fraction of the largest magnitude in its neighbourhood ...
+LOCAL_RADIUS = 32        # ... of this many samples either side, along every axis (images and volumes: Gaussians of sigma 5)
+LOCAL_RADIUS_1D = 256    # ... and for 1-D signals: the audio biquads (apps/audio) ring for hundreds of samples
+
+
+def local_radius(ndim):
+    return LOCAL_RADIUS_1D if ndim == 1 else LOCAL_RADIUS
+
+
+def rel_err_local_floor(out, ref):
+    """THE parity metric of the tests: max over samples of |out - ref| / max(|ref|, LOCAL_FLOOR x the largest |ref| within
+    LOCAL_RADIUS samples along every axis (LOCAL_RADIUS_1D for 1-D signals), 1e-6).
+
+    Where the result is smooth and keeps its sign -- every low-pass BASELINE config on the positive synthetic images: summed-area
+    tables, Gaussians, B-splines of positive data, the 3-D filter -- a sample IS of its neighbourhood's magnitude and this is
+    the strict pointwise relative error of SURVEY 8d (lib/recfilter.h:818-821 made relative), large dynamic ranges included (a
+    summed-area table runs from 0.8 to 3e7 smoothly).  Where a result passes through or near zero between samples of ordinary
+    size -- a high-pass filter, random coefficients with negative lobes, a centred input -- that sample is a sum of cancelling
+    terms of its neighbours' size, and a relative error against the cancelled value is ill-conditioned for ANY f32
+    implementation, the reference operator's own loops included: one rounding of an O(1) term is 6e-8 absolute, 2e-4 "relative"
+    at a sample of 3e-4.  There the error is held to 1e-4 x 10 % of the LOCAL peak (not the image's: a response that grows
+    across the image is judged by what surrounds the sample).  tests/metric_margin.py replays every recorded assertion of the
+    GPU suite through the f32 oracle on 200 seeds to show the reference passes this metric with a margin."""
+    from scipy.ndimage import maximum_filter
+    dt = getattr(out, "dtype", None)
+    out = np.asarray(out, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    mag = np.abs(ref)
+    floor = LOCAL_FLOOR * maximum_filter(mag, size=2 * local_radius(mag.ndim) + 1, mode="nearest") if mag.size else mag
+    return _note("local", float(np.max(np.abs(out - ref) / np.maximum(np.maximum(mag, floor), 1e-6))) if mag.size else 0.0, out, ref, dt)
+
+
+def rel_err(out, ref, scale=None):
+    """The parity metric the tests assert against 1e-4: rel_err_local_floor -- strict pointwise wherever the result is smooth
+    and one-signed, floored at 10 % of the local peak where it cancels.  `scale` (the magnitude of the terms a pointwise stage
+    adds up, see pointwise_want) selects rel_err_scaled instead."""
+    if scale is not None:
+        return rel_err_scaled(out, ref, scale)
+    return rel_err_local_floor(out, ref)
+
+
+def pointwise_want(img, scans, clamped, prologue=None, epilogue=None, apply_filter=None):
+    """(want, scale) of a plan with pointwise stages (rf_pointwise_desc): x' = p0 x + p1 evaluated in the pixel type as the
+    kernels do, F = the f64 oracle on x', want = e0 F + e1 x' + e2, scale = |e0 F| + |e1 x'| + |e2| (the terms' magnitudes:
+    what rel_err(out, want, scale=scale) judges the error against).  Without an epilogue scale is None: the plain metric."""
+    import oracle
+    import parity_record
+    x = img.astype(np.float64)
+    if prologue is not None:
+        x = (np.float32(prologue[0]) * img + np.float32(prologue[1])).astype(np.float64) if img.dtype == np.float32 \
+            else prologue[0] * x + prologue[1]
+    f = (apply_filter or oracle.apply_filter)(x, scans, clamped)
+    if epilogue is None:
+        return f, None
+    parity_record.note_epilogue(epilogue, x)
+    e0, e1, e2 = (float(v) for v in epilogue)
+    return e0 * f + e1 * x + e2, pointwise_scale(f, x, epilogue)
+
+
+def pointwise_scale(f, x, epilogue):
+    """|e0 F| + |e1 x'| + |e2|, pixel by pixel.  Where F itself changes sign (a prologue that centres the input, a high-pass
+    filter) its small values are sums of large cancelling contributions, ill-conditioned like any zero crossing: there the
+    filtered term counts with at least HIGHPASS_FLOOR of its peak, the floor rel_err_highpass_floor gives such an F on its own."""
+    e0, e1, e2 = (float(v) for v in epilogue)
+    tf = np.abs(e0 * f)
+    if has_zero_crossings(f):
+        tf = np.maximum(tf, HIGHPASS_FLOOR * float(tf.max()))
+    return tf + np.abs(e1 * x) + abs(e2)

@@ -209,6 +209,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 assert dist.get_backend() == "nccl"
 # the exchange of ShardedFilter._run: byte buffers, all_gather_into_tensor issued under a side stream, twice in flight
 streams = [torch.cuda.Stream() for _ in range(2)]
+torch.manual_seed(212)
 send = [torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, device="cuda") for _ in range(2)]
 got = [torch.zeros(1 << 20, dtype=torch.uint8, device="cuda") for _ in range(2)]
 for it in range(4):

@@ -182,11 +182,7 @@ def test_cfg5_1024_cubed_against_the_oracle_strict():
     got = _gpu((n, n, n), scans, False, img)
     want = img.astype(np.float64)
     del img
-    ext = (oracle.ctypes.c_int64 * 3)(n, n, n)
-    arr, ns = oracle._scan_array(scans)
-    rcode = oracle.lib().orc_apply_filter(want.ctypes.data_as(oracle.ctypes.c_void_p), oracle.F64, 3, ext, arr, ns,
-                                          oracle.BORDER_ZERO, _threads())            # in place: no second 8 GiB copy
-    assert rcode == 0
+    oracle.apply_filter(want, scans, False, threads=_threads(), inplace=True)         # in place: no second 8 GiB copy
     assert _strict_err(got, want, rows=4096) < TOL
 
 

@@ -260,9 +260,8 @@ def test_matrix_path_with_pointwise_stages():
     with rfa.Plan(img.shape, scans, clamped=True, prologue=(0.5, 0.25), epilogue=(2.0, -1.0, 0.125), path=MX) as plan:
         assert plan.path == MX
         out = plan.execute([dev])[0].cpu().numpy()
-    xp = img.astype(np.float64) * 0.5 + 0.25
-    want = 2.0 * oracle.apply_filter(xp, scans, True) - xp + 0.125
-    assert rc.rel_err(out, want) < TOL
+    want, scale = rc.pointwise_want(img, scans, True, (0.5, 0.25), (2.0, -1.0, 0.125))
+    assert rc.rel_err(out, want, scale=scale) < TOL        # judged against the terms' magnitudes: 2 F - x' may cancel
 
 
 PAIR_CASES = {

@@ -81,7 +81,7 @@ def test_small_images_take_the_line_kernels_and_pointwise_stages_the_tiled_passe
     assert path == "untiled"
     _check(imgs, outs, scans, True)
     # uint8 input + prologue + unsharp-mask epilogue: fused into the tiled passes, as shipped
-    img8 = torch.randint(0, 256, (300, 768), dtype=torch.uint8, device="cuda")
+    img8 = rc.cuda_image((300, 768), np.uint8, 84)
     w = 0.7
     with rfa.Plan((300, 768), scans, clamped=True, prologue=(1.0 / 255.0, 0.0), epilogue=(-w, 1.0 + w, 0.0), input_dtype=np.uint8) as plan:
         assert plan.path_name == "tiled_fused"
