@@ -380,8 +380,13 @@ __global__ void __launch_bounds__(kCarryLines * NCHB)
 carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__restrict__ incoming,
                   const Acc *__restrict__ Wtab, const Acc *__restrict__ Atab, const Acc *__restrict__ AC, int C,
                   Acc *__restrict__ send) {
-    __shared__ Acc exits[kCarryChunks][kCarryLines][K];
-    __shared__ Acc edge[kCarryChunks][2][kCarryLines][K];      // first / last completed tail of every chunk (scan s0)
+    // LDS by the launch's chunk count (pair_lds_bytes): sized for 16 chunks it was 24 KiB -- six workgroups per CU, and where the
+    // lines alone fill the chip (a volume's 4 M lines: ONE chunk-wave per workgroup) that meant six WAVES per CU on a kernel
+    // that does nothing but wait for its 64 loads (config 5 at 2048^3: x / y / z carries 0.47 / 0.67 / 0.69 ms at 2.3-3.1 TB/s)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pair_raw[];
+    const int n_chunks = (int)blockDim.x / kCarryLines;
+    Acc (*exits)[kCarryLines][K] = reinterpret_cast<Acc (*)[kCarryLines][K]>(pair_raw);                       // [n_chunks]
+    Acc (*edge)[2][kCarryLines][K] = reinterpret_cast<Acc (*)[2][kCarryLines][K]>(exits + n_chunks);          // [n_chunks]: first / last completed tail of every chunk (scan s0)
 
     const int ln = threadIdx.x & (kCarryLines - 1);
     const int ch = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kCarryLines);    // wave-uniform
@@ -390,7 +395,6 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
     const bool line_ok = line_raw < L;
     const uint32_t line = line_ok ? line_raw : L - 1;
     const int M = g.M;
-    const int n_chunks = (int)blockDim.x / kCarryLines;
     const int t0 = ch * C;                                   // first owned tile (memory order)
     int nvalid = M - t0;
     nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);     // wave-uniform
@@ -695,9 +699,10 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     if constexpr (sizeof(Acc) == 4) {
         static const bool pair_off = RF_KNOB("RF_CARRY_NO_PAIR") != nullptr;     // tuning knob: always the general kernel
         if (s_end - s_begin == 2 && K <= 2 && (int64_t)n_chunks * C >= a.M && !pair_off) {
-            if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1, kCarryMaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+            const size_t lds = (size_t)n_chunks * 3 * kCarryLines * K * sizeof(Acc);      // exits + edge, per chunk-wave
+            if (K == 1) hipLaunchKernelGGL((carry_pair_kernel<Acc, 1, kCarryMaxC>), dim3(grid), dim3(threads), lds, stream, g, s_begin, a.tails,
                                            (const Acc *)a.incoming, a.W, a.A, AC, C, send);
-            else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2, kCarryMaxC>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+            else        hipLaunchKernelGGL((carry_pair_kernel<Acc, 2, kCarryMaxC>), dim3(grid), dim3(threads), lds, stream, g, s_begin, a.tails,
                                            (const Acc *)a.incoming, a.W, a.A, AC, C, send);
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
@@ -706,7 +711,8 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
         if (s_end - s_begin == 2 && K == 3 && a.M > 64 && C > kCarryPair3MaxC && C <= kCarryMaxC && n_chunks <= kCarryPair3Chunks &&
             (int64_t)n_chunks * C >= a.M && !pair_off && !pair3_off) {
             // order 3: eight waves of up to 16 tiles (158 registers, no scratch)
-            hipLaunchKernelGGL((carry_pair_kernel<Acc, 3, kCarryMaxC, kCarryPair3Chunks>), dim3(grid), dim3(threads), 0, stream, g, s_begin, a.tails,
+            hipLaunchKernelGGL((carry_pair_kernel<Acc, 3, kCarryMaxC, kCarryPair3Chunks>), dim3(grid), dim3(threads),
+                               (size_t)n_chunks * 3 * kCarryLines * 3 * sizeof(Acc), stream, g, s_begin, a.tails,
                                (const Acc *)a.incoming, a.W, a.A, AC, C, send);
             RF_HIP_CHECK(hipGetLastError());
             return RF_OK;
