@@ -152,7 +152,14 @@ typedef struct {
  *   RF_PLAN_TILE_ROWS(n) /  n = 32, 64 or 128: tile height of the fused x/y stage / tile width of the strided z stage,
  *   RF_PLAN_TILE_PLANES(n)  where the shape admits it (default: chosen from the image size; rf_plan_tiles reports it).
  *                           rf_filter_desc.tile[] stays what RecFilter::split passes: binding on the generic and
- *                           overlapped paths, a hint on the fused path (the tile size never changes the result). */
+ *                           overlapped paths, a hint on the fused path (the tile size never changes the result).
+ *   RF_PLAN_INPLACE_Z       3-D on the fused path: the z stage filters the x/y stage's result where it lies, in the output
+ *                           planes.  Default for volumes of at least 2^28 samples: the x/y stage writes a plan-owned
+ *                           INTERMEDIATE VOLUME and the z stage reads it (rf_plan_workspace_bytes grows by one volume) --
+ *                           a final z pass that reads and writes the same addresses runs 4 % slower (its read and write
+ *                           fronts chase each other through the same DRAM banks: tools/microbench/zpass_shape.hip) -- as
+ *                           long as that volume is at most a third of the device memory free when the plan is built.
+ *                           Same kernels, same results either way. */
 #define RF_PLAN_FORCE_EXCHANGE  0x01u
 #define RF_PLAN_TILED_ONLY      0x02u
 #define RF_PLAN_NO_CASCADE      0x04u
@@ -165,7 +172,8 @@ typedef struct {
 #define RF_PLAN_MFMA_PASS1      0x02000000u
 #define RF_PLAN_WALK_PASS1      0x04000000u
 #define RF_PLAN_NO_OVERLAP      0x08000000u
-#define RF_PLAN_ALL_FLAGS       0x0f0000ffu
+#define RF_PLAN_INPLACE_Z       0x10000000u
+#define RF_PLAN_ALL_FLAGS       0x1f0000ffu
 #define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
 #define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
 

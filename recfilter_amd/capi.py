@@ -34,6 +34,7 @@ RF_PLAN_SERIAL_UNTILED = 0x01000000
 RF_PLAN_MFMA_PASS1 = 0x02000000
 RF_PLAN_WALK_PASS1 = 0x04000000
 RF_PLAN_NO_OVERLAP = 0x08000000
+RF_PLAN_INPLACE_Z = 0x10000000
 
 
 def RF_PLAN_TILE_ROWS(n: int) -> int:

@@ -109,6 +109,10 @@ struct rf_plan {
     const void *in[RF_MAX_PLANES] = {nullptr};       // what the first filter stage reads (== out after pointwise_pre)
     const void *orig_in[RF_MAX_PLANES] = {nullptr};  // the caller's input planes
     void *out[RF_MAX_PLANES] = {nullptr};
+    // 3-D on the fused path (plan_fused.cpp, "intermediate volume"): where the x/y stage writes and the strided z stage
+    // reads -- a workspace volume per plane, or null: the output planes themselves (the z stage then runs in place)
+    void *mid[RF_MAX_PLANES] = {nullptr};
+    void *xy_result(int pl) const { return mid[pl] ? mid[pl] : out[pl]; }
     hipStream_t stream = nullptr;
     int phase = 0;   // 0 idle, 1 begun
     // 1-D signals whose length is not a multiple of 8192 on the fused path: zero-padded copies the kernels run on

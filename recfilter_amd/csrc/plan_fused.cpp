@@ -394,7 +394,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         a.x_incoming = xin + (size_t)pl * xin_pp;
         a.plane_batch = batch ? 1 : 0;
         if (batch)
-            for (int i = 0; i < plan->n_planes; i++) { a.in_planes[i] = plan->in[i]; a.out_planes[i] = plan->out[i]; }
+            for (int i = 0; i < plan->n_planes; i++) { a.in_planes[i] = plan->in[i]; a.out_planes[i] = plan->xy_result(i); }
         return a;
     };
     GenericDimArgs<Acc> gx{};
@@ -615,9 +615,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         a.y_apply = d_Yapply;
         if (merged_cx) a.xt = xt_done + (size_t)pl * xt_pp;
         if constexpr (sizeof(Acc) == 4) {
-            if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->out[pl], a, plan->stream);
+            if (TY == 128) return launch_fused_pass2_tall<P>(K, plan->in[pl], plan->pw.in_u8, (P *)plan->xy_result(pl), a, plan->stream);
         }
-        return launch_fused_pass2<P>(K, TY, padded ? plan->pad_in[pl] : plan->in[pl], plan->pw.in_u8, (P *)(padded ? plan->pad_out[pl] : plan->out[pl]), a,
+        return launch_fused_pass2<P>(K, TY, padded ? plan->pad_in[pl] : plan->in[pl], plan->pw.in_u8, (P *)(padded ? plan->pad_out[pl] : plan->xy_result(pl)), a,
                                      plan->stream);
     };
     if (y_is_exchange_dim) plan->finish_steps.push_back(p2);
@@ -635,6 +635,23 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
 
     // ---- z (3-D): filtered after the fused x/y stage, reading and writing the output planes ----
     if (plan->ndim > 2 && !plan->dims[2].scan_ids.empty()) {
+        // Intermediate volume (RF_PLAN_INPLACE_Z forbids it): a final z pass that reads and writes the SAME addresses is 4 %
+        // slower than one from one volume to another -- its write front follows its read front through the same DRAM banks
+        // (tools/microbench/zpass_shape.hip: 2.95 against 2.82 ms per 512 planes of 2048^2; config 5 at 2048^3: 12.3 -> 11.8 ms).
+        // Large volumes on the strided kernels therefore get a plan-owned volume between the two stages, as long as it is at
+        // most a third of the memory the device has free now.  The x/y stage writes it, the z stage reads it and writes the
+        // output planes; nothing else looks at the x/y stage's result.
+        if constexpr (sizeof(Acc) == 4) {
+            const size_t mid_bytes = (size_t)plan->total * sizeof(P);
+            if (!(plan->flags & RF_PLAN_INPLACE_Z) && !plan->host_only && !padded && strided_tile(plan, 2) > 0 &&
+                plan->total >= ((int64_t)1 << 28)) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && mid_bytes * (size_t)plan->n_planes <= free_b / 3) {
+                    for (int pl = 0; pl < plan->n_planes && status == RF_OK; pl++) plan->mid[pl] = plan->alloc(mid_bytes, false, &status);
+                    if (status != RF_OK) return status;
+                }
+            }
+        }
         int rc;
         if constexpr (sizeof(Acc) == 4)
             rc = strided_tile(plan, 2) > 0 ? add_strided_dimension<P, S>(plan, 2, /*from_input=*/false, desc, first_begin_step,

@@ -209,7 +209,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
     p1.name = "strided_pass1_" + dn;
     if (walk) { walk->zt = reinterpret_cast<float *>(tails); walk->zt_stride = tails_stride; }
     p1.run = [plan, sargs, K, TZ, from_input, early](int pl) {
-        const P *src = (from_input || early) ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
+        const P *src = (from_input || early) ? (const P *)plan->in[pl] : (const P *)plan->xy_result(pl);
         return launch_strided_pass<P>(false, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
     };
     if (early) {
@@ -314,7 +314,7 @@ int add_strided_dimension(rf_plan *plan, int d, bool from_input, const rf_filter
     Step p2;
     p2.name = "strided_pass2_" + dn;
     p2.run = [plan, sargs, K, TZ, from_input](int pl) {
-        const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->out[pl];
+        const P *src = from_input ? (const P *)plan->in[pl] : (const P *)plan->xy_result(pl);
         return launch_strided_pass<P>(true, K, TZ, src, (P *)plan->out[pl], sargs(pl), plan->stream);
     };
     if (d == outer) plan->finish_steps.push_back(p2);

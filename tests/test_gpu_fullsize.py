@@ -221,6 +221,30 @@ def test_cfg5_2048_cubed_separable_volumes_and_sharded_equality():
         p.close()
 
 
+def test_volume_between_the_stages_changes_nothing_but_the_workspace():
+    """Volumes of 2^28 samples and more: the x/y stage writes a plan-owned intermediate volume that the z stage reads (a final z
+    pass that reads and writes the same addresses is 4 % slower: tools/microbench/zpass_shape.hip); RF_PLAN_INPLACE_Z keeps the
+    z stage in the output planes.  Same kernels either way: bit-identical results, in place (in == out) too; the workspace
+    differs by one volume per plane.  (test_cfg5_1024_cubed_against_the_oracle_strict holds the default against the oracle.)"""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    shape = (256, 1024, 1024)                            # 2^28 samples: the smallest volume that takes it
+    scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+    x = rc.cuda_image(shape, np.float32, 41)
+    with rfa.Plan(shape, scans) as plan, rfa.Plan(shape, scans, flags=capi.RF_PLAN_INPLACE_Z) as inplace:
+        assert plan.path == 3 and inplace.path == 3
+        assert plan.workspace_bytes() - inplace.workspace_bytes() == x.numel() * 4
+        a = plan.execute([x])[0]
+        b = inplace.execute([x])[0]
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        y = x.clone()
+        c = plan.execute([y], [y])[0]                    # in == out: the intermediate volume is what makes this an out-of-place z pass
+        torch.cuda.synchronize()
+        assert torch.equal(a, c)
+
+
 def test_cfg5_256_cubed_separable_matches_direct_oracle():
     """Sanity of the separable reference itself at a size where the direct oracle is cheap: both must agree."""
     import torch
