@@ -82,6 +82,9 @@ struct GenericDimArgs {
                                // tail of the i-th tile in scan direction (carry_apply); may be null (serial fallback)
     int32_t tile_major;        // tails laid out [tile][line / 256][scan][r][256] (the y tails of the fused path) -- only the
                                // blocked carry scan (kernels_carry.hip) reads this flag
+    const Acc *tails_part2;    // the tile-local tails arrive in TWO parts (the tall patches of kernels_tails_walk.hip: a tile's
+                               // column halves): tails + tails_part2, same layout; the blocked carry scan adds them up as it
+                               // loads them and stores the completed tails to `tails`.  Null: one part.
 };
 
 template <typename P>

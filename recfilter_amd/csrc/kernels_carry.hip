@@ -50,6 +50,7 @@ struct CarryGeom {
     int32_t n_scans;
     int32_t first_is_border, last_is_border;
     uint32_t causal_mask;    // bit s = scan s is causal
+    const void *part2;       // second part of the tile-local tails (GenericDimArgs::tails_part2), or null
 };
 
 // element offset of tail (scan s, tile tt, component r) of `line`
@@ -186,6 +187,10 @@ carry_block_kernel(CarryGeom g, int s_begin, int s_end, Acc *__restrict__ tails,
                     const int tt = causal ? base_i + ii : M - 1 - (base_i + ii);
 #pragma unroll
                     for (int r = 0; r < K; r++) cur[ii][r] = tails[tail_off<K>(g, s, tt, r, line)];
+                    if (g.part2 != nullptr) {
+#pragma unroll
+                        for (int r = 0; r < K; r++) cur[ii][r] = cur[ii][r] + static_cast<const Acc *>(g.part2)[tail_off<K>(g, s, tt, r, line)];
+                    }
                 }
             }
             for (int q = 0; q < s; q++) {
@@ -410,6 +415,23 @@ carry_pair_kernel(CarryGeom g, int s0, Acc *__restrict__ tails, const Acc *__res
 #pragma unroll
                 for (int r = 0; r < K; r++) t[ii][r] = tails[tail_off<K>(g, s, t0 + ii, r, line)];
             }
+        }
+        if (g.part2 != nullptr) {          // the tile-local tails in two parts: requested with the first, added once both are there
+            const Acc *p2 = static_cast<const Acc *>(g.part2);
+            Acc u[MAXC][KP];
+#pragma unroll
+            for (int ii = 0; ii < MAXC; ii++) {
+#pragma unroll
+                for (int r = 0; r < KP; r++) u[ii][r] = Acc(0);
+                if (ii < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < K; r++) u[ii][r] = p2[tail_off<K>(g, s, t0 + ii, r, line)];
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < MAXC; ii++)
+#pragma unroll
+                for (int r = 0; r < KP; r++) t[ii][r] = t[ii][r] + u[ii][r];
         }
     };
     load_scan(ta, s0);
@@ -683,6 +705,8 @@ int launch_carry_block(int K, const GenericDimArgs<Acc> &a, uint32_t causal_mask
     g.M = a.M; g.n_scans = a.n_scans;
     g.first_is_border = a.first_is_border; g.last_is_border = a.last_is_border;
     g.causal_mask = causal_mask;
+    g.part2 = a.tails_part2;
+    if (g.part2 != nullptr && pre != nullptr) { set_error("carry: tails in two parts do not go with a chain prologue"); return RF_ERR_INVALID_ARG; }
     const unsigned grid = (unsigned)((a.g.lines + kCarryLines - 1) / kCarryLines);
     // one wave per chunk of C tiles; a line with few tiles gets fewer waves instead of idle ones
     int n_chunks = carry_chunk_count(a.M, a.g.lines, C, K);

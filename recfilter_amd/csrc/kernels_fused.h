@@ -211,6 +211,10 @@ struct WalkArgs {
     int32_t parts_log2;      // log2(TY / 32)
     int32_t z_first_border, z_last_border;      // the slab holds the volume's first / last z tile
     int32_t nzk, KZ;         // z tails per sample (= scans along z * KZ), order of the z scans
+    // tall patches (128 columns x 64 rows, kernels_tails_walk.hip TALL): TY / 64 parts of the combined rows, and the x tails of
+    // a tile in two parts -- its left half in FusedArgs::xt, its right half in xt2 (same layout)
+    int32_t tall;
+    float *xt2;
 };
 bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ, int last_cols, int last_rows);
 int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const WalkArgs &wa, const float *Hx, const float *Hy,

@@ -326,7 +326,12 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
                             for (int z = 0; z < TZ; z++)
                                 hHz[((size_t)v * TZ + z) * 4 + j] = table_to_acc<S, Acc>(H[((size_t)v * nz * KZ + j) * TZ + z]);
                     plan->tables["H_z"] = dHz;
-                    const int parts = TY / 32;
+                    // tall patches (128 columns x 64 rows, round 6): 128-row y tiles, at most four x tails
+                    static const bool tall_off = RF_KNOB("RF_WALK_NO_TALL") != nullptr;       // A/B
+                    const bool tall = !tall_off && TY == 128 && K <= 2 && nx * K <= 4;
+                    const int parts = tall ? TY / 64 : TY / 32;
+                    walk_args.tall = tall ? 1 : 0;
+                    walk_args.xt2 = tall ? (float *)plan->alloc(xt_pp * np * sizeof(float), false, &status) : nullptr;      // (per Tuple plane)
                     walk_args.HzT = (const float *)plan->upload(hHz.data(), hHz.size() * sizeof(float), &status);
                     walk_args.TY = TY; walk_args.TZ = TZ; walk_args.MZ = MZ; walk_args.nzk = nz * KZ; walk_args.KZ = KZ;
                     walk_args.parts_log2 = parts == 4 ? 2 : parts == 2 ? 1 : 0;
@@ -373,7 +378,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     fbase.lin_limit = in_place_tail ? dx.N : 0;
     if constexpr (std::is_same<P, float>::value) {
         // (pass 1 left the combined rows in parts: xscan_rows adds them up)
-        if (walk && walk_args.ytp) { fbase.yt_parts = TY / 32; fbase.yt_part_stride = walk_args.part_stride; fbase.ytp = walk_args.ytp; }
+        if (walk && walk_args.ytp) { fbase.yt_parts = walk_args.tall ? TY / 64 : TY / 32; fbase.yt_part_stride = walk_args.part_stride; fbase.ytp = walk_args.ytp; }
     }
     std::memset(fbase.xs, 0, sizeof(fbase.xs));
     std::memset(fbase.ys, 0, sizeof(fbase.ys));
@@ -406,6 +411,9 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
         GenericDimArgs<Acc> a = gx;
         a.tails = xt + (size_t)pl * xt_pp;
         a.incoming = xin + (size_t)pl * xin_pp;
+        if constexpr (std::is_same<P, float>::value) {
+            if (walk_args.xt2) a.tails_part2 = walk_args.xt2 + (size_t)pl * xt_pp;       // (tall patches: the x tails in two parts)
+        }
         return a;
     };
     GenericDimArgs<Acc> gy{};
@@ -432,7 +440,8 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
     const int stream_mode = (plan->flags & RF_PLAN_STREAM_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
     const int mfma_mode = (plan->flags & RF_PLAN_MFMA_PASS1) ? 1 : (plan->flags & RF_PLAN_STAGED_PASS1) ? -1 : 0;
     if (walk) p1.name = "walk_tails";
-    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode, mfma_mode, walk_args, walk_hook](int pl) {
+    p1.run = [plan, fargs, K, TY, d_Hx, d_Hy, padded, stream_mode, mfma_mode, walk_args, walk_hook, xt_pp](int pl) {
+        (void)xt_pp;
         const FusedArgs<Acc> a = fargs(pl);
         (void)stream_mode;
         (void)mfma_mode;
@@ -441,6 +450,7 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             if (walk_hook) {
                 WalkArgs wa = walk_args;
                 wa.zt = walk_hook->zt + (size_t)pl * walk_hook->zt_stride;
+                if (wa.xt2) wa.xt2 += (size_t)pl * xt_pp;
                 if (wa.ytp) wa.ytp = const_cast<float *>(a.ytp);       // this plane's parts (fargs)
                 else wa.ytp = a.yt;                         // one patch per y tile: the combined rows go where they belong
                 return launch_walk_tails(K, (const float *)plan->in[pl], a, wa, d_Hx, d_Hy, plan->stream);

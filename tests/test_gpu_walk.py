@@ -170,6 +170,34 @@ def test_one_read_pass1_partial_tiles(shape, clamped):
         assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < (2e-5 if scans is XY_ORDER3 else 2e-6), (shape, clamped, pro)
 
 
+@pytest.mark.parametrize("shape", [(32, 200, 444), (32, 128, 356), (32, 129, 388), (64, 256, 512), (32, 70, 132), (32, 250, 640)])
+@pytest.mark.parametrize("clamped", [False, True])
+def test_one_read_pass1_tall_patches(shape, clamped):
+    """128-row y tiles, orders <= 2 along x / y: the pass runs on patches of 128 columns x 64 rows (round 6) -- two parts of
+    the combined rows per y tile instead of four, the x tails of a tile in two parts (its column halves) that the carry scan
+    along x adds up.  Whole tiles; a last tile whose right half is partial, missing, or four columns wide; a last tile row of
+    72, 1 and 6 rows; one scan per dimension and order 1 as well."""
+    import torch
+    import recfilter_amd as rfa
+    from recfilter_amd import capi
+    rng = np.random.default_rng(29)
+    img = rng.random(shape, dtype=np.float32)
+    x = torch.from_numpy(img).cuda()
+    out = torch.empty_like(x)
+    flags = capi.RF_PLAN_WALK_PASS1 | capi.RF_PLAN_TILE_ROWS(128)
+    for scans, pro in ((XYZ, None), (ONE_EACH, (0.5, 0.25)), (ORDER1, None), (TWO_X_ONE_Y, None)):
+        kw = dict(prologue=pro) if pro else {}
+        with rfa.Plan(shape, scans, clamped=clamped, flags=flags, path=capi.RF_PATH_TILED_FUSED, **kw) as plan:
+            assert list(plan.tiles)[:2] == [256, 128]
+            _, timed = plan.execute_timed([x], [out])
+            torch.cuda.synchronize()
+        steps = [k for k, _ in timed]
+        assert "walk_tails" in steps and "strided_pass1_z" not in steps, steps
+        src = img.astype(np.float64) * pro[0] + pro[1] if pro else img.astype(np.float64)
+        want = oracle.apply_filter(src, scans, clamped)
+        assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6, (shape, clamped, len(scans))
+
+
 @pytest.mark.parametrize("what", ["int32", "odd_width", "u8_input"])   # (asked for, refused by the shape rules)
 def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
     """Integer pixels, a width that is no multiple of four, 8-bit input: the z stage runs its own first pass."""

@@ -10,13 +10,14 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int D, bool BARRIER, int STORES>     // STORES: 0 none, 1 per patch column [column][plane][288], 2 plane-major [plane][column][288]
+// TALL: the patch is 128 columns x 64 rows (grid n / 128 x n / 64) instead of 256 x 32: rows of 512 B, half the combined-row parts
+template <int D, bool BARRIER, int STORES, bool TALL = false>     // STORES: 0 none, 1 per patch column [column][plane][288], 2 plane-major [plane][column][288]
 __global__ void __launch_bounds__(1024) walk_kernel(const float *src, float *out, f4 *parts, int n, int tz) {
-    const int t = threadIdx.x, cc = t & 63, rg = t >> 6;
+    const int t = threadIdx.x, cc = TALL ? t & 31 : t & 63, rg = TALL ? t >> 5 : t >> 6;
     const int tx = blockIdx.x, py = blockIdx.y, zt = blockIdx.z;
     const size_t plane = (size_t)n * n;
-    const char *spb = reinterpret_cast<const char *>(src + (size_t)zt * tz * plane + ((size_t)py * 32) * n + (size_t)tx * 256);
-    const unsigned off0 = (unsigned)rg * n * 4u + cc * 16u, off1 = off0 + 16u * n * 4u;
+    const char *spb = reinterpret_cast<const char *>(src + (size_t)zt * tz * plane + ((size_t)py * (TALL ? 64 : 32)) * n + (size_t)tx * (TALL ? 128 : 256));
+    const unsigned off0 = (unsigned)rg * n * 4u + cc * 16u, off1 = off0 + (TALL ? 32u : 16u) * n * 4u;
     f4 pre[D][2];
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -49,6 +50,7 @@ __global__ void __launch_bounds__(1024) walk_kernel(const float *src, float *out
                 for (int i = t; i < 9216; i += 1024) q[i] = acc;
             }
             if (STORES == 8 && t < 32) parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t] = acc;      // 512 B per plane
+            if (STORES == 11 && t < 192) parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t] = acc;     // 3 KiB per plane
             if (STORES == 9 && t < 128) parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t] = acc;     // 2 KiB per plane
             if (STORES == 10) {                                                                                                 // a copy: 32 KiB per plane
                 f4 *q = reinterpret_cast<f4 *>(out) + ((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 2048;
@@ -103,6 +105,16 @@ int main(int argc, char **argv) {
     time("2 in flight, barrier, 512 B of stores per plane", L(2, true, 8));
     time("2 in flight, barrier, 2 KiB of stores per plane", L(2, true, 9));
     time("2 in flight, barrier, 32 KiB of stores per plane (copy)", L(2, true, 10));
+    {
+        dim3 gt(n / 128, n / 64, planes / tz);
+#define LT(D, B, S) [&] { hipLaunchKernelGGL((walk_kernel<D, B, S, true>), gt, dim3(1024), 0, 0, src, out, parts, n, tz); }
+        time("128 x 64 patches: 2 in flight, barrier", LT(2, true, 0));
+        time("128 x 64 patches: 2 in flight, barrier, 3 KiB of stores per plane", LT(2, true, 11));
+        time("128 x 64 patches: 2 in flight, barrier, 4.6 KiB of stores per plane", LT(2, true, 2));
+        time("256 x 32 patches: 2 in flight, barrier, 3 KiB of stores per plane", L(2, true, 11));
+        time("256 x 32 patches: 2 in flight, barrier, 4.6 KiB (again)", L(2, true, 2));
+        time("256 x 32 patches: 2 in flight, barrier, no stores (again)", L(2, true, 0));
+    }
     time("2 in flight, barrier, stores sc0", L(2, true, 20));
     time("2 in flight, barrier, stores sc1", L(2, true, 21));
     time("2 in flight, barrier, stores sc0 sc1", L(2, true, 22));
