@@ -234,7 +234,7 @@ def test_volume_between_the_stages_changes_nothing_but_the_workspace():
     x = rc.cuda_image(shape, np.float32, 41)
     with rfa.Plan(shape, scans) as plan, rfa.Plan(shape, scans, flags=capi.RF_PLAN_INPLACE_Z) as inplace:
         assert plan.path == 3 and inplace.path == 3
-        assert plan.workspace_bytes() - inplace.workspace_bytes() == x.numel() * 4
+        assert plan.workspace_bytes - inplace.workspace_bytes == x.numel() * 4
         a = plan.execute([x])[0]
         b = inplace.execute([x])[0]
         torch.cuda.synchronize()
