@@ -39,7 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def workload(name, size):
+def workload(name, size, rows=0):
     import ref_cases as rc
     if name == "order12":
         # not a BASELINE config: the matrix path's reference point -- a 16384^2 f32 image through causal +
@@ -55,6 +55,8 @@ def workload(name, size):
                                     "cfg5": "cfg5_generic_xyz"}[name]])
     if size:
         cfg["shape"] = tuple(size for _ in cfg["shape"])
+    if rows:
+        cfg["shape"] = (rows,) + tuple(cfg["shape"][1:])          # the outermost extent alone: one rank's slab of a strong-scaling run
     cfg.setdefault("planes", 1)
     return cfg
 
@@ -101,7 +103,7 @@ def pmc_traffic(kernel_name, workload, shape):
         fname = f"pmc_traffic_{workload}_{shape[0]}.json"
     else:
         return None, info
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         rel = os.path.join("profiles", rnd, fname)
         try:
             doc = json.load(open(os.path.join(ROOT, rel)))
@@ -238,7 +240,7 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
     import recfilter_amd as rfa
     from recfilter_amd.dist import ShardedFilter
 
-    cfg = workload(name, size)
+    cfg = workload(name, size, getattr(args, "rows", 0) if primary else 0)
     shape, planes = cfg["shape"], cfg["planes"]
     global_shape = tuple(shape)
     if strong and world > 1:
@@ -328,17 +330,23 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, **traffic_info,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg}
-        # device-to-device copy of the same image with torch's own kernel, timed with HIP events: what a plain
-        # read-once/write-once pass reaches on this box (SURVEY 8d asks for a measured stream-copy ceiling)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        outputs[0].copy_(inputs[0])
-        e0.record()
-        for _ in range(5):
-            outputs[0].copy_(inputs[0])
-        e1.record()
-        torch.cuda.synchronize()
-        copy_ms = e0.elapsed_time(e1) / 5
-        roofline["copy_ceiling_gbps"] = round(2 * 4 * (samples_local // planes) / (copy_ms * 1e-3) / 1e9, 1)
+        # The measured ceiling of a read-once / write-once pass on this box (SURVEY 8d asks for one): the library's own
+        # rf_stream_copy -- the final pass's access shape (256 x 128 tiles, 16-byte non-temporal loads and stores, eight loads
+        # per thread in flight) with the arithmetic and the LDS taken out -- over one plane of this workload, HIP events on the
+        # stream it runs on.  (Rounds 1-5 timed torch's copy_ here: 4.8 TB/s, BELOW what the final pass itself reaches.)
+        # two_pass_ceiling_frac: an EXACT filter reads every sample twice and writes it once -- every output depends on every
+        # input, and the image (1 GiB) does not fit the 256 MiB Infinity Cache -- so under the 8-bytes-per-sample accounting
+        # no two-pass scheme can exceed 8/12 of the rate a copy reaches; filter_frac_of_two_pass_ceiling (the line's top
+        # level) is the whole filter against that.
+        plane_rows = (samples_local // planes) // shape[-1]
+        if shape[-1] % 256 == 0 and plane_rows % 128 == 0:
+            copy_ms = rfa.stream_copy_ms(inputs[0], outputs[0], reps=5)
+            roofline["copy_ceiling_gbps"] = round(2 * 4 * (samples_local // planes) / (copy_ms * 1e-3) / 1e9, 1)
+            roofline["copy_kernel"] = "rf_stream_copy: 256 x 128 tiles, 16-byte non-temporal loads and stores (this library)"
+            roofline["two_pass_ceiling_frac"] = round((8.0 / 12.0) * roofline["copy_ceiling_gbps"] / HBM_PEAK_GBPS, 4)
+        else:
+            roofline["copy_ceiling_gbps"] = None
+            roofline["two_pass_ceiling_frac"] = None
         if not own_plan:
             plan.close()
         return roofline, kernels, preheat
@@ -481,6 +489,9 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
         # not cover
         "step_phases": phases,
         "filter_gbps": round(whole, 1), "filter_roofline_frac": round(whole / HBM_PEAK_GBPS / joined, 4),
+        # the whole filter against what an exact two-pass scheme can reach at this box's measured copy rate (see roofline)
+        "filter_frac_of_two_pass_ceiling": (round(whole / HBM_PEAK_GBPS / joined / roofline["two_pass_ceiling_frac"], 4)
+                                            if roofline.get("two_pass_ceiling_frac") else None),
         "mibipixels_per_s": round(total_px * 1000.0 / (ms_per_step * 2 ** 20), 1),   # lib/timing.cpp:3-5
         "roofline": roofline,
         "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
@@ -507,6 +518,9 @@ def main():
                     "metric is quoted on, followed by BASELINE config 5 -- 2048^3 sharded along z, strong scaling -- whose line "
                     "rides in the same JSON object under \"configs\")")
     ap.add_argument("--size", type=int, default=0, help="override every extent (debug)")
+    ap.add_argument("--rows", type=int, default=0, help="override the outermost extent alone: `--workload cfg3 --rows 2048 --force-stepping` "
+                    "under a one-rank launcher is ONE rank's share of `--gpus 8 --workload cfg3 --strong`, driven through the "
+                    "sharded protocol on one GPU (tools/rehearse_n8.py)")
     ap.add_argument("--path", type=int, default=0, help="rf_path override (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="default run: only the headline workload, not config 5 behind it")
@@ -561,7 +575,7 @@ def main():
     # GPUs) AND north_star's config 5: 2048^3, six scans of order 2, sharded along z over the N GPUs (strong scaling, the
     # early exchange); its line, same keys, is the one entry of "configs".  Any explicit --workload / --size / --path /
     # --force-stepping runs exactly what it names.
-    default_run = args.workload is None and not args.size and not args.path and not args.force_stepping and not args.strong
+    default_run = args.workload is None and not args.size and not args.rows and not args.path and not args.force_stepping and not args.strong
     name = args.workload or "cfg3"
     line = run_workload(args, dist, rank, world, name, args.size, args.strong, primary=True)
     if default_run and not args.no_extra_configs:
@@ -571,6 +585,12 @@ def main():
             line["configs"] = [extra]
         else:
             line["configs_skipped"] = f"cfg5 --strong: 2048 planes do not split into {world} slabs of whole 64-plane tiles"
+        # north_star's ">= 6x throughput at 8 GPUs" on the 16384^2 Gaussian reads as STRONG scaling: the headline image itself
+        # split into N row slabs of whole tiles, beside the weak line above (every rank a full 16384-row slab).  On one GPU the
+        # two are the same run.
+        if world > 1 and 16384 % (world * 128) == 0:
+            strong_line = run_workload(args, dist, rank, world, "cfg3", 0, True, primary=False)
+            line.setdefault("configs", []).append(strong_line)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

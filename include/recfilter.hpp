@@ -174,6 +174,7 @@ class RecFilter {
         std::map<std::string, int> tile;
         bool clamped = false, tiled = false, compiled = false, has_consumer = false;
         bool merged = false;                     // the plan holds the scans of the whole cascade this stage ends (compile_jit)
+        bool merge_at_compile = true;            // merge_cascades() when the plan was built (toggled since: execute_chain plans again)
         RecFilterPointwise consumer;
         rf_plan *plan = nullptr;
         void *stream = nullptr;                  // HIP stream of enqueue() / realize() (set_stream); null = default stream
@@ -425,7 +426,15 @@ public:
     void compile_jit(std::string = "") {
         if (c->dims.empty()) fail("filter has no definition");
         if (c->plan) { rf_plan_destroy(c->plan); c->plan = nullptr; }
-        const std::vector<const Contents *> chain = cascade_chain();
+        // The merged plan of a cascade may not exist where every stage's own plan does (more than RF_MAX_SCANS scans in all, a
+        // combination no path accepts): then this stage is planned by itself and reads its source's result, as before the
+        // merge existed.
+        if (!cascade_chain().empty() && build_plan_for(cascade_chain())) return;
+        if (!build_plan_for({})) fail(rf_last_error_string());
+    }
+
+    /** one attempt of compile_jit: the whole cascade `chain` as one plan, or (empty chain) this stage alone */
+    bool build_plan_for(const std::vector<const Contents *> &chain) {
         c->merged = !chain.empty();
         std::vector<Scan> all;                              // the stage's scans, or those of the whole cascade in stage order
         if (c->merged) { for (const Contents *p : chain) all.insert(all.end(), p->scans.begin(), p->scans.end()); }
@@ -441,6 +450,7 @@ public:
             for (size_t j = 1; j < s.coeff.size(); j++) sd[i].feedback[j - 1] = s.coeff[j];
         }
         rf_filter_desc d{};
+        d.abi = RF_ABI;
         d.ndim = (int)c->dims.size();
         for (int i = 0; i < d.ndim; i++) {
             d.extent[i] = c->dims[i].num_pixels();
@@ -465,13 +475,16 @@ public:
             d.pointwise.post_filtered = c->consumer.w_filtered; d.pointwise.post_input = c->consumer.w_input;
             d.pointwise.post_bias = c->consumer.bias;
         }
-        if (rf_plan_create(&d, &c->plan) != RF_OK) fail(rf_last_error_string());
+        if (rf_plan_create(&d, &c->plan) != RF_OK) { c->plan = nullptr; c->merged = false; return false; }
         c->compiled = true;
+        c->merge_at_compile = merge_cascades();
+        return true;
     }
 
     /** launches every upstream cascade stage, then this one, without synchronising: Func::realize on the last stage of
      *  a cascade recomputes all of its producers (they are compute_root Funcs) */
     void execute_chain() {
+        if (c->compiled && c->merge_at_compile != merge_cascades()) c->compiled = false;      // toggled since: plan again
         if (!c->compiled) compile_jit();
         std::vector<const void *> in;
         if (c->merged) {                          // the whole cascade is this one plan: it reads the head's image

@@ -177,8 +177,15 @@ typedef struct {
 #define RF_PLAN_TILE_ROWS(n)    (((uint32_t)(n) & 0xffu) << 8)
 #define RF_PLAN_TILE_PLANES(n)  (((uint32_t)(n) & 0xffu) << 16)
 
+/* Revision of the binary interface: the layout of the structs below as this header declares them.  rf_plan_create refuses a
+ * descriptor whose `abi` is not RF_ABI -- a caller compiled against another revision of the header (revision 3: RF_MAX_ORDER
+ * went from 8 to 32 in round 5, which changed sizeof(rf_scan_desc) and the row layout of rf_plan_table("scans")) gets
+ * RF_ERR_INVALID_ARG instead of a mis-strided scans array.  The field sits in what used to be the padding behind `ndim`. */
+#define RF_ABI 3u
+
 typedef struct {
     int32_t  ndim;                    /* 1..RF_MAX_DIMS                                          */
+    uint32_t abi;                     /* RF_ABI                                                  */
     int64_t  extent[RF_MAX_DIMS];     /* extent[0] = width (x)                                   */
     int32_t  dtype;                   /* rf_dtype                                                */
     int32_t  n_planes;                /* Tuple size, >= 1                                        */
@@ -325,6 +332,14 @@ typedef struct {
 } rf_tap;
 int rf_tap_filter(const void *const *in_planes, int n_in, void *out, int ndim, const int64_t *extent, int dtype,
                   const rf_tap *taps, int n_taps, void *stream);
+
+/* ---- measured copy ceiling ("also report against a measured stream-copy ceiling") ---------- */
+/* MEASUREMENT UTILITY: the final pass of the fused path with its arithmetic taken out -- every 256 x 128 tile of a dense f32
+ * image of `rows` x `width` samples (width a multiple of 256, rows a multiple of 128) read with 16-byte non-temporal loads and
+ * written with 16-byte non-temporal stores by one workgroup of 256 threads, eight loads per thread in flight.  What a
+ * read-once / write-once pass over an image reaches on the device it runs on: bench.py times it beside the filter
+ * (roofline.copy_ceiling_gbps).  src != dst.  Nothing of the filter path calls it. */
+int rf_stream_copy(const float *src, float *dst, int64_t width, int64_t rows, void *stream);
 
 /* ---- misc ------------------------------------------------------------------------------- */
 const char *rf_last_error_string(void);

@@ -9,7 +9,7 @@ from . import capi
 from .capi import RecFilterError, build_library
 from .filter import (Pointwise, RecFilter, RecFilterDim, RecFilterDimAndCausality, RecFilterSchedule,
                      RecFilterUsageError)
-from .plan import (Plan, box_difference, tap_filter, gaussian_box_filter, second_order_sections, gaussian_weights, integral_image_coeff,
+from .plan import (Plan, box_difference, tap_filter, stream_copy_ms, gaussian_box_filter, second_order_sections, gaussian_weights, integral_image_coeff,
                    overlap_feedback_coeff)
 
 __all__ = [

@@ -17,6 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 RF_MAX_DIMS = 3
 RF_MAX_ORDER = 32
+RF_ABI = 3          # revision of include/recfilter_amd.h this module mirrors (rf_filter_desc.abi)
 RF_MAX_SCANS = 32
 RF_MAX_PLANES = 16
 RF_DEVICE_HOST_ONLY = -2
@@ -56,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "rf_plan_exchange_bytes",
     "rf_plan_begin", "rf_plan_exchange_local", "rf_plan_exchange_apply", "rf_plan_has_interior", "rf_plan_interior", "rf_plan_finish", "rf_plan_abort",
     "rf_plan_table", "rf_plan_debug_buffer", "rf_gaussian_weights", "rf_integral_image_coeff", "rf_overlap_feedback_coeff",
-    "rf_gaussian_box_filter", "rf_box_difference", "rf_tap_filter", "rf_last_error_string", "rf_version", "rf_device_count",
+    "rf_gaussian_box_filter", "rf_box_difference", "rf_tap_filter", "rf_stream_copy", "rf_last_error_string", "rf_version", "rf_device_count",
 ]
 
 
@@ -72,7 +73,7 @@ class PointwiseDesc(ctypes.Structure):
 
 
 class FilterDesc(ctypes.Structure):
-    _fields_ = [("ndim", ctypes.c_int32), ("extent", ctypes.c_int64 * RF_MAX_DIMS),
+    _fields_ = [("ndim", ctypes.c_int32), ("abi", ctypes.c_uint32), ("extent", ctypes.c_int64 * RF_MAX_DIMS),
                 ("dtype", ctypes.c_int32), ("n_planes", ctypes.c_int32), ("border", ctypes.c_int32),
                 ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDesc)),
                 ("tile", ctypes.c_int32 * RF_MAX_DIMS), ("path", ctypes.c_int32),
@@ -149,6 +150,7 @@ def lib() -> ctypes.CDLL:
     L.rf_gaussian_box_filter.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
     L.rf_box_difference.argtypes = [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_int32), vp]
+    L.rf_stream_copy.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.rf_tap_filter.argtypes = [vpp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
                                 ctypes.POINTER(Tap), ctypes.c_int, vp]
     L.rf_last_error_string.restype = ctypes.c_char_p

@@ -467,6 +467,12 @@ int rf_box_difference(const void *in, void *out, int ndim, const int64_t *extent
     return RF_ERR_UNSUPPORTED;
 }
 
+int rf_stream_copy(const float *src, float *dst, int64_t width, int64_t rows, void *stream) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (this library has no CPU fallback)"); return RF_ERR_HIP; }
+    return launch_stream_copy(src, dst, width, rows, (hipStream_t)stream);
+}
+
 int rf_tap_filter(const void *const *in_planes, int n_in, void *out, int ndim, const int64_t *extent, int dtype,
                   const rf_tap *taps, int n_taps, void *stream) {
     if (!in_planes || !out || !extent || !taps) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
@@ -502,7 +508,7 @@ int rf_tap_filter(const void *const *in_planes, int n_in, void *out, int ndim, c
 }
 
 const char *rf_last_error_string(void) { return g_last_error.c_str(); }
-const char *rf_version(void) { return "recfilter_amd 0.2 (gfx950)"; }
+const char *rf_version(void) { return "recfilter_amd 0.3 (gfx950; abi 3)"; }
 
 int rf_device_count(void) {
     int n = 0;

@@ -48,6 +48,9 @@ struct BoxDiffArgs {
 template <typename P>
 int launch_box_difference(const P *in, P *out, const BoxDiffArgs &a, hipStream_t stream);
 
+// ---- rf_stream_copy: the tile-shaped non-temporal copy bench.py measures its ceiling with (kernels_strided.hip) ----
+int launch_stream_copy(const float *src, float *dst, int64_t width, int64_t rows, hipStream_t stream);
+
 // ---- clamped tap combinations (rf_tap_filter) ----
 struct TapArgs {
     int64_t n[RF_MAX_DIMS];                  // extents, x first (1 for missing dimensions)

@@ -15,7 +15,7 @@ constexpr int kFusedTX = 256;       // tile width: 16 lanes x 16 samples = one D
 constexpr int kFusedSeg = 16;       // samples per lane in the x phase
 constexpr int kFusedThreads = 256;  // 4 waves
 constexpr int kFusedMaxK = 3;       // max feedback order on the fused path
-constexpr int kFusedMaxMod = 8;     // == RF_MAX_ORDER: samples a border modification touches
+constexpr int kFusedMaxMod = 8;     // samples a border modification touches: the orders the fused path rewrites into sections (4..8; RF_MAX_ORDER is 32 since round 5)
 constexpr int kFusedMaxScans = 4;   // max scans per dimension on the fused path
 
 // One scan as the fused kernels read it (device memory, uniform -> scalar loads).

@@ -379,7 +379,7 @@ mx_pass1s_kernel(const float *__restrict__ src, MxPassArgs a) {
 // previous sub-block -- are then a fixed set of registers, requested from LDS ahead of the MFMAs that use them.
 template <bool XM, int NLQ, bool CAUSAL, bool NT, int NBT>
 __global__ void __launch_bounds__(kMxThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
-mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+mx_pass2s_kernel(const float *src, float *dst, MxPassArgs a) {      // (src == dst for every stage after the first and for in-place executes: no __restrict__)
     const int NB = NBT ? NBT : a.NB;       // (NBT: the usual eight sub-blocks of a tile of 256 as a constant; see mx_pass2p_kernel)
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     // (one staging buffer per wave: x_b is in registers by the time y_b is written over it)
@@ -532,7 +532,7 @@ mx_pass2s_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassA
 // under a branch, and the compiler keeps count of what is in flight (behind a branch it waits for more than the step needs).
 template <bool XM, int NLQ, bool NT, int NBT>
 __global__ void __launch_bounds__(kMxThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
-mx_pass2p_kernel(const float *__restrict__ src, float *__restrict__ dst, MxPassArgs a) {
+mx_pass2p_kernel(const float *src, float *dst, MxPassArgs a) {      // (src == dst for every stage after the first and for in-place executes: no __restrict__)
     const int NB = NBT ? NBT : a.NB;
     extern __shared__ __attribute__((aligned(16))) float mx_lds[];
     // constants: dG1 [32], dG2 [32], G1, R1, G2, R2 [16][64] each

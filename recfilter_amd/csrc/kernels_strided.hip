@@ -155,6 +155,36 @@ int launch_strided_pass(bool final_pass, int K, int TZ, const P *src, P *dst,
     return RF_ERR_UNSUPPORTED;
 }
 
+// rf_stream_copy (include/recfilter_amd.h): the access shape of the fused final pass -- one workgroup of 256 threads per
+// 256 x 128 tile, a tile row = 64 chunks of 16 bytes = one wave, non-temporal both ways, eight loads per thread in flight --
+// without LDS and without arithmetic.
+namespace {
+typedef float CopyF4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stream_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t width) {
+    const int cc = threadIdx.x & 63, rg = threadIdx.x >> 6;                 // chunk of the row, row of a group of four
+    const int64_t base = ((int64_t)blockIdx.y * 128 + rg) * width + (int64_t)blockIdx.x * 256 + 4 * cc;
+#pragma unroll
+    for (int half = 0; half < 4; half++) {
+        CopyF4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = __builtin_nontemporal_load(reinterpret_cast<const CopyF4 *>(src + base + (int64_t)(32 * half + 4 * i) * width));
+#pragma unroll
+        for (int i = 0; i < 8; i++) __builtin_nontemporal_store(v[i], reinterpret_cast<CopyF4 *>(dst + base + (int64_t)(32 * half + 4 * i) * width));
+    }
+}
+}  // namespace
+
+int launch_stream_copy(const float *src, float *dst, int64_t width, int64_t rows, hipStream_t stream) {
+    if (src == nullptr || dst == nullptr || src == dst || width <= 0 || rows <= 0 || width % 256 != 0 || rows % 128 != 0 ||
+        rows / 128 > 65535 || (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16 != 0) {
+        set_error("stream copy: needs two distinct 16-byte aligned f32 images of whole 256 x 128 tiles");
+        return RF_ERR_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)(width / 256), (unsigned)(rows / 128)), dim3(256), 0, stream, src, dst, width);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
 template int launch_strided_pass<float>(bool, int, int, const float *, float *, const StridedArgs<float> &, hipStream_t);
 template int launch_strided_pass<int32_t>(bool, int, int, const int32_t *, int32_t *, const StridedArgs<uint32_t> &, hipStream_t);
 template int launch_strided_pass<int16_t>(bool, int, int, const int16_t *, int16_t *, const StridedArgs<uint32_t> &, hipStream_t);

@@ -392,6 +392,11 @@ void save_desc(rf_plan *plan, const rf_filter_desc *desc) {
 int build_plan(const rf_filter_desc *desc, rf_plan **out) {
     if (!desc || !out) { set_error("null argument"); return RF_ERR_INVALID_ARG; }
     *out = nullptr;
+    if (desc->abi != RF_ABI) {
+        set_error("rf_filter_desc.abi is %u, this library speaks revision %u of include/recfilter_amd.h (set .abi = RF_ABI; a caller built "
+                  "against another revision of the header must be rebuilt)", desc->abi, (unsigned)RF_ABI);
+        return RF_ERR_INVALID_ARG;
+    }
     if (desc->ndim < 1 || desc->ndim > RF_MAX_DIMS) { set_error("ndim must be 1..%d", RF_MAX_DIMS); return RF_ERR_INVALID_ARG; }
     if (desc->n_planes < 1 || desc->n_planes > RF_MAX_PLANES) { set_error("n_planes must be 1..%d", RF_MAX_PLANES); return RF_ERR_INVALID_ARG; }
     if (desc->dtype < RF_F32 || desc->dtype > RF_I16) { set_error("unknown dtype %d", desc->dtype); return RF_ERR_INVALID_ARG; }
@@ -484,7 +489,16 @@ int build_plan(const rf_filter_desc *desc, rf_plan **out) {
             md.scans = merged.data();
             md.n_scans = (int32_t)merged.size();
             md.flags |= RF_PLAN_NO_OVERLAP;
-            return build_plan(&md, out);
+            // The merge is kept only if every merged run of order above 3 really runs in its DIRECT form, one matrix stage each
+            // (ADVICE r5): a plan that sends the merged scans elsewhere -- back into sections of the f32-rounded product: a second
+            // rounding of the poles -- is dropped and the scans are planned as given.
+            rf_plan *mp = nullptr;
+            const int rc = build_plan(&md, &mp);
+            int max_order = 0;
+            for (const rf_scan_desc &m : merged) max_order = std::max(max_order, (int)m.order);
+            if (rc == RF_OK && mp != nullptr && (mp->path == RF_PATH_TILED_MATRIX || max_order <= kFusedMaxK)) { *out = mp; return RF_OK; }
+            delete mp;
+            *out = nullptr;
         }
     }
 

@@ -162,35 +162,50 @@ inline bool sections_well_conditioned(const Scan &direct, const std::vector<Scan
 // overlap_to_higher_order_filter, lib/reorder.cpp:231-381, does this on request).  Whether the direct form of the product,
 // evaluated in f32, is a good way to compute the cascade is again tried, not assumed: the cascade in double against the merged
 // scan in float on the probe signal.
+// The probe runs until the cascade's response has DIED OUT (round 6): an impulse plus 768 samples of noise, then
+// silence, both forms evaluated until the double-precision response has stayed below 1e-7 of its peak for 256 samples.  A cascade
+// with slow poles (time constants of thousands of samples: audio biquads near DC) is then compared over its whole memory --
+// rounding the product polynomial to f32 moves clustered poles, and the drift shows only after many time constants, which a
+// fixed 768-sample window passed.  A response that has not died out after 2^17 samples is not merged.
 inline bool merged_well_conditioned(const std::vector<Scan> &cascade, const Scan &merged, double bar = 2e-5) {
-    const int L = 768;
-    std::vector<double> cur(L);
+    const int L0 = 768, Lmax = 1 << 17, quiet_needed = 256;
     uint32_t lcg = 4242u;
-    for (int i = 0; i < L; i++) { lcg = lcg * 1664525u + 1013904223u; cur[i] = (double)(lcg >> 8) / 16777216.0 - 0.5; }
-    cur[0] += 1.0;
-    std::vector<float> x32(L), y32(L);
-    for (int i = 0; i < L; i++) x32[i] = (float)cur[i];
-    for (const Scan &sc : cascade) {
-        std::vector<double> nxt(L);
-        for (int i = 0; i < L; i++) {
-            double acc = sc.b * cur[i];
-            for (int j = 0; j < sc.order && j < i; j++) acc += sc.a[j] * nxt[i - 1 - j];
-            nxt[i] = acc;
-        }
-        cur.swap(nxt);
-    }
-    for (int i = 0; i < L; i++) {
-        float acc = (float)merged.b * x32[i];
-        for (int j = 0; j < merged.order && j < i; j++) acc = std::fmaf((float)merged.a[j], y32[i - 1 - j], acc);
-        y32[i] = acc;
-    }
+    auto input = [&](int i) -> double {
+        if (i >= L0) return 0.0;
+        lcg = lcg * 1664525u + 1013904223u;
+        return (double)(lcg >> 8) / 16777216.0 - 0.5 + (i == 0 ? 1.0 : 0.0);
+    };
+    // running state of every scan of the cascade (double) and of the merged scan (float): the last `order` outputs, newest first
+    std::vector<std::vector<double>> hist(cascade.size());
+    for (size_t q = 0; q < cascade.size(); q++) hist[q].assign((size_t)std::max(cascade[q].order, 1), 0.0);
+    std::vector<float> hist32((size_t)std::max(merged.order, 1), 0.0f);
     double peak = 0.0, err = 0.0;
-    for (int i = 0; i < L; i++) {
-        if (!std::isfinite(cur[i]) || !std::isfinite((double)y32[i])) return false;
-        peak = std::max(peak, std::fabs(cur[i]));
-        err = std::max(err, std::fabs((double)y32[i] - cur[i]));
+    int quiet = 0;
+    for (int i = 0; i < Lmax; i++) {
+        const double x = input(i);
+        double v = x;
+        for (size_t q = 0; q < cascade.size(); q++) {
+            const Scan &sc = cascade[q];
+            double acc = sc.b * v;
+            for (int jj = 0; jj < sc.order; jj++) acc += sc.a[jj] * hist[q][(size_t)jj];
+            for (int jj = sc.order - 1; jj > 0; jj--) hist[q][(size_t)jj] = hist[q][(size_t)jj - 1];
+            hist[q][0] = acc;
+            v = acc;
+        }
+        float acc32 = (float)merged.b * (float)x;
+        for (int jj = 0; jj < merged.order; jj++) acc32 = std::fmaf((float)merged.a[jj], hist32[(size_t)jj], acc32);
+        for (int jj = merged.order - 1; jj > 0; jj--) hist32[(size_t)jj] = hist32[(size_t)jj - 1];
+        hist32[0] = acc32;
+        if (!std::isfinite(v) || !std::isfinite((double)acc32)) return false;
+        peak = std::max(peak, std::fabs(v));
+        err = std::max(err, std::fabs((double)acc32 - v));
+        if (err > bar * std::max(peak, 1e-30) && i >= L0) return false;       // (already beyond the bar: no need to go on)
+        if (i >= L0) {
+            quiet = std::fabs(v) <= 1e-7 * peak ? quiet + 1 : 0;
+            if (quiet >= quiet_needed) return err <= bar * std::max(peak, 1e-30);
+        }
     }
-    return err <= bar * std::max(peak, 1e-30);
+    return false;           // the response outlives the probe: keep the scans as given
 }
 
 }  // namespace rf

@@ -357,6 +357,8 @@ class RecFilter:
             sc = st._contents
             if [(d.var(), d.num_pixels()) for d in sc["dims"]] != sig or sc["clamped"] != c["clamped"]:
                 return None
+            if sc["tile"] != c["tile"]:          # (stages split to different tile widths stay plans of their own)
+                return None
         if any(st._contents["epilogue"] is not None for st in chain[:-1]) or any(st._contents["prologue"] is not None for st in chain[1:]):
             return None
         return chain
@@ -374,18 +376,33 @@ class RecFilter:
             scans = [s for st in chain for s in st._contents["scans"]]
             prologue = chain[0]._contents["prologue"]
             tiled = any(st._contents["tiled"] for st in chain)
+        asked_path = path
         if path is None:
             path = capi.RF_PATH_AUTO if tiled else capi.RF_PATH_UNTILED
-        c["plan"] = Plan(shape, scans, dtype=inputs[0].dtype, clamped=c["clamped"], planes=len(inputs),
-                         tile=tile, path=path, device=inputs[0].device.index or 0,
-                         prologue=prologue, epilogue=c["epilogue"])
-        c["merged_stages"] = len(chain) if chain is not None else 0
+        kw = dict(dtype=inputs[0].dtype, clamped=c["clamped"], planes=len(inputs), tile=tile, device=inputs[0].device.index or 0,
+                  epilogue=c["epilogue"])
+        try:
+            c["plan"] = Plan(shape, scans, path=path, prologue=prologue, **kw)
+            c["merged_stages"] = len(chain) if chain is not None else 0
+        except (RecFilterError, ValueError):
+            # The merged plan of a cascade may not exist where every stage's own plan does -- more than RF_MAX_SCANS scans in
+            # all, a combination no path accepts: fall back to the chain of per-stage plans (this stage reads its source's
+            # result), as before the merge existed.
+            if chain is None:
+                raise
+            if asked_path is None:
+                path = capi.RF_PATH_AUTO if c["tiled"] else capi.RF_PATH_UNTILED
+            c["plan"] = Plan(shape, c["scans"], path=path, prologue=c["prologue"], **kw)
+            c["merged_stages"] = 0
+        c["merge_cascades_at_compile"] = RecFilter.merge_cascades
         c["compiled"] = True
 
     def _execute_chain(self, fresh_outputs: bool):
         """Launches every upstream cascade stage, then this one (asynchronous).  Like Func::realize on the last stage of
         a cascade, which recomputes all of its producers (they are compute_root Funcs)."""
         c = self._contents
+        if c["compiled"] and c.get("merge_cascades_at_compile") != RecFilter.merge_cascades:
+            c["compiled"] = False               # merge_cascades was toggled since: the plan no longer says what it should run
         if not c["compiled"]:
             self.compile_jit()
         if c.get("merged_stages"):

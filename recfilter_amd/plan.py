@@ -71,6 +71,7 @@ class Plan:
             for j, c in enumerate(coeff[1:]):
                 s.feedback[j] = c
         d = capi.FilterDesc()
+        d.abi = capi.RF_ABI
         d.ndim = len(shape)
         for i, e in enumerate(reversed(shape)):      # numpy (z,y,x) -> extent[0] = x
             d.extent[i] = e
@@ -328,6 +329,28 @@ def tap_filter(inputs, taps, out=None, stream=None):
     capi.check(capi.lib().rf_tap_filter(ptrs, len(inputs), ctypes.c_void_p(out.data_ptr()), nd, ext, _dtype_code(inputs[0].dtype),
                                         arr, len(taps), Plan._stream(stream)))
     return out
+
+
+def stream_copy_ms(src, dst, reps: int = 5, stream=None) -> float:
+    """rf_stream_copy timed with HIP events on `stream` (the current stream by default): milliseconds per copy of the f32
+    image `src` (rows x width, whole 256 x 128 tiles) into `dst`, mean of `reps` after one untimed copy.  The measured
+    ceiling of a read-once / write-once pass in the final pass's access shape (bench.py: roofline.copy_ceiling_gbps)."""
+    import torch
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or src.dim() < 2 or src.shape != dst.shape or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("stream_copy_ms needs two contiguous f32 device tensors of one shape")
+    width, rows = int(src.shape[-1]), int(src.numel() // src.shape[-1])
+    st = torch.cuda.current_stream() if stream is None else stream
+    h = ctypes.c_void_p(st.cuda_stream)
+    call = lambda: capi.check(capi.lib().rf_stream_copy(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), width, rows, h))
+    call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(st):
+        e0.record(st)
+        for _ in range(reps):
+            call()
+        e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def second_order_sections(coeff: Sequence[float]) -> List[List[float]]:

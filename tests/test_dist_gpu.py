@@ -150,7 +150,8 @@ def test_bench_fails_on_a_corrupted_exchange():
 
 def test_bench_default_run_carries_config5_strong():
     """What a driver that only varies --gpus gets: the headline line (cfg3, weak) with north_star's config 5 -- the volume
-    sharded along z, strong scaling, early exchange -- as configs[0], both checked against the unsharded plan.  Two ranks on
+    sharded along z, strong scaling, early exchange -- as configs[0] and the headline image in strong scaling (16384^2 split
+    into N row slabs) as configs[1], all checked against the unsharded plan.  Two ranks on
     this box's one GPU over gloo; config 5 shrunk to 256^3 (two ranks of the full volume do not fit one device)."""
     import json
     import subprocess
@@ -164,9 +165,15 @@ def test_bench_default_run_carries_config5_strong():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_shape"] == [32768, 16384]
     assert d["metric"].startswith("Mpixels/s + achieved HBM GB/s, 16384^2 order-2") and 0 <= d["sharded_parity"] < 1e-4
-    (e,) = d["configs"]
+    e, s = d["configs"]
     assert e["scaling"] == "strong" and e["n_gpus"] == 2 and e["config"]["global_shape"] == [256, 256, 256]
     assert e["config"]["interior_beside_collective"] is True and 0 <= e["sharded_parity"] < 1e-4 and e["value"] > 0
+    # ... and the headline image itself split into row slabs (north_star's ">= 6x at 8 GPUs" read as strong scaling): same keys
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["config"]["global_shape"] == [16384, 16384]
+    assert "8192x16384" in s["config"]["workload"] and s["metric"] == d["metric"] and s["value"] > 0
+    assert 0 <= s["sharded_parity"] < 1e-4 and 0 <= s["sharded_parity_sat"] < 1e-4
+    assert s["step_phases"]["exchanges_per_step"] == 1 and s["step_phases"]["allgather_bytes"] == 2 * (2 * 2 * 16384 * 4)
+    assert d["roofline"]["copy_kernel"].startswith("rf_stream_copy") and 0.3 < d["roofline"]["two_pass_ceiling_frac"] < 0.67
 
 
 def test_bench_strong_scaling_volume_two_ranks_over_gloo():

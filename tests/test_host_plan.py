@@ -622,3 +622,53 @@ def test_matrix_path_sharded_plan_structure():
         assert plan.path != capi.RF_PATH_TILED_MATRIX            # unequal slabs: the generic path's per-slab transfer tables
     with pytest.raises(rfa.RecFilterError):
         rfa.Plan((128, 512), scans, shard_rank=1, shard_world=2, shard_extents=[256, 128], path=capi.RF_PATH_TILED_MATRIX, **H)
+
+
+def test_merged_runs_are_probed_over_the_whole_memory_of_the_cascade():
+    """Consecutive same-direction scans of a 1-D signal become ONE direct-form scan only where (i) the f32 direct form tracks the
+    f64 cascade until the cascade's response has died out -- not over a fixed 768 samples: slow poles drift later -- and (ii)
+    the merged scan really runs in its direct form on the matrix path (no second rounding into sections); otherwise the scans
+    stay as given."""
+    n = 1 << 20
+    row = 5 + 2 * capi.RF_MAX_ORDER
+
+    def planned_orders(scans):
+        with _host_plan((n,), scans) as p:
+            return [int(r[2]) for r in p.table("scans").reshape(-1, row)], p.path
+    fast = (0, True, [1.0, 0.1, 0.1])                       # poles at 0.37 and -0.27: five of them are one scan of order 10
+    orders, path = planned_orders([fast] * 5)
+    assert orders == [10] and path == capi.RF_PATH_TILED_MATRIX
+    # two resonators with poles of radius 0.9995 (time constant 2000 samples): a 768-sample window cannot see the merged
+    # f32 polynomial drift; the probe that follows the response to its end refuses the merge
+    r, th = 0.9995, 0.01
+    slow = (0, True, [1e-3, 2 * r * np.cos(th), -r * r])
+    orders, _ = planned_orders([slow, slow])
+    assert orders == [2, 2]
+    # merged orders 5 and 4 that the planner would split into sections again: kept as given -- six scans, an in-plan cascade of
+    # two fused stages (the table lists the first stage's four scans)
+    mild = [(0, True, [0.5, 0.3, 0.1]), (0, True, [0.8, 0.2]), (0, True, [0.7, 0.2, -0.1]), (0, False, [0.6, 0.3]), (0, False, [0.9, 0.1, 0.05]), (0, False, [0.6, 0.4])]
+    orders, path = planned_orders(mild)
+    assert orders == [2, 1, 2, 1] and path == capi.RF_PATH_TILED_FUSED
+
+
+def test_a_descriptor_of_another_abi_revision_is_refused():
+    """rf_filter_desc.abi: a caller built against another revision of the header (RF_MAX_ORDER 8: other scan strides) gets an
+    error instead of a mis-strided scans array."""
+    d = capi.FilterDesc()
+    d.ndim, d.n_planes, d.dtype, d.n_scans = 1, 1, capi.RF_F32, 1
+    d.extent[0] = 64
+    d.device = capi.RF_DEVICE_HOST_ONLY
+    sc = (capi.ScanDesc * 1)()
+    sc[0].dim, sc[0].causal, sc[0].order, sc[0].feedfwd = 0, 1, 1, 1.0
+    sc[0].feedback[0] = 0.5
+    d.scans = sc
+    h = ctypes.c_void_p()
+    for abi, want in ((0, capi.RF_ERR_INVALID_ARG), (2, capi.RF_ERR_INVALID_ARG), (capi.RF_ABI, capi.RF_OK)):
+        d.abi = abi
+        rc_ = capi.lib().rf_plan_create(ctypes.byref(d), ctypes.byref(h))
+        assert rc_ == want, (abi, rc_)
+        if rc_ == capi.RF_OK:
+            capi.lib().rf_plan_destroy(h)
+        else:
+            assert b"abi" in capi.lib().rf_last_error_string()
+    assert b"abi 3" in capi.lib().rf_version()

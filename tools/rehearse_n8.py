@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rehearsal of `bench.py --gpus 8`'s sharded-parity leg on ONE GPU (the pool has no multi-GPU box).
 
-    python tools/rehearse_n8.py [--world 8] [--slab 16384] [--cfg5 2048]
+    python tools/rehearse_n8.py [--world 8] [--slab 16384] [--cfg5 2048]      (cfg3 weak, cfg3 strong, cfg5 strong)
 
 cfg3, weak scaling: `world` slabs of slab x 16384 rows go through the stepping protocol (emulated ranks: one plan per rank
 on this device, the all-gather a rank-major device buffer), and the concatenated result is compared with the UNSHARDED plan
@@ -32,22 +32,37 @@ def emulate(name, local_shape, world, cfg):
     outs = list(sharded_out.split(local_shape[0]))
     t0 = time.perf_counter()
     plans = [rfa.Plan(local_shape, cfg["scans"], clamped=cfg["clamped"], shard_rank=r, shard_world=world) for r in range(world)]
-    for r in range(world):
-        plans[r].begin([ins[r]], [outs[r]])
     nex = plans[0].num_exchanges
-    for e in range(nex):
-        nbytes = plans[0].exchange_bytes(e)
-        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda")
+    gathered = [torch.empty(world * plans[0].exchange_bytes(e), dtype=torch.uint8, device="cuda") for e in range(nex)]
+
+    def all_ranks_one_step():
         for r in range(world):
-            plans[r].exchange_local(e, gathered.data_ptr() + r * nbytes)
-        if e == nex - 1:
+            plans[r].begin([ins[r]], [outs[r]])
+        for e in range(nex):
+            nbytes = plans[0].exchange_bytes(e)
             for r in range(world):
-                plans[r].interior()
+                plans[r].exchange_local(e, gathered[e].data_ptr() + r * nbytes)
+            if e == nex - 1:
+                for r in range(world):
+                    plans[r].interior()
+            for r in range(world):
+                plans[r].exchange_apply(e, gathered[e].data_ptr())
         for r in range(world):
-            plans[r].exchange_apply(e, gathered.data_ptr())
-    for r in range(world):
-        plans[r].finish()
+            plans[r].finish()
+
+    all_ranks_one_step()
     torch.cuda.synchronize()
+    # the device time of ONE rank's step: all `world` ranks' steps back to back on this GPU (the all-gather a device buffer that
+    # the ranks' exchange_local launches fill), divided by `world` -- what a rank of the real run spends on its own kernels
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        all_ranks_one_step()
+    s0.record()
+    for _ in range(5):
+        all_ranks_one_step()
+    s1.record()
+    torch.cuda.synchronize()
+    rank_ms = s0.elapsed_time(s1) / 5 / world
     path, tiles = plans[0].path_name, list(plans[0].tiles)
     for p in plans:
         p.close()
@@ -63,8 +78,13 @@ def emulate(name, local_shape, world, cfg):
         whole_ms = e0.elapsed_time(e1)
         whole_path, whole_tiles = plan.path_name, list(plan.tiles)
     err = max(strict_rel_err(outs[r], whole_out.split(local_shape[0])[r]) for r in range(world))
+    px = 1.0
+    for n in global_shape:
+        px *= n
     print(f"{name}: world {world}, slab {'x'.join(map(str, local_shape))} ({path}, tiles {tiles}), {nex} exchange(s); unsharded "
           f"{'x'.join(map(str, global_shape))} ({whole_path}, tiles {whole_tiles}) {whole_ms:.3f} ms; "
+          f"one rank's step {rank_ms:.3f} ms of kernels (x {world} ranks in parallel = {px / rank_ms / 1e3:.0f} Mpixels/s before the "
+          f"all-gather's latency; the unsharded plan: {px / whole_ms / 1e3:.0f}); "
           f"sharded_parity {err:.3e}  [{time.perf_counter() - t0:.1f} s]", flush=True)
     assert err < 1e-4
     del whole_in, whole_out, sharded_out
@@ -85,6 +105,11 @@ def main():
     # table (A^M, X[q][s] over two or more slabs); a summed-area table hands every slab the sum over ALL slabs before it.
     sat2 = {"scans": [(0, True, [1.0, 1.0]), (1, True, [1.0, 1.0])], "clamped": False}
     emulate("summed-area table weak", (args.slab, 16384), args.world, sat2)
+    # north_star's ">= 6x at 8 GPUs" read as STRONG scaling: the 16384^2 image itself in `world` row slabs of whole 128-row tiles
+    # (bench.py's configs[1] at N > 1): 2048-row slabs at world 8
+    if 16384 % (args.world * 128) == 0:
+        emulate("cfg3 strong", (16384 // args.world, 16384), args.world, cfg3)
+        emulate("summed-area table strong", (16384 // args.world, 16384), args.world, sat2)
     if args.cfg5:
         cfg5 = dict(rc.BASELINE_CONFIGS["cfg5_generic_xyz"])
         emulate("cfg5 strong", (args.cfg5 // args.world, args.cfg5, args.cfg5), args.world, cfg5)
