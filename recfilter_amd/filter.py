@@ -15,6 +15,7 @@ import itertools
 from typing import Dict, List, Optional, Sequence, Union
 
 from . import capi
+from .capi import RecFilterError
 from .plan import Plan
 
 _counter = itertools.count()
