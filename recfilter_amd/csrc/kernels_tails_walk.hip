@@ -62,7 +62,11 @@ constexpr int kTallPitch4 = kTallCols / 4 + 1;
 // quarter of the bytes the y parts save), which the carry scan along x adds up as it loads them (CarryGeom::part2).  The bare
 // read of that shape is 5 % faster as well (tools/microbench/walk_read.hip: 1.19 against 1.25 ms per 8 GiB; with the stores
 // 1.75 against 1.91).  Orders <= 2 along x / y (four x tails: one flushing wave), 128-row y tiles.
-template <int K, int NX, int NY, bool EDGE, bool TALL>
+// U4 (round 6): widths that are not multiples of four.  Rows are then only element-aligned: a thread's chunk is four 4-byte
+// loads instead of one 16-byte load (same registers, four times the load instructions), the last chunk of a row may exist in
+// part (masked per element, like everything that does not exist: zeros when the plane is staged), and the z tails -- the one
+// unpadded destination -- are stored sample by sample.  Everything behind the staging works on the padded patch as before.
+template <int K, int NX, int NY, bool EDGE, bool TALL, bool U4>
 __device__ __forceinline__ void walk_tails_body(const float *__restrict__ src, const FusedArgs<float> &a, const WalkArgs &wa,
                                                 const float *__restrict__ Hx,     // [vx][s][r][256]
                                                 const float *__restrict__ Hy,     // [vy][j][r][TY]
@@ -107,11 +111,25 @@ __device__ __forceinline__ void walk_tails_body(const float *__restrict__ src, c
     const int cols_here = (tx == a.MX - 1 ? a.last_cols : kFusedTX) - PW * xh;                // columns of the patch that exist (may be <= 0)
     const int rows_left = (ty == a.MY - 1 ? a.last_rows : wa.TY) - PH * h;                    // rows of the patch that exist (may be <= 0)
     const bool ok0 = !EDGE || (4 * cc < cols_here && rg < rows_left), ok1 = !EDGE || (4 * cc < cols_here && rg + PH / 2 < rows_left);
+    bool okE[4];                                                     // U4: which samples of this thread's chunk exist
+#pragma unroll
+    for (int e = 0; e < 4; e++) okE[e] = !EDGE || !U4 || 4 * cc + e < cols_here;
     auto ld = [&](const char *pb, uint32_t off, bool ok) {
         // (a chunk that does not exist reads the volume's first chunk; `put` replaces it by zeros -- not here: a select behind
         //  the load would be waited for on the spot)
-        if constexpr (EDGE) return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(ok ? pb + off : reinterpret_cast<const char *>(src)));
-        else return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(pb + off));
+        if constexpr (U4) {
+            F4 r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const char *p = pb + off + 4 * e;
+                if constexpr (EDGE) p = (ok && okE[e]) ? p : reinterpret_cast<const char *>(src);
+                r[e] = __builtin_nontemporal_load(reinterpret_cast<const float *>(p));
+            }
+            return r;
+        } else {
+            if constexpr (EDGE) return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(ok ? pb + off : reinterpret_cast<const char *>(src)));
+            else return __builtin_nontemporal_load(reinterpret_cast<const F4 *>(pb + off));
+        }
     };
 
     // ---- operands that do not change from plane to plane, requested before the first pixels ----
@@ -221,8 +239,16 @@ __device__ __forceinline__ void walk_tails_body(const float *__restrict__ src, c
             v1 = v1 * a.pre_s + a.pre_b;
         }
         if constexpr (EDGE) {                                      // samples beyond the image stay zero: they do not exist
-            if (!ok0) v0 = F4{0.f, 0.f, 0.f, 0.f};
-            if (!ok1) v1 = F4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (U4) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (!(ok0 && okE[e])) v0[e] = 0.f;
+                    if (!(ok1 && okE[e])) v1[e] = 0.f;
+                }
+            } else {
+                if (!ok0) v0 = F4{0.f, 0.f, 0.f, 0.f};
+                if (!ok1) v1 = F4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         F4 *tl = tile4 + par * kTile4;
         tl[rg * P4 + cc] = v0;
@@ -329,13 +355,19 @@ __device__ __forceinline__ void walk_tails_body(const float *__restrict__ src, c
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 // (the z tails are [..][NX * NY], unpadded: nothing of a row or column that does not exist is stored)
+                if constexpr (U4) {              // element-aligned rows: sample by sample
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (!EDGE || (rg + (PH / 2) * k < rows_left && 16 * cblk + 4 * i + e < cols_here)) q[k * half + 4 * i + e] = zacc[k][e][i];
+                    continue;
+                }
                 if (EDGE && !(rg + (PH / 2) * k < rows_left && 16 * cblk + 4 * i < cols_here)) continue;
                 *reinterpret_cast<F4 *>(q + k * half + 4 * i) = F4{zacc[k][0][i], zacc[k][1][i], zacc[k][2][i], zacc[k][3][i]};
             }
     }
 }
 
-template <int K, int NX, int NY, bool TALL = false>
+template <int K, int NX, int NY, bool TALL = false, bool U4 = false>
 __global__ void __launch_bounds__(kWalkThreads)
 walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa, const float *__restrict__ Hx, const float *__restrict__ Hy,
                   const float *__restrict__ HzT) {
@@ -343,8 +375,8 @@ walk_tails_kernel(const float *__restrict__ src, FusedArgs<float> a, WalkArgs wa
     const int ty = blockIdx.y >> wa.parts_log2, h = blockIdx.y & ((1 << wa.parts_log2) - 1);
     const int tx = TALL ? (int)blockIdx.x >> 1 : (int)blockIdx.x, xh = TALL ? (int)blockIdx.x & 1 : 0;
     const bool whole = (tx != a.MX - 1 || a.last_cols - PW * xh >= PW) && (ty != a.MY - 1 || a.last_rows - PH * h >= PH);
-    if (whole) walk_tails_body<K, NX, NY, false, TALL>(src, a, wa, Hx, Hy, HzT);
-    else walk_tails_body<K, NX, NY, true, TALL>(src, a, wa, Hx, Hy, HzT);
+    if (whole) walk_tails_body<K, NX, NY, false, TALL, U4>(src, a, wa, Hx, Hy, HzT);
+    else walk_tails_body<K, NX, NY, true, TALL, U4>(src, a, wa, Hx, Hy, HzT);
 }
 
 }  // namespace
@@ -357,7 +389,7 @@ bool walk_tails_applicable(int K, int TY, int nx, int ny, int nz, int KZ, int TZ
     if (nx < 1 || nx > 2 || ny < 1 || ny > 2 || nz < 1 || nz > 2) return false;
     if (TY != 32 && TY != 64 && TY != 128) return false;
     if (TZ != 32 && TZ != 64 && TZ != 128) return false;
-    if (last_cols < 4 || last_cols > kFusedTX || last_cols % 4 != 0 || last_rows < 1 || last_rows > TY) return false;
+    if (last_cols < 1 || last_cols > kFusedTX || last_rows < 1 || last_rows > TY) return false;      // (any width since round 6: U4)
     return true;
 }
 
@@ -375,9 +407,10 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
                         (size_t)((nxk + 3) / 4) * 1024 + (size_t)((nyk + 3) / 4) * (tall ? 256 : 128)) * sizeof(float);
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
-#define RF_CASE_T(KK, XX, YY, TT)                                                                                          \
-    if (K == KK && a.nx == XX && a.ny == YY && tall == TT) {                                                               \
-        auto kern = walk_tails_kernel<KK, XX, YY, TT>;                                                                     \
+    const bool u4 = a.NX % 4 != 0;                   // rows that are only element-aligned
+#define RF_CASE_TU(KK, XX, YY, TT, UU)                                                                                     \
+    if (K == KK && a.nx == XX && a.ny == YY && tall == TT && u4 == UU) {                                                   \
+        auto kern = walk_tails_kernel<KK, XX, YY, TT, UU>;                                                                 \
         static std::atomic<bool> opted[64];                                                                                \
         std::atomic<bool> &done = opted[dev & 63];                                                                         \
         if (!done.load(std::memory_order_acquire)) {        /* more than 64 KiB of dynamic LDS: opt in, once per kernel and device */ \
@@ -388,6 +421,7 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
         RF_HIP_CHECK(hipGetLastError());                                                                                   \
         return RF_OK;                                                                                                      \
     }
+#define RF_CASE_T(KK, XX, YY, TT) RF_CASE_TU(KK, XX, YY, TT, false) RF_CASE_TU(KK, XX, YY, TT, true)
 #define RF_CASE(KK, XX, YY) RF_CASE_T(KK, XX, YY, false)
     RF_CASE(2, 2, 2) RF_CASE(2, 1, 1) RF_CASE(2, 2, 1) RF_CASE(2, 1, 2) RF_CASE(1, 2, 2) RF_CASE(1, 1, 1) RF_CASE(1, 2, 1) RF_CASE(1, 1, 2)
     RF_CASE(3, 2, 2) RF_CASE(3, 1, 1) RF_CASE(3, 2, 1) RF_CASE(3, 1, 2)
@@ -395,6 +429,7 @@ int launch_walk_tails(int K, const float *src, const FusedArgs<float> &a, const 
     RF_CASE_T(1, 2, 2, true) RF_CASE_T(1, 1, 1, true) RF_CASE_T(1, 2, 1, true) RF_CASE_T(1, 1, 2, true)
 #undef RF_CASE
 #undef RF_CASE_T
+#undef RF_CASE_TU
     set_error("walk tails: unsupported order %d / %d scans / %d z tails", K, a.nx, wa.nzk);
     return RF_ERR_UNSUPPORTED;
 }

@@ -311,8 +311,11 @@ int build_fused(rf_plan *plan, const rf_filter_desc *desc) {
             const DimInfo &dz = plan->dims[2];
             const int TZ = strided_tile(plan, 2), nz = (int)dz.scan_ids.size(), KZ = dz.k;
             const int64_t patch_columns = TZ > 0 ? (int64_t)MX * ((NY + 31) / 32) * (dz.N / TZ) : 0;
+            // (widths that are not multiples of four: the pass takes them since round 6 -- 4-byte loads, kernels_tails_walk.hip U4 --
+            //  but loses to the two first passes there, 1024 x 1021 x 1021: walk 2.27 ms against 1.15 + 0.94, 1022 wide: 2.09 against
+            //  1.13 + 1.04 (profiles/r6/walk_odd_widths.txt); only RF_PLAN_WALK_PASS1 selects it for such volumes)
             if (TZ > 0 && dz.N % TZ == 0 && walk_tails_applicable(K, TY, nx, ny, nz, KZ, TZ, TVx, TVy) &&
-                (patch_columns >= 256 || (plan->flags & RF_PLAN_WALK_PASS1))) {
+                ((patch_columns >= 256 && NX % 4 == 0) || (plan->flags & RF_PLAN_WALK_PASS1))) {
                 const int MZ = (int)(dz.N / TZ);
                 walk_child.reset(build_carry_planes_plan(plan, desc, 2, (int64_t)nz * KZ * (MZ + (z_slabs ? 1 : 0))));
                 if (walk_child) {

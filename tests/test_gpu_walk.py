@@ -146,11 +146,14 @@ def test_one_read_pass1_with_a_prologue(clamped):
     assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6
 
 
-@pytest.mark.parametrize("shape", [(64, 80, 256), (64, 64, 300), (32, 100, 520), (64, 33, 260), (32, 160, 1020)])
+@pytest.mark.parametrize("shape", [(64, 80, 256), (64, 64, 300), (32, 100, 520), (64, 33, 260), (32, 160, 1020),
+                                   (64, 64, 258), (32, 100, 521), (32, 77, 1023), (64, 40, 255), (32, 64, 1)])
 @pytest.mark.parametrize("clamped", [False, True])
 def test_one_read_pass1_partial_tiles(shape, clamped):
-    """Heights that are not whole tile rows and widths that are not whole tiles (multiples of four): what does not exist loads as
-    zeros and is never stored (round 5; the staged pass 1 has always done so, lib/split.cpp:503-665 takes any extent the tile divides)."""
+    """Heights that are not whole tile rows and widths that are not whole tiles: what does not exist loads as zeros and is never
+    stored (round 5; the staged pass 1 has always done so, lib/split.cpp:503-665 takes any extent the tile divides).  Round 6:
+    widths that are not multiples of four as well (rows only element-aligned: 4-byte loads, a partial last chunk, z tails
+    stored sample by sample) -- 258, 521, 1023, 255 and a volume one sample wide."""
     import torch
     import recfilter_amd as rfa
     from recfilter_amd import capi
@@ -170,7 +173,8 @@ def test_one_read_pass1_partial_tiles(shape, clamped):
         assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < (2e-5 if scans is XY_ORDER3 else 2e-6), (shape, clamped, pro)
 
 
-@pytest.mark.parametrize("shape", [(32, 200, 444), (32, 128, 356), (32, 129, 388), (64, 256, 512), (32, 70, 132), (32, 250, 640)])
+@pytest.mark.parametrize("shape", [(32, 200, 444), (32, 128, 356), (32, 129, 388), (64, 256, 512), (32, 70, 132), (32, 250, 640),
+                                   (32, 200, 445), (32, 129, 387), (32, 140, 131)])
 @pytest.mark.parametrize("clamped", [False, True])
 def test_one_read_pass1_tall_patches(shape, clamped):
     """128-row y tiles, orders <= 2 along x / y: the pass runs on patches of 128 columns x 64 rows (round 6) -- two parts of
@@ -198,9 +202,11 @@ def test_one_read_pass1_tall_patches(shape, clamped):
         assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6, (shape, clamped, len(scans))
 
 
-@pytest.mark.parametrize("what", ["int32", "odd_width", "u8_input"])   # (asked for, refused by the shape rules)
+@pytest.mark.parametrize("what", ["int32", "u8_input"])   # (asked for, refused by the shape rules)
 def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
-    """Integer pixels, a width that is no multiple of four, 8-bit input: the z stage runs its own first pass."""
+    """Integer pixels (the pass contracts on the f32 matrix cores; with the products on the vector ALU it ran as long as the two
+    passes it replaces: NOTES round 4) and 8-bit input: the z stage runs its own first pass.  (Widths that are no multiples of
+    four take the one-read pass since round 6: test_one_read_pass1_partial_tiles.)"""
     import torch
     import recfilter_amd as rfa
     from recfilter_amd import capi
@@ -211,8 +217,6 @@ def test_volumes_the_one_read_pass_does_not_take_keep_two_first_passes(what):
         scans = [(0, True, [1, 1]), (1, True, [1, 1]), (2, True, [1, 1])]
     else:
         scans = XYZ
-    if what == "odd_width":
-        shape = (64, 64, 258)
     if what == "u8_input":
         kw["input_dtype"] = np.uint8
     rng = np.random.default_rng(13)
@@ -243,7 +247,9 @@ def test_one_read_pass1_is_the_default_from_256_patch_columns_on():
     import recfilter_amd as rfa
     rng = np.random.default_rng(14)
     threads = min(16, os.cpu_count() or 1)
-    for shape, clamped, expect in (((128, 512, 512), False, False), ((512, 512, 512), False, True), ((512, 512, 512), True, True)):
+    # (a width that is no multiple of four: the pass exists for it -- RF_PLAN_WALK_PASS1 -- but two first passes are faster there)
+    for shape, clamped, expect in (((128, 512, 512), False, False), ((512, 512, 512), False, True), ((512, 512, 512), True, True),
+                                   ((512, 512, 514), False, False)):
         x = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
         with rfa.Plan(shape, XYZ, clamped=clamped) as plan:
             out, timed = plan.execute_timed([x])
