@@ -430,6 +430,28 @@ def test_sharded_unequal_slabs_other_paths():
     _check(full, got, three, True)
 
 
+def test_high_order_filters_outside_the_matrix_paths_shape_rules():
+    """Orders above 8 run in their direct form on the matrix path, whose passes move 16 bytes per lane and whose slabs are equal
+    (plan_matrix.cpp: matrix_plan_applicable).  Outside those rules -- a width that is no multiple of four, slabs of different
+    extents (the reference only asks that the tile divide the extent, lib/recfilter.h:311) -- the automatic choice falls back to
+    the generic tiled path, which takes every order up to 32 (the reach is there, not the matrix cores' speed)."""
+    from test_gpu_high_order import stable_coeff, MX
+    c12, c9 = stable_coeff(12, 51), stable_coeff(9, 52)
+    scans = [(0, True, c12), (0, False, c9), (1, True, c9), (1, False, c12)]
+    for shape in ((96, 301), (130, 258)):
+        for clamped in (False, True):
+            imgs, outs, (path, _) = _run(shape, scans, clamped=clamped)
+            assert path not in (MX, 3), (shape, path)
+            _check(imgs, outs, scans, clamped)
+    full, got, (path, nex) = _run_sharded((64 + 128 + 32, 256), scans, True, 3, path=0, extents=[64, 128, 32])
+    assert path != MX and nex >= 1
+    _check(full, got, scans, True)
+    # (equal slabs of the same filter do take the matrix path)
+    full, got, (path, nex) = _run_sharded((64 * 3, 256), scans, True, 3, path=0)
+    assert path == MX
+    _check(full, got, scans, True)
+
+
 def test_shard_extents_are_validated():
     import recfilter_amd as rfa
     scans = rc.xy_pm(rc.GAUSS2)

@@ -10,6 +10,25 @@ from recfilter_amd import capi
 import ref_cases as rc
 
 scans = rc.BASELINE_CONFIGS["cfg5_generic_xyz"]["scans"]
+if "--int32" in sys.argv:
+    # a summed-volume table of int32 samples (bit-exact ring arithmetic): integer pixels keep two first passes -- the one-read pass
+    # contracts on the f32 matrix cores, and with the products on the vector ALU it took as long as the passes it replaces
+    sys.argv.remove("--int32")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    sat = [(d, True, [1.0, 1.0]) for d in range(3)]
+    x = torch.randint(0, 4, (n, n, n), device="cuda", dtype=torch.int32)
+    out = torch.empty_like(x)
+    with rfa.Plan((n, n, n), sat, dtype=np.int32) as plan:
+        for _ in range(3):
+            plan.execute([x], [out])
+        acc = {}
+        for _ in range(8):
+            _, times = plan.execute_timed([x], [out])
+            for k, ms in times:
+                acc.setdefault(k, []).append(ms)
+        med = {k: float(np.median(v)) for k, v in acc.items()}
+    print(f"int32 summed-volume table {n}^3 ({plan.path_name}): {sum(med.values()):.3f} ms (" + ", ".join(f"{k} {v:.3f}" for k, v in med.items()) + ")")
+    sys.exit(0)
 for n in [int(a) for a in sys.argv[1:]] or [1021, 1020, 1024]:
     shape = (n, n, n) if n % 64 == 0 else (1024, n, n)        # (the depth stays whole z tiles: what the one-read pass needs)
     x = torch.rand(shape, device="cuda")
