@@ -90,6 +90,18 @@ int main(int argc, char **argv) {
         time("  IN PLACE, loads in two halves", [&] { hipLaunchKernelGGL((zcopy<256, 128, 2, 0, 1, true, true>), dim3((unsigned)(plane / 256), planes / 128), dim3(256), 53 * 1024, 0, src, src, (long long)plane, (int)(plane / 256), tails); });
         CK(hipFree(tails));
     }
+    {
+        // does the RELATIVE placement of the two volumes matter?  Both allocations are 2 MiB aligned, so a sample's source and
+        // destination share their low address bits; dst2 + delta shifts the destination by delta bytes
+        float *dst2; CK(hipMalloc(&dst2, elems * 4 + ((size_t)64 << 20))); CK(hipMemset(dst2, 0, elems * 4 + ((size_t)64 << 20)));
+        const size_t deltas[] = {0, 256, 1024, 4096, 16384, 65536, 262144, 1048576, 2097152 + 4096, (size_t)33 << 20};
+        for (size_t d : deltas) {
+            char name[96]; std::snprintf(name, sizeof name, "  out of place, destination shifted by %zu bytes", d);
+            float *q = dst2 + d / 4;
+            time(name, [&] { hipLaunchKernelGGL((zcopy<256, 128, 1, 0, 0, true, true>), dim3((unsigned)(plane / 256), planes / 128), dim3(256), 53 * 1024, 0, src, q, (long long)plane, (int)(plane / 256), nullptr); });
+        }
+        CK(hipFree(dst2));
+    }
     time("  2 wg/CU", Z(256, 128, 1, 0, 0, true, true, 2));
     time("  2 wg/CU + recurrences", Z(256, 128, 1, 0, 1, true, true, 2));
     time("  (64 KiB LDS cap = 2 wg/CU) 1 wg/CU asked", Z(256, 128, 1, 0, 0, true, true, 1));
