@@ -1,3 +1,5 @@
+# What the driver does at round end, on one GPU box: the GPU suite with -x, smoke(), the default bench line with 5 + 20 steps.
+#   gpurun -- bash tools/driver_rehearsal.sh   -> gpurun_out/r6i/
 mkdir -p gpurun_out/r6i
 python -m pytest tests -x -q -m gpu > gpurun_out/r6i/suite_run_x.log 2>&1; echo "suite (-x, as the driver runs it) rc=$?"; tail -2 gpurun_out/r6i/suite_run_x.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r6i/smoke.log 2>&1; echo smoke rc=$?; tail -1 gpurun_out/r6i/smoke.log
