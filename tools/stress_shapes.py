@@ -369,6 +369,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "walk":
         ty, tz = int(rng.choice([32, 64, 128])), int(rng.choice([32, 64, 128]))
         world = int(rng.choice([1, 1, 2, 3]))
         shape = (tz * int(rng.integers(1, 4)) * world, ty * int(rng.integers(1, 5)), 256 * int(rng.integers(1, 5)))
+        if case % 2 == 1:          # ragged: a partial last tile row / column (round 6: tall patches, and with --odd any width)
+            shape = (shape[0], int(rng.integers(1, 4 * ty + 1)), width(int(rng.integers(1, 300))))
         kxy, kz = int(rng.integers(1, 3)), int(rng.integers(1, 3))
         scans = []
         for d in range(3):
