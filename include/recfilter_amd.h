@@ -292,7 +292,10 @@ int rf_plan_abort(rf_plan *plan);
 
 /* ---- plan tables (host side of the tiling algebra; also what the CPU tests inspect) ------- */
 /* Copies a named table into out (as doubles) and returns its element count through n_out;
- * pass out = NULL to query the size.  Names are documented in DESIGN.md ("plan tables"). */
+ * pass out = NULL to query the size.  Names are documented in DESIGN.md ("plan tables").
+ * "scans" lists the scans the plan EXECUTES, one row of 5 + 2 * RF_MAX_ORDER doubles each: where the plan rewrote the filter --
+ * merged runs of a 1-D signal (one scan per run, RF_PLAN_NO_OVERLAP forbids it), sections of order <= 3 in place of a scan of
+ * order 4..8 (RF_PLAN_NO_SECTIONS), the first stage of an in-plan cascade -- these are not the scans the caller gave. */
 int rf_plan_table(const rf_plan *plan, const char *name, double *out, size_t capacity, size_t *n_out);
 
 /* Debugging aid: device pointer and size of the i-th buffer the plan owns (tables, tails, carries,
