@@ -1,6 +1,6 @@
 #!/bin/bash
 # AddressSanitizer + UBSan run of the HOST side of the library (plan construction, table algebra, the C ABI) on a box
-# without a GPU: the four host translation units are rebuilt with -fsanitize=address,undefined (-fno-gpu-sanitize: the
+# without a GPU: the five host translation units are rebuilt with -fsanitize=address,undefined (-fno-gpu-sanitize: the
 # device code objects stay as they are; GPU ASan is not available on this pool), linked with the regular kernel
 # objects, and the host-plan tests (RF_DEVICE_HOST_ONLY plans: every table of every path) run against that build.
 #   bash tools/asan_host.sh            -> prints the pytest summary; any sanitizer report fails the run
@@ -10,12 +10,12 @@ out=${TMPDIR:-/tmp}/recfilter_asan
 mkdir -p "$out"
 make -C "$root/recfilter_amd/csrc" -j8 > /dev/null
 cd "$root/recfilter_amd/csrc"
-for f in plan.cpp plan_fused.cpp plan_overlap.cpp capi.cpp; do
+for f in plan.cpp plan_fused.cpp plan_overlap.cpp plan_matrix.cpp capi.cpp; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fno-slp-vectorize -fsanitize=address,undefined \
         -fno-gpu-sanitize -fno-omit-frame-pointer -x hip -c $f -o "$out/${f%.cpp}.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize \
-    -o "$out/librecfilter_amd_asan.so" kernels_*.o "$out"/plan.o "$out"/plan_fused.o "$out"/plan_overlap.o "$out"/capi.o
+    -o "$out/librecfilter_amd_asan.so" kernels_*.o "$out"/plan.o "$out"/plan_fused.o "$out"/plan_overlap.o "$out"/plan_matrix.o "$out"/capi.o
 rt=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 cd "$root"
 log="$out/asan_host.log"
