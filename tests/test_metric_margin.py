@@ -10,7 +10,7 @@ import metric_margin as mm
 def test_no_recorded_assertion_is_ill_conditioned():
     asserts, skipped = mm.load_assertions()
     assert len(asserts) > 500, "the record of the GPU suite's assertions is missing or truncated"
-    with mp.get_context("fork").Pool(min(4, os.cpu_count() or 1)) as pool:
+    with mp.get_context("spawn").Pool(min(4, os.cpu_count() or 1)) as pool:
         results = pool.map(mm._job, [(a, 2) for a in asserts], chunksize=4)
     bad = []
     for a, (worst, worst_norm, _shape) in zip(asserts, results):
