@@ -49,6 +49,14 @@ __global__ void __launch_bounds__(1024) walk_kernel(const float *src, float *out
                 f4 *q = parts + ((((size_t)zt * (tz / 32) + (z >> 5)) * gridDim.y + py) * gridDim.x + tx) * 9216;
                 for (int i = t; i < 9216; i += 1024) q[i] = acc;
             }
+            if (STORES == 12 && (z & 7) == 7) {         // TALL: eight planes' worth of 3 KiB at once: 24 KiB per workgroup
+                f4 *q = parts + ((((size_t)zt * (tz / 8) + (z >> 3)) * gridDim.y + py) * gridDim.x + tx) * 1536;
+                for (int i = t; i < 1536; i += 1024) q[i] = acc;
+            }
+            if (STORES == 13 && (z & 31) == 31) {       // TALL: thirty-two planes' worth at once: 96 KiB per workgroup
+                f4 *q = parts + ((((size_t)zt * (tz / 32) + (z >> 5)) * gridDim.y + py) * gridDim.x + tx) * 6144;
+                for (int i = t; i < 6144; i += 1024) q[i] = acc;
+            }
             if (STORES == 8 && t < 32) parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t] = acc;      // 512 B per plane
             if (STORES == 11 && t < 192) parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t] = acc;     // 3 KiB per plane
             if (STORES == 9 && t < 128) parts[((((size_t)zt * tz + z) * gridDim.y + py) * gridDim.x + tx) * 288 + t] = acc;     // 2 KiB per plane
@@ -111,6 +119,9 @@ int main(int argc, char **argv) {
         time("128 x 64 patches: 2 in flight, barrier", LT(2, true, 0));
         time("128 x 64 patches: 2 in flight, barrier, 3 KiB of stores per plane", LT(2, true, 11));
         time("128 x 64 patches: 2 in flight, barrier, 4.6 KiB of stores per plane", LT(2, true, 2));
+        time("128 x 64 patches: 3 KiB x 8 planes stored at once", LT(2, true, 12));
+        time("128 x 64 patches: 3 KiB x 32 planes stored at once", LT(2, true, 13));
+        time("128 x 64 patches: 2 in flight, barrier, 3 KiB of stores per plane (again)", LT(2, true, 11));
         time("256 x 32 patches: 2 in flight, barrier, 3 KiB of stores per plane", L(2, true, 11));
         time("256 x 32 patches: 2 in flight, barrier, 4.6 KiB (again)", L(2, true, 2));
         time("256 x 32 patches: 2 in flight, barrier, no stores (again)", L(2, true, 0));
