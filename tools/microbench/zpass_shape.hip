@@ -15,10 +15,12 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int W, int TZ, int SPLIT, int SWZ, int RECUR, bool NT_LD, bool NT_ST>
-__global__ void __launch_bounds__(W) zcopy(const float *src, float *dst, long long plane, int runs, const float *tails = nullptr) {
+__global__ void __launch_bounds__(W) zcopy(const float *src, float *dst, long long plane, int runs, const float *tails = nullptr,
+                                           long long plane_src = 0, long long plane_dst = 0) {      // (plane pitches; 0 = dense)
     int b = blockIdx.x;
     if (SWZ == 1) b = (b & 7) * (runs >> 3) + (b >> 3);
-    const long long base = (long long)blockIdx.y * TZ * plane + (long long)b * W;
+    const long long ps = plane_src ? plane_src : plane, pd = plane_dst ? plane_dst : plane;
+    const long long base = (long long)blockIdx.y * TZ * ps + (long long)b * W, based = (long long)blockIdx.y * TZ * pd + (long long)b * W;
     const unsigned lane = threadIdx.x;
     float col[TZ];
     constexpr int H = TZ / SPLIT;
@@ -35,7 +37,7 @@ __global__ void __launch_bounds__(W) zcopy(const float *src, float *dst, long lo
     for (int h = 0; h < SPLIT; h++) {
 #pragma unroll
         for (int i = 0; i < H; i++) {
-            const float *p = src + (base + (long long)(h * H + i) * plane) + lane;
+            const float *p = src + (base + (long long)(h * H + i) * ps) + lane;
             col[h * H + i] = NT_LD ? __builtin_nontemporal_load(p) : *p;
         }
         if (RECUR) {
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(W) zcopy(const float *src, float *dst, long lo
     }
 #pragma unroll
     for (int i = 0; i < TZ; i++) {
-        float *q = dst + (base + (long long)i * plane) + lane;
+        float *q = dst + (based + (long long)i * pd) + lane;
         if (NT_ST) __builtin_nontemporal_store(col[i], q); else *q = col[i];
     }
 }
@@ -101,6 +103,23 @@ int main(int argc, char **argv) {
             time(name, [&] { hipLaunchKernelGGL((zcopy<256, 128, 1, 0, 0, true, true>), dim3((unsigned)(plane / 256), planes / 128), dim3(256), 53 * 1024, 0, src, q, (long long)plane, (int)(plane / 256), nullptr); });
         }
         CK(hipFree(dst2));
+    }
+    {
+        // does the PLANE PITCH matter?  Planes of 2048^2 floats lie exactly 16 MiB apart: the 128 rows a wave touches may share
+        // their DRAM bank bits.  A padded copy of the volume (the plan-owned one between the stages could be laid out so)
+        const long long pads[] = {0, 256, 2048, 16384, 131072};          // floats added to the plane pitch
+        for (long long pad : pads) {
+            const long long pp = (long long)plane + pad;
+            float *psrc, *pdst;
+            CK(hipMalloc(&psrc, (size_t)pp * planes * 4)); CK(hipMalloc(&pdst, (size_t)pp * planes * 4));
+            CK(hipMemset(psrc, 0, (size_t)pp * planes * 4)); CK(hipMemset(pdst, 0, (size_t)pp * planes * 4));
+            char name[112];
+            std::snprintf(name, sizeof name, "  source pitch + %lld floats, destination dense", pad);
+            time(name, [&] { hipLaunchKernelGGL((zcopy<256, 128, 1, 0, 0, true, true>), dim3((unsigned)(plane / 256), planes / 128), dim3(256), 53 * 1024, 0, psrc, dst, (long long)plane, (int)(plane / 256), nullptr, pp, 0LL); });
+            std::snprintf(name, sizeof name, "  source and destination pitch + %lld floats", pad);
+            time(name, [&] { hipLaunchKernelGGL((zcopy<256, 128, 1, 0, 0, true, true>), dim3((unsigned)(plane / 256), planes / 128), dim3(256), 53 * 1024, 0, psrc, pdst, (long long)plane, (int)(plane / 256), nullptr, pp, pp); });
+            CK(hipFree(psrc)); CK(hipFree(pdst));
+        }
     }
     time("  2 wg/CU", Z(256, 128, 1, 0, 0, true, true, 2));
     time("  2 wg/CU + recurrences", Z(256, 128, 1, 0, 1, true, true, 2));
