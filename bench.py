@@ -336,14 +336,18 @@ def run_workload(args, dist, rank, world, name, size, strong, primary):
         # stream it runs on.  (Rounds 1-5 timed torch's copy_ here: 4.8 TB/s, BELOW what the final pass itself reaches.)
         # two_pass_ceiling_frac: an EXACT filter reads every sample twice and writes it once -- every output depends on every
         # input, and the image (1 GiB) does not fit the 256 MiB Infinity Cache -- so under the 8-bytes-per-sample accounting
-        # no two-pass scheme can exceed 8/12 of the rate a copy reaches; filter_frac_of_two_pass_ceiling (the line's top
-        # level) is the whole filter against that.
+        # no two-pass scheme can exceed 8/12 of the rate a copy reaches (a volume, whose z stage is a tiled pass of its own:
+        # 8/20, min_bytes_per_sample); filter_frac_of_two_pass_ceiling (the line's top level) is the whole filter against that.
         plane_rows = (samples_local // planes) // shape[-1]
         if shape[-1] % 256 == 0 and plane_rows % 128 == 0:
             copy_ms = rfa.stream_copy_ms(inputs[0], outputs[0], reps=5)
             roofline["copy_ceiling_gbps"] = round(2 * 4 * (samples_local // planes) / (copy_ms * 1e-3) / 1e9, 1)
             roofline["copy_kernel"] = "rf_stream_copy: 256 x 128 tiles, 16-byte non-temporal loads and stores (this library)"
-            roofline["two_pass_ceiling_frac"] = round((8.0 / 12.0) * roofline["copy_ceiling_gbps"] / HBM_PEAK_GBPS, 4)
+            # (a volume on this design: the one-read first pass 4 B + two tiled final passes of 8 B each = 20 B per sample;
+            #  an image or a signal: 4 + 8 = 12)
+            min_bytes = 20.0 if len(shape) == 3 else 12.0
+            roofline["min_bytes_per_sample"] = min_bytes
+            roofline["two_pass_ceiling_frac"] = round((8.0 / min_bytes) * roofline["copy_ceiling_gbps"] / HBM_PEAK_GBPS, 4)
         else:
             roofline["copy_ceiling_gbps"] = None
             roofline["two_pass_ceiling_frac"] = None
